@@ -1,0 +1,132 @@
+"""Deterministic synthetic genomes for the BASELINE.json configs.
+
+Ancestor: iid uniform ACGT.  Star phylogeny: every genome is an independently mutated descendant at
+per-lineage rate d/2 (pairwise divergence ~ d); events are 90 % substitutions (uniform over the three
+alternatives) and 10 % indels (half insertions, half deletions; geometric length, mean 3, cap 50).
+Inversions reverse-complement non-overlapping segments with log-uniform lengths.
+
+PRNG: numpy PCG64 seeded with 0x4D41555645 + config id (+ genome index); only `integers` and
+`random` draws are used, in a fixed order, so a (config, scale) pair always yields the same genomes.
+Bases are returned as uint8 codes A,C,G,T = 0..3.
+"""
+import numpy as np
+
+BASE_SEED = 0x4D41555645
+
+
+def _rng(*keys):
+    return np.random.Generator(np.random.PCG64([BASE_SEED, *[int(k) for k in keys]]))
+
+
+def random_genome(length, rng):
+    return rng.integers(0, 4, size=int(length), dtype=np.uint8)
+
+
+def mutate(codes, rate, rng, indel_frac=0.10, mean_indel=3.0, cap=50):
+    """Point-mutate `codes` at per-base event rate `rate`."""
+    L = len(codes)
+    if rate <= 0 or L == 0:
+        return codes.copy()
+    ev = rng.random(L) < rate
+    pos = np.flatnonzero(ev)
+    kind = rng.random(len(pos))
+    out = codes.copy()
+    sub = pos[kind >= indel_frac]
+    out[sub] = (out[sub] + rng.integers(1, 4, size=len(sub), dtype=np.uint8)) & 3
+    ind = pos[kind < indel_frac]
+    if len(ind) == 0:
+        return out
+    lens = np.minimum(rng.geometric(1.0 / mean_indel, size=len(ind)), cap)
+    is_ins = rng.random(len(ind)) < 0.5
+    pieces = []
+    cur = 0
+    for p, ln, ins in zip(ind.tolist(), lens.tolist(), is_ins.tolist()):
+        if p < cur:
+            continue
+        pieces.append(out[cur:p])
+        if ins:
+            pieces.append(rng.integers(0, 4, size=ln, dtype=np.uint8))
+            cur = p
+        else:
+            cur = min(L, p + ln)
+    pieces.append(out[cur:])
+    return np.concatenate(pieces)
+
+
+def revcomp(codes):
+    return (3 - codes[::-1]).astype(np.uint8)
+
+
+def invert_segments(codes, n_inv, rng, min_len, max_len):
+    """Reverse-complement n_inv non-overlapping segments (log-uniform lengths)."""
+    L = len(codes)
+    out = codes.copy()
+    if n_inv <= 0:
+        return out, []
+    slot = L // n_inv
+    segs = []
+    for i in range(n_inv):
+        ln = int(np.exp(rng.uniform(np.log(min_len), np.log(max_len))))
+        ln = max(1, min(ln, slot - 2))
+        st = i * slot + int(rng.integers(0, max(1, slot - ln)))
+        out[st:st + ln] = revcomp(out[st:st + ln])
+        segs.append((st, ln))
+    return out, segs
+
+
+def star_genomes(n, length, divergence, seed_key, inversions=0, inv_min=5000, inv_max=500000):
+    """n descendants of one random ancestor; `inversions` total, spread over genomes 1..n-1."""
+    anc = random_genome(length, _rng(seed_key, 0))
+    genomes = []
+    per = [0] * n
+    for i in range(inversions):
+        per[1 + i % (n - 1)] += 1
+    for g in range(n):
+        rng = _rng(seed_key, 1 + g)
+        x = anc
+        if per[g]:
+            x, _ = invert_segments(x, per[g], rng, min(inv_min, max(50, length // 400)),
+                                   min(inv_max, max(100, length // (2 * max(1, per[g])))))
+        genomes.append(mutate(x, divergence / 2.0, rng))
+    return genomes
+
+
+def make_config(name, scale=1.0):
+    """BASELINE.json configs.  `scale` < 1 shrinks genome lengths (parity tests, bounded CPU baselines)."""
+    name = name.upper()
+    if name == "C1":
+        return star_genomes(2, int(200_000 * scale), 0.03, 1)
+    if name == "C2":
+        return star_genomes(3, int(5_000_000 * scale), 0.03, 2)
+    if name == "C3":
+        L = int(5_000_000 * scale)
+        return star_genomes(5, L, 0.03, 3, inversions=max(1, int(round(50 * min(1.0, scale * 4)))) if scale < 0.25 else 50)
+    if name == "C4":
+        return star_genomes(8, int(2_000_000 * scale), 0.06, 4, inversions=14)
+    if name == "C5":
+        L = int(100_000_000 * scale)
+        gs = star_genomes(2, L, 0.03, 5)
+        out = []
+        for g, x in enumerate(gs):
+            rng = _rng(5, 100 + g)
+            n_ins = max(1, int(2000 * scale))
+            pos = np.sort(rng.integers(0, len(x), size=n_ins))
+            pieces, cur = [], 0
+            for p in pos.tolist():
+                pieces.append(x[cur:p])
+                pieces.append(rng.integers(0, 4, size=int(rng.integers(1000, 10000)), dtype=np.uint8))
+                cur = p
+            pieces.append(x[cur:])
+            y = np.concatenate(pieces)
+            n_hd = max(1, int(200 * scale))
+            for _ in range(n_hd):
+                ln = int(rng.integers(2000, 20000))
+                st = int(rng.integers(0, max(1, len(y) - ln)))
+                y[st:st + ln] = mutate(y[st:st + ln], 0.25, rng, indel_frac=0.0)[:ln]
+            out.append(y)
+        return out
+    raise ValueError("unknown config " + name)
+
+
+def to_ascii(codes):
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[codes].tobytes()

@@ -1,0 +1,143 @@
+/*
+ * mauve_oracle.h -- CPU restatement ("oracle") of the mauveAligner / progressiveMauve hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under mauvealigner_amd/ may include, link or call this.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * PARITY UNPINNED: the reference's arithmetic for this path lives in libMems 1.6 / libGenome /
+ * libMUSCLE (configure.ac:46), which are absent from /root/reference and from this image, and the
+ * reference ships no tests, fixtures or golden vectors.  This restatement
+ * follows the in-tree call sites and subclasses (cited per function) and the published Mauve
+ * algorithm; every semantic choice that the tree does not pin is frozen in DESIGN.md.
+ */
+#ifndef MAUVE_ORACLE_H
+#define MAUVE_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_SEQ 32
+#define ORC_CODING_SEED 3                 /* mauveAligner.cpp:266-279 seed ranks */
+#define ORC_SOLID_SEED 0x7fffffff         /* repeatoire.cpp:1847: SOLID_SEED == INT_MAX */
+
+/* seed-hit rule (who calls HashMatch) */
+#define ORC_MODE_MEM 0        /* MemHash default: a mer repeated in any genome is dropped entirely */
+#define ORC_MODE_UNIQUE 1     /* UniqueMatchFinder.cpp:36-60: drop only the genomes with repeats */
+
+typedef struct {
+    int32_t gap_open;         /* cost of the first gap column of a run (negative) */
+    int32_t gap_extend;       /* cost of each further gap column (negative) */
+    int32_t matrix[4][4];     /* substitution scores, A,C,G,T order */
+} orc_scoring;
+
+typedef struct {
+    int64_t n;                /* number of matches */
+    int32_t nseq;
+    int64_t *length;          /* [n] */
+    int64_t *start;           /* [n*nseq] signed 1-based, 0 = absent (NO_MATCH) */
+} orc_matches;
+
+typedef struct {
+    int64_t n_lcb;
+    int32_t nseq;
+    int64_t *match_lcb;       /* [n_matches] LCB id or -1 (eliminated) */
+    int64_t *left_end;        /* [n_lcb*nseq] signed (negative = reverse strand) */
+    int64_t *right_end;       /* [n_lcb*nseq] signed */
+    int64_t *weight;          /* [n_lcb] */
+    int64_t *left_adj;        /* [n_lcb*nseq] LCB id left of this one in genome g, -1 = none */
+    int64_t *right_adj;       /* [n_lcb*nseq] */
+} orc_lcbs;
+
+typedef struct {
+    int64_t n_iv;             /* number of intervals (LCBs, then unaligned single-genome islands) */
+    int32_t nseq;
+    int64_t *left;            /* [n_iv*nseq] 1-based left end, 0 = genome absent */
+    int64_t *right;           /* [n_iv*nseq] 1-based inclusive right end */
+    int8_t  *reverse;         /* [n_iv*nseq] 1 = reverse strand */
+    int64_t *col_off;         /* [n_iv+1] offsets into cols */
+    uint32_t *cols;           /* presence mask per alignment column (bit g = genome g has a base) */
+    int64_t *dp_score;        /* [n_iv] sum of DP scores of the gapped intervals of the LCB */
+    int64_t n_anchor;         /* anchors used (after overlap trimming) */
+    int64_t *anchor_length;   /* [n_anchor] */
+    int64_t *anchor_start;    /* [n_anchor*nseq] signed 1-based */
+    int64_t *anchor_lcb;      /* [n_anchor] */
+    int64_t n_gap_dp;         /* number of inter-anchor intervals that went through DP */
+    int64_t n_dp_cells;       /* total DP cells evaluated */
+} orc_alignment;
+
+typedef struct {
+    uint64_t seed_pattern;    /* 0 -> getSeed(default weight, seed_rank) */
+    int32_t seed_weight;      /* 0 -> default (mauveAligner.cpp:92) */
+    int32_t seed_rank;
+    int32_t mode;             /* ORC_MODE_* */
+    int64_t lcb_weight;       /* -1 -> 3*weight*N (mauveAligner.cpp:648-653); already multiplied by N */
+    int32_t collinear;        /* mauveAligner.cpp:665-666 */
+    int32_t recursive;        /* mauveAligner.cpp:94 */
+    int32_t gapped;           /* mauveAligner.cpp:96 */
+    int32_t add_unaligned;    /* mauveAligner.cpp:748 addUnalignedIntervals */
+    int64_t min_recursive_gap;/* default 200 (mauveAligner.cpp:899) */
+    int64_t max_gapped_len;   /* default 10000 */
+    orc_scoring scoring;
+} orc_params;
+
+/* ---- seeds ---------------------------------------------------------------------------------- */
+uint64_t orc_get_seed(int weight, int rank);
+int orc_seed_length(uint64_t pattern);
+int orc_seed_weight(uint64_t pattern);
+int orc_default_seed_weight(int64_t avg_len);
+void orc_default_scoring(orc_scoring *s);
+void orc_default_params(orc_params *p);
+
+/* ---- sequence encoding ------------------------------------------------------------------------ */
+void orc_encode(const char *ascii, int64_t n, uint8_t *codes);       /* A,C,G,T -> 0..3, other -> 0 */
+void orc_pack2bit(const uint8_t *codes, int64_t n, uint32_t *words); /* base i -> word i/16 bits 2*(i%16) */
+
+/* ---- sorted mer list (SML) -------------------------------------------------------------------- */
+/* per-position canonical masked mer + strand flag; returns number of positions (L-span+1 or 0) */
+int64_t orc_mers(const uint8_t *codes, int64_t len, uint64_t pattern, uint64_t *canon, uint8_t *strand);
+/* SML: positions sorted by (canon mer, position); mer_out is libMems-style: left-aligned | strand */
+int64_t orc_sorted_mer_list(const uint8_t *codes, int64_t len, uint64_t pattern,
+                            uint64_t *mer_out, int64_t *pos_out);
+
+/* ---- multi-MUM enumeration + ungapped extension ---------------------------------------------- */
+int orc_find_matches(int nseq, const uint8_t *const *codes, const int64_t *lens, uint64_t pattern,
+                     int mode, uint64_t mask, int extend, orc_matches *out);
+/* SeedMatchEnumerator (SeedMatchEnumerator.h:19-141): single genome, every repeated seed -> Match */
+int orc_seed_match_enumerate(const uint8_t *codes, int64_t len, uint64_t pattern, int64_t min_multi,
+                             int64_t max_multi, int direct_only, int64_t *n_out, int64_t **mult_out,
+                             int64_t **start_off_out, int64_t **starts_out);
+void orc_free_matches(orc_matches *m);
+void orc_free(void *p);
+
+/* ---- LCBs ------------------------------------------------------------------------------------ */
+int orc_multiplicity_filter(const orc_matches *in, int mult, orc_matches *out);
+int orc_eliminate_overlaps(orc_matches *m);   /* in place, N-way input */
+int orc_compute_lcbs(const orc_matches *m, int64_t min_weight, int collinear, orc_lcbs *out);
+void orc_free_lcbs(orc_lcbs *l);
+
+/* ---- gapped DP -------------------------------------------------------------------------------- */
+/* progressive N-way alignment of one inter-anchor interval; seqs[g] are codes already in LCB
+   orientation; cols_out must hold sum(lens) entries; returns number of columns, score in *score */
+int64_t orc_align_interval(int nseq, const uint8_t *const *seqs, const int64_t *lens,
+                           const orc_scoring *sc, uint32_t *cols_out, int64_t *score,
+                           int64_t *cells);
+/* one profile-vs-sequence step (exposed for known-answer tests): profile given as per-column
+   base counts cnt[m*4] and residue count; ops_out[m+n]: 1=profile only,2=seq only,3=both */
+int64_t orc_profile_dp(int64_t m, const uint8_t *cnt, int k_rows, int64_t n, const uint8_t *seq,
+                       const orc_scoring *sc, uint8_t *ops_out, int64_t *score);
+
+/* ---- whole path -------------------------------------------------------------------------------- */
+int orc_align(int nseq, const uint8_t *const *codes, const int64_t *lens, const orc_params *p,
+              orc_matches *mums_out, orc_lcbs *lcbs_out, orc_alignment *aln_out);
+void orc_free_alignment(orc_alignment *a);
+/* XMFA text (format pinned by mfa2xmfa.cpp:64,89-91,104-115); returns malloc'd NUL-terminated text */
+char *orc_write_xmfa(int nseq, const uint8_t *const *codes, const int64_t *lens,
+                     const char *const *names, const orc_alignment *a, int64_t *text_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
