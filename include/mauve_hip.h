@@ -1,0 +1,181 @@
+/*
+ * mauve_hip.h -- C-ABI of the MI355X-native mauveAligner hot path (libmauve_hip.so).
+ *
+ * This is the drop-in boundary.  The reference has no C plugin ABI: its seams are the
+ * C++ virtual interfaces of libMems.  Each entry point below names the libMems interface it stands
+ * behind, cited by the in-tree call site that pins its contract (file:line relative to the
+ * reference tree).  The C++ adapters in include/libMems/ (namespace mems) call these and nothing
+ * else; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions: plain pointers and sizes, caller-owned output buffers (two-phase count / fill),
+ * every call returns an int status (0 = MAUVE_OK) and never throws; mauve_last_error() gives the
+ * text.  A context is thread-compatible (one thread at a time); there are no hidden globals.
+ * Coordinates follow libMems: signed 1-based starts, negative = reverse strand, 0 = NO_MATCH
+ * (SeedMatchEnumerator.h:83,127-141; sortContigs.cpp:46).
+ */
+#ifndef MAUVE_HIP_H
+#define MAUVE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAUVE_OK 0
+#define MAUVE_ERR_ARG (-1)        /* bad argument */
+#define MAUVE_ERR_HIP (-2)        /* HIP runtime failure (text in mauve_last_error) */
+#define MAUVE_ERR_NOGPU (-3)      /* no usable device: the product has no CPU fallback */
+#define MAUVE_ERR_LIMIT (-4)      /* input exceeds a documented limit */
+#define MAUVE_ERR_STATE (-5)      /* call order violated (e.g. no genomes set) */
+
+#define MAUVE_MAX_SEQ 32
+#define MAUVE_MAX_SEED_SPAN 49
+#define MAUVE_CODING_SEED 3                /* mauveAligner.cpp:266-279 */
+#define MAUVE_SOLID_SEED 0x7fffffff        /* repeatoire.cpp:1847 (SOLID_SEED == INT_MAX) */
+
+/* seed-hit rule = which MatchFinder subclass's EnumerateMatches is in force */
+#define MAUVE_MODE_MEM 0      /* mems::MemHash / MaskedMemHash (mauveAligner.cpp:523-531) */
+#define MAUVE_MODE_UNIQUE 1   /* UniqueMatchFinder::EnumerateMatches (UniqueMatchFinder.cpp:36-60) */
+
+typedef struct mauve_ctx mauve_ctx;
+
+typedef struct {
+    int32_t gap_open;             /* PairwiseScoringScheme.gap_open  (progressiveMauve.cpp:666-687) */
+    int32_t gap_extend;           /* PairwiseScoringScheme.gap_extend */
+    int32_t matrix[4][4];         /* score_t matrix[4][4], A,C,G,T (readSubstitutionMatrix, :684) */
+} mauve_scoring;
+
+typedef struct {
+    uint64_t seed_pattern;        /* 0 -> getSeed(weight, rank) */
+    int32_t seed_weight;          /* 0 -> getDefaultSeedWeight(avg length)  (mauveAligner.cpp:92,650) */
+    int32_t seed_rank;            /* mauveAligner.cpp:93 */
+    int32_t mode;                 /* MAUVE_MODE_* */
+    int64_t lcb_weight;           /* -1 -> 3*weight*N (mauveAligner.cpp:648-653); total, i.e. already *N */
+    int32_t collinear;            /* mauveAligner.cpp:665-666 */
+    int32_t recursive;            /* mauveAligner.cpp:94 */
+    int32_t gapped;               /* mauveAligner.cpp:96 */
+    int32_t add_unaligned;        /* mauveAligner.cpp:748 addUnalignedIntervals */
+    int64_t min_recursive_gap;    /* Aligner::SetMinRecursionGapLength, default 200 (:670-672,899) */
+    int64_t max_gapped_len;       /* Aligner::SetMaxGappedAlignmentLength (:674-676), default 10000 */
+    mauve_scoring scoring;
+} mauve_params;
+
+/* sizes of the result of mauve_align(), for the caller to allocate the fill buffers */
+typedef struct {
+    int64_t n_mums;               /* N-way multi-MUMs found by the seed pass */
+    int64_t n_lcb;
+    int64_t n_anchor;             /* anchors after overlap elimination + recursive anchoring */
+    int64_t n_iv;                 /* intervals: LCBs first, then unaligned single-genome islands */
+    int64_t n_cols;               /* total alignment columns over all intervals */
+    int64_t n_gap_dp;             /* inter-anchor intervals aligned by DP */
+    int64_t n_dp_cells;           /* DP cells evaluated */
+} mauve_align_sizes;
+
+/* ---- context ----------------------------------------------------------------------------------- */
+int mauve_ctx_create(int device, mauve_ctx **out);
+void mauve_ctx_destroy(mauve_ctx *ctx);
+const char *mauve_last_error(const mauve_ctx *ctx);       /* ctx may be NULL: last create error */
+int mauve_device_name(const mauve_ctx *ctx, char *buf, size_t buflen);
+int mauve_synchronize(mauve_ctx *ctx);
+
+/* ---- seeds (host-side helpers; libMems free functions getSeed/getSeedLength/getDefaultSeedWeight,
+        progressiveMauve.cpp:217,511-517; MatchList::GetDefaultMerSize, mauveAligner.cpp:651) ------ */
+uint64_t mauve_get_seed(int weight, int rank);
+int mauve_seed_length(uint64_t pattern);
+int mauve_seed_weight(uint64_t pattern);
+int mauve_default_seed_weight(int64_t avg_len);
+void mauve_default_scoring(mauve_scoring *s);              /* hoxd_matrix, -400, -30 */
+void mauve_default_params(mauve_params *p);
+/* 2-bit packing used at the boundary: base i -> 64-bit word i/32, bits 2*(i%32); A,C,G,T=0..3,
+   anything else -> 0.  words must hold mauve_packed_words(len) entries. */
+size_t mauve_packed_words(int64_t len);
+void mauve_pack_ascii(const char *ascii, int64_t len, uint64_t *words);
+void mauve_pack_codes(const uint8_t *codes, int64_t len, uint64_t *words);
+
+/* ---- genomes: gnSequence table of a MatchList (MatchList.seq_table; mauveAligner.cpp:453-465).
+        Uploads the packed genomes; they stay resident in HBM until the next call / destroy. ------- */
+int mauve_set_genomes(mauve_ctx *ctx, int nseq, const uint64_t *const *packed, const int64_t *lens);
+
+/* ---- sorted mer list: MatchList::CreateMemorySMLs / DNAFileSML for one genome
+        (mauveAligner.cpp:456,465; SortedMerList::GetMer semantics SeedMatchEnumerator.h:133).
+        mer_out: mer left-aligned in 64 bits | strand flag in bit 0; pos_out: 0-based positions;
+        both must hold len-span+1 entries.  Returns the entry count in *n_out. ------------------- */
+int mauve_sorted_mer_list(mauve_ctx *ctx, int seq, uint64_t pattern, uint64_t *mer_out,
+                          int64_t *pos_out, int64_t *n_out);
+
+/* ---- multi-MUMs: MatchFinder::FindMatches(MatchList&) = AddSequence* + CreateMatches + GetMatchList
+        (progressiveMauve.cpp:490-501; mauveAligner.cpp:577-589).  mask != 0 keeps only matches
+        whose component set equals mask (MaskedMemHash::SetMask, mauveAligner.cpp:525-531);
+        extend = 0 returns seed-length matches (SeedMatchEnumerator.h:71-123).  The result stays on
+        the device; *n_matches receives the count.  mauve_get_matches copies it out in canonical
+        order: length[n], start[n*nseq]. ---------------------------------------------------------- */
+int mauve_seed_mums(mauve_ctx *ctx, uint64_t pattern, int mode, uint64_t mask, int extend,
+                    int64_t *n_matches);
+int mauve_get_matches(mauve_ctx *ctx, int64_t *length, int64_t *start);
+
+/* ---- SeedMatchEnumerator::FindMatches (SeedMatchEnumerator.h:19-33): single genome `seq`, every
+        mer with min_multi..max_multi occurrences becomes one match (CSR output).  Two-phase: call
+        with starts == NULL to get *n_out and *n_starts, then again with buffers. ----------------- */
+int mauve_seed_match_enumerate(mauve_ctx *ctx, int seq, uint64_t pattern, int64_t min_multi,
+                               int64_t max_multi, int direct_only, int64_t *n_out, int64_t *n_starts,
+                               int64_t *mult, int64_t *start_off, int64_t *starts);
+
+/* ---- chaining: MultiplicityFilter + EliminateOverlaps + Aligner::align's LCB stage
+        (IdentifyBreakpoints / ComputeLCBs_v2 / greedy breakpoint elimination /
+        computeLCBAdjacencies_v2; mauveAligner.cpp:596,600,698; toGrimmFormat.cpp:51-79).
+        Host-side (sequential by nature); inputs/outputs are host arrays. ------ */
+int mauve_eliminate_overlaps(int nseq, int64_t *n_inout, int64_t *length, int64_t *start);
+int mauve_lcb_chain(int nseq, int64_t n, const int64_t *length, const int64_t *start,
+                    int64_t min_weight, int collinear, int64_t *match_lcb, int64_t *n_lcb_out,
+                    int64_t *left_end, int64_t *right_end, int64_t *weight, int64_t *left_adj,
+                    int64_t *right_adj);   /* per-LCB arrays sized for n entries * nseq */
+
+/* ---- gapped DP: the GappedAligner seam (Aligner::SetGappedAligner, mauveAligner.cpp:674;
+        MuscleInterface::Align, MatchRecord.h:311; CallMuscleFast, repeatoire.cpp:1262).
+        Batch of n_iv intervals; interval i has nseq sequences given as 0..3 codes, concatenated in
+        `codes` with offsets seq_off[i*nseq+g] .. seq_off[i*nseq+g+1].  Output: presence-mask
+        columns (bit g = sequence g has a residue), col_off[n_iv+1], per-interval score.
+        cols must hold seq_off[n_iv*nseq] entries. ------------------------------------------------ */
+int mauve_dp_batch(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
+                   const int64_t *seq_off, const mauve_scoring *sc, uint32_t *cols,
+                   int64_t *col_off, int64_t *score);
+
+/* ---- whole path: doAlignment's hot section (mauveAligner.cpp:523-531,585,629-698,746-760):
+        multi-MUMs -> N-way filter -> overlap elimination -> LCBs -> recursive anchoring -> gapped
+        alignment of every inter-anchor interval -> interval table.  Results are held by the context
+        until the next call; fetch them with mauve_align_fetch.  Any fetch pointer may be NULL. ---- */
+int mauve_align(mauve_ctx *ctx, const mauve_params *p, mauve_align_sizes *sizes);
+int mauve_align_fetch(mauve_ctx *ctx,
+                      int64_t *mum_length, int64_t *mum_start,            /* [n_mums], [n_mums*nseq] */
+                      int64_t *lcb_left, int64_t *lcb_right, int64_t *lcb_weight, /* [n_lcb*nseq] x2, [n_lcb] */
+                      int64_t *anchor_length, int64_t *anchor_start, int64_t *anchor_lcb,
+                      int64_t *iv_left, int64_t *iv_right, int8_t *iv_reverse,   /* [n_iv*nseq] */
+                      int64_t *col_off, uint32_t *cols, int64_t *dp_score);     /* [n_iv+1],[n_cols],[n_iv] */
+/* IntervalList::WriteStandardAlignment (mauveAligner.cpp:746-760; format mfa2xmfa.cpp:64-115).
+   Two-phase: buf == NULL returns the needed size (including NUL) in *len. */
+int mauve_write_xmfa(mauve_ctx *ctx, const char *const *names, char *buf, int64_t *len);
+
+/* ---- measurement -------------------------------------------------------------------------------
+   Per-kernel HIP-event timing on the context's stream (bench.py roofline).  Kernel ids: */
+#define MAUVE_K_EXTRACT 0
+#define MAUVE_K_SORT_HIST 1
+#define MAUVE_K_SORT_SCAN 2
+#define MAUVE_K_SORT_SCATTER 3
+#define MAUVE_K_JOIN 4
+#define MAUVE_K_EXTEND 5
+#define MAUVE_K_DP 6
+#define MAUVE_K_COUNT 8
+int mauve_profile_enable(mauve_ctx *ctx, int on);
+int mauve_profile_reset(mauve_ctx *ctx);
+int mauve_profile_get(mauve_ctx *ctx, int kernel, double *total_ms, int64_t *launches, int64_t *units);
+/* wall-clock of the stages of the last mauve_align call, milliseconds */
+typedef struct {
+    double seed_ms, chain_ms, recurse_ms, dp_ms, assemble_ms, total_ms;
+} mauve_stage_times;
+int mauve_last_stage_times(mauve_ctx *ctx, mauve_stage_times *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,309 @@
+"""ctypes loader for libmauve_hip.so (the C-ABI declared in include/mauve_hip.h).
+
+Plumbing only: tests, bench.py and __graft_entry__ call the product through this module.  There is no
+CPU fallback -- `Context()` raises if the library or a GPU is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmauve_hip.so")
+
+MODE_MEM, MODE_UNIQUE = 0, 1
+CODING_SEED, SOLID_SEED = 3, 0x7FFFFFFF
+K_EXTRACT, K_SORT_HIST, K_SORT_SCAN, K_SORT_SCATTER, K_JOIN, K_EXTEND, K_DP = range(7)
+KERNEL_NAMES = ["seed_extract", "rs_hist", "rs_rowscan", "rs_scatter", "mum_join", "mum_extend", "dp_batch"]
+
+# every symbol include/mauve_hip.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTS = [
+    "mauve_ctx_create", "mauve_ctx_destroy", "mauve_last_error", "mauve_device_name", "mauve_synchronize",
+    "mauve_get_seed", "mauve_seed_length", "mauve_seed_weight", "mauve_default_seed_weight", "mauve_default_scoring",
+    "mauve_default_params", "mauve_packed_words", "mauve_pack_ascii", "mauve_pack_codes", "mauve_set_genomes",
+    "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_seed_match_enumerate",
+    "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_align", "mauve_align_fetch",
+    "mauve_write_xmfa", "mauve_profile_enable", "mauve_profile_reset", "mauve_profile_get", "mauve_last_stage_times",
+]
+
+
+class Scoring(C.Structure):
+    _fields_ = [("gap_open", C.c_int32), ("gap_extend", C.c_int32), ("matrix", (C.c_int32 * 4) * 4)]
+
+
+class Params(C.Structure):
+    _fields_ = [("seed_pattern", C.c_uint64), ("seed_weight", C.c_int32), ("seed_rank", C.c_int32),
+                ("mode", C.c_int32), ("lcb_weight", C.c_int64), ("collinear", C.c_int32),
+                ("recursive", C.c_int32), ("gapped", C.c_int32), ("add_unaligned", C.c_int32),
+                ("min_recursive_gap", C.c_int64), ("max_gapped_len", C.c_int64), ("scoring", Scoring)]
+
+
+class AlignSizes(C.Structure):
+    _fields_ = [("n_mums", C.c_int64), ("n_lcb", C.c_int64), ("n_anchor", C.c_int64), ("n_iv", C.c_int64),
+                ("n_cols", C.c_int64), ("n_gap_dp", C.c_int64), ("n_dp_cells", C.c_int64)]
+
+
+class StageTimes(C.Structure):
+    _fields_ = [("seed_ms", C.c_double), ("chain_ms", C.c_double), ("recurse_ms", C.c_double),
+                ("dp_ms", C.c_double), ("assemble_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen the product library; raises OSError with a clear message when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("libmauve_hip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(make -C mauvealigner_amd/csrc); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.mauve_last_error.restype = C.c_char_p
+    L.mauve_last_error.argtypes = [C.c_void_p]
+    L.mauve_get_seed.restype = C.c_uint64
+    L.mauve_get_seed.argtypes = [C.c_int, C.c_int]
+    L.mauve_seed_length.argtypes = [C.c_uint64]
+    L.mauve_seed_weight.argtypes = [C.c_uint64]
+    L.mauve_default_seed_weight.argtypes = [C.c_int64]
+    L.mauve_packed_words.restype = C.c_size_t
+    L.mauve_packed_words.argtypes = [C.c_int64]
+    L.mauve_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.mauve_ctx_destroy.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def get_seed(weight, rank=0):
+    return int(load().mauve_get_seed(weight, rank))
+
+
+def seed_length(p):
+    return int(load().mauve_seed_length(C.c_uint64(p)))
+
+
+def seed_weight(p):
+    return int(load().mauve_seed_weight(C.c_uint64(p)))
+
+
+def default_seed_weight(avg_len):
+    return int(load().mauve_default_seed_weight(C.c_int64(int(avg_len))))
+
+
+def default_params(**kw):
+    p = Params()
+    load().mauve_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def default_scoring():
+    s = Scoring()
+    load().mauve_default_scoring(C.byref(s))
+    return s
+
+
+def pack_codes(codes):
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    L = load()
+    words = np.zeros(L.mauve_packed_words(len(codes)), dtype=np.uint64)
+    L.mauve_pack_codes(_p(codes, C.c_uint8), C.c_int64(len(codes)), _p(words, C.c_uint64))
+    return words
+
+
+def pack_ascii(text):
+    b = text if isinstance(text, (bytes, bytearray)) else text.encode()
+    L = load()
+    words = np.zeros(L.mauve_packed_words(len(b)), dtype=np.uint64)
+    L.mauve_pack_ascii(C.c_char_p(bytes(b)), C.c_int64(len(b)), _p(words, C.c_uint64))
+    return words
+
+
+def eliminate_overlaps(length, start):
+    length = np.array(length, dtype=np.int64, copy=True)
+    start = np.array(start, dtype=np.int64, copy=True)
+    n = C.c_int64(len(length))
+    N = start.shape[1]
+    rc = load().mauve_eliminate_overlaps(N, C.byref(n), _p(length, C.c_int64), _p(start, C.c_int64))
+    if rc:
+        raise RuntimeError("mauve_eliminate_overlaps: %d" % rc)
+    return length[:n.value].copy(), start[:n.value].copy()
+
+
+def lcb_chain(length, start, min_weight, collinear=False):
+    length = np.ascontiguousarray(length, dtype=np.int64)
+    start = np.ascontiguousarray(start, dtype=np.int64)
+    n, N = len(length), start.shape[1]
+    ml = np.zeros(max(n, 1), np.int64)
+    le = np.zeros((max(n, 1), N), np.int64)
+    re = np.zeros((max(n, 1), N), np.int64)
+    wt = np.zeros(max(n, 1), np.int64)
+    la = np.zeros((max(n, 1), N), np.int64)
+    ra = np.zeros((max(n, 1), N), np.int64)
+    k = C.c_int64()
+    rc = load().mauve_lcb_chain(N, C.c_int64(n), _p(length, C.c_int64), _p(start, C.c_int64), C.c_int64(min_weight),
+                                int(collinear), _p(ml, C.c_int64), C.byref(k), _p(le, C.c_int64), _p(re, C.c_int64),
+                                _p(wt, C.c_int64), _p(la, C.c_int64), _p(ra, C.c_int64))
+    if rc:
+        raise RuntimeError("mauve_lcb_chain: %d" % rc)
+    K = k.value
+    return {"n_lcb": K, "match_lcb": ml[:n].copy(), "left_end": le[:K].copy(), "right_end": re[:K].copy(),
+            "weight": wt[:K].copy(), "left_adj": la[:K].copy(), "right_adj": ra[:K].copy()}
+
+
+class Context:
+    """One mauve_ctx = one GPU + one stream.  Fails loudly when the extension or the GPU is absent."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.mauve_ctx_create(device, C.byref(h))
+        if rc:
+            raise RuntimeError("mauve_ctx_create failed (%d): %s" % (rc, self.L.mauve_last_error(None).decode()))
+        self.h = h
+        self.nseq = 0
+        self._keep = None
+
+    def close(self):
+        if self.h:
+            self.L.mauve_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.L.mauve_last_error(self.h).decode()))
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self.L.mauve_device_name(self.h, buf, 256)
+        return buf.value.decode()
+
+    def synchronize(self):
+        self._chk(self.L.mauve_synchronize(self.h), "mauve_synchronize")
+
+    def set_genomes(self, codes_list):
+        """codes_list: list of uint8 arrays of 0..3 codes (packed here with mauve_pack_codes)."""
+        packed = [pack_codes(c) for c in codes_list]
+        n = len(packed)
+        arr = (C.POINTER(C.c_uint64) * n)(*[_p(w, C.c_uint64) for w in packed])
+        lens = (C.c_int64 * n)(*[len(c) for c in codes_list])
+        self._chk(self.L.mauve_set_genomes(self.h, n, arr, lens), "mauve_set_genomes")
+        self.nseq = n
+        self.lens = [len(c) for c in codes_list]
+
+    def seed_mums(self, pattern, mode=MODE_MEM, mask=0, extend=True, fetch=True):
+        n = C.c_int64()
+        self._chk(self.L.mauve_seed_mums(self.h, C.c_uint64(pattern), mode, C.c_uint64(mask), int(bool(extend)),
+                                         C.byref(n)), "mauve_seed_mums")
+        if not fetch:
+            return n.value
+        ln = np.zeros(n.value, np.int64)
+        st = np.zeros((n.value, self.nseq), np.int64)
+        self._chk(self.L.mauve_get_matches(self.h, _p(ln, C.c_int64), _p(st, C.c_int64)), "mauve_get_matches")
+        return ln, st
+
+    def sorted_mer_list(self, seq, pattern):
+        n = max(0, self.lens[seq] - seed_length(pattern) + 1)
+        mer = np.zeros(n, np.uint64)
+        pos = np.zeros(n, np.int64)
+        k = C.c_int64()
+        self._chk(self.L.mauve_sorted_mer_list(self.h, seq, C.c_uint64(pattern), _p(mer, C.c_uint64),
+                                               _p(pos, C.c_int64), C.byref(k)), "mauve_sorted_mer_list")
+        return mer[:k.value], pos[:k.value]
+
+    def seed_match_enumerate(self, seq, pattern, min_multi=2, max_multi=1000, direct_only=False):
+        n, ns = C.c_int64(), C.c_int64()
+        args = (self.h, seq, C.c_uint64(pattern), C.c_int64(min_multi), C.c_int64(max_multi), int(direct_only))
+        self._chk(self.L.mauve_seed_match_enumerate(*args, C.byref(n), C.byref(ns), None, None, None), "seed_match_enumerate")
+        mult = np.zeros(n.value, np.int64)
+        off = np.zeros(n.value + 1, np.int64)
+        st = np.zeros(ns.value, np.int64)
+        self._chk(self.L.mauve_seed_match_enumerate(*args, C.byref(n), C.byref(ns), _p(mult, C.c_int64), _p(off, C.c_int64),
+                                                    _p(st, C.c_int64)), "seed_match_enumerate")
+        return mult, off, st
+
+    def dp_batch(self, intervals, scoring=None):
+        """intervals: list of lists of code arrays (nseq each).  -> (cols list, scores)"""
+        sc = scoring or default_scoring()
+        n_iv = len(intervals)
+        nseq = len(intervals[0]) if n_iv else 1
+        flat, off = [], [0]
+        for iv in intervals:
+            for s in iv:
+                flat.append(np.asarray(s, dtype=np.uint8))
+                off.append(off[-1] + len(s))
+        codes = np.concatenate(flat) if flat and off[-1] else np.zeros(1, np.uint8)
+        off = np.array(off, dtype=np.int64)
+        cols = np.zeros(max(int(off[-1]), 1), np.uint32)
+        col_off = np.zeros(n_iv + 1, np.int64)
+        score = np.zeros(max(n_iv, 1), np.int64)
+        self._chk(self.L.mauve_dp_batch(self.h, nseq, C.c_int64(n_iv), _p(codes, C.c_uint8), _p(off, C.c_int64),
+                                        C.byref(sc), _p(cols, C.c_uint32), _p(col_off, C.c_int64), _p(score, C.c_int64)),
+                  "mauve_dp_batch")
+        return [cols[col_off[i]:col_off[i + 1]].copy() for i in range(n_iv)], score[:n_iv].copy()
+
+    def align(self, params=None, fetch=True, names=None, want_xmfa=False):
+        p = params or default_params()
+        sz = AlignSizes()
+        self._chk(self.L.mauve_align(self.h, C.byref(p), C.byref(sz)), "mauve_align")
+        out = {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
+        if not fetch:
+            return out
+        N = self.nseq
+        a = {
+            "mum_length": np.zeros(sz.n_mums, np.int64), "mum_start": np.zeros((sz.n_mums, N), np.int64),
+            "lcb_left": np.zeros((sz.n_lcb, N), np.int64), "lcb_right": np.zeros((sz.n_lcb, N), np.int64),
+            "lcb_weight": np.zeros(sz.n_lcb, np.int64),
+            "anchor_length": np.zeros(sz.n_anchor, np.int64), "anchor_start": np.zeros((sz.n_anchor, N), np.int64),
+            "anchor_lcb": np.zeros(sz.n_anchor, np.int64),
+            "left": np.zeros((sz.n_iv, N), np.int64), "right": np.zeros((sz.n_iv, N), np.int64),
+            "reverse": np.zeros((sz.n_iv, N), np.int8), "col_off": np.zeros(sz.n_iv + 1, np.int64),
+            "cols": np.zeros(sz.n_cols, np.uint32), "dp_score": np.zeros(sz.n_iv, np.int64),
+        }
+        self._chk(self.L.mauve_align_fetch(
+            self.h, _p(a["mum_length"], C.c_int64), _p(a["mum_start"], C.c_int64), _p(a["lcb_left"], C.c_int64),
+            _p(a["lcb_right"], C.c_int64), _p(a["lcb_weight"], C.c_int64), _p(a["anchor_length"], C.c_int64),
+            _p(a["anchor_start"], C.c_int64), _p(a["anchor_lcb"], C.c_int64), _p(a["left"], C.c_int64),
+            _p(a["right"], C.c_int64), _p(a["reverse"], C.c_int8), _p(a["col_off"], C.c_int64),
+            _p(a["cols"], C.c_uint32), _p(a["dp_score"], C.c_int64)), "mauve_align_fetch")
+        out.update(a)
+        if want_xmfa:
+            nm = names or ["seq%d" % i for i in range(N)]
+            narr = (C.c_char_p * N)(*[s.encode() for s in nm])
+            ln = C.c_int64()
+            self._chk(self.L.mauve_write_xmfa(self.h, narr, None, C.byref(ln)), "mauve_write_xmfa")
+            buf = C.create_string_buffer(ln.value)
+            self._chk(self.L.mauve_write_xmfa(self.h, narr, buf, C.byref(ln)), "mauve_write_xmfa")
+            out["xmfa"] = buf.value.decode()
+        return out
+
+    def stage_times(self):
+        t = StageTimes()
+        self.L.mauve_last_stage_times(self.h, C.byref(t))
+        return {k: getattr(t, k) for k, _ in StageTimes._fields_}
+
+    def profile(self, on=True):
+        self.L.mauve_profile_enable(self.h, int(on))
+
+    def profile_reset(self):
+        self.L.mauve_profile_reset(self.h)
+
+    def profile_get(self):
+        out = {}
+        for i, nm in enumerate(KERNEL_NAMES):
+            ms, ln, un = C.c_double(), C.c_int64(), C.c_int64()
+            self.L.mauve_profile_get(self.h, i, C.byref(ms), C.byref(ln), C.byref(un))
+            out[nm] = {"ms": ms.value, "launches": ln.value, "units": un.value}
+        return out

@@ -1,0 +1,215 @@
+// api.cpp -- context management and the seed-side entry points of the C-ABI (include/mauve_hip.h).
+#include "common.hpp"
+#include <algorithm>
+#include <cstring>
+
+static thread_local std::string g_create_err;
+
+extern "C" {
+
+int mauve_ctx_create(int device, mauve_ctx **out)
+{
+    if (!out) return MAUVE_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0") +
+                       "); libmauve_hip has no CPU fallback";
+        return MAUVE_ERR_NOGPU;
+    }
+    if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return MAUVE_ERR_ARG; }
+    mauve_ctx *c = new (std::nothrow) mauve_ctx();
+    if (!c) { g_create_err = "out of host memory"; return MAUVE_ERR_ARG; }
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        g_create_err = std::string("HIP init failed: ") + hipGetErrorString(e);
+        delete c;
+        return MAUVE_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        snprintf(c->devname, sizeof c->devname, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    }
+    *out = c;
+    return MAUVE_OK;
+}
+
+void mauve_ctx_destroy(mauve_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->genomes, &c->keysA, &c->keysB, &c->valsA, &c->valsB, &c->hist, &c->totals, &c->posmask,
+                      &c->hit_mask, &c->hit_pos, &c->cand, &c->mlen, &c->mstart, &c->counters, &c->dp_codes, &c->dp_off,
+                      &c->dp_prof_cnt, &c->dp_prof_mask, &c->dp_prof2_cnt, &c->dp_prof2_mask, &c->dp_tb, &c->dp_meta,
+                      &c->dp_score, &c->dp_cols, &c->dp_rows};
+    for (DevBuf *b : bufs) b->release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *mauve_last_error(const mauve_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int mauve_device_name(const mauve_ctx *c, char *buf, size_t buflen)
+{
+    if (!c || !buf || !buflen) return MAUVE_ERR_ARG;
+    snprintf(buf, buflen, "%s", c->devname);
+    return MAUVE_OK;
+}
+
+int mauve_synchronize(mauve_ctx *c)
+{
+    if (!c) return MAUVE_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MAUVE_OK;
+}
+
+int mauve_set_genomes(mauve_ctx *c, int nseq, const uint64_t *const *packed, const int64_t *lens)
+{
+    if (!c) return MAUVE_ERR_ARG;
+    if (nseq < 1 || nseq > MAUVE_MAX_SEQ || !packed || !lens) { c->err = "set_genomes: 1..32 sequences required"; return MAUVE_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t total_words = 0;
+    std::vector<uint64_t> off(nseq);
+    int64_t total_len = 0;
+    for (int g = 0; g < nseq; g++) {
+        if (lens[g] < 0 || (lens[g] > 0 && !packed[g])) { c->err = "set_genomes: bad length or null pointer"; return MAUVE_ERR_ARG; }
+        off[g] = total_words;
+        total_words += mauve_packed_words(lens[g]);
+        total_len += lens[g];
+    }
+    if (total_len >= (1LL << 31)) { c->err = "set_genomes: total length must stay below 2^31 bases"; return MAUVE_ERR_LIMIT; }
+    HIPCHK(c, c->genomes.ensure((total_words + 4) * sizeof(uint64_t)));
+    c->host_packed.assign(nseq, {});
+    for (int g = 0; g < nseq; g++) {
+        size_t nw = mauve_packed_words(lens[g]);
+        c->host_packed[g].assign(nw, 0);
+        size_t data = (size_t)((lens[g] + 31) / 32);
+        if (data) memcpy(c->host_packed[g].data(), packed[g], data * sizeof(uint64_t));
+        // clear any bits past the last base so window reads beyond the end are deterministic
+        if (lens[g] & 31) c->host_packed[g][data - 1] &= (1ULL << (2 * (lens[g] & 31))) - 1ULL;
+        HIPCHK(c, hipMemcpyAsync(c->genomes.as<uint64_t>() + off[g], c->host_packed[g].data(), nw * sizeof(uint64_t),
+                                 hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->nseq = nseq;
+    c->lens.assign(lens, lens + nseq);
+    c->word_off = off;
+    c->n_matches = 0; c->match_len.clear(); c->match_start.clear();
+    return MAUVE_OK;
+}
+
+int mauve_seed_mums(mauve_ctx *c, uint64_t pattern, int mode, uint64_t mask, int extend, int64_t *n_matches)
+{
+    if (!c) return MAUVE_ERR_ARG;
+    if (mode != MAUVE_MODE_MEM && mode != MAUVE_MODE_UNIQUE) { c->err = "seed_mums: unknown mode"; return MAUVE_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    return seedpass_run(c, pattern, mode, mask, extend, -1, n_matches);
+}
+
+int mauve_get_matches(mauve_ctx *c, int64_t *length, int64_t *start)
+{
+    if (!c) return MAUVE_ERR_ARG;
+    if (c->n_matches && (!length || !start)) { c->err = "get_matches: null output"; return MAUVE_ERR_ARG; }
+    if (c->n_matches) {
+        memcpy(length, c->match_len.data(), c->match_len.size() * sizeof(int64_t));
+        memcpy(start, c->match_start.data(), c->match_start.size() * sizeof(int64_t));
+    }
+    return MAUVE_OK;
+}
+
+int mauve_sorted_mer_list(mauve_ctx *c, int seq, uint64_t pattern, uint64_t *mer_out, int64_t *pos_out, int64_t *n_out)
+{
+    if (!c || !n_out) return MAUVE_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> keys; std::vector<uint32_t> vals; int w = 0;
+    int rc = seedpass_sorted_list(c, seq, pattern, &keys, &vals, &w);
+    if (rc) return rc;
+    *n_out = (int64_t)keys.size();
+    if (mer_out && pos_out)
+        for (size_t i = 0; i < keys.size(); i++) {
+            mer_out[i] = (keys[i] << (64 - 2 * w)) | (vals[i] >> 31);
+            pos_out[i] = vals[i] & 0x7fffffffu;
+        }
+    return MAUVE_OK;
+}
+
+// SeedMatchEnumerator::FindMatches / HashMatch / SetDirection (SeedMatchEnumerator.h:19-33,71-141).
+// The sorted mer list comes from the device; the run walk over it is host work (every run becomes
+// one variable-multiplicity record, there is no extension to do).
+int mauve_seed_match_enumerate(mauve_ctx *c, int seq, uint64_t pattern, int64_t min_multi, int64_t max_multi,
+                               int direct_only, int64_t *n_out, int64_t *n_starts, int64_t *mult, int64_t *start_off,
+                               int64_t *starts)
+{
+    if (!c || !n_out || !n_starts) return MAUVE_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> keys; std::vector<uint32_t> vals; int w = 0;
+    int rc = seedpass_sorted_list(c, seq, pattern, &keys, &vals, &w);
+    if (rc) return rc;
+    int64_t n = 0, ns = 0;
+    const size_t np = keys.size();
+    for (size_t s = 0; s < np;) {
+        size_t e = s + 1;
+        while (e < np && keys[e] == keys[s]) e++;
+        int64_t m = (int64_t)(e - s);
+        if (m >= 2 && m >= min_multi && m <= max_multi) {
+            uint32_t ref = vals[s] >> 31; bool found_rev = false; int64_t kept = 0;
+            for (size_t i = s; i < e; i++) { if ((vals[i] >> 31) != ref) found_rev = true; else kept++; }
+            int64_t emit = m;
+            if (direct_only && found_rev) emit = kept > 1 ? kept : 0;
+            if (emit) {
+                if (starts) {
+                    start_off[n] = ns; mult[n] = emit;
+                    int64_t k = ns;
+                    for (size_t i = s; i < e; i++) {
+                        bool rv = (vals[i] >> 31) != ref;
+                        int64_t p1 = (int64_t)(vals[i] & 0x7fffffffu) + 1;
+                        if (direct_only && found_rev) { if (!rv) starts[k++] = p1; }
+                        else starts[k++] = rv ? -p1 : p1;
+                    }
+                }
+                n++; ns += emit;
+            }
+        }
+        s = e;
+    }
+    if (starts) start_off[n] = ns;
+    *n_out = n; *n_starts = ns;
+    return MAUVE_OK;
+}
+
+int mauve_profile_enable(mauve_ctx *c, int on)
+{
+    if (!c) return MAUVE_ERR_ARG;
+    c->prof = on != 0;
+    return MAUVE_OK;
+}
+
+int mauve_profile_reset(mauve_ctx *c)
+{
+    if (!c) return MAUVE_ERR_ARG;
+    for (int i = 0; i < MAUVE_K_COUNT; i++) { c->k_ms[i] = 0; c->k_launch[i] = 0; c->k_units[i] = 0; }
+    return MAUVE_OK;
+}
+
+int mauve_profile_get(mauve_ctx *c, int kernel, double *total_ms, int64_t *launches, int64_t *units)
+{
+    if (!c || kernel < 0 || kernel >= MAUVE_K_COUNT) return MAUVE_ERR_ARG;
+    if (total_ms) *total_ms = c->k_ms[kernel];
+    if (launches) *launches = c->k_launch[kernel];
+    if (units) *units = c->k_units[kernel];
+    return MAUVE_OK;
+}
+
+int mauve_last_stage_times(mauve_ctx *c, mauve_stage_times *t)
+{
+    if (!c || !t) return MAUVE_ERR_ARG;
+    *t = c->stage;
+    return MAUVE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+// common.hpp -- internal declarations shared by the translation units of libmauve_hip.so.
+// Product code: must never include anything from oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include <chrono>
+
+#include "../../include/mauve_hip.h"
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__) + " (" __FILE__ ":" + \
+                         std::to_string(__LINE__) + ")";                                          \
+            return MAUVE_ERR_HIP;                                                                 \
+        }                                                                                         \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Seed pattern decomposed into runs of contiguous care positions (kernel argument, by value).
+// K' ("digit-reversed forward mer"): care offset t_j contributes code << 2j, so that
+//   reverse-complement mer = ~K' (masked) and forward mer = digit_reverse(K').
+struct SeedShape {
+    int span, weight, nruns;
+    uint64_t keymask;          // (1 << 2*weight) - 1
+    uint8_t run_src[32];       // bit offset of the run in the window (2 * first care offset)
+    uint8_t run_bits[32];      // 2 * run length
+    uint8_t run_dst[32];       // bit offset in K'
+};
+
+// The genomes as the kernels see them: one packed buffer, windows numbered globally.
+struct GenomeTab {
+    int nseq;
+    uint32_t gpos_off[MAUVE_MAX_SEQ + 1];   // first global window index of genome g
+    uint32_t nwin[MAUVE_MAX_SEQ];           // valid window starts of genome g
+    uint64_t word_off[MAUVE_MAX_SEQ];       // first 64-bit word of genome g in the packed buffer
+};
+
+struct AlignResult {
+    mauve_align_sizes sz{};
+    std::vector<int64_t> mum_length, mum_start;
+    std::vector<int64_t> lcb_left, lcb_right, lcb_weight;
+    std::vector<int64_t> anchor_length, anchor_start, anchor_lcb;
+    std::vector<int64_t> iv_left, iv_right;
+    std::vector<int8_t> iv_reverse;
+    std::vector<int64_t> col_off;
+    std::vector<uint32_t> cols;
+    std::vector<int64_t> dp_score;
+};
+
+struct mauve_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    char devname[256] = {0};
+
+    // genomes
+    int nseq = 0;
+    std::vector<int64_t> lens;
+    std::vector<uint64_t> word_off;      // per genome, in 64-bit words
+    std::vector<std::vector<uint64_t>> host_packed;   // host copy (XMFA text, interval extraction)
+    DevBuf genomes;
+
+    // seed-pass workspace
+    DevBuf keysA, keysB, valsA, valsB, hist, totals, posmask, hit_mask, hit_pos, cand, mlen, mstart, counters;
+    // last match list (canonical order, host) + nseq it refers to
+    std::vector<int64_t> match_len, match_start;
+    int64_t n_matches = 0;
+
+    // DP workspace
+    DevBuf dp_codes, dp_off, dp_prof_cnt, dp_prof_mask, dp_prof2_cnt, dp_prof2_mask, dp_tb, dp_meta, dp_score,
+        dp_cols, dp_rows;
+
+    // profiling
+    bool prof = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double k_ms[MAUVE_K_COUNT] = {0};
+    int64_t k_launch[MAUVE_K_COUNT] = {0};
+    int64_t k_units[MAUVE_K_COUNT] = {0};
+
+    AlignResult res;
+    mauve_stage_times stage{};
+};
+
+// RAII-less helper: time one kernel launch on ctx->stream when profiling is on.
+struct KernelTimer {
+    mauve_ctx *c; int id; int64_t units;
+    KernelTimer(mauve_ctx *ctx, int kid, int64_t u) : c(ctx), id(kid), units(u)
+    {
+        if (c->prof) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    ~KernelTimer()
+    {
+        if (!c->prof) return;
+        (void)hipEventRecord(c->ev1, c->stream);
+        (void)hipEventSynchronize(c->ev1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        c->k_ms[id] += ms; c->k_launch[id] += 1; c->k_units[id] += units;
+    }
+};
+
+static inline double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- internal entry points between translation units ----
+bool make_seed_shape(uint64_t pattern, SeedShape *out);
+int seedpass_build_tab(mauve_ctx *ctx, int span, GenomeTab *tab, int64_t *total_windows);
+int seedpass_run(mauve_ctx *ctx, uint64_t pattern, int mode, uint64_t mask, int extend, int only_seq,
+                 int64_t *n_matches);
+int seedpass_sorted_list(mauve_ctx *ctx, int seq, uint64_t pattern, std::vector<uint64_t> *keys,
+                         std::vector<uint32_t> *vals, int *weight);
+
+// host chaining (chain_host.cpp)
+struct HMatch { int64_t len; int64_t st[MAUVE_MAX_SEQ]; };
+void host_eliminate_overlaps(int N, std::vector<HMatch> &m);
+void host_lcb_chain(int N, const std::vector<HMatch> &m, int64_t min_weight, bool collinear,
+                    std::vector<int64_t> &match_lcb, int64_t &n_lcb);
+
+// DP (dp_batch.hip)
+int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,
+                 const mauve_scoring *sc, uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells);

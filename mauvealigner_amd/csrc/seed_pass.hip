@@ -1,0 +1,640 @@
+// seed_pass.hip -- the seed pass of the hot path on gfx950:
+//   seed_extract  : 2-bit packed genomes -> (canonical masked mer, global position | strand)
+//   rs_*          : LSD radix sort of the pairs (the sorted mer list of all genomes at once)
+//   mum_join      : runs of identical mers -> seed hits by the MatchFinder subclass rule
+//   mum_candidates / mum_extend : ungapped extension of every hit into its maximal match
+//
+// Stands behind mems::MatchFinder::FindMatches [EXT] (call sites mauveAligner.cpp:523-589,
+// progressiveMauve.cpp:490-501), with the in-tree rules of UniqueMatchFinder.cpp:36-60 and
+// SeedMatchEnumerator.h:71-141.  Semantics are frozen in DESIGN.md S3/S4 and checked bit-exactly
+// against oracle/ by tests/ (the oracle is never linked here).
+//
+// All kernels are HBM-bound integer work: coalesced 4/8-byte streams, LDS staging for
+// the scatter, wave64 ballots for ranking and for the extension walk.  No MFMA by design.
+#include "common.hpp"
+#include <algorithm>
+#include <cstring>
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t bits_from128(uint64_t lo, uint64_t hi, int start, int nbits)
+{
+    uint64_t v;
+    if (start >= 64) v = hi >> (start - 64);
+    else v = start ? ((lo >> start) | (hi << (64 - start))) : lo;
+    return nbits >= 64 ? v : (v & ((1ULL << nbits) - 1ULL));
+}
+
+// K' of the window starting at base p of the genome whose packed words start at G
+__device__ __forceinline__ uint64_t kprime_at(const uint64_t *__restrict__ G, uint32_t p, const SeedShape &sh)
+{
+    uint32_t q = p >> 5; int r = (p & 31) * 2;
+    uint64_t w0 = G[q], w1 = G[q + 1], w2 = G[q + 2];
+    uint64_t lo = r ? ((w0 >> r) | (w1 << (64 - r))) : w0;
+    uint64_t hi = r ? ((w1 >> r) | (w2 << (64 - r))) : w1;
+    uint64_t k = 0;
+    for (int i = 0; i < sh.nruns; i++)
+        k |= bits_from128(lo, hi, sh.run_src[i], sh.run_bits[i]) << sh.run_dst[i];
+    return k;
+}
+
+// reverse the order of the 2-bit digits of a 2*weight-bit value
+__device__ __forceinline__ uint64_t digit_reverse(uint64_t k, int weight)
+{
+    uint64_t x = __brevll(k) >> (64 - 2 * weight);
+    return ((x & 0xAAAAAAAAAAAAAAAAULL) >> 1) | ((x & 0x5555555555555555ULL) << 1);
+}
+
+__device__ __forceinline__ int genome_of(uint32_t gpos, const GenomeTab &t)
+{
+    int g = 0;
+    for (int i = 1; i < t.nseq; i++) g += (gpos >= t.gpos_off[i]) ? 1 : 0;
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// seed_extract: one thread per window.  Reads 0.25 B/position (L1-shared), writes key + val.
+// val = global window index | strand << 31.
+// ------------------------------------------------------------------------------------------------
+template <typename KeyT>
+__global__ void __launch_bounds__(256) seed_extract(const uint64_t *__restrict__ packed, GenomeTab tab,
+                                                    SeedShape sh, int g, KeyT *__restrict__ keys,
+                                                    uint32_t *__restrict__ vals, uint32_t out_base)
+{
+    uint32_t n = tab.nwin[g];
+    const uint64_t *G = packed + tab.word_off[g];
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        uint64_t kp = kprime_at(G, p, sh);
+        uint64_t f = digit_reverse(kp, sh.weight);
+        uint64_t r = (~kp) & sh.keymask;
+        uint32_t s = r < f;
+        keys[out_base + p] = (KeyT)(s ? r : f);
+        vals[out_base + p] = (tab.gpos_off[g] + p) | (s << 31);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix sort (LSD, 8-bit digits, stable): histogram / row scan / scatter per pass
+// ------------------------------------------------------------------------------------------------
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;   // 4096 keys per workgroup
+constexpr int RS_WAVES = RS_THREADS / 64;
+
+template <typename KeyT>
+__global__ void __launch_bounds__(RS_THREADS) rs_hist(const KeyT *__restrict__ keys, uint32_t n, int shift,
+                                                      uint32_t *__restrict__ hist, uint32_t nblk)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        uint32_t idx = base + i * RS_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+// block d: exclusive scan of row d (length nblk) in place, row total -> totals[d]
+__global__ void __launch_bounds__(256) rs_rowscan(uint32_t *__restrict__ hist, uint32_t nblk,
+                                                  uint32_t *__restrict__ totals)
+{
+    __shared__ uint32_t part[256];
+    uint32_t *row = hist + (size_t)blockIdx.x * nblk;
+    uint32_t chunk = (nblk + 255) / 256;
+    uint32_t lo = threadIdx.x * chunk, hi = min(lo + chunk, nblk);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += row[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 256 partials
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = threadIdx.x >= (uint32_t)off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t i = lo; i < hi; i++) { uint32_t v = row[i]; row[i] = run; run += v; }
+    if (threadIdx.x == 255) totals[blockIdx.x] = part[255];
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict__ keys_in,
+                                                         const uint32_t *__restrict__ vals_in,
+                                                         KeyT *__restrict__ keys_out,
+                                                         uint32_t *__restrict__ vals_out, uint32_t n, int shift,
+                                                         const uint32_t *__restrict__ hist,
+                                                         const uint32_t *__restrict__ totals, uint32_t nblk)
+{
+    __shared__ KeyT s_keys[RS_TILE];
+    __shared__ uint32_t s_vals[RS_TILE];
+    __shared__ uint32_t wcount[RS_WAVES][256];
+    __shared__ uint32_t gbase[256];       // global output index of this tile's first key of digit d
+    __shared__ uint32_t tstart[256];      // tile-local start of digit d
+    __shared__ uint32_t scan[256];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile_base = blockIdx.x * RS_TILE;
+    const uint32_t tile_n = min((uint32_t)RS_TILE, n - tile_base);
+
+    for (int w = 0; w < RS_WAVES; w++) wcount[w][tid] = 0;
+    // digit base = exclusive scan of the digit totals
+    uint32_t tot = totals[tid];
+    scan[tid] = tot;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = tid >= off ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    gbase[tid] = scan[tid] - tot + hist[(size_t)tid * nblk + blockIdx.x];
+    __syncthreads();
+
+    // load (wave-striped: wave w owns [w*1024, (w+1)*1024), item i of lane l is index i*64+l)
+    KeyT k[RS_ITEMS]; uint32_t v[RS_ITEMS]; uint32_t rank[RS_ITEMS];
+    const uint32_t wbase = wave * (64 * RS_ITEMS);
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        uint32_t li = wbase + i * 64 + lane;
+        bool ok = li < tile_n;
+        k[i] = ok ? keys_in[tile_base + li] : (KeyT)0;
+        v[i] = ok ? vals_in[tile_base + li] : 0u;
+    }
+    // wave-level multisplit ranking, stable in (i, lane) order
+    const uint64_t lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        uint32_t li = wbase + i * 64 + lane;
+        bool ok = li < tile_n;
+        uint32_t d = (uint32_t)(k[i] >> shift) & 255u;
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            uint64_t m = __ballot(ok && ((d >> b) & 1));
+            peers &= ((d >> b) & 1) ? m : ~m;
+        }
+        // one atomic per distinct digit (its lowest lane), the old count broadcast to its peers
+        int leader = ok ? (__ffsll((unsigned long long)peers) - 1) : lane;
+        uint32_t old = 0;
+        if (ok && lane == leader) old = atomicAdd(&wcount[wave][d], (uint32_t)__popcll(peers));
+        old = __shfl(old, leader);
+        rank[i] = old + (uint32_t)__popcll(peers & lt);
+    }
+    __syncthreads();
+    // per-digit prefix over the waves, then the tile-level digit starts
+    uint32_t c[RS_WAVES], sum = 0;
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; w++) { c[w] = wcount[w][tid]; }
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; w++) { uint32_t t = c[w]; wcount[w][tid] = sum; sum += t; }
+    scan[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t t = tid >= off ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += t;
+        __syncthreads();
+    }
+    tstart[tid] = scan[tid] - sum;
+    __syncthreads();
+    // stage in LDS at the tile-sorted position
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        uint32_t li = wbase + i * 64 + lane;
+        if (li < tile_n) {
+            uint32_t d = (uint32_t)(k[i] >> shift) & 255u;
+            uint32_t pos = tstart[d] + wcount[wave][d] + rank[i];
+            s_keys[pos] = k[i]; s_vals[pos] = v[i];
+        }
+    }
+    __syncthreads();
+    // coalesced write-out: consecutive threads write consecutive addresses inside a digit's run
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        uint32_t pos = i * RS_THREADS + tid;
+        if (pos < tile_n) {
+            KeyT kk = s_keys[pos];
+            uint32_t d = (uint32_t)(kk >> shift) & 255u;
+            uint32_t dst = gbase[d] + (pos - tstart[d]);
+            keys_out[dst] = kk; vals_out[dst] = s_vals[pos];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mum_join: one thread per sorted entry; the thread at the first entry of a run of identical mers
+// decides the hit by the finder's rule and writes the hit record + the per-position component mask.
+//   MODE_MEM    : MemHash -- a genome with more than one copy kills the seed
+//   MODE_UNIQUE : UniqueMatchFinder.cpp:44-58 -- genomes with more than one copy are dropped, >= 2 stay
+// hit_pos[h*nseq+g] = global window index | strand << 31, 0xFFFFFFFF = absent.
+// ------------------------------------------------------------------------------------------------
+template <typename KeyT>
+__global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                uint32_t n, GenomeTab tab, int mode, uint32_t want_mask,
+                                                uint32_t *__restrict__ posmask, uint32_t *__restrict__ hit_mask,
+                                                uint32_t *__restrict__ hit_pos, uint32_t *__restrict__ counters)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    KeyT k = keys[i];
+    if (i > 0 && keys[i - 1] == k) return;
+    if (i + 1 >= n || keys[i + 1] != k) return;        // singleton run
+    uint32_t once = 0, multi = 0, j = i;
+    while (j < n && keys[j] == k) {
+        uint32_t bit = 1u << genome_of(vals[j] & 0x7fffffffu, tab);
+        multi |= once & bit; once |= bit; j++;
+    }
+    uint32_t m = once & ~multi;
+    if (mode == MAUVE_MODE_MEM && multi) return;
+    if (__popc(m) < 2) return;
+    if (want_mask && m != want_mask) return;
+    uint32_t h = atomicAdd(&counters[0], 1u);
+    hit_mask[h] = m;
+    uint32_t *hp = hit_pos + (size_t)h * tab.nseq;
+    for (int g = 0; g < tab.nseq; g++) hp[g] = 0xFFFFFFFFu;
+    for (uint32_t t = i; t < j; t++) {
+        uint32_t v = vals[t], gp = v & 0x7fffffffu;
+        int g = genome_of(gp, tab);
+        if (m >> g & 1) { hp[g] = v; posmask[gp] = m; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// extension.  A hit fixes a generalized diagonal: component c moves +k (same strand
+// as the anchor) or -k (opposite strand) when the anchor moves +k.  Offset k "agrees" when the masked
+// windows of all components are equal there.  Agreeing offsets at most `span` apart chain into a
+// cluster; the match is the cluster through the hit, emitted by its leftmost same-mask hit.
+// ------------------------------------------------------------------------------------------------
+struct HitView {
+    uint32_t mask; int anchor;
+    uint32_t apos;       // anchor local window index
+    uint32_t agpos;      // anchor global window index
+};
+
+__device__ __forceinline__ bool agree_at(const uint64_t *__restrict__ packed, const GenomeTab &tab,
+                                         const SeedShape &sh, const uint32_t *__restrict__ hp, uint32_t mask,
+                                         int anchor, int64_t k)
+{
+    uint32_t va = hp[anchor];
+    int64_t qa = (int64_t)((va & 0x7fffffffu) - tab.gpos_off[anchor]) + k;
+    if (qa < 0 || qa >= (int64_t)tab.nwin[anchor]) return false;
+    uint64_t ka = kprime_at(packed + tab.word_off[anchor], (uint32_t)qa, sh);
+    uint64_t ka_rev = digit_reverse(ka, sh.weight);
+    uint32_t sa = va >> 31;
+    bool ok = true;
+    for (int g = anchor + 1; g < tab.nseq; g++) {
+        if (!(mask >> g & 1)) continue;
+        uint32_t vg = hp[g];
+        uint32_t o = (vg >> 31) ^ sa;
+        int64_t pg = (int64_t)((vg & 0x7fffffffu) - tab.gpos_off[g]);
+        int64_t qg = o ? pg - k : pg + k;
+        if (qg < 0 || qg >= (int64_t)tab.nwin[g]) { ok = false; break; }
+        uint64_t kg = kprime_at(packed + tab.word_off[g], (uint32_t)qg, sh);
+        if (o ? (((~kg) & sh.keymask) != ka_rev) : (kg != ka)) { ok = false; break; }
+    }
+    return ok;
+}
+
+// phase A: thread per hit.  A hit whose nearest agreeing offset to the left (within span) is a
+// same-mask hit is certainly not the leftmost hit of its cluster; everything else is a candidate.
+__global__ void __launch_bounds__(256) mum_candidates(const uint64_t *__restrict__ packed, GenomeTab tab,
+                                                      SeedShape sh, const uint32_t *__restrict__ hit_mask,
+                                                      const uint32_t *__restrict__ hit_pos,
+                                                      const uint32_t *__restrict__ posmask, uint32_t nhit,
+                                                      uint32_t *__restrict__ cand, uint32_t *__restrict__ counters)
+{
+    uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= nhit) return;
+    uint32_t mask = hit_mask[h];
+    const uint32_t *hp = hit_pos + (size_t)h * tab.nseq;
+    int anchor = __ffs(mask) - 1;
+    uint32_t agpos = hp[anchor] & 0x7fffffffu;
+    bool is_cand = true;
+    for (int d = 1; d <= sh.span; d++) {
+        if (agree_at(packed, tab, sh, hp, mask, anchor, -(int64_t)d)) {
+            if (posmask[agpos - d] == mask) is_cand = false;
+            break;
+        }
+    }
+    if (is_cand) cand[atomicAdd(&counters[1], 1u)] = h;
+}
+
+// phase B: one wave per candidate; the 64 lanes test 64 consecutive offsets at a time and the
+// resulting agreement bitmap is walked with scalar bit operations.
+__global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ packed, GenomeTab tab, SeedShape sh,
+                                                  const uint32_t *__restrict__ hit_mask,
+                                                  const uint32_t *__restrict__ hit_pos,
+                                                  const uint32_t *__restrict__ posmask,
+                                                  const uint32_t *__restrict__ cand, uint32_t ncand, int extend,
+                                                  int32_t *__restrict__ mlen, int32_t *__restrict__ mstart,
+                                                  uint32_t *__restrict__ counters)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint64_t spanmask = (sh.span >= 64) ? ~0ULL : ((1ULL << sh.span) - 1ULL);
+    for (uint32_t ci = wave_global; ci < ncand; ci += nwaves) {
+        uint32_t h = cand[ci];
+        uint32_t mask = hit_mask[h];
+        const uint32_t *hp = hit_pos + (size_t)h * tab.nseq;
+        int anchor = __ffs(mask) - 1;
+        uint32_t agpos = hp[anchor] & 0x7fffffffu;
+        int64_t klo = 0, khi = 0;
+        bool leftmost = true;
+        if (extend) {
+            // ---- left walk: offsets cur-1 .. cur-64 per round ----
+            int64_t cur = 0;
+            for (bool done = false; !done;) {
+                int64_t k = cur - 1 - lane;
+                bool a = agree_at(packed, tab, sh, hp, mask, anchor, k);
+                bool hh = a && (posmask[(int64_t)agpos + k] == mask);
+                uint64_t A = __ballot(a), H = __ballot(hh);
+                int p = 0;                      // offsets consumed in this round
+                for (;;) {
+                    if (p + sh.span > 64) break;                       // need a fresh round from cur-p
+                    uint64_t x = (A >> p) & spanmask;
+                    if (x == 0) { done = true; break; }
+                    int d = __ffsll((unsigned long long)x) - 1;
+                    p += d + 1;
+                    if (H >> (p - 1) & 1) { leftmost = false; done = true; break; }
+                }
+                cur -= p;
+            }
+            if (!leftmost) continue;
+            klo = cur;
+            // ---- right walk ----
+            cur = 0;
+            for (bool done = false; !done;) {
+                int64_t k = cur + 1 + lane;
+                bool a = agree_at(packed, tab, sh, hp, mask, anchor, k);
+                uint64_t A = __ballot(a);
+                int p = 0;
+                for (;;) {
+                    if (p + sh.span > 64) break;
+                    uint64_t x = (A >> p) & spanmask;
+                    if (x == 0) { done = true; break; }
+                    p += __ffsll((unsigned long long)x);
+                }
+                cur += p;
+            }
+            khi = cur;
+        }
+        if (lane == 0) {
+            uint32_t m = atomicAdd(&counters[2], 1u);
+            mlen[m] = (int32_t)(khi - klo) + sh.span;
+            uint32_t sa = hp[anchor] >> 31;
+            for (int g = 0; g < tab.nseq; g++) {
+                int32_t s = 0;
+                if (mask >> g & 1) {
+                    uint32_t vg = hp[g];
+                    int64_t pg = (int64_t)((vg & 0x7fffffffu) - tab.gpos_off[g]);
+                    s = ((vg >> 31) ^ sa) ? (int32_t)(-(pg - khi + 1)) : (int32_t)(pg + klo + 1);
+                }
+                mstart[(size_t)m * tab.nseq + g] = s;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+bool make_seed_shape(uint64_t pattern, SeedShape *sh)
+{
+    memset(sh, 0, sizeof *sh);
+    int span = mauve_seed_length(pattern), w = mauve_seed_weight(pattern);
+    if (span < 1 || span > MAUVE_MAX_SEED_SPAN || w < 1 || w > 31) return false;
+    // palindromic, first and last set
+    for (int t = 0; t < span; t++)
+        if (((pattern >> t) & 1) != ((pattern >> (span - 1 - t)) & 1)) return false;
+    if (!(pattern & 1)) return false;
+    sh->span = span; sh->weight = w; sh->keymask = (w == 32) ? ~0ULL : ((1ULL << (2 * w)) - 1ULL);
+    int j = 0, nr = 0;
+    for (int t = 0; t < span;) {
+        if (!((pattern >> (span - 1 - t)) & 1)) { t++; continue; }
+        int t0 = t;
+        while (t < span && ((pattern >> (span - 1 - t)) & 1)) t++;
+        int len = t - t0;
+        if (nr >= 32) return false;
+        sh->run_src[nr] = (uint8_t)(2 * t0); sh->run_bits[nr] = (uint8_t)(2 * len); sh->run_dst[nr] = (uint8_t)(2 * j);
+        nr++; j += len;
+    }
+    sh->nruns = nr;
+    return true;
+}
+
+int seedpass_build_tab(mauve_ctx *ctx, int span, GenomeTab *tab, int64_t *total_windows)
+{
+    memset(tab, 0, sizeof *tab);
+    tab->nseq = ctx->nseq;
+    int64_t tot = 0;
+    for (int g = 0; g < ctx->nseq; g++) {
+        int64_t nw = ctx->lens[g] - span + 1; if (nw < 0) nw = 0;
+        tab->gpos_off[g] = (uint32_t)tot; tab->nwin[g] = (uint32_t)nw; tab->word_off[g] = ctx->word_off[g];
+        tot += nw;
+        if (tot >= (1LL << 31)) { ctx->err = "total genome length exceeds 2^31 windows"; return MAUVE_ERR_LIMIT; }
+    }
+    tab->gpos_off[ctx->nseq] = (uint32_t)tot;
+    *total_windows = tot;
+    return MAUVE_OK;
+}
+
+template <typename KeyT>
+static int sort_pairs(mauve_ctx *ctx, uint32_t n, int key_bits, KeyT **keys_io, uint32_t **vals_io, KeyT *keys_alt,
+                      uint32_t *vals_alt)
+{
+    uint32_t nblk = (n + RS_TILE - 1) / RS_TILE;
+    HIPCHK(ctx, ctx->hist.ensure((size_t)nblk * 256 * sizeof(uint32_t)));
+    HIPCHK(ctx, ctx->totals.ensure(256 * sizeof(uint32_t)));
+    KeyT *kin = *keys_io, *kout = keys_alt; uint32_t *vin = *vals_io, *vout = vals_alt;
+    for (int shift = 0; shift < key_bits; shift += 8) {
+        { KernelTimer t(ctx, MAUVE_K_SORT_HIST, n);
+          hipLaunchKernelGGL(rs_hist<KeyT>, dim3(nblk), dim3(RS_THREADS), 0, ctx->stream, kin, n, shift,
+                             ctx->hist.as<uint32_t>(), nblk); }
+        { KernelTimer t(ctx, MAUVE_K_SORT_SCAN, n);
+          hipLaunchKernelGGL(rs_rowscan, dim3(256), dim3(256), 0, ctx->stream, ctx->hist.as<uint32_t>(), nblk,
+                             ctx->totals.as<uint32_t>()); }
+        { KernelTimer t(ctx, MAUVE_K_SORT_SCATTER, n);
+          hipLaunchKernelGGL(rs_scatter<KeyT>, dim3(nblk), dim3(RS_THREADS), 0, ctx->stream, kin, vin, kout, vout, n,
+                             shift, ctx->hist.as<uint32_t>(), ctx->totals.as<uint32_t>(), nblk); }
+        std::swap(kin, kout); std::swap(vin, vout);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    *keys_io = kin; *vals_io = vin;
+    return MAUVE_OK;
+}
+
+template <typename KeyT>
+static int seedpass_impl(mauve_ctx *ctx, const SeedShape &sh, const GenomeTab &tab, int64_t total, int mode,
+                         uint64_t mask, int extend, int only_seq, int64_t *n_matches, std::vector<uint64_t> *out_keys,
+                         std::vector<uint32_t> *out_vals)
+{
+    const uint32_t n = (uint32_t)total;
+    HIPCHK(ctx, ctx->keysA.ensure((size_t)n * sizeof(KeyT)));
+    HIPCHK(ctx, ctx->keysB.ensure((size_t)n * sizeof(KeyT)));
+    HIPCHK(ctx, ctx->valsA.ensure((size_t)n * 4));
+    HIPCHK(ctx, ctx->valsB.ensure((size_t)n * 4));
+    HIPCHK(ctx, ctx->counters.ensure(64));
+    KeyT *keys = ctx->keysA.as<KeyT>(); uint32_t *vals = ctx->valsA.as<uint32_t>();
+    const uint64_t *packed = ctx->genomes.as<uint64_t>();
+
+    uint32_t sorted_n = 0;
+    for (int g = 0; g < tab.nseq; g++) {
+        if (only_seq >= 0 && g != only_seq) continue;
+        uint32_t nw = tab.nwin[g];
+        if (!nw) continue;
+        uint32_t base = only_seq >= 0 ? 0u : tab.gpos_off[g];
+        uint32_t blocks = std::min<uint32_t>((nw + 255) / 256, 256 * 16);
+        KernelTimer t(ctx, MAUVE_K_EXTRACT, nw);
+        hipLaunchKernelGGL(seed_extract<KeyT>, dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh, g, keys, vals,
+                           base);
+        sorted_n += nw;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (sorted_n == 0) { if (n_matches) *n_matches = 0; return MAUVE_OK; }
+    int rc = sort_pairs<KeyT>(ctx, sorted_n, 2 * sh.weight, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>());
+    if (rc) return rc;
+
+    if (out_keys) {   // sorted-mer-list export / SeedMatchEnumerator path: hand the sorted pairs to the host
+        std::vector<KeyT> hk(sorted_n);
+        out_vals->resize(sorted_n);
+        HIPCHK(ctx, hipMemcpyAsync(hk.data(), keys, (size_t)sorted_n * sizeof(KeyT), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out_vals->data(), vals, (size_t)sorted_n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        out_keys->resize(sorted_n);
+        for (uint32_t i = 0; i < sorted_n; i++) (*out_keys)[i] = (uint64_t)hk[i];
+        return MAUVE_OK;
+    }
+
+    // ---- join ----
+    const int N = tab.nseq;
+    const size_t hit_cap = (size_t)n / 2 + 1;
+    HIPCHK(ctx, ctx->posmask.ensure((size_t)n * 4));
+    HIPCHK(ctx, ctx->hit_mask.ensure(hit_cap * 4));
+    HIPCHK(ctx, ctx->hit_pos.ensure(hit_cap * 4 * N));
+    HIPCHK(ctx, hipMemsetAsync(ctx->posmask.p, 0, (size_t)n * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+    { KernelTimer t(ctx, MAUVE_K_JOIN, n);
+      hipLaunchKernelGGL(mum_join<KeyT>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, n, tab, mode,
+                         (uint32_t)mask, ctx->posmask.as<uint32_t>(), ctx->hit_mask.as<uint32_t>(),
+                         ctx->hit_pos.as<uint32_t>(), ctx->counters.as<uint32_t>()); }
+    HIPCHK(ctx, hipGetLastError());
+    uint32_t hc[4] = {0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t nhit = hc[0];
+    ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear();
+    if (n_matches) *n_matches = 0;
+    if (nhit == 0) return MAUVE_OK;
+
+    // ---- extension ----
+    HIPCHK(ctx, ctx->cand.ensure((size_t)nhit * 4));
+    uint32_t ncand = nhit;
+    if (extend) {
+        KernelTimer t(ctx, MAUVE_K_EXTEND, nhit);
+        hipLaunchKernelGGL(mum_candidates, dim3((nhit + 255) / 256), dim3(256), 0, ctx->stream, packed, tab, sh,
+                           ctx->hit_mask.as<uint32_t>(), ctx->hit_pos.as<uint32_t>(), ctx->posmask.as<uint32_t>(), nhit,
+                           ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>());
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ncand = hc[1];
+    } else {
+        // every hit is its own match: candidate list = identity
+        std::vector<uint32_t> ident(nhit);
+        for (uint32_t i = 0; i < nhit; i++) ident[i] = i;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->cand.p, ident.data(), (size_t)nhit * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    HIPCHK(ctx, ctx->mlen.ensure((size_t)ncand * 4 + 4));
+    HIPCHK(ctx, ctx->mstart.ensure((size_t)ncand * 4 * N + 4));
+    if (ncand) {
+        uint32_t waves = ncand;
+        uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, 256 * 8);
+        KernelTimer t(ctx, MAUVE_K_EXTEND, ncand);
+        hipLaunchKernelGGL(mum_extend, dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh,
+                           ctx->hit_mask.as<uint32_t>(), ctx->hit_pos.as<uint32_t>(), ctx->posmask.as<uint32_t>(),
+                           ctx->cand.as<uint32_t>(), ncand, extend, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(),
+                           ctx->counters.as<uint32_t>());
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t nm = hc[2];
+    // ---- copy out + canonical order (first component, |start|, mask, starts, length) ----
+    std::vector<int32_t> hl(nm), hs((size_t)nm * N);
+    if (nm) {
+        HIPCHK(ctx, hipMemcpyAsync(hl.data(), ctx->mlen.p, (size_t)nm * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hs.data(), ctx->mstart.p, (size_t)nm * 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<uint32_t> order(nm);
+    std::vector<uint64_t> k1(nm);      // (first component, |start|) packed for a fast first-level compare
+    for (uint32_t i = 0; i < nm; i++) {
+        order[i] = i;
+        const int32_t *s = &hs[(size_t)i * N];
+        int f = 0; while (f < N && s[f] == 0) f++;
+        uint64_t a = f < N ? (uint64_t)std::abs((int64_t)s[f]) : 0;
+        k1[i] = ((uint64_t)f << 40) | a;
+    }
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        if (k1[x] != k1[y]) return k1[x] < k1[y];
+        const int32_t *a = &hs[(size_t)x * N], *b = &hs[(size_t)y * N];
+        uint32_t ma = 0, mb = 0;
+        for (int g = 0; g < N; g++) { if (a[g]) ma |= 1u << g; if (b[g]) mb |= 1u << g; }
+        if (ma != mb) return ma < mb;
+        for (int g = 0; g < N; g++) if (a[g] != b[g]) return a[g] < b[g];
+        return hl[x] < hl[y];
+    });
+    ctx->match_len.resize(nm); ctx->match_start.resize((size_t)nm * N);
+    for (uint32_t i = 0; i < nm; i++) {
+        uint32_t o = order[i];
+        ctx->match_len[i] = hl[o];
+        for (int g = 0; g < N; g++) ctx->match_start[(size_t)i * N + g] = hs[(size_t)o * N + g];
+    }
+    ctx->n_matches = nm;
+    if (n_matches) *n_matches = nm;
+    return MAUVE_OK;
+}
+
+int seedpass_run(mauve_ctx *ctx, uint64_t pattern, int mode, uint64_t mask, int extend, int only_seq,
+                 int64_t *n_matches)
+{
+    SeedShape sh;
+    if (!make_seed_shape(pattern, &sh)) { ctx->err = "seed pattern must be palindromic, span <= 49, weight <= 31"; return MAUVE_ERR_ARG; }
+    if (ctx->nseq < 1) { ctx->err = "no genomes set"; return MAUVE_ERR_STATE; }
+    GenomeTab tab; int64_t total = 0;
+    int rc = seedpass_build_tab(ctx, sh.span, &tab, &total);
+    if (rc) return rc;
+    ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear();
+    if (n_matches) *n_matches = 0;
+    if (total == 0) return MAUVE_OK;
+    if (2 * sh.weight <= 32) return seedpass_impl<uint32_t>(ctx, sh, tab, total, mode, mask, extend, only_seq, n_matches, nullptr, nullptr);
+    return seedpass_impl<uint64_t>(ctx, sh, tab, total, mode, mask, extend, only_seq, n_matches, nullptr, nullptr);
+}
+
+int seedpass_sorted_list(mauve_ctx *ctx, int seq, uint64_t pattern, std::vector<uint64_t> *keys,
+                         std::vector<uint32_t> *vals, int *weight)
+{
+    SeedShape sh;
+    if (!make_seed_shape(pattern, &sh)) { ctx->err = "seed pattern must be palindromic, span <= 49, weight <= 31"; return MAUVE_ERR_ARG; }
+    if (seq < 0 || seq >= ctx->nseq) { ctx->err = "sequence index out of range"; return MAUVE_ERR_ARG; }
+    GenomeTab tab; int64_t total = 0;
+    int rc = seedpass_build_tab(ctx, sh.span, &tab, &total);
+    if (rc) return rc;
+    *weight = sh.weight;
+    keys->clear(); vals->clear();
+    if (tab.nwin[seq] == 0) return MAUVE_OK;
+    if (2 * sh.weight <= 32) rc = seedpass_impl<uint32_t>(ctx, sh, tab, total, 0, 0, 0, seq, nullptr, keys, vals);
+    else rc = seedpass_impl<uint64_t>(ctx, sh, tab, total, 0, 0, 0, seq, nullptr, keys, vals);
+    if (rc) return rc;
+    // vals carry global window indices; make them local to the genome
+    for (auto &v : *vals) v = ((v & 0x7fffffffu) - tab.gpos_off[seq]) | (v & 0x80000000u);
+    return MAUVE_OK;
+}
