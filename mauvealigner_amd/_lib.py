@@ -239,6 +239,8 @@ class Context:
         sc = scoring or default_scoring()
         n_iv = len(intervals)
         nseq = len(intervals[0]) if n_iv else 1
+        if any(len(iv) != nseq for iv in intervals):
+            raise ValueError("dp_batch: every interval must hold the same number of sequences")
         flat, off = [], [0]
         for iv in intervals:
             for s in iv:

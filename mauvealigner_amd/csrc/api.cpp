@@ -5,6 +5,13 @@
 
 static thread_local std::string g_create_err;
 
+GenomeSet main_genome_set(mauve_ctx *c)
+{
+    GenomeSet gs;
+    gs.buf = &c->genomes; gs.nseq = c->nseq; gs.lens = c->lens; gs.word_off = c->word_off;
+    return gs;
+}
+
 extern "C" {
 
 int mauve_ctx_create(int device, mauve_ctx **out)
@@ -42,7 +49,7 @@ void mauve_ctx_destroy(mauve_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->genomes, &c->keysA, &c->keysB, &c->valsA, &c->valsB, &c->hist, &c->totals, &c->posmask,
-                      &c->hit_mask, &c->hit_pos, &c->cand, &c->mlen, &c->mstart, &c->counters, &c->dp_codes, &c->dp_off,
+                      &c->hit_mask, &c->hit_pos, &c->hit_seg, &c->rec_genomes, &c->rec_seg, &c->cand, &c->mlen, &c->mstart, &c->counters, &c->dp_codes, &c->dp_off,
                       &c->dp_prof_cnt, &c->dp_prof_mask, &c->dp_prof2_cnt, &c->dp_prof2_mask, &c->dp_tb, &c->dp_meta,
                       &c->dp_score, &c->dp_cols, &c->dp_rows};
     for (DevBuf *b : bufs) b->release();
@@ -108,7 +115,7 @@ int mauve_seed_mums(mauve_ctx *c, uint64_t pattern, int mode, uint64_t mask, int
     if (!c) return MAUVE_ERR_ARG;
     if (mode != MAUVE_MODE_MEM && mode != MAUVE_MODE_UNIQUE) { c->err = "seed_mums: unknown mode"; return MAUVE_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
-    return seedpass_run(c, pattern, mode, mask, extend, -1, n_matches);
+    return seedpass_run(c, main_genome_set(c), pattern, mode, mask, extend, nullptr, 0, n_matches);
 }
 
 int mauve_get_matches(mauve_ctx *c, int64_t *length, int64_t *start)
@@ -127,7 +134,7 @@ int mauve_sorted_mer_list(mauve_ctx *c, int seq, uint64_t pattern, uint64_t *mer
     if (!c || !n_out) return MAUVE_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<uint64_t> keys; std::vector<uint32_t> vals; int w = 0;
-    int rc = seedpass_sorted_list(c, seq, pattern, &keys, &vals, &w);
+    int rc = seedpass_sorted_list(c, main_genome_set(c), seq, pattern, &keys, &vals, &w);
     if (rc) return rc;
     *n_out = (int64_t)keys.size();
     if (mer_out && pos_out)
@@ -148,7 +155,7 @@ int mauve_seed_match_enumerate(mauve_ctx *c, int seq, uint64_t pattern, int64_t 
     if (!c || !n_out || !n_starts) return MAUVE_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<uint64_t> keys; std::vector<uint32_t> vals; int w = 0;
-    int rc = seedpass_sorted_list(c, seq, pattern, &keys, &vals, &w);
+    int rc = seedpass_sorted_list(c, main_genome_set(c), seq, pattern, &keys, &vals, &w);
     if (rc) return rc;
     int64_t n = 0, ns = 0;
     const size_t np = keys.size();

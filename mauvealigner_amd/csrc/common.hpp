@@ -55,6 +55,15 @@ struct GenomeTab {
     uint64_t word_off[MAUVE_MAX_SEQ];       // first 64-bit word of genome g in the packed buffer
 };
 
+// A set of packed genomes resident on the device (the main genomes, or the gap sub-sequences of one
+// recursive-anchoring level).
+struct GenomeSet {
+    DevBuf *buf = nullptr;
+    int nseq = 0;
+    std::vector<int64_t> lens;
+    std::vector<uint64_t> word_off;
+};
+
 struct AlignResult {
     mauve_align_sizes sz{};
     std::vector<int64_t> mum_length, mum_start;
@@ -81,7 +90,8 @@ struct mauve_ctx {
     DevBuf genomes;
 
     // seed-pass workspace
-    DevBuf keysA, keysB, valsA, valsB, hist, totals, posmask, hit_mask, hit_pos, cand, mlen, mstart, counters;
+    DevBuf keysA, keysB, valsA, valsB, hist, totals, posmask, hit_mask, hit_pos, hit_seg, cand, mlen, mstart, counters;
+    DevBuf rec_genomes, rec_seg;         // recursive anchoring: gap sub-sequences + segment table
     // last match list (canonical order, host) + nseq it refers to
     std::vector<int64_t> match_len, match_start;
     int64_t n_matches = 0;
@@ -127,10 +137,10 @@ static inline double now_ms()
 
 // ---- internal entry points between translation units ----
 bool make_seed_shape(uint64_t pattern, SeedShape *out);
-int seedpass_build_tab(mauve_ctx *ctx, int span, GenomeTab *tab, int64_t *total_windows);
-int seedpass_run(mauve_ctx *ctx, uint64_t pattern, int mode, uint64_t mask, int extend, int only_seq,
-                 int64_t *n_matches);
-int seedpass_sorted_list(mauve_ctx *ctx, int seq, uint64_t pattern, std::vector<uint64_t> *keys,
+GenomeSet main_genome_set(mauve_ctx *ctx);
+int seedpass_run(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, int mode, uint64_t mask, int extend,
+                 const uint32_t *seg_dev, uint32_t nseg, int64_t *n_matches);
+int seedpass_sorted_list(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t pattern, std::vector<uint64_t> *keys,
                          std::vector<uint32_t> *vals, int *weight);
 
 // host chaining (chain_host.cpp)

@@ -1,0 +1,285 @@
+// dp_batch.hip -- batched gapped alignment of inter-anchor intervals on gfx950.
+//
+// Stands behind the mems::GappedAligner seam (Aligner::SetGappedAligner, mauveAligner.cpp:674;
+// MuscleInterface::Align, MatchRecord.h:302-321; CallMuscleFast, repeatoire.cpp:1262): libMUSCLE is
+// [EXT]; the frozen replacement is a progressive N-way alignment in genome order whose
+// every step is a 3-state affine-gap (Gotoh) DP of the current profile against the next sequence,
+// sum-of-pairs scores from per-column base counts, predecessor preference M > X > Y on ties.
+//
+// Mapping: one wave64 per interval.  The profile columns are the DP rows; the 64 lanes hold 64
+// consecutive rows and sweep the sequence as a systolic anti-diagonal wavefront: lane l works on
+// column j = t - l at step t, takes (i-1, j) from lane l-1 by a wave shuffle, (i-1, j-1) from what it
+// took one step earlier and (i, j-1) from its own registers.  Profiles longer than 64 columns run in
+// stripes; the last row of a stripe is parked in a per-interval HBM row buffer.  Traceback bytes are
+// written anti-diagonal-major (one coalesced 64-byte store per step), walked back by the wave, and
+// the new profile is rebuilt in forward order with ballot prefix counts.  Integer VALU + shuffle
+// bound, not HBM and not MFMA.
+#include "common.hpp"
+#include <algorithm>
+#include <cstring>
+
+#define DP_NEG_INF (-(1 << 29))
+
+struct DpMeta {
+    int32_t m;        // current profile length
+    int32_t krows;    // sequences merged so far
+    int32_t cur;      // which profile buffer is current (0 = A, 1 = B)
+    int32_t pad;
+    int64_t score;
+    int64_t cells;
+};
+
+struct DpScoring { int32_t go, ge; int32_t s[4][4]; };
+
+__device__ __forceinline__ void max3(int32_t a, int32_t b, int32_t c, int32_t &best, uint32_t &p)
+{
+    best = a; p = 0;
+    if (b > best) { best = b; p = 1; }
+    if (c > best) { best = c; p = 2; }
+}
+
+__global__ void __launch_bounds__(256) dp_step(int g, int nseq, int64_t n_iv, const uint8_t *__restrict__ codes,
+                                               const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
+                                               uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
+                                               uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
+                                               uint8_t *__restrict__ tb, const int64_t *__restrict__ tb_off,
+                                               int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
+                                               uint8_t *__restrict__ ops, DpScoring sc)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+
+    for (int64_t iv = wave_global; iv < n_iv; iv += nwaves) {
+        const int64_t so = seq_off[iv * nseq + g];
+        const int32_t n = (int32_t)(seq_off[iv * nseq + g + 1] - so);
+        if (n == 0) continue;
+        const uint8_t *seq = codes + so;
+        const int64_t base = seq_off[iv * nseq];
+        DpMeta mt = meta[iv];
+        uint32_t *Pc = (mt.cur ? cntB : cntA) + base, *Pm = (mt.cur ? maskB : maskA) + base;
+        uint32_t *Qc = (mt.cur ? cntA : cntB) + base, *Qm = (mt.cur ? maskA : maskB) + base;
+        if (mt.krows == 0) {           // first non-empty sequence becomes the profile
+            for (int32_t c = lane; c < n; c += 64) { Pc[c] = 1u << (8 * seq[c]); Pm[c] = 1u << g; }
+            if (lane == 0) { mt.m = n; mt.krows = 1; meta[iv] = mt; }
+            continue;
+        }
+        const int32_t m = mt.m;
+        const int32_t gyo = sc.go * mt.krows, gye = sc.ge * mt.krows;
+        const int32_t T = n + 64;                          // traceback stride per stripe (steps)
+        uint8_t *tbp = tb + tb_off[iv];
+        int32_t *rowbuf = rows + rows_off[iv];             // 2 x 3 x (n+1)
+        const int32_t nstripes = (m + 63) / 64;
+        int32_t fM = DP_NEG_INF, fX = DP_NEG_INF, fY = DP_NEG_INF;   // values at (m, n)
+
+        for (int32_t s = 0; s < nstripes; s++) {
+            const int32_t i = s * 64 + lane + 1;
+            const bool active = i <= m;
+            const int32_t rows_here = min(64, m - s * 64);
+            uint32_t cn = active ? Pc[i - 1] : 0u;
+            const int32_t c0 = cn & 255, c1 = (cn >> 8) & 255, c2 = (cn >> 16) & 255, c3 = cn >> 24;
+            const int32_t r = c0 + c1 + c2 + c3;
+            // sum-of-pairs substitution score of this column against each base (kept in named registers:
+            // a runtime-indexed array would go to scratch)
+            const int32_t sub0 = c0 * sc.s[0][0] + c1 * sc.s[1][0] + c2 * sc.s[2][0] + c3 * sc.s[3][0];
+            const int32_t sub1 = c0 * sc.s[0][1] + c1 * sc.s[1][1] + c2 * sc.s[2][1] + c3 * sc.s[3][1];
+            const int32_t sub2 = c0 * sc.s[0][2] + c1 * sc.s[1][2] + c2 * sc.s[2][2] + c3 * sc.s[3][2];
+            const int32_t sub3 = c0 * sc.s[0][3] + c1 * sc.s[1][3] + c2 * sc.s[2][3] + c3 * sc.s[3][3];
+            const int32_t gxo = sc.go * r, gxe = sc.ge * r;
+            const int32_t *rin = rowbuf + (size_t)((s & 1) ^ 1) * 3 * (n + 1);   // written by stripe s-1
+            int32_t *rout = rowbuf + (size_t)(s & 1) * 3 * (n + 1);
+            const bool park = s + 1 < nstripes;
+
+            int32_t Mc = DP_NEG_INF, Xc = DP_NEG_INF, Yc = DP_NEG_INF;   // (i, j) just computed
+            int32_t Md = DP_NEG_INF, Xd = DP_NEG_INF, Yd = DP_NEG_INF;   // (i-1, j-1)
+            uint32_t bcur = 0;
+            const int32_t steps = n + rows_here;                         // t = 0 .. n + rows_here - 1
+            for (int32_t t = 0; t < steps; t++) {
+                const int32_t j = t - lane;
+                // (i-1, j): lane-1's newest values; lane 0 reads the stripe's upper boundary row
+                int32_t Mu = __shfl_up(Mc, 1), Xu = __shfl_up(Xc, 1), Yu = __shfl_up(Yc, 1);
+                uint32_t bnext = __shfl_up(bcur, 1);
+                if (lane == 0) {
+                    if (j <= n) {
+                        if (s == 0) {
+                            Mu = (j == 0) ? 0 : DP_NEG_INF; Xu = DP_NEG_INF;
+                            Yu = (j == 0) ? DP_NEG_INF : gyo + (j - 1) * gye;
+                        } else { Mu = rin[j]; Xu = rin[(n + 1) + j]; Yu = rin[2 * (n + 1) + j]; }
+                    }
+                    bnext = (j >= 1 && j <= n) ? seq[j - 1] : 0u;
+                }
+                bcur = bnext;
+                const bool on = active && j >= 0 && j <= n;
+                int32_t Ml = Mc, Xl = Xc, Yl = Yc;           // (i, j-1): own previous column
+                if (on) {
+                    int32_t best; uint32_t pm = 0, px, py = 0;
+                    if (j >= 1) { max3(Md, Xd, Yd, best, pm); best += (bcur == 0 ? sub0 : bcur == 1 ? sub1 : bcur == 2 ? sub2 : sub3); Mc = best < DP_NEG_INF ? DP_NEG_INF : best; }
+                    else Mc = DP_NEG_INF;
+                    max3(Mu + gxo, Xu + gxe, Yu + gxo, best, px);
+                    Xc = best < DP_NEG_INF ? DP_NEG_INF : best;
+                    if (j >= 1) { max3(Ml + gyo, Xl + gyo, Yl + gye, best, py); Yc = best < DP_NEG_INF ? DP_NEG_INF : best; }
+                    else Yc = DP_NEG_INF;
+                    tbp[((size_t)s * T + t) * 64 + lane] = (uint8_t)(pm | (px << 2) | (py << 4));
+                    if (park && lane == 63) { rout[j] = Mc; rout[(n + 1) + j] = Xc; rout[2 * (n + 1) + j] = Yc; }
+                    if (i == m && j == n) { fM = Mc; fX = Xc; fY = Yc; }
+                }
+                Md = Mu; Xd = Xu; Yd = Yu;
+            }
+            __threadfence_block();   // the parked row / traceback bytes are read back by this wave
+        }
+        // result lives in the lane that owns row m
+        const int owner = (m - 1) & 63;
+        fM = __shfl(fM, owner); fX = __shfl(fX, owner); fY = __shfl(fY, owner);
+        int32_t best = fM; int state = 0;
+        if (fX > best) { best = fX; state = 1; }
+        if (fY > best) { best = fY; state = 2; }
+
+        // ---- traceback (wave-uniform walk; bytes were written by this wave) ----
+        uint8_t *opr = ops + base;                  // reversed ops, capacity m + n
+        int32_t ti = m, tj = n, len = 0;
+        while (ti > 0 || tj > 0) {
+            uint32_t op, nstate;
+            if (ti == 0) { op = 2; nstate = (tj == 1) ? 0 : 2; }
+            else {
+                const int32_t s = (ti - 1) >> 6, l = (ti - 1) & 63;
+                const uint8_t bt = tbp[((size_t)s * T + (tj + l)) * 64 + l];
+                if (state == 0) { op = 3; nstate = bt & 3; }
+                else if (state == 1) { op = 1; nstate = (bt >> 2) & 3; }
+                else { op = 2; nstate = (bt >> 4) & 3; }
+            }
+            if (lane == 0) opr[len] = (uint8_t)op;
+            len++;
+            if (op & 1) ti--;
+            if (op & 2) tj--;
+            state = (int)nstate;
+        }
+        __threadfence_block();
+        // ---- new profile in forward order: ballot prefix counts give each column its sources ----
+        int32_t carry_p = 0, carry_s = 0;
+        for (int32_t c0i = 0; c0i < len; c0i += 64) {
+            const int32_t c = c0i + lane;
+            const bool ok = c < len;
+            const uint32_t op = ok ? opr[len - 1 - c] : 0u;
+            const uint64_t bp = __ballot(ok && (op & 1)), bs = __ballot(ok && (op & 2));
+            if (ok) {
+                const int32_t pi = carry_p + (int32_t)__popcll(bp & lt), sj = carry_s + (int32_t)__popcll(bs & lt);
+                uint32_t cv = 0, mv = 0;
+                if (op & 1) { cv = Pc[pi]; mv = Pm[pi]; }
+                if (op & 2) { cv += 1u << (8 * seq[sj]); mv |= 1u << g; }
+                Qc[c] = cv; Qm[c] = mv;
+            }
+            carry_p += (int32_t)__popcll(bp); carry_s += (int32_t)__popcll(bs);
+        }
+        if (lane == 0) {
+            mt.cells += (int64_t)m * n; mt.score += best; mt.m = len; mt.krows += 1; mt.cur ^= 1;
+            meta[iv] = mt;
+        }
+    }
+}
+
+// masks of the final profiles, compacted: cols[col_off[iv] + c]
+__global__ void __launch_bounds__(256) dp_gather(int nseq, int64_t n_iv, const int64_t *__restrict__ seq_off,
+                                                 const DpMeta *__restrict__ meta, const uint32_t *__restrict__ maskA,
+                                                 const uint32_t *__restrict__ maskB, const int64_t *__restrict__ col_off,
+                                                 uint32_t *__restrict__ cols)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t iv = wave_global; iv < n_iv; iv += nwaves) {
+        const DpMeta mt = meta[iv];
+        const uint32_t *src = (mt.cur ? maskB : maskA) + seq_off[iv * nseq];
+        uint32_t *dst = cols + col_off[iv];
+        for (int32_t c = lane; c < mt.m; c += 64) dst[c] = src[c];
+    }
+}
+
+int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,
+                 const mauve_scoring *scoring, uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells)
+{
+    if (cells) *cells = 0;
+    col_off[0] = 0;
+    if (n_iv == 0) return MAUVE_OK;
+    const int64_t total = seq_off[n_iv * nseq];
+    // per-interval scratch: traceback (worst profile length before each step) and parked rows
+    std::vector<int64_t> tb_off(n_iv + 1), rows_off(n_iv + 1);
+    int64_t tbt = 0, rwt = 0;
+    for (int64_t iv = 0; iv < n_iv; iv++) {
+        int64_t mmax = 0, need = 0, nmax = 0; bool first = true;
+        for (int g = 0; g < nseq; g++) {
+            int64_t n = seq_off[iv * nseq + g + 1] - seq_off[iv * nseq + g];
+            if (n == 0) continue;
+            if (first) { first = false; mmax = n; continue; }
+            need = std::max(need, ((mmax + 63) / 64) * (n + 64) * 64);
+            nmax = std::max(nmax, n);
+            mmax += n;
+        }
+        tb_off[iv] = tbt; rows_off[iv] = rwt;
+        tbt += need; rwt += 6 * (nmax + 1);
+    }
+    tb_off[n_iv] = tbt; rows_off[n_iv] = rwt;
+
+    HIPCHK(ctx, ctx->dp_codes.ensure((size_t)total + 16));
+    HIPCHK(ctx, ctx->dp_off.ensure((size_t)(n_iv * nseq + 1 + 3 * (n_iv + 1)) * sizeof(int64_t)));
+    HIPCHK(ctx, ctx->dp_prof_cnt.ensure((size_t)(total + 1) * 4));
+    HIPCHK(ctx, ctx->dp_prof_mask.ensure((size_t)(total + 1) * 4));
+    HIPCHK(ctx, ctx->dp_prof2_cnt.ensure((size_t)(total + 1) * 4));
+    HIPCHK(ctx, ctx->dp_prof2_mask.ensure((size_t)(total + 1) * 4));
+    HIPCHK(ctx, ctx->dp_tb.ensure((size_t)tbt + 64));
+    HIPCHK(ctx, ctx->dp_rows.ensure((size_t)(rwt + 1) * 4));
+    HIPCHK(ctx, ctx->dp_meta.ensure((size_t)n_iv * sizeof(DpMeta)));
+    HIPCHK(ctx, ctx->dp_score.ensure((size_t)total + 16));           // reversed-ops scratch
+    HIPCHK(ctx, ctx->dp_cols.ensure((size_t)(total + 1) * 4));
+    int64_t *d_seq_off = ctx->dp_off.as<int64_t>();
+    int64_t *d_tb_off = d_seq_off + (n_iv * nseq + 1);
+    int64_t *d_rows_off = d_tb_off + (n_iv + 1);
+    int64_t *d_col_off = d_rows_off + (n_iv + 1);
+    if (total) HIPCHK(ctx, hipMemcpyAsync(ctx->dp_codes.p, codes, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_seq_off, seq_off, (size_t)(n_iv * nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_tb_off, tb_off.data(), (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_rows_off, rows_off.data(), (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->dp_meta.p, 0, (size_t)n_iv * sizeof(DpMeta), ctx->stream));
+    DpScoring sc; sc.go = scoring->gap_open; sc.ge = scoring->gap_extend; memcpy(sc.s, scoring->matrix, sizeof sc.s);
+    const uint32_t blocks = (uint32_t)std::min<int64_t>((n_iv + 3) / 4, 256 * 8);
+    for (int g = 0; g < nseq; g++) {
+        KernelTimer t(ctx, MAUVE_K_DP, n_iv);
+        hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, g, nseq, n_iv, ctx->dp_codes.as<uint8_t>(),
+                           d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
+                           ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
+                           ctx->dp_prof2_mask.as<uint32_t>(), ctx->dp_tb.as<uint8_t>(), d_tb_off, ctx->dp_rows.as<int32_t>(),
+                           d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<DpMeta> hm(n_iv);
+    HIPCHK(ctx, hipMemcpyAsync(hm.data(), ctx->dp_meta.p, (size_t)n_iv * sizeof(DpMeta), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t tc = 0, cl = 0;
+    for (int64_t iv = 0; iv < n_iv; iv++) {
+        col_off[iv] = tc; tc += hm[iv].m; cl += hm[iv].cells;
+        if (score) score[iv] = hm[iv].score;
+    }
+    col_off[n_iv] = tc;
+    if (cells) *cells = cl;
+    if (tc) {
+        HIPCHK(ctx, hipMemcpyAsync(d_col_off, col_off, (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(dp_gather, dim3(blocks), dim3(256), 0, ctx->stream, nseq, n_iv, d_seq_off, ctx->dp_meta.as<DpMeta>(),
+                           ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_mask.as<uint32_t>(), d_col_off,
+                           ctx->dp_cols.as<uint32_t>());
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(cols, ctx->dp_cols.p, (size_t)tc * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MAUVE_OK;
+}
+
+extern "C" int mauve_dp_batch(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,
+                              const mauve_scoring *sc, uint32_t *cols, int64_t *col_off, int64_t *score)
+{
+    if (!ctx) return MAUVE_ERR_ARG;
+    if (nseq < 1 || nseq > MAUVE_MAX_SEQ || n_iv < 0 || !seq_off || !sc || !col_off || (n_iv && !cols)) {
+        ctx->err = "dp_batch: bad argument"; return MAUVE_ERR_ARG;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return dp_batch_run(ctx, nseq, n_iv, codes, seq_off, sc, cols, col_off, score, nullptr);
+}

@@ -57,10 +57,22 @@ __device__ __forceinline__ int genome_of(uint32_t gpos, const GenomeTab &t)
 // seed_extract: one thread per window.  Reads 0.25 B/position (L1-shared), writes key + val.
 // val = global window index | strand << 31.
 // ------------------------------------------------------------------------------------------------
-template <typename KeyT>
+// Segmented mode (recursive anchoring): genome g is a concatenation of nseg gap
+// sub-sequences; seg[g*(nseg+1)+k] is the first base of segment k.  A window is valid only inside one
+// segment and its key is prefixed with the segment id, so mers only meet inside their own gap; invalid
+// windows get the all-ones key, which the join ignores.
+__device__ __forceinline__ uint32_t seg_of(const uint32_t *__restrict__ segs, uint32_t nseg, uint32_t p)
+{
+    uint32_t lo = 0, hi = nseg;            // segs[lo] <= p < segs[hi]
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (segs[mid] <= p) lo = mid; else hi = mid; }
+    return lo;
+}
+
+template <typename KeyT, bool SEG>
 __global__ void __launch_bounds__(256) seed_extract(const uint64_t *__restrict__ packed, GenomeTab tab,
                                                     SeedShape sh, int g, KeyT *__restrict__ keys,
-                                                    uint32_t *__restrict__ vals, uint32_t out_base)
+                                                    uint32_t *__restrict__ vals, uint32_t out_base,
+                                                    const uint32_t *__restrict__ seg, uint32_t nseg)
 {
     uint32_t n = tab.nwin[g];
     const uint64_t *G = packed + tab.word_off[g];
@@ -69,7 +81,13 @@ __global__ void __launch_bounds__(256) seed_extract(const uint64_t *__restrict__
         uint64_t f = digit_reverse(kp, sh.weight);
         uint64_t r = (~kp) & sh.keymask;
         uint32_t s = r < f;
-        keys[out_base + p] = (KeyT)(s ? r : f);
+        uint64_t key = s ? r : f;
+        if (SEG) {
+            const uint32_t *sg = seg + (size_t)g * (nseg + 1);
+            uint32_t k = seg_of(sg, nseg, p);
+            key = (p + sh.span <= sg[k + 1]) ? (((uint64_t)k << (2 * sh.weight)) | key) : ~0ULL;
+        }
+        keys[out_base + p] = (KeyT)key;
         vals[out_base + p] = (tab.gpos_off[g] + p) | (s << 31);
     }
 }
@@ -234,15 +252,17 @@ __global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict_
 //   MODE_UNIQUE : UniqueMatchFinder.cpp:44-58 -- genomes with more than one copy are dropped, >= 2 stay
 // hit_pos[h*nseq+g] = global window index | strand << 31, 0xFFFFFFFF = absent.
 // ------------------------------------------------------------------------------------------------
-template <typename KeyT>
+template <typename KeyT, bool SEG>
 __global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                 uint32_t n, GenomeTab tab, int mode, uint32_t want_mask,
                                                 uint32_t *__restrict__ posmask, uint32_t *__restrict__ hit_mask,
-                                                uint32_t *__restrict__ hit_pos, uint32_t *__restrict__ counters)
+                                                uint32_t *__restrict__ hit_pos, uint32_t *__restrict__ hit_seg,
+                                                int key_shift, uint32_t *__restrict__ counters)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     KeyT k = keys[i];
+    if (SEG && k == (KeyT)~0ULL) return;
     if (i > 0 && keys[i - 1] == k) return;
     if (i + 1 >= n || keys[i + 1] != k) return;        // singleton run
     uint32_t once = 0, multi = 0, j = i;
@@ -256,6 +276,7 @@ __global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, c
     if (want_mask && m != want_mask) return;
     uint32_t h = atomicAdd(&counters[0], 1u);
     hit_mask[h] = m;
+    if (SEG) hit_seg[h] = (uint32_t)((uint64_t)k >> key_shift);
     uint32_t *hp = hit_pos + (size_t)h * tab.nseq;
     for (int g = 0; g < tab.nseq; g++) hp[g] = 0xFFFFFFFFu;
     for (uint32_t t = i; t < j; t++) {
@@ -277,13 +298,17 @@ struct HitView {
     uint32_t agpos;      // anchor global window index
 };
 
+template <bool SEG>
 __device__ __forceinline__ bool agree_at(const uint64_t *__restrict__ packed, const GenomeTab &tab,
                                          const SeedShape &sh, const uint32_t *__restrict__ hp, uint32_t mask,
-                                         int anchor, int64_t k)
+                                         int anchor, int64_t k, const uint32_t *__restrict__ seg, uint32_t nseg,
+                                         uint32_t segid)
 {
     uint32_t va = hp[anchor];
     int64_t qa = (int64_t)((va & 0x7fffffffu) - tab.gpos_off[anchor]) + k;
-    if (qa < 0 || qa >= (int64_t)tab.nwin[anchor]) return false;
+    int64_t lo = 0, hi = (int64_t)tab.nwin[anchor] - 1;
+    if (SEG) { const uint32_t *sg = seg + (size_t)anchor * (nseg + 1) + segid; lo = sg[0]; hi = (int64_t)sg[1] - sh.span; }
+    if (qa < lo || qa > hi) return false;
     uint64_t ka = kprime_at(packed + tab.word_off[anchor], (uint32_t)qa, sh);
     uint64_t ka_rev = digit_reverse(ka, sh.weight);
     uint32_t sa = va >> 31;
@@ -294,7 +319,9 @@ __device__ __forceinline__ bool agree_at(const uint64_t *__restrict__ packed, co
         uint32_t o = (vg >> 31) ^ sa;
         int64_t pg = (int64_t)((vg & 0x7fffffffu) - tab.gpos_off[g]);
         int64_t qg = o ? pg - k : pg + k;
-        if (qg < 0 || qg >= (int64_t)tab.nwin[g]) { ok = false; break; }
+        lo = 0; hi = (int64_t)tab.nwin[g] - 1;
+        if (SEG) { const uint32_t *sg = seg + (size_t)g * (nseg + 1) + segid; lo = sg[0]; hi = (int64_t)sg[1] - sh.span; }
+        if (qg < lo || qg > hi) { ok = false; break; }
         uint64_t kg = kprime_at(packed + tab.word_off[g], (uint32_t)qg, sh);
         if (o ? (((~kg) & sh.keymask) != ka_rev) : (kg != ka)) { ok = false; break; }
     }
@@ -303,11 +330,14 @@ __device__ __forceinline__ bool agree_at(const uint64_t *__restrict__ packed, co
 
 // phase A: thread per hit.  A hit whose nearest agreeing offset to the left (within span) is a
 // same-mask hit is certainly not the leftmost hit of its cluster; everything else is a candidate.
+template <bool SEG>
 __global__ void __launch_bounds__(256) mum_candidates(const uint64_t *__restrict__ packed, GenomeTab tab,
                                                       SeedShape sh, const uint32_t *__restrict__ hit_mask,
                                                       const uint32_t *__restrict__ hit_pos,
                                                       const uint32_t *__restrict__ posmask, uint32_t nhit,
-                                                      uint32_t *__restrict__ cand, uint32_t *__restrict__ counters)
+                                                      uint32_t *__restrict__ cand, uint32_t *__restrict__ counters,
+                                                      const uint32_t *__restrict__ seg, uint32_t nseg,
+                                                      const uint32_t *__restrict__ hit_seg)
 {
     uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= nhit) return;
@@ -315,9 +345,10 @@ __global__ void __launch_bounds__(256) mum_candidates(const uint64_t *__restrict
     const uint32_t *hp = hit_pos + (size_t)h * tab.nseq;
     int anchor = __ffs(mask) - 1;
     uint32_t agpos = hp[anchor] & 0x7fffffffu;
+    const uint32_t segid = SEG ? hit_seg[h] : 0u;
     bool is_cand = true;
     for (int d = 1; d <= sh.span; d++) {
-        if (agree_at(packed, tab, sh, hp, mask, anchor, -(int64_t)d)) {
+        if (agree_at<SEG>(packed, tab, sh, hp, mask, anchor, -(int64_t)d, seg, nseg, segid)) {
             if (posmask[agpos - d] == mask) is_cand = false;
             break;
         }
@@ -327,13 +358,15 @@ __global__ void __launch_bounds__(256) mum_candidates(const uint64_t *__restrict
 
 // phase B: one wave per candidate; the 64 lanes test 64 consecutive offsets at a time and the
 // resulting agreement bitmap is walked with scalar bit operations.
+template <bool SEG>
 __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ packed, GenomeTab tab, SeedShape sh,
                                                   const uint32_t *__restrict__ hit_mask,
                                                   const uint32_t *__restrict__ hit_pos,
                                                   const uint32_t *__restrict__ posmask,
                                                   const uint32_t *__restrict__ cand, uint32_t ncand, int extend,
                                                   int32_t *__restrict__ mlen, int32_t *__restrict__ mstart,
-                                                  uint32_t *__restrict__ counters)
+                                                  uint32_t *__restrict__ counters, const uint32_t *__restrict__ seg,
+                                                  uint32_t nseg, const uint32_t *__restrict__ hit_seg)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -345,6 +378,7 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
         const uint32_t *hp = hit_pos + (size_t)h * tab.nseq;
         int anchor = __ffs(mask) - 1;
         uint32_t agpos = hp[anchor] & 0x7fffffffu;
+        const uint32_t segid = SEG ? hit_seg[h] : 0u;
         int64_t klo = 0, khi = 0;
         bool leftmost = true;
         if (extend) {
@@ -352,7 +386,7 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
             int64_t cur = 0;
             for (bool done = false; !done;) {
                 int64_t k = cur - 1 - lane;
-                bool a = agree_at(packed, tab, sh, hp, mask, anchor, k);
+                bool a = agree_at<SEG>(packed, tab, sh, hp, mask, anchor, k, seg, nseg, segid);
                 bool hh = a && (posmask[(int64_t)agpos + k] == mask);
                 uint64_t A = __ballot(a), H = __ballot(hh);
                 int p = 0;                      // offsets consumed in this round
@@ -372,7 +406,7 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
             cur = 0;
             for (bool done = false; !done;) {
                 int64_t k = cur + 1 + lane;
-                bool a = agree_at(packed, tab, sh, hp, mask, anchor, k);
+                bool a = agree_at<SEG>(packed, tab, sh, hp, mask, anchor, k, seg, nseg, segid);
                 uint64_t A = __ballot(a);
                 int p = 0;
                 for (;;) {
@@ -414,7 +448,7 @@ bool make_seed_shape(uint64_t pattern, SeedShape *sh)
     for (int t = 0; t < span; t++)
         if (((pattern >> t) & 1) != ((pattern >> (span - 1 - t)) & 1)) return false;
     if (!(pattern & 1)) return false;
-    sh->span = span; sh->weight = w; sh->keymask = (w == 32) ? ~0ULL : ((1ULL << (2 * w)) - 1ULL);
+    sh->span = span; sh->weight = w; sh->keymask = (1ULL << (2 * w)) - 1ULL;
     int j = 0, nr = 0;
     for (int t = 0; t < span;) {
         if (!((pattern >> (span - 1 - t)) & 1)) { t++; continue; }
@@ -429,18 +463,18 @@ bool make_seed_shape(uint64_t pattern, SeedShape *sh)
     return true;
 }
 
-int seedpass_build_tab(mauve_ctx *ctx, int span, GenomeTab *tab, int64_t *total_windows)
+static int build_tab(mauve_ctx *ctx, const GenomeSet &gs, int span, GenomeTab *tab, int64_t *total_windows)
 {
     memset(tab, 0, sizeof *tab);
-    tab->nseq = ctx->nseq;
+    tab->nseq = gs.nseq;
     int64_t tot = 0;
-    for (int g = 0; g < ctx->nseq; g++) {
-        int64_t nw = ctx->lens[g] - span + 1; if (nw < 0) nw = 0;
-        tab->gpos_off[g] = (uint32_t)tot; tab->nwin[g] = (uint32_t)nw; tab->word_off[g] = ctx->word_off[g];
+    for (int g = 0; g < gs.nseq; g++) {
+        int64_t nw = gs.lens[g] - span + 1; if (nw < 0) nw = 0;
+        tab->gpos_off[g] = (uint32_t)tot; tab->nwin[g] = (uint32_t)nw; tab->word_off[g] = gs.word_off[g];
         tot += nw;
         if (tot >= (1LL << 31)) { ctx->err = "total genome length exceeds 2^31 windows"; return MAUVE_ERR_LIMIT; }
     }
-    tab->gpos_off[ctx->nseq] = (uint32_t)tot;
+    tab->gpos_off[gs.nseq] = (uint32_t)tot;
     *total_windows = tot;
     return MAUVE_OK;
 }
@@ -470,10 +504,12 @@ static int sort_pairs(mauve_ctx *ctx, uint32_t n, int key_bits, KeyT **keys_io, 
     return MAUVE_OK;
 }
 
-template <typename KeyT>
-static int seedpass_impl(mauve_ctx *ctx, const SeedShape &sh, const GenomeTab &tab, int64_t total, int mode,
-                         uint64_t mask, int extend, int only_seq, int64_t *n_matches, std::vector<uint64_t> *out_keys,
-                         std::vector<uint32_t> *out_vals)
+// One seed pass over a genome set.  SEG: the set is segmented (recursive anchoring); seg = device array
+// [nseq][nseg+1] of segment starts.  Results land in ctx->match_len / match_start (canonical order).
+template <typename KeyT, bool SEG>
+static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &sh, const GenomeTab &tab, int64_t total,
+                         int mode, uint64_t mask, int extend, int only_seq, const uint32_t *seg, uint32_t nseg,
+                         int64_t *n_matches, std::vector<uint64_t> *out_keys, std::vector<uint32_t> *out_vals)
 {
     const uint32_t n = (uint32_t)total;
     HIPCHK(ctx, ctx->keysA.ensure((size_t)n * sizeof(KeyT)));
@@ -482,7 +518,7 @@ static int seedpass_impl(mauve_ctx *ctx, const SeedShape &sh, const GenomeTab &t
     HIPCHK(ctx, ctx->valsB.ensure((size_t)n * 4));
     HIPCHK(ctx, ctx->counters.ensure(64));
     KeyT *keys = ctx->keysA.as<KeyT>(); uint32_t *vals = ctx->valsA.as<uint32_t>();
-    const uint64_t *packed = ctx->genomes.as<uint64_t>();
+    const uint64_t *packed = gs.buf->as<uint64_t>();
 
     uint32_t sorted_n = 0;
     for (int g = 0; g < tab.nseq; g++) {
@@ -492,13 +528,15 @@ static int seedpass_impl(mauve_ctx *ctx, const SeedShape &sh, const GenomeTab &t
         uint32_t base = only_seq >= 0 ? 0u : tab.gpos_off[g];
         uint32_t blocks = std::min<uint32_t>((nw + 255) / 256, 256 * 16);
         KernelTimer t(ctx, MAUVE_K_EXTRACT, nw);
-        hipLaunchKernelGGL(seed_extract<KeyT>, dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh, g, keys, vals,
-                           base);
+        hipLaunchKernelGGL((seed_extract<KeyT, SEG>), dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh, g, keys,
+                           vals, base, seg, nseg);
         sorted_n += nw;
     }
     HIPCHK(ctx, hipGetLastError());
     if (sorted_n == 0) { if (n_matches) *n_matches = 0; return MAUVE_OK; }
-    int rc = sort_pairs<KeyT>(ctx, sorted_n, 2 * sh.weight, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>());
+    // segmented keys: segment id above the mer; the all-ones invalid key needs every bit, so sort all 64
+    const int key_bits = SEG ? 64 : 2 * sh.weight;
+    int rc = sort_pairs<KeyT>(ctx, sorted_n, key_bits, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>());
     if (rc) return rc;
 
     if (out_keys) {   // sorted-mer-list export / SeedMatchEnumerator path: hand the sorted pairs to the host
@@ -518,12 +556,14 @@ static int seedpass_impl(mauve_ctx *ctx, const SeedShape &sh, const GenomeTab &t
     HIPCHK(ctx, ctx->posmask.ensure((size_t)n * 4));
     HIPCHK(ctx, ctx->hit_mask.ensure(hit_cap * 4));
     HIPCHK(ctx, ctx->hit_pos.ensure(hit_cap * 4 * N));
+    if (SEG) HIPCHK(ctx, ctx->hit_seg.ensure(hit_cap * 4));
     HIPCHK(ctx, hipMemsetAsync(ctx->posmask.p, 0, (size_t)n * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
     { KernelTimer t(ctx, MAUVE_K_JOIN, n);
-      hipLaunchKernelGGL(mum_join<KeyT>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, n, tab, mode,
+      hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, n, tab, mode,
                          (uint32_t)mask, ctx->posmask.as<uint32_t>(), ctx->hit_mask.as<uint32_t>(),
-                         ctx->hit_pos.as<uint32_t>(), ctx->counters.as<uint32_t>()); }
+                         ctx->hit_pos.as<uint32_t>(), ctx->hit_seg.as<uint32_t>(), 2 * sh.weight,
+                         ctx->counters.as<uint32_t>()); }
     HIPCHK(ctx, hipGetLastError());
     uint32_t hc[4] = {0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -538,9 +578,9 @@ static int seedpass_impl(mauve_ctx *ctx, const SeedShape &sh, const GenomeTab &t
     uint32_t ncand = nhit;
     if (extend) {
         KernelTimer t(ctx, MAUVE_K_EXTEND, nhit);
-        hipLaunchKernelGGL(mum_candidates, dim3((nhit + 255) / 256), dim3(256), 0, ctx->stream, packed, tab, sh,
+        hipLaunchKernelGGL((mum_candidates<SEG>), dim3((nhit + 255) / 256), dim3(256), 0, ctx->stream, packed, tab, sh,
                            ctx->hit_mask.as<uint32_t>(), ctx->hit_pos.as<uint32_t>(), ctx->posmask.as<uint32_t>(), nhit,
-                           ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>());
+                           ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg, nseg, ctx->hit_seg.as<uint32_t>());
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -555,13 +595,12 @@ static int seedpass_impl(mauve_ctx *ctx, const SeedShape &sh, const GenomeTab &t
     HIPCHK(ctx, ctx->mlen.ensure((size_t)ncand * 4 + 4));
     HIPCHK(ctx, ctx->mstart.ensure((size_t)ncand * 4 * N + 4));
     if (ncand) {
-        uint32_t waves = ncand;
-        uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, 256 * 8);
+        uint32_t blocks = std::min<uint32_t>((ncand + 3) / 4, 256 * 8);
         KernelTimer t(ctx, MAUVE_K_EXTEND, ncand);
-        hipLaunchKernelGGL(mum_extend, dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh,
+        hipLaunchKernelGGL((mum_extend<SEG>), dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh,
                            ctx->hit_mask.as<uint32_t>(), ctx->hit_pos.as<uint32_t>(), ctx->posmask.as<uint32_t>(),
                            ctx->cand.as<uint32_t>(), ncand, extend, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(),
-                           ctx->counters.as<uint32_t>());
+                           ctx->counters.as<uint32_t>(), seg, nseg, ctx->hit_seg.as<uint32_t>());
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -603,36 +642,37 @@ static int seedpass_impl(mauve_ctx *ctx, const SeedShape &sh, const GenomeTab &t
     return MAUVE_OK;
 }
 
-int seedpass_run(mauve_ctx *ctx, uint64_t pattern, int mode, uint64_t mask, int extend, int only_seq,
-                 int64_t *n_matches)
+int seedpass_run(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, int mode, uint64_t mask, int extend,
+                 const uint32_t *seg_dev, uint32_t nseg, int64_t *n_matches)
 {
     SeedShape sh;
     if (!make_seed_shape(pattern, &sh)) { ctx->err = "seed pattern must be palindromic, span <= 49, weight <= 31"; return MAUVE_ERR_ARG; }
-    if (ctx->nseq < 1) { ctx->err = "no genomes set"; return MAUVE_ERR_STATE; }
+    if (gs.nseq < 1) { ctx->err = "no genomes set"; return MAUVE_ERR_STATE; }
     GenomeTab tab; int64_t total = 0;
-    int rc = seedpass_build_tab(ctx, sh.span, &tab, &total);
+    int rc = build_tab(ctx, gs, sh.span, &tab, &total);
     if (rc) return rc;
     ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear();
     if (n_matches) *n_matches = 0;
     if (total == 0) return MAUVE_OK;
-    if (2 * sh.weight <= 32) return seedpass_impl<uint32_t>(ctx, sh, tab, total, mode, mask, extend, only_seq, n_matches, nullptr, nullptr);
-    return seedpass_impl<uint64_t>(ctx, sh, tab, total, mode, mask, extend, only_seq, n_matches, nullptr, nullptr);
+    if (seg_dev) return seedpass_impl<uint64_t, true>(ctx, gs, sh, tab, total, mode, mask, extend, -1, seg_dev, nseg, n_matches, nullptr, nullptr);
+    if (2 * sh.weight <= 32) return seedpass_impl<uint32_t, false>(ctx, gs, sh, tab, total, mode, mask, extend, -1, nullptr, 0, n_matches, nullptr, nullptr);
+    return seedpass_impl<uint64_t, false>(ctx, gs, sh, tab, total, mode, mask, extend, -1, nullptr, 0, n_matches, nullptr, nullptr);
 }
 
-int seedpass_sorted_list(mauve_ctx *ctx, int seq, uint64_t pattern, std::vector<uint64_t> *keys,
+int seedpass_sorted_list(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t pattern, std::vector<uint64_t> *keys,
                          std::vector<uint32_t> *vals, int *weight)
 {
     SeedShape sh;
     if (!make_seed_shape(pattern, &sh)) { ctx->err = "seed pattern must be palindromic, span <= 49, weight <= 31"; return MAUVE_ERR_ARG; }
-    if (seq < 0 || seq >= ctx->nseq) { ctx->err = "sequence index out of range"; return MAUVE_ERR_ARG; }
+    if (seq < 0 || seq >= gs.nseq) { ctx->err = "sequence index out of range"; return MAUVE_ERR_ARG; }
     GenomeTab tab; int64_t total = 0;
-    int rc = seedpass_build_tab(ctx, sh.span, &tab, &total);
+    int rc = build_tab(ctx, gs, sh.span, &tab, &total);
     if (rc) return rc;
     *weight = sh.weight;
     keys->clear(); vals->clear();
     if (tab.nwin[seq] == 0) return MAUVE_OK;
-    if (2 * sh.weight <= 32) rc = seedpass_impl<uint32_t>(ctx, sh, tab, total, 0, 0, 0, seq, nullptr, keys, vals);
-    else rc = seedpass_impl<uint64_t>(ctx, sh, tab, total, 0, 0, 0, seq, nullptr, keys, vals);
+    if (2 * sh.weight <= 32) rc = seedpass_impl<uint32_t, false>(ctx, gs, sh, tab, total, 0, 0, 0, seq, nullptr, 0, nullptr, keys, vals);
+    else rc = seedpass_impl<uint64_t, false>(ctx, gs, sh, tab, total, 0, 0, 0, seq, nullptr, 0, nullptr, keys, vals);
     if (rc) return rc;
     // vals carry global window indices; make them local to the genome
     for (auto &v : *vals) v = ((v & 0x7fffffffu) - tab.gpos_off[seq]) | (v & 0x80000000u);

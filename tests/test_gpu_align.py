@@ -1,0 +1,197 @@
+"""GPU parity tests of the batched DP kernel and of the whole path (mauve_align) against the CPU oracle and the
+golden fixtures.  Integer scores and alignment columns must match bit-exactly."""
+import os
+
+import numpy as np
+import pytest
+
+from mauvealigner_amd import synth
+from oracle import pyoracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from mauvealigner_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _rand_interval(rng, nseq, L, div, empty_prob=0.15):
+    base = rng.integers(0, 4, L, dtype=np.uint8)
+    out = []
+    for _ in range(nseq):
+        if rng.random() < empty_prob:
+            out.append(np.zeros(0, np.uint8))
+        else:
+            out.append(synth.mutate(base, div, rng, indel_frac=0.3))
+    return out
+
+
+def _check_dp(ctx, intervals):
+    cols, score = ctx.dp_batch(intervals)
+    for iv, c, s in zip(intervals, cols, score):
+        ec, es = O.align_interval(iv)
+        assert len(c) == len(ec)
+        assert np.array_equal(c, ec)
+        assert int(s) == es
+
+
+def test_dp_small_intervals(ctx):
+    rng = np.random.default_rng(1)
+    for nseq in (2, 3, 5):
+        ivs = [_rand_interval(rng, nseq, int(rng.integers(1, 40)), 0.15) for _ in range(300)]
+        _check_dp(ctx, ivs)
+
+
+def test_dp_known_answers(ctx):
+    A, C_, G, T = 0, 1, 2, 3
+    s = np.array([A, C_, G, T, A, C_, G, T], dtype=np.uint8)
+    cols, score = ctx.dp_batch([[s, s.copy()], [s, np.delete(s, 3)], [s, np.delete(s, [3, 4])],
+                                [np.zeros(0, np.uint8), s], [s, np.zeros(0, np.uint8)],
+                                [np.array([A, A, A], np.uint8), np.array([A, G, A], np.uint8)]])
+    assert score.tolist() == [764, 764 - 91 - 400, 764 - 182 - 430, 0, 0, 91 - 31 + 91]
+    assert cols[0].tolist() == [3] * 8
+    assert sorted(cols[1].tolist()) == [1] + [3] * 7
+    assert cols[3].tolist() == [2] * 8 and cols[4].tolist() == [1] * 8
+    assert cols[5].tolist() == [3, 3, 3]
+
+
+def test_dp_multi_stripe_and_ragged(ctx):
+    rng = np.random.default_rng(2)
+    ivs, ivs4 = [], []
+    for L in (63, 64, 65, 128, 129, 200, 500):
+        ivs.append(_rand_interval(rng, 2, L, 0.1, empty_prob=0.0))
+        ivs4.append(_rand_interval(rng, 4, L, 0.2, empty_prob=0.1))
+    _check_dp(ctx, ivs4)
+    # very unequal lengths, single bases, all-empty interval
+    ivs.append([rng.integers(0, 4, 300, dtype=np.uint8), rng.integers(0, 4, 3, dtype=np.uint8)])
+    ivs.append([rng.integers(0, 4, 2, dtype=np.uint8), rng.integers(0, 4, 400, dtype=np.uint8)])
+    ivs.append([np.array([1], np.uint8), np.array([2], np.uint8)])
+    _check_dp(ctx, ivs)
+    ivs3 = [[np.zeros(0, np.uint8)] * 3, _rand_interval(rng, 3, 20, 0.1, 0.0), [np.zeros(0, np.uint8), np.array([3], np.uint8), np.zeros(0, np.uint8)]]
+    _check_dp(ctx, ivs3)
+
+
+def test_dp_many_sequences(ctx):
+    rng = np.random.default_rng(3)
+    ivs = [_rand_interval(rng, 12, int(rng.integers(5, 90)), 0.1) for _ in range(40)]
+    _check_dp(ctx, ivs)
+
+
+def test_dp_long_interval(ctx):
+    rng = np.random.default_rng(4)
+    _check_dp(ctx, [_rand_interval(rng, 2, 3000, 0.2, 0.0)])
+    _check_dp(ctx, [_rand_interval(rng, 3, 1500, 0.25, 0.0), _rand_interval(rng, 3, 700, 0.1, 0.0)])
+
+
+def _same_align(ctx, gs, **kw):
+    from mauvealigner_amd import _lib
+    ctx.set_genomes(gs)
+    names = ["g%d" % i for i in range(len(gs))]
+    r = ctx.align(_lib.default_params(**kw), names=names, want_xmfa=True)
+    e = O.align(gs, O.default_params(**kw), names=names, want_xmfa=True)
+    N = len(gs)
+    eml, ems = O.multiplicity_filter(e["mums"][0], e["mums"][1], N)
+    assert np.array_equal(r["mum_length"], eml) and np.array_equal(r["mum_start"], ems)
+    assert r["n_lcb"] == e["lcbs"]["n_lcb"]
+    assert np.array_equal(r["lcb_weight"], e["lcbs"]["weight"])
+    a = e["aln"]
+    assert np.array_equal(r["anchor_length"], a["anchor_length"])
+    assert np.array_equal(r["anchor_start"], a["anchor_start"])
+    assert np.array_equal(r["anchor_lcb"], a["anchor_lcb"])
+    assert r["n_iv"] == a["n_iv"]
+    assert np.array_equal(r["left"], a["left"]) and np.array_equal(r["right"], a["right"])
+    assert np.array_equal(r["reverse"], a["reverse"])
+    assert np.array_equal(r["col_off"], a["col_off"])
+    assert np.array_equal(r["cols"], a["cols"])
+    assert np.array_equal(r["dp_score"], a["dp_score"])
+    assert r["n_gap_dp"] == a["n_gap_dp"] and r["n_dp_cells"] == a["n_dp_cells"]
+    assert r["xmfa"] == e["xmfa"]
+    return r
+
+
+@pytest.mark.parametrize("name", ["g2x2k", "g3x5k_inv", "g5x3k_unique"])
+def test_golden_alignment(ctx, name):
+    from mauvealigner_amd import _lib
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    N = int(z["nseq"])
+    gs = [z["genome%d" % g] for g in range(N)]
+    ctx.set_genomes(gs)
+    r = ctx.align(_lib.default_params(seed_pattern=int(z["pattern"]), mode=int(z["mode"])),
+                  names=["g%d" % g for g in range(N)], want_xmfa=True)
+    assert np.array_equal(r["cols"], z["cols"]) and np.array_equal(r["col_off"], z["col_off"])
+    assert np.array_equal(r["left"], z["left"]) and np.array_equal(r["right"], z["right"])
+    assert np.array_equal(r["dp_score"], z["dp_score"])
+    assert np.array_equal(r["lcb_weight"], z["lcb_weight"])
+    assert np.array_equal(r["anchor_start"], z["anchor_start"])
+    with open(os.path.join(GOLDEN, name + ".xmfa")) as f:
+        assert f.read() == r["xmfa"]
+
+
+@pytest.mark.parametrize("cfg,scale", [("C1", 0.25), ("C2", 0.02), ("C3", 0.03), ("C4", 0.02)])
+def test_align_equals_oracle(ctx, cfg, scale):
+    gs = synth.make_config(cfg, scale=scale)
+    _same_align(ctx, gs, recursive=0)
+    _same_align(ctx, gs, recursive=1)
+
+
+def test_align_options(ctx):
+    gs = synth.make_config("C3", scale=0.02)
+    _same_align(ctx, gs, collinear=1)
+    _same_align(ctx, gs, gapped=0)
+    _same_align(ctx, gs, add_unaligned=0)
+    _same_align(ctx, gs, seed_weight=11, lcb_weight=500)
+    _same_align(ctx, gs, mode=1)
+    _same_align(ctx, gs, max_gapped_len=30)
+    _same_align(ctx, gs, seed_rank=1)
+
+
+def test_align_recursion_hyperdivergent(ctx):
+    rng = np.random.default_rng(21)
+    anc = rng.integers(0, 4, 60000, dtype=np.uint8)
+    gs = []
+    for g in range(3):
+        b = synth.mutate(anc, 0.01, rng)
+        if g:
+            b[10000:14000] = synth.mutate(b[10000:14000], 0.33, rng, indel_frac=0.0)[:4000]
+            b[30000:42000] = synth.mutate(b[30000:42000], 0.30, rng, indel_frac=0.0)[:12000]
+        gs.append(b)
+    gs[2] = gs[2].copy()
+    gs[2][25000:50000] = synth.revcomp(gs[2][25000:50000])
+    r1 = _same_align(ctx, gs, recursive=1)
+    r0 = _same_align(ctx, gs, recursive=0)
+    assert r1["n_anchor"] > r0["n_anchor"]
+
+
+def test_full_size_c2_properties(ctx):
+    """BASELINE config C2 (3 x 5 Mbp, weight 15) through the whole path: size-independent properties --
+    every base of every genome appears in exactly one interval, rows reproduce the genomes, determinism."""
+    from mauvealigner_amd import _lib
+    gs = synth.make_config("C2", scale=1.0)
+    ctx.set_genomes(gs)
+    p = _lib.default_params(seed_weight=15)
+    r = ctx.align(p)
+    r2 = ctx.align(p)
+    for k in ("cols", "col_off", "left", "right", "anchor_start", "dp_score"):
+        assert np.array_equal(r[k], r2[k])
+    N = len(gs)
+    assert r["n_lcb"] == 1
+    cols, off = r["cols"], r["col_off"]
+    for g in range(N):
+        cover = np.zeros(len(gs[g]), np.int32)
+        for iv in range(r["n_iv"]):
+            le, re = r["left"][iv, g], r["right"][iv, g]
+            n_res = int(((cols[off[iv]:off[iv + 1]] >> g) & 1).sum())
+            if le == 0:
+                assert n_res == 0
+                continue
+            assert n_res == re - le + 1
+            cover[le - 1:re] += 1
+        assert np.all(cover == 1)
+    lcb_cols = cols[off[0]:off[1]]
+    assert np.mean(lcb_cols == 7) > 0.9
+    assert r["n_dp_cells"] > 0
