@@ -11,50 +11,89 @@
 #include <numeric>
 #include <set>
 
-void host_eliminate_overlaps(int N, std::vector<HMatch> &m)
+namespace {
+// stable LSD radix sort of packed (left end << 32 | index) keys by the left end: 3 passes of 11 bits.
+// Indices enter in ascending order, so ties keep index order -- the (left, index) order of the spec.
+void sort_by_left(std::vector<uint64_t> &k, std::vector<uint64_t> &tmp)
 {
+    const size_t n = k.size();
+    if (n < 2) return;
+    bool sorted = true;
+    for (size_t i = 1; i < n && sorted; i++) sorted = (k[i - 1] >> 32) <= (k[i] >> 32);
+    if (sorted) return;
+    tmp.resize(n);
+    uint64_t *src = k.data(), *dst = tmp.data();
+    for (int pass = 0; pass < 3; pass++) {
+        const int sh = 32 + 11 * pass;
+        uint32_t cnt[2049] = {0};
+        for (size_t i = 0; i < n; i++) cnt[((src[i] >> sh) & 2047) + 1]++;
+        for (int b = 0; b < 2048; b++) cnt[b + 1] += cnt[b];
+        for (size_t i = 0; i < n; i++) dst[cnt[(src[i] >> sh) & 2047]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != k.data()) std::copy(src, src + n, k.data());
+}
+}  // namespace
+
+void MatchVec::sort_by_start0()
+{
+    const size_t n = size();
+    std::vector<uint64_t> key(n), tmp;
+    for (size_t i = 0; i < n; i++) key[i] = ((uint64_t)std::llabs(st(i)[0]) << 32) | (uint64_t)i;
+    sort_by_left(key, tmp);
+    std::vector<int64_t> nd(d.size());
+    for (size_t r = 0; r < n; r++) std::copy(rec((uint32_t)key[r]), rec((uint32_t)key[r]) + 1 + N, nd.begin() + r * (1 + N));
+    d.swap(nd);
+}
+
+void host_eliminate_overlaps(MatchVec &m)
+{
+    const int N = m.N;
     const size_t n = m.size();
     if (n < 2) return;
     std::vector<uint8_t> alive(n, 1);
-    std::vector<uint32_t> ord; ord.reserve(n);
-    std::vector<int64_t> cf(n), cl(n);
+    std::vector<uint64_t> key, tmp; key.reserve(n);
+    std::vector<int64_t> cf(n), cl(n), lenv(n), leftv(n);
+    std::vector<int8_t> fwd(n);
     for (int g = 0; g < N; g++) {
         for (;;) {
-            ord.clear();
-            for (size_t i = 0; i < n; i++) if (alive[i]) ord.push_back((uint32_t)i);
-            std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
-                int64_t x = std::llabs(m[a].st[g]), y = std::llabs(m[b].st[g]);
-                return x != y ? x < y : a < b;
-            });
+            key.clear();
+            for (size_t i = 0; i < n; i++) {
+                if (!alive[i]) continue;
+                leftv[i] = std::llabs(m.st(i)[g]); lenv[i] = m.len(i); fwd[i] = m.st(i)[g] > 0;
+                key.push_back(((uint64_t)leftv[i] << 32) | (uint64_t)i);
+            }
+            sort_by_left(key, tmp);
             bool any = false;
-            for (size_t r = 0; r + 1 < ord.size(); r++) {
-                uint32_t A = ord[r], B = ord[r + 1];
-                int64_t ov = std::llabs(m[A].st[g]) + m[A].len - std::llabs(m[B].st[g]);
+            for (size_t r = 0; r + 1 < key.size(); r++) {
+                const uint32_t A = (uint32_t)key[r], B = (uint32_t)key[r + 1];
+                const int64_t ov = leftv[A] + lenv[A] - leftv[B];
                 if (ov <= 0) continue;
                 if (!any) { std::fill(cf.begin(), cf.end(), 0); std::fill(cl.begin(), cl.end(), 0); any = true; }
-                if (m[A].len < m[B].len) {            // A gives up its right side in g
-                    int64_t &c = m[A].st[g] > 0 ? cl[A] : cf[A];
+                if (lenv[A] < lenv[B]) {              // A gives up its right side in g
+                    int64_t &c = fwd[A] ? cl[A] : cf[A];
                     c = std::max(c, ov);
                 } else {                               // B gives up its left side in g
-                    int64_t &c = m[B].st[g] > 0 ? cf[B] : cl[B];
+                    int64_t &c = fwd[B] ? cf[B] : cl[B];
                     c = std::max(c, ov);
                 }
             }
             if (!any) break;
-            for (uint32_t i : ord) {
+            for (uint64_t kk : key) {
+                const uint32_t i = (uint32_t)kk;
                 if (!cf[i] && !cl[i]) continue;
-                int64_t nl = m[i].len - cf[i] - cl[i];
+                int64_t nl = m.len(i) - cf[i] - cl[i];
                 if (nl <= 0) { alive[i] = 0; continue; }
                 for (int c = 0; c < N; c++) {
-                    if (m[i].st[c] > 0) m[i].st[c] += cf[i];
-                    else m[i].st[c] -= cl[i];
+                    if (m.st(i)[c] > 0) m.st(i)[c] += cf[i];
+                    else m.st(i)[c] -= cl[i];
                 }
-                m[i].len = nl;
+                m.len(i) = nl;
             }
         }
     }
     size_t k = 0;
-    for (size_t i = 0; i < n; i++) if (alive[i]) m[k++] = m[i];
+    for (size_t i = 0; i < n; i++) if (alive[i]) m.move(k++, i);
     m.resize(k);
 }
 
@@ -67,22 +106,22 @@ struct Node {
 };
 }
 
-void host_lcb_chain(int N, const std::vector<HMatch> &m, int64_t min_weight, bool collinear,
-                    std::vector<int64_t> &match_lcb, int64_t &n_lcb)
+void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb)
 {
+    const int N = m.N;
     const size_t n = m.size();
     match_lcb.assign(n, -1);
     n_lcb = 0;
     if (n == 0) return;
     // per-genome order of the matches
     std::vector<std::vector<uint32_t>> order(N, std::vector<uint32_t>(n)), rank(N, std::vector<uint32_t>(n));
-    for (int g = 0; g < N; g++) {
-        std::iota(order[g].begin(), order[g].end(), 0u);
-        std::sort(order[g].begin(), order[g].end(), [&](uint32_t a, uint32_t b) {
-            int64_t x = std::llabs(m[a].st[g]), y = std::llabs(m[b].st[g]);
-            return x != y ? x < y : a < b;
-        });
-        for (uint32_t r = 0; r < n; r++) rank[g][order[g][r]] = r;
+    {
+        std::vector<uint64_t> key(n), tmp;
+        for (int g = 0; g < N; g++) {
+            for (size_t i = 0; i < n; i++) key[i] = ((uint64_t)std::llabs(m.st(i)[g]) << 32) | (uint64_t)i;
+            sort_by_left(key, tmp);
+            for (uint32_t r = 0; r < n; r++) { order[g][r] = (uint32_t)key[r]; rank[g][order[g][r]] = r; }
+        }
     }
     // initial nodes: maximal collinear runs in genome-0 order
     std::vector<int32_t> node_of(n);
@@ -94,7 +133,7 @@ void host_lcb_chain(int N, const std::vector<HMatch> &m, int64_t min_weight, boo
         if (join) {
             uint32_t p = order[0][k - 1];
             for (int g = 1; g < N && join; g++) {
-                bool oi = m[i].st[g] < 0, op = m[p].st[g] < 0;
+                bool oi = m.st(i)[g] < 0, op = m.st(p)[g] < 0;
                 if (oi != op) join = false;
                 else if (!oi) join = rank[g][i] == rank[g][p] + 1;
                 else join = rank[g][i] + 1 == rank[g][p];
@@ -102,7 +141,7 @@ void host_lcb_chain(int N, const std::vector<HMatch> &m, int64_t min_weight, boo
         }
         if (!join) { nodes.emplace_back(); nodes.back().prev.assign(N, -1); nodes.back().next.assign(N, -1); node_first.push_back(i); }
         node_of[i] = (int32_t)nodes.size() - 1;
-        nodes.back().weight += m[i].len * N;
+        nodes.back().weight += m.len(i) * N;
     }
     const int32_t K = (int32_t)nodes.size();
     // per-genome linked lists of nodes
@@ -117,7 +156,7 @@ void host_lcb_chain(int N, const std::vector<HMatch> &m, int64_t min_weight, boo
             last = nd;
         }
     }
-    auto orient = [&](int32_t nd, int g) { return m[node_first[nd]].st[g] < 0; };
+    auto orient = [&](int32_t nd, int g) { return m.st(node_first[nd])[g] < 0; };
     auto mergeable = [&](int32_t a, int32_t b) {   // b == next_0(a)
         for (int g = 1; g < N; g++) {
             bool oa = orient(a, g);
@@ -176,15 +215,15 @@ extern "C" {
 int mauve_eliminate_overlaps(int nseq, int64_t *n_inout, int64_t *length, int64_t *start)
 {
     if (nseq < 1 || nseq > MAUVE_MAX_SEQ || !n_inout || *n_inout < 0) return MAUVE_ERR_ARG;
-    std::vector<HMatch> m((size_t)*n_inout);
+    MatchVec m(nseq); m.resize((size_t)*n_inout);
     for (size_t i = 0; i < m.size(); i++) {
-        m[i].len = length[i];
-        for (int g = 0; g < nseq; g++) { m[i].st[g] = start[i * nseq + g]; if (!m[i].st[g]) return MAUVE_ERR_ARG; }
+        m.len(i) = length[i];
+        for (int g = 0; g < nseq; g++) { m.st(i)[g] = start[i * nseq + g]; if (!m.st(i)[g]) return MAUVE_ERR_ARG; }
     }
-    host_eliminate_overlaps(nseq, m);
+    host_eliminate_overlaps(m);
     for (size_t i = 0; i < m.size(); i++) {
-        length[i] = m[i].len;
-        for (int g = 0; g < nseq; g++) start[i * nseq + g] = m[i].st[g];
+        length[i] = m.len(i);
+        for (int g = 0; g < nseq; g++) start[i * nseq + g] = m.st(i)[g];
     }
     *n_inout = (int64_t)m.size();
     return MAUVE_OK;
@@ -196,13 +235,13 @@ int mauve_lcb_chain(int nseq, int64_t n, const int64_t *length, const int64_t *s
 {
     if (nseq < 1 || nseq > MAUVE_MAX_SEQ || n < 0 || !n_lcb_out) return MAUVE_ERR_ARG;
     const int N = nseq;
-    std::vector<HMatch> m((size_t)n);
+    MatchVec m(N); m.resize((size_t)n);
     for (int64_t i = 0; i < n; i++) {
-        m[i].len = length[i];
-        for (int g = 0; g < N; g++) { m[i].st[g] = start[i * N + g]; if (!m[i].st[g]) return MAUVE_ERR_ARG; }
+        m.len(i) = length[i];
+        for (int g = 0; g < N; g++) { m.st(i)[g] = start[i * N + g]; if (!m.st(i)[g]) return MAUVE_ERR_ARG; }
     }
     std::vector<int64_t> ml; int64_t K = 0;
-    host_lcb_chain(N, m, min_weight, collinear != 0, ml, K);
+    host_lcb_chain(m, min_weight, collinear != 0, ml, K);
     *n_lcb_out = K;
     if (match_lcb) std::copy(ml.begin(), ml.end(), match_lcb);
     if (left_end && right_end && weight) {
@@ -210,9 +249,9 @@ int mauve_lcb_chain(int nseq, int64_t n, const int64_t *length, const int64_t *s
         for (int64_t i = 0; i < K; i++) weight[i] = 0;
         for (int64_t i = 0; i < n; i++) {
             int64_t l = ml[i]; if (l < 0) continue;
-            weight[l] += m[i].len * N;
+            weight[l] += m.len(i) * N;
             for (int g = 0; g < N; g++) {
-                int64_t s = m[i].st[g], le = std::llabs(s), re = le + m[i].len - 1;
+                int64_t s = m.st(i)[g], le = std::llabs(s), re = le + m.len(i) - 1;
                 int64_t &L = left_end[l * N + g], &R = right_end[l * N + g];
                 if (L == 0 || le < std::llabs(L)) L = s < 0 ? -le : le;
                 if (R == 0 || re > std::llabs(R)) R = s < 0 ? -re : re;

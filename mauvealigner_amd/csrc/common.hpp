@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <algorithm>
 
 #include "../../include/mauve_hip.h"
 
@@ -97,7 +98,7 @@ struct mauve_ctx {
     int64_t n_matches = 0;
 
     // DP workspace
-    DevBuf dp_codes, dp_off, dp_prof_cnt, dp_prof_mask, dp_prof2_cnt, dp_prof2_mask, dp_tb, dp_meta, dp_score,
+    DevBuf dp_desc, dp_codes, dp_off, dp_prof_cnt, dp_prof_mask, dp_prof2_cnt, dp_prof2_mask, dp_tb, dp_meta, dp_score,
         dp_cols, dp_rows;
 
     // profiling
@@ -144,11 +145,31 @@ int seedpass_sorted_list(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t 
                          std::vector<uint32_t> *vals, int *weight);
 
 // host chaining (chain_host.cpp)
-struct HMatch { int64_t len; int64_t st[MAUVE_MAX_SEQ]; };
-void host_eliminate_overlaps(int N, std::vector<HMatch> &m);
-void host_lcb_chain(int N, const std::vector<HMatch> &m, int64_t min_weight, bool collinear,
-                    std::vector<int64_t> &match_lcb, int64_t &n_lcb);
+// N-way match list in flat records of (1 + N) int64: length, signed 1-based starts (libMems Match layout).
+struct MatchVec {
+    int N = 0;
+    std::vector<int64_t> d;
+    explicit MatchVec(int n = 0) : N(n) {}
+    size_t size() const { return d.size() / (size_t)(1 + N); }
+    bool empty() const { return d.empty(); }
+    int64_t &len(size_t i) { return d[i * (1 + N)]; }
+    int64_t len(size_t i) const { return d[i * (1 + N)]; }
+    int64_t *st(size_t i) { return &d[i * (1 + N) + 1]; }
+    const int64_t *st(size_t i) const { return &d[i * (1 + N) + 1]; }
+    const int64_t *rec(size_t i) const { return &d[i * (1 + N)]; }
+    void push(const int64_t *r) { d.insert(d.end(), r, r + 1 + N); }
+    void push(int64_t l, const int64_t *starts) { d.push_back(l); d.insert(d.end(), starts, starts + N); }
+    void resize(size_t n) { d.resize(n * (1 + N)); }
+    void move(size_t dst, size_t src) { if (dst != src) std::copy(d.begin() + src * (1 + N), d.begin() + (src + 1) * (1 + N), d.begin() + dst * (1 + N)); }
+    void reserve(size_t n) { d.reserve(n * (1 + N)); }
+    void sort_by_start0();
+};
+void host_eliminate_overlaps(MatchVec &m);
+void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb);
 
 // DP (dp_batch.hip)
+struct DpSeqDesc { int32_t genome; int32_t rev; int64_t lo0; int64_t len; };   // lo0: 0-based left end in the genome
+int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *sc,
+                      uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells);
 int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,
                  const mauve_scoring *sc, uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells);

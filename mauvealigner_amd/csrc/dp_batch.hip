@@ -195,8 +195,33 @@ __global__ void __launch_bounds__(256) dp_gather(int nseq, int64_t n_iv, const i
     }
 }
 
-int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,
-                 const mauve_scoring *scoring, uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells)
+// bases of the interval sequences, gathered on the device from the resident packed genomes:
+// one wave per (interval, genome) descriptor; reverse descriptors are reverse-complemented.
+struct DpGenomeWords { uint64_t word_off[MAUVE_MAX_SEQ]; };
+
+__global__ void __launch_bounds__(256) dp_gather_codes(const uint64_t *__restrict__ packed, DpGenomeWords gw,
+                                                       const DpSeqDesc *__restrict__ desc, const int64_t *__restrict__ seq_off,
+                                                       int64_t ndesc, uint8_t *__restrict__ codes)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t d = wave_global; d < ndesc; d += nwaves) {
+        const DpSeqDesc ds = desc[d];
+        const uint64_t *G = packed + gw.word_off[ds.genome];
+        uint8_t *out = codes + seq_off[d];
+        for (int64_t i = lane; i < ds.len; i += 64) {
+            const int64_t p = ds.rev ? ds.lo0 + ds.len - 1 - i : ds.lo0 + i;
+            const uint32_t b = (uint32_t)(G[p >> 5] >> (2 * (p & 31))) & 3u;
+            out[i] = (uint8_t)(ds.rev ? 3u - b : b);
+        }
+    }
+}
+
+// shared core: seq_off is a host array; the codes are either uploaded from `codes` or gathered from `desc`
+static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const DpSeqDesc *desc,
+                   const int64_t *seq_off, const mauve_scoring *scoring, uint32_t *cols, int64_t *col_off,
+                   int64_t *score, int64_t *cells)
 {
     if (cells) *cells = 0;
     col_off[0] = 0;
@@ -235,13 +260,24 @@ int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, c
     int64_t *d_tb_off = d_seq_off + (n_iv * nseq + 1);
     int64_t *d_rows_off = d_tb_off + (n_iv + 1);
     int64_t *d_col_off = d_rows_off + (n_iv + 1);
-    if (total) HIPCHK(ctx, hipMemcpyAsync(ctx->dp_codes.p, codes, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_seq_off, seq_off, (size_t)(n_iv * nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_tb_off, tb_off.data(), (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_rows_off, rows_off.data(), (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->dp_meta.p, 0, (size_t)n_iv * sizeof(DpMeta), ctx->stream));
-    DpScoring sc; sc.go = scoring->gap_open; sc.ge = scoring->gap_extend; memcpy(sc.s, scoring->matrix, sizeof sc.s);
     const uint32_t blocks = (uint32_t)std::min<int64_t>((n_iv + 3) / 4, 256 * 8);
+    if (desc) {
+        const int64_t nd = n_iv * nseq;
+        HIPCHK(ctx, ctx->dp_desc.ensure((size_t)nd * sizeof(DpSeqDesc)));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dp_desc.p, desc, (size_t)nd * sizeof(DpSeqDesc), hipMemcpyHostToDevice, ctx->stream));
+        DpGenomeWords gw; memset(&gw, 0, sizeof gw);
+        for (int g = 0; g < ctx->nseq; g++) gw.word_off[g] = ctx->word_off[g];
+        const uint32_t gb = (uint32_t)std::min<int64_t>((nd + 3) / 4, 256 * 8);
+        hipLaunchKernelGGL(dp_gather_codes, dim3(gb), dim3(256), 0, ctx->stream, ctx->genomes.as<uint64_t>(), gw,
+                           ctx->dp_desc.as<DpSeqDesc>(), d_seq_off, nd, ctx->dp_codes.as<uint8_t>());
+    } else if (total) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dp_codes.p, codes, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+    }
+    DpScoring sc; sc.go = scoring->gap_open; sc.ge = scoring->gap_extend; memcpy(sc.s, scoring->matrix, sizeof sc.s);
     for (int g = 0; g < nseq; g++) {
         KernelTimer t(ctx, MAUVE_K_DP, n_iv);
         hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, g, nseq, n_iv, ctx->dp_codes.as<uint8_t>(),
@@ -271,6 +307,22 @@ int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, c
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     return MAUVE_OK;
+}
+
+int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,
+                 const mauve_scoring *scoring, uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells)
+{
+    return dp_core(ctx, nseq, n_iv, codes, nullptr, seq_off, scoring, cols, col_off, score, cells);
+}
+
+int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *scoring,
+                      uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells)
+{
+    std::vector<int64_t> seq_off((size_t)(n_iv * nseq + 1));
+    int64_t t = 0;
+    for (int64_t i = 0; i < n_iv * nseq; i++) { seq_off[(size_t)i] = t; t += desc[i].len; }
+    seq_off[(size_t)(n_iv * nseq)] = t;
+    return dp_core(ctx, nseq, n_iv, nullptr, desc, seq_off.data(), scoring, cols, col_off, score, cells);
 }
 
 extern "C" int mauve_dp_batch(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,

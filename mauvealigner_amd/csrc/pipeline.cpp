@@ -15,33 +15,19 @@ namespace {
 
 inline uint8_t base_at(const std::vector<uint64_t> &w, int64_t i) { return (uint8_t)((w[(size_t)(i >> 5)] >> (2 * (i & 31))) & 3); }
 
-struct Gap {            // inter-anchor interval in LCB orientation
-    int64_t lo[MAUVE_MAX_SEQ];    // 1-based left end in genome coordinates
-    int64_t len[MAUVE_MAX_SEQ];
-    bool rev[MAUVE_MAX_SEQ];
-};
-
-void gap_between(int N, const HMatch &a, const HMatch &b, Gap &gp)
+// inter-anchor interval of genome g between anchors a (left in genome-0 order) and b, LCB orientation
+inline void gap_of(const int64_t *a, const int64_t *b, int g, int64_t &lo, int64_t &len, bool &rev)
 {
-    for (int g = 0; g < N; g++) {
-        int64_t lo, hi;
-        if (a.st[g] > 0) { lo = a.st[g] + a.len; hi = b.st[g] - 1; gp.rev[g] = false; }
-        else { lo = -b.st[g] + b.len; hi = -a.st[g] - 1; gp.rev[g] = true; }
-        gp.lo[g] = lo; gp.len[g] = std::max<int64_t>(0, hi - lo + 1);
-    }
-}
-
-void gap_codes(const mauve_ctx *c, const Gap &gp, int g, uint8_t *out)
-{
-    const auto &w = c->host_packed[g];
-    const int64_t lo0 = gp.lo[g] - 1, n = gp.len[g];
-    if (!gp.rev[g]) for (int64_t i = 0; i < n; i++) out[i] = base_at(w, lo0 + i);
-    else for (int64_t i = 0; i < n; i++) out[i] = (uint8_t)(3 - base_at(w, lo0 + n - 1 - i));
+    const int64_t sa = a[1 + g], sb = b[1 + g];
+    int64_t hi;
+    if (sa > 0) { lo = sa + a[0]; hi = sb - 1; rev = false; }
+    else { lo = -sb + b[0]; hi = -sa - 1; rev = true; }
+    len = hi - lo + 1; if (len < 0) len = 0;
 }
 
 }  // namespace
 
-int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector<std::vector<HMatch>> &chains);
+int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector<MatchVec> &chains);
 
 extern "C" {
 
@@ -72,21 +58,21 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     c->stage.seed_ms = t1 - t0;
 
     // ---- chaining ----
-    std::vector<HMatch> m((size_t)nm);
+    MatchVec m(N); m.resize((size_t)nm);
     for (int64_t i = 0; i < nm; i++) {
-        m[i].len = c->match_len[i];
-        for (int g = 0; g < N; g++) m[i].st[g] = c->match_start[(size_t)i * N + g];
+        m.len((size_t)i) = c->match_len[(size_t)i];
+        std::copy(&c->match_start[(size_t)i * N], &c->match_start[(size_t)i * N] + N, m.st((size_t)i));
     }
-    host_eliminate_overlaps(N, m);
+    host_eliminate_overlaps(m);
     const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight : (int64_t)3 * w * N;
     std::vector<int64_t> match_lcb; int64_t nl = 0;
-    host_lcb_chain(N, m, lcbw, p->collinear != 0, match_lcb, nl);
-    std::vector<std::vector<HMatch>> chains((size_t)nl);
+    host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl);
+    std::vector<MatchVec> chains((size_t)nl, MatchVec(N));
     R.lcb_weight.assign((size_t)nl, 0);
     for (size_t i = 0; i < m.size(); i++) {
         int64_t l = match_lcb[i]; if (l < 0) continue;
-        chains[(size_t)l].push_back(m[i]);            // m is sorted by genome-0 start (canonical order)
-        R.lcb_weight[(size_t)l] += m[i].len * N;
+        chains[(size_t)l].push(m.rec(i));              // m is sorted by genome-0 start (canonical order)
+        R.lcb_weight[(size_t)l] += m.len(i) * N;
     }
     const double t2 = now_ms();
     c->stage.chain_ms = t2 - t1;
@@ -100,67 +86,85 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     c->stage.recurse_ms = t3 - t2;
 
     // ---- gapped alignment of every inter-anchor interval ----
-    struct GapRef { int64_t lcb, idx; Gap gp; bool dp; int64_t dp_slot; };
+    // Interval descriptors only: the bases are gathered from the resident packed genomes on the device.
+    struct GapRef { int64_t lcb, idx; bool dp; int64_t dp_slot; int64_t tot; };
     std::vector<GapRef> gaps;
-    std::vector<int64_t> seq_off; seq_off.push_back(0);
-    int64_t n_dp = 0, code_total = 0;
+    std::vector<DpSeqDesc> desc;
+    int64_t n_dp = 0, code_total = 0, n_anchor = 0, anchor_cols = 0;
     for (int64_t l = 0; l < nl; l++) {
-        auto &ch = chains[(size_t)l];
-        for (size_t i = 0; i + 1 < ch.size(); i++) {
-            GapRef gr; gr.lcb = l; gr.idx = (int64_t)i; gr.dp = false; gr.dp_slot = -1;
-            gap_between(N, ch[i], ch[i + 1], gr.gp);
+        const MatchVec &ch = chains[(size_t)l];
+        n_anchor += (int64_t)ch.size();
+        for (size_t i = 0; i < ch.size(); i++) {
+            anchor_cols += ch.len(i);
+            if (i + 1 == ch.size()) break;
             int64_t tot = 0, mx = 0; int nonempty = 0;
-            for (int g = 0; g < N; g++) { tot += gr.gp.len[g]; mx = std::max(mx, gr.gp.len[g]); nonempty += gr.gp.len[g] > 0; }
+            int64_t lo[MAUVE_MAX_SEQ], ln[MAUVE_MAX_SEQ]; bool rv[MAUVE_MAX_SEQ];
+            for (int g = 0; g < N; g++) {
+                gap_of(ch.rec(i), ch.rec(i + 1), g, lo[g], ln[g], rv[g]);
+                tot += ln[g]; mx = std::max(mx, ln[g]); nonempty += ln[g] > 0;
+            }
             if (tot == 0) continue;
+            GapRef gr; gr.lcb = l; gr.idx = (int64_t)i; gr.dp = false; gr.dp_slot = -1; gr.tot = tot;
             if (p->gapped && nonempty >= 2 && mx <= p->max_gapped_len) {
                 gr.dp = true; gr.dp_slot = n_dp++;
-                for (int g = 0; g < N; g++) { code_total += gr.gp.len[g]; seq_off.push_back(code_total); }
+                for (int g = 0; g < N; g++) {
+                    DpSeqDesc d; d.genome = g; d.rev = rv[g]; d.lo0 = lo[g] - 1; d.len = ln[g];
+                    desc.push_back(d);
+                }
+                code_total += tot;
             }
             gaps.push_back(gr);
         }
     }
-    std::vector<uint8_t> codes((size_t)code_total + 1);
-    for (const GapRef &gr : gaps) {
-        if (!gr.dp) continue;
-        for (int g = 0; g < N; g++) gap_codes(c, gr.gp, g, codes.data() + seq_off[(size_t)gr.dp_slot * N + g]);
-    }
     std::vector<uint32_t> dcols((size_t)code_total + 1);
     std::vector<int64_t> dcol_off((size_t)n_dp + 1, 0), dscore((size_t)n_dp + 1, 0);
     int64_t cells = 0;
-    rc = dp_batch_run(c, N, n_dp, codes.data(), seq_off.data(), &p->scoring, dcols.data(), dcol_off.data(), dscore.data(), &cells);
+    rc = dp_batch_run_desc(c, N, n_dp, desc.data(), &p->scoring, dcols.data(), dcol_off.data(), dscore.data(), &cells);
     if (rc) return rc;
     const double t4 = now_ms();
     c->stage.dp_ms = t4 - t3;
 
     // ---- assemble the interval table ----
+    int64_t unaligned_cols = 0;
+    for (const GapRef &gr : gaps) if (!gr.dp) unaligned_cols += gr.tot;
     R.col_off.clear(); R.cols.clear();
-    int64_t n_anchor = 0; for (auto &ch : chains) n_anchor += (int64_t)ch.size();
+    R.cols.reserve((size_t)(anchor_cols + dcol_off[(size_t)n_dp] + unaligned_cols + (p->add_unaligned ? sum : 0)));
     R.anchor_length.reserve((size_t)n_anchor); R.anchor_start.reserve((size_t)n_anchor * N); R.anchor_lcb.reserve((size_t)n_anchor);
     R.lcb_left.assign((size_t)nl * N, 0); R.lcb_right.assign((size_t)nl * N, 0);
     R.dp_score.assign((size_t)nl, 0);
     size_t gi = 0;
     for (int64_t l = 0; l < nl; l++) {
-        auto &ch = chains[(size_t)l];
+        const MatchVec &ch = chains[(size_t)l];
         R.col_off.push_back((int64_t)R.cols.size());
         for (size_t i = 0; i < ch.size(); i++) {
-            const HMatch &a = ch[i];
-            R.anchor_length.push_back(a.len); R.anchor_lcb.push_back(l);
-            for (int g = 0; g < N; g++) R.anchor_start.push_back(a.st[g]);
-            R.cols.insert(R.cols.end(), (size_t)a.len, full);
+            const int64_t alen = ch.len(i); const int64_t *ast = ch.st(i);
+            R.anchor_length.push_back(alen); R.anchor_lcb.push_back(l);
+            R.anchor_start.insert(R.anchor_start.end(), ast, ast + N);
+            R.cols.insert(R.cols.end(), (size_t)alen, full);
             if (gi < gaps.size() && gaps[gi].lcb == l && gaps[gi].idx == (int64_t)i) {
                 const GapRef &gr = gaps[gi++];
                 if (gr.dp) {
                     R.cols.insert(R.cols.end(), dcols.begin() + dcol_off[(size_t)gr.dp_slot], dcols.begin() + dcol_off[(size_t)gr.dp_slot + 1]);
                     R.dp_score[(size_t)l] += dscore[(size_t)gr.dp_slot];
                 } else {
-                    for (int g = 0; g < N; g++) R.cols.insert(R.cols.end(), (size_t)gr.gp.len[g], 1u << g);
+                    for (int g = 0; g < N; g++) {
+                        int64_t lo, ln; bool rv;
+                        gap_of(ch.rec(i), ch.rec(i + 1), g, lo, ln, rv);
+                        R.cols.insert(R.cols.end(), (size_t)ln, 1u << g);
+                    }
                 }
             }
+        }
+        // LCB extent: anchors are ordered, so the ends come from the first and last anchor
+        if (ch.size()) {
+            const size_t last = ch.size() - 1;
             for (int g = 0; g < N; g++) {
-                int64_t le = std::llabs(a.st[g]), re = le + a.len - 1;
-                int64_t &L = R.lcb_left[(size_t)l * N + g], &Rr = R.lcb_right[(size_t)l * N + g];
-                if (L == 0 || le < std::llabs(L)) L = a.st[g] < 0 ? -le : le;
-                if (Rr == 0 || re > std::llabs(Rr)) Rr = a.st[g] < 0 ? -re : re;
+                const int64_t s0 = ch.st(0)[g], s1 = ch.st(last)[g];
+                int64_t le, re;
+                if (s0 > 0) { le = s0; re = s1 + ch.len(last) - 1; }
+                else { le = -s1; re = -s0 + ch.len(0) - 1; }
+                R.lcb_left[(size_t)l * N + g] = s0 < 0 ? -le : le;
+                R.lcb_right[(size_t)l * N + g] = s0 < 0 ? -re : re;
             }
         }
     }

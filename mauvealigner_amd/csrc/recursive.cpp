@@ -16,75 +16,97 @@ namespace {
 
 inline uint8_t base_at(const std::vector<uint64_t> &w, int64_t i) { return (uint8_t)((w[(size_t)(i >> 5)] >> (2 * (i & 31))) & 3); }
 
-struct RGap {
-    int64_t lcb;
-    HMatch a, b;
-    int prev_w;
-    int64_t lo[MAUVE_MAX_SEQ], len[MAUVE_MAX_SEQ];
+// A gap waiting for a recursive search: flat record [lcb, prev_w, a(1+N), b(1+N)] in `work`.
+struct WorkList {
+    int N; std::vector<int64_t> d;
+    explicit WorkList(int n) : N(n) {}
+    size_t rec() const { return 2 + 2 * (size_t)(1 + N); }
+    size_t size() const { return d.size() / rec(); }
+    void push(int64_t lcb, int prev_w, const int64_t *a, const int64_t *b)
+    {
+        d.push_back(lcb); d.push_back(prev_w); d.insert(d.end(), a, a + 1 + N); d.insert(d.end(), b, b + 1 + N);
+    }
+    int64_t lcb(size_t i) const { return d[i * rec()]; }
+    int prev_w(size_t i) const { return (int)d[i * rec() + 1]; }
+    const int64_t *a(size_t i) const { return &d[i * rec() + 2]; }
+    const int64_t *b(size_t i) const { return &d[i * rec() + 2 + 1 + N]; }
 };
 
-void measure(int N, RGap &r)
+inline void gap_of(const int64_t *a, const int64_t *b, int g, int64_t &lo, int64_t &len)
 {
+    const int64_t sa = a[1 + g], sb = b[1 + g];
+    int64_t hi;
+    if (sa > 0) { lo = sa + a[0]; hi = sb - 1; }
+    else { lo = -sb + b[0]; hi = -sa - 1; }
+    len = hi - lo + 1; if (len < 0) len = 0;
+}
+
+// which seed weight a gap wants at this level (0 = none), DESIGN.md S8
+inline int gap_weight(int N, const int64_t *a, const int64_t *b, int prev_w, int64_t min_gap)
+{
+    int64_t mx = 0, mn = -1, sum = 0;
     for (int g = 0; g < N; g++) {
-        int64_t lo, hi;
-        if (r.a.st[g] > 0) { lo = r.a.st[g] + r.a.len; hi = r.b.st[g] - 1; }
-        else { lo = -r.b.st[g] + r.b.len; hi = -r.a.st[g] - 1; }
-        r.lo[g] = lo; r.len[g] = std::max<int64_t>(0, hi - lo + 1);
+        int64_t lo, ln; gap_of(a, b, g, lo, ln);
+        mx = std::max(mx, ln); mn = mn < 0 ? ln : std::min(mn, ln); sum += ln;
     }
+    if (mx <= min_gap) return 0;
+    int w = mauve_default_seed_weight(sum / N);
+    if (w > prev_w - 2) w = prev_w - 2;
+    if (w < 5) return 0;
+    if (mn < mauve_seed_length(mauve_get_seed(w, 0))) return 0;
+    return w;
 }
 
 }  // namespace
 
-int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector<std::vector<HMatch>> &chains)
+int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector<MatchVec> &chains)
 {
     const int N = c->nseq;
     const uint32_t full = N >= 32 ? 0xffffffffu : ((1u << N) - 1);
-    std::vector<RGap> work;
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    WorkList work(N);
     for (size_t l = 0; l < chains.size(); l++)
-        for (size_t i = 0; i + 1 < chains[l].size(); i++) {
-            RGap r; r.lcb = (int64_t)l; r.a = chains[l][i]; r.b = chains[l][i + 1]; r.prev_w = w0;
-            work.push_back(r);
-        }
-    std::vector<std::vector<HMatch>> found(chains.size());
+        for (size_t i = 0; i + 1 < chains[l].size(); i++)
+            if (gap_weight(N, chains[l].rec(i), chains[l].rec(i + 1), w0, p->min_recursive_gap))
+                work.push((int64_t)l, w0, chains[l].rec(i), chains[l].rec(i + 1));
+    std::vector<MatchVec> found(chains.size(), MatchVec(N));
+    int level = 0;
 
-    while (!work.empty()) {
+    while (work.size()) {
         std::map<int, std::vector<size_t>> classes;     // seed weight -> gaps of this level
         for (size_t i = 0; i < work.size(); i++) {
-            RGap &r = work[i];
-            measure(N, r);
-            int64_t mx = 0, mn = -1, sum = 0;
-            for (int g = 0; g < N; g++) { mx = std::max(mx, r.len[g]); mn = mn < 0 ? r.len[g] : std::min(mn, r.len[g]); sum += r.len[g]; }
-            if (mx <= p->min_recursive_gap) continue;
-            int w = mauve_default_seed_weight(sum / N);
-            if (w > r.prev_w - 2) w = r.prev_w - 2;
-            if (w < 5) continue;
-            if (mn < mauve_seed_length(mauve_get_seed(w, 0))) continue;
-            classes[w].push_back(i);
+            int w = gap_weight(N, work.a(i), work.b(i), work.prev_w(i), p->min_recursive_gap);
+            if (w) classes[w].push_back(i);
         }
-        std::vector<RGap> next;
+        WorkList next(N);
+        level++;
         for (auto &cls : classes) {
             const int w = cls.first;
             const std::vector<size_t> &ids = cls.second;
             const uint32_t K = (uint32_t)ids.size();
+            const double tc0 = now_ms();
             const uint64_t pat = mauve_get_seed(w, 0);
             // ---- virtual genomes: per genome, the gap sub-sequences in LCB orientation, concatenated ----
             GenomeSet vs; vs.buf = &c->rec_genomes; vs.nseq = N; vs.lens.assign(N, 0); vs.word_off.assign(N, 0);
             std::vector<uint32_t> seg((size_t)N * (K + 1));
+            std::vector<int64_t> glo((size_t)N * K), glen((size_t)N * K);
             std::vector<std::vector<uint64_t>> packed(N);
             size_t words = 0;
             for (int g = 0; g < N; g++) {
                 int64_t tot = 0;
-                for (uint32_t k = 0; k < K; k++) { seg[(size_t)g * (K + 1) + k] = (uint32_t)tot; tot += work[ids[k]].len[g]; }
+                for (uint32_t k = 0; k < K; k++) {
+                    gap_of(work.a(ids[k]), work.b(ids[k]), g, glo[(size_t)g * K + k], glen[(size_t)g * K + k]);
+                    seg[(size_t)g * (K + 1) + k] = (uint32_t)tot; tot += glen[(size_t)g * K + k];
+                }
                 seg[(size_t)g * (K + 1) + K] = (uint32_t)tot;
                 if (tot >= (1LL << 31)) { c->err = "recursive anchoring: gap set too large"; return MAUVE_ERR_LIMIT; }
                 vs.lens[g] = tot;
                 std::vector<uint8_t> codes((size_t)tot + 1);
                 const auto &hw = c->host_packed[g];
                 for (uint32_t k = 0; k < K; k++) {
-                    const RGap &r = work[ids[k]];
                     uint8_t *out = codes.data() + seg[(size_t)g * (K + 1) + k];
-                    const int64_t lo0 = r.lo[g] - 1, n = r.len[g];
-                    if (r.a.st[g] > 0) for (int64_t i = 0; i < n; i++) out[i] = base_at(hw, lo0 + i);
+                    const int64_t lo0 = glo[(size_t)g * K + k] - 1, n = glen[(size_t)g * K + k];
+                    if (work.a(ids[k])[1 + g] > 0) for (int64_t i = 0; i < n; i++) out[i] = base_at(hw, lo0 + i);
                     else for (int64_t i = 0; i < n; i++) out[i] = (uint8_t)(3 - base_at(hw, lo0 + n - 1 - i));
                 }
                 packed[g].assign(mauve_packed_words(tot), 0);
@@ -101,57 +123,57 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
             int64_t nm = 0;
             int rc = seedpass_run(c, vs, pat, MAUVE_MODE_MEM, full, 1, c->rec_seg.as<uint32_t>(), K, &nm);
             if (rc) return rc;
+            if (trace) fprintf(stderr, "[trace] recursion level %d weight %d: %u gaps, %lld bases, %lld matches, %.3f ms\n", level, w, K,
+                               (long long)vs.lens[0], (long long)nm, now_ms() - tc0);
             // ---- per-gap chaining of the N-way forward matches ----
             const uint32_t *seg0 = seg.data();
             int64_t i = 0;
             while (i < nm) {
                 const int64_t s0 = c->match_start[(size_t)i * N];      // genome 0 is always forward
-                uint32_t k = (uint32_t)(std::upper_bound(seg0, seg0 + K + 1, (uint32_t)(s0 - 1)) - seg0) - 1;
-                std::vector<HMatch> loc;
+                const uint32_t k = (uint32_t)(std::upper_bound(seg0, seg0 + K + 1, (uint32_t)(s0 - 1)) - seg0) - 1;
+                MatchVec loc(N);
                 while (i < nm && (uint32_t)(c->match_start[(size_t)i * N] - 1) < seg0[k + 1]) {
                     bool fwd = true;
-                    HMatch h; h.len = c->match_len[(size_t)i];
+                    int64_t rec[1 + MAUVE_MAX_SEQ]; rec[0] = c->match_len[(size_t)i];
                     for (int g = 0; g < N; g++) {
                         int64_t s = c->match_start[(size_t)i * N + g];
                         if (s <= 0) { fwd = false; break; }
-                        h.st[g] = s - seg[(size_t)g * (K + 1) + k];        // 1-based inside the gap
+                        rec[1 + g] = s - seg[(size_t)g * (K + 1) + k];     // 1-based inside the gap
                     }
-                    if (fwd) loc.push_back(h);
+                    if (fwd) loc.push(rec);
                     i++;
                 }
                 if (loc.empty()) continue;
-                host_eliminate_overlaps(N, loc);
+                host_eliminate_overlaps(loc);
                 std::vector<int64_t> ml; int64_t nl = 0;
-                host_lcb_chain(N, loc, 0, true, ml, nl);
-                const RGap &r = work[ids[k]];
-                std::vector<HMatch> glob;
+                host_lcb_chain(loc, 0, true, ml, nl);
+                const size_t wi = ids[k];
+                const int64_t *A = work.a(wi);
+                MatchVec glob(N);
                 for (size_t q = 0; q < loc.size(); q++) {
                     if (ml[q] < 0) continue;
-                    HMatch x; x.len = loc[q].len;
+                    int64_t rec[1 + MAUVE_MAX_SEQ]; rec[0] = loc.len(q);
                     for (int g = 0; g < N; g++) {
-                        const int64_t s = loc[q].st[g];
-                        if (r.a.st[g] > 0) x.st[g] = r.lo[g] + s - 1;
-                        else { const int64_t hi = r.lo[g] + r.len[g] - 1; x.st[g] = -(hi - (s - 1) - x.len + 1); }
+                        const int64_t s = loc.st(q)[g], lo = glo[(size_t)g * K + k], ln = glen[(size_t)g * K + k];
+                        if (A[1 + g] > 0) rec[1 + g] = lo + s - 1;
+                        else { const int64_t hi = lo + ln - 1; rec[1 + g] = -(hi - (s - 1) - rec[0] + 1); }
                     }
-                    glob.push_back(x);
+                    glob.push(rec);
                 }
                 if (glob.empty()) continue;
-                std::sort(glob.begin(), glob.end(), [](const HMatch &x, const HMatch &y) { return x.st[0] < y.st[0]; });
-                for (size_t q = 0; q <= glob.size(); q++) {
-                    RGap sub; sub.lcb = r.lcb; sub.prev_w = w;
-                    sub.a = q == 0 ? r.a : glob[q - 1];
-                    sub.b = q == glob.size() ? r.b : glob[q];
-                    next.push_back(sub);
-                }
-                for (const HMatch &x : glob) found[(size_t)r.lcb].push_back(x);
+                glob.sort_by_start0();
+                const int64_t lcb = work.lcb(wi);
+                for (size_t q = 0; q <= glob.size(); q++)
+                    next.push(lcb, w, q == 0 ? work.a(wi) : glob.rec(q - 1), q == glob.size() ? work.b(wi) : glob.rec(q));
+                for (size_t q = 0; q < glob.size(); q++) found[(size_t)lcb].push(glob.rec(q));
             }
         }
-        work.swap(next);
+        work.d.swap(next.d);
     }
     for (size_t l = 0; l < chains.size(); l++) {
         if (found[l].empty()) continue;
-        chains[l].insert(chains[l].end(), found[l].begin(), found[l].end());
-        std::sort(chains[l].begin(), chains[l].end(), [](const HMatch &x, const HMatch &y) { return x.st[0] < y.st[0]; });
+        chains[l].d.insert(chains[l].d.end(), found[l].d.begin(), found[l].d.end());
+        chains[l].sort_by_start0();
     }
     return MAUVE_OK;
 }

@@ -14,6 +14,10 @@
 #include "common.hpp"
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
+
+static const bool g_trace = getenv("MAUVE_TRACE") != nullptr;
+#define TRACE(ctx, label) do { if (g_trace) { (void)hipStreamSynchronize((ctx)->stream); double t__ = now_ms(); fprintf(stderr, "[trace] %-22s +%.3f ms\n", label, t__ - trace_t0); trace_t0 = t__; } } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
@@ -252,6 +256,50 @@ __global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict_
 //   MODE_UNIQUE : UniqueMatchFinder.cpp:44-58 -- genomes with more than one copy are dropped, >= 2 stay
 // hit_pos[h*nseq+g] = global window index | strand << 31, 0xFFFFFFFF = absent.
 // ------------------------------------------------------------------------------------------------
+constexpr int JOIN_ITEMS = 8;
+constexpr int JOIN_TILE = 256 * JOIN_ITEMS;
+
+// block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix, *total
+// receives the block sum.  One global atomic per block instead of one per wave keeps the single output
+// counter far below its ~12 ns-per-atomic serial rate (MI355X_MICROARCH.md "fanin").
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *lds /*[8]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { uint32_t c = lds[w]; if (w < wave) wbase += c; tot += c; }
+    __syncthreads();
+    *total = tot;
+    return wbase + inc - v;
+}
+
+template <typename KeyT, bool SEG>
+__device__ __forceinline__ uint32_t run_hit_mask(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                 uint32_t n, uint32_t i, const GenomeTab &tab, int mode,
+                                                 uint32_t want_mask)
+{
+    if (i >= n) return 0;
+    KeyT k = keys[i];
+    if (SEG && k == (KeyT)~0ULL) return 0;
+    if (i > 0 && keys[i - 1] == k) return 0;
+    if (i + 1 >= n || keys[i + 1] != k) return 0;        // singleton run
+    uint32_t once = 0, multi = 0, j = i;
+    while (j < n && keys[j] == k) {
+        uint32_t bit = 1u << genome_of(vals[j] & 0x7fffffffu, tab);
+        multi |= once & bit; once |= bit; j++;
+    }
+    uint32_t m = once & ~multi;
+    if (mode == MAUVE_MODE_MEM && multi) return 0;
+    if (__popc(m) < 2) return 0;
+    if (want_mask && m != want_mask) return 0;
+    return m;
+}
+
 template <typename KeyT, bool SEG>
 __global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                 uint32_t n, GenomeTab tab, int mode, uint32_t want_mask,
@@ -259,30 +307,36 @@ __global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, c
                                                 uint32_t *__restrict__ hit_pos, uint32_t *__restrict__ hit_seg,
                                                 int key_shift, uint32_t *__restrict__ counters)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    KeyT k = keys[i];
-    if (SEG && k == (KeyT)~0ULL) return;
-    if (i > 0 && keys[i - 1] == k) return;
-    if (i + 1 >= n || keys[i + 1] != k) return;        // singleton run
-    uint32_t once = 0, multi = 0, j = i;
-    while (j < n && keys[j] == k) {
-        uint32_t bit = 1u << genome_of(vals[j] & 0x7fffffffu, tab);
-        multi |= once & bit; once |= bit; j++;
+    __shared__ uint32_t lds[8];
+    __shared__ uint32_t s_base;
+    const uint32_t base = blockIdx.x * JOIN_TILE;
+    uint32_t m[JOIN_ITEMS];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < JOIN_ITEMS; k++) {
+        m[k] = run_hit_mask<KeyT, SEG>(keys, vals, n, base + k * 256 + threadIdx.x, tab, mode, want_mask);
+        cnt += m[k] != 0;
     }
-    uint32_t m = once & ~multi;
-    if (mode == MAUVE_MODE_MEM && multi) return;
-    if (__popc(m) < 2) return;
-    if (want_mask && m != want_mask) return;
-    uint32_t h = atomicAdd(&counters[0], 1u);
-    hit_mask[h] = m;
-    if (SEG) hit_seg[h] = (uint32_t)((uint64_t)k >> key_shift);
-    uint32_t *hp = hit_pos + (size_t)h * tab.nseq;
-    for (int g = 0; g < tab.nseq; g++) hp[g] = 0xFFFFFFFFu;
-    for (uint32_t t = i; t < j; t++) {
-        uint32_t v = vals[t], gp = v & 0x7fffffffu;
-        int g = genome_of(gp, tab);
-        if (m >> g & 1) { hp[g] = v; posmask[gp] = m; }
+    uint32_t total;
+    uint32_t off = block_excl_scan(cnt, &total, lds);
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&counters[0], total) : 0u;
+    __syncthreads();
+    uint32_t h = s_base + off;
+#pragma unroll
+    for (int k = 0; k < JOIN_ITEMS; k++) {
+        if (!m[k]) continue;
+        const uint32_t i = base + k * 256 + threadIdx.x;
+        const KeyT key = keys[i];
+        hit_mask[h] = m[k];
+        if (SEG) hit_seg[h] = (uint32_t)((uint64_t)key >> key_shift);
+        uint32_t *hp = hit_pos + (size_t)h * tab.nseq;
+        for (int g = 0; g < tab.nseq; g++) hp[g] = 0xFFFFFFFFu;
+        for (uint32_t t = i; t < n && keys[t] == key; t++) {
+            uint32_t v = vals[t], gp = v & 0x7fffffffu;
+            int g = genome_of(gp, tab);
+            if (m[k] >> g & 1) { hp[g] = v; posmask[gp] = m[k]; }
+        }
+        h++;
     }
 }
 
@@ -330,6 +384,8 @@ __device__ __forceinline__ bool agree_at(const uint64_t *__restrict__ packed, co
 
 // phase A: thread per hit.  A hit whose nearest agreeing offset to the left (within span) is a
 // same-mask hit is certainly not the leftmost hit of its cluster; everything else is a candidate.
+constexpr int CAND_ITEMS = 4;
+
 template <bool SEG>
 __global__ void __launch_bounds__(256) mum_candidates(const uint64_t *__restrict__ packed, GenomeTab tab,
                                                       SeedShape sh, const uint32_t *__restrict__ hit_mask,
@@ -339,21 +395,36 @@ __global__ void __launch_bounds__(256) mum_candidates(const uint64_t *__restrict
                                                       const uint32_t *__restrict__ seg, uint32_t nseg,
                                                       const uint32_t *__restrict__ hit_seg)
 {
-    uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= nhit) return;
-    uint32_t mask = hit_mask[h];
-    const uint32_t *hp = hit_pos + (size_t)h * tab.nseq;
-    int anchor = __ffs(mask) - 1;
-    uint32_t agpos = hp[anchor] & 0x7fffffffu;
-    const uint32_t segid = SEG ? hit_seg[h] : 0u;
-    bool is_cand = true;
-    for (int d = 1; d <= sh.span; d++) {
-        if (agree_at<SEG>(packed, tab, sh, hp, mask, anchor, -(int64_t)d, seg, nseg, segid)) {
-            if (posmask[agpos - d] == mask) is_cand = false;
-            break;
+    __shared__ uint32_t lds[8];
+    __shared__ uint32_t s_base;
+    const uint32_t base = blockIdx.x * (256 * CAND_ITEMS);
+    uint32_t flags = 0, cnt = 0;
+#pragma unroll
+    for (int k = 0; k < CAND_ITEMS; k++) {
+        const uint32_t h = base + k * 256 + threadIdx.x;
+        if (h >= nhit) continue;
+        const uint32_t mask = hit_mask[h];
+        const uint32_t *hp = hit_pos + (size_t)h * tab.nseq;
+        const int anchor = __ffs(mask) - 1;
+        const uint32_t agpos = hp[anchor] & 0x7fffffffu;
+        const uint32_t segid = SEG ? hit_seg[h] : 0u;
+        bool is_cand = true;
+        for (int d = 1; d <= sh.span; d++) {
+            if (agree_at<SEG>(packed, tab, sh, hp, mask, anchor, -(int64_t)d, seg, nseg, segid)) {
+                if (posmask[agpos - d] == mask) is_cand = false;
+                break;
+            }
         }
+        if (is_cand) { flags |= 1u << k; cnt++; }
     }
-    if (is_cand) cand[atomicAdd(&counters[1], 1u)] = h;
+    uint32_t total;
+    uint32_t off = block_excl_scan(cnt, &total, lds);
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&counters[1], total) : 0u;
+    __syncthreads();
+    uint32_t o = s_base + off;
+#pragma unroll
+    for (int k = 0; k < CAND_ITEMS; k++)
+        if (flags >> k & 1) cand[o++] = base + k * 256 + threadIdx.x;
 }
 
 // phase B: one wave per candidate; the 64 lanes test 64 consecutive offsets at a time and the
@@ -400,7 +471,7 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
                 }
                 cur -= p;
             }
-            if (!leftmost) continue;
+            if (!leftmost) { if (lane == 0) mlen[ci] = 0; continue; }
             klo = cur;
             // ---- right walk ----
             cur = 0;
@@ -419,8 +490,8 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
             }
             khi = cur;
         }
-        if (lane == 0) {
-            uint32_t m = atomicAdd(&counters[2], 1u);
+        if (lane == 0) {          // record slot = candidate index (length 0 = not the leftmost hit): no atomics
+            const uint32_t m = ci;
             mlen[m] = (int32_t)(khi - klo) + sh.span;
             uint32_t sa = hp[anchor] >> 31;
             for (int g = 0; g < tab.nseq; g++) {
@@ -512,6 +583,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
                          int64_t *n_matches, std::vector<uint64_t> *out_keys, std::vector<uint32_t> *out_vals)
 {
     const uint32_t n = (uint32_t)total;
+    double trace_t0 = now_ms();
     HIPCHK(ctx, ctx->keysA.ensure((size_t)n * sizeof(KeyT)));
     HIPCHK(ctx, ctx->keysB.ensure((size_t)n * sizeof(KeyT)));
     HIPCHK(ctx, ctx->valsA.ensure((size_t)n * 4));
@@ -533,11 +605,13 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         sorted_n += nw;
     }
     HIPCHK(ctx, hipGetLastError());
+    TRACE(ctx, "extract");
     if (sorted_n == 0) { if (n_matches) *n_matches = 0; return MAUVE_OK; }
     // segmented keys: segment id above the mer; the all-ones invalid key needs every bit, so sort all 64
     const int key_bits = SEG ? 64 : 2 * sh.weight;
     int rc = sort_pairs<KeyT>(ctx, sorted_n, key_bits, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>());
     if (rc) return rc;
+    TRACE(ctx, "sort");
 
     if (out_keys) {   // sorted-mer-list export / SeedMatchEnumerator path: hand the sorted pairs to the host
         std::vector<KeyT> hk(sorted_n);
@@ -560,7 +634,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     HIPCHK(ctx, hipMemsetAsync(ctx->posmask.p, 0, (size_t)n * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
     { KernelTimer t(ctx, MAUVE_K_JOIN, n);
-      hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, n, tab, mode,
+      hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((n + JOIN_TILE - 1) / JOIN_TILE), dim3(256), 0, ctx->stream, keys, vals, n, tab, mode,
                          (uint32_t)mask, ctx->posmask.as<uint32_t>(), ctx->hit_mask.as<uint32_t>(),
                          ctx->hit_pos.as<uint32_t>(), ctx->hit_seg.as<uint32_t>(), 2 * sh.weight,
                          ctx->counters.as<uint32_t>()); }
@@ -569,6 +643,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t nhit = hc[0];
+    TRACE(ctx, "join");
     ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear();
     if (n_matches) *n_matches = 0;
     if (nhit == 0) return MAUVE_OK;
@@ -578,13 +653,14 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     uint32_t ncand = nhit;
     if (extend) {
         KernelTimer t(ctx, MAUVE_K_EXTEND, nhit);
-        hipLaunchKernelGGL((mum_candidates<SEG>), dim3((nhit + 255) / 256), dim3(256), 0, ctx->stream, packed, tab, sh,
+        hipLaunchKernelGGL((mum_candidates<SEG>), dim3((nhit + 256 * CAND_ITEMS - 1) / (256 * CAND_ITEMS)), dim3(256), 0, ctx->stream, packed, tab, sh,
                            ctx->hit_mask.as<uint32_t>(), ctx->hit_pos.as<uint32_t>(), ctx->posmask.as<uint32_t>(), nhit,
                            ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg, nseg, ctx->hit_seg.as<uint32_t>());
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         ncand = hc[1];
+        TRACE(ctx, "candidates");
     } else {
         // every hit is its own match: candidate list = identity
         std::vector<uint32_t> ident(nhit);
@@ -603,25 +679,26 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
                            ctx->counters.as<uint32_t>(), seg, nseg, ctx->hit_seg.as<uint32_t>());
         HIPCHK(ctx, hipGetLastError());
     }
-    HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t nm = hc[2];
-    // ---- copy out + canonical order (first component, |start|, mask, starts, length) ----
-    std::vector<int32_t> hl(nm), hs((size_t)nm * N);
-    if (nm) {
-        HIPCHK(ctx, hipMemcpyAsync(hl.data(), ctx->mlen.p, (size_t)nm * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(hs.data(), ctx->mstart.p, (size_t)nm * 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+    // ---- copy out (one record slot per candidate; length 0 = the candidate was not a leftmost hit) ----
+    std::vector<int32_t> hl(ncand), hs((size_t)ncand * N);
+    if (ncand) {
+        HIPCHK(ctx, hipMemcpyAsync(hl.data(), ctx->mlen.p, (size_t)ncand * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hs.data(), ctx->mstart.p, (size_t)ncand * 4 * N, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    std::vector<uint32_t> order(nm);
-    std::vector<uint64_t> k1(nm);      // (first component, |start|) packed for a fast first-level compare
-    for (uint32_t i = 0; i < nm; i++) {
-        order[i] = i;
+    TRACE(ctx, "extend+copy");
+    // ---- canonical order (first component, |start|, mask, starts, length) ----
+    std::vector<uint32_t> order; order.reserve(ncand);
+    std::vector<uint64_t> k1(ncand);   // (first component, |start|) packed for a fast first-level compare
+    for (uint32_t i = 0; i < ncand; i++) {
+        if (hl[i] == 0) continue;
+        order.push_back(i);
         const int32_t *s = &hs[(size_t)i * N];
         int f = 0; while (f < N && s[f] == 0) f++;
         uint64_t a = f < N ? (uint64_t)std::abs((int64_t)s[f]) : 0;
         k1[i] = ((uint64_t)f << 40) | a;
     }
+    const uint32_t nm = (uint32_t)order.size();
     std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         if (k1[x] != k1[y]) return k1[x] < k1[y];
         const int32_t *a = &hs[(size_t)x * N], *b = &hs[(size_t)y * N];
@@ -639,6 +716,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     }
     ctx->n_matches = nm;
     if (n_matches) *n_matches = nm;
+    TRACE(ctx, "canonical sort");
     return MAUVE_OK;
 }
 
