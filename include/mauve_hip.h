@@ -165,6 +165,7 @@ int mauve_write_xmfa(mauve_ctx *ctx, const char *const *names, char *buf, int64_
 #define MAUVE_K_JOIN 4
 #define MAUVE_K_EXTEND 5
 #define MAUVE_K_DP 6
+#define MAUVE_K_RUNS 7
 #define MAUVE_K_COUNT 8
 int mauve_profile_enable(mauve_ctx *ctx, int on);
 int mauve_profile_reset(mauve_ctx *ctx);

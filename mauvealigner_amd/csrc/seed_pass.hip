@@ -256,11 +256,8 @@ __global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict_
 //   MODE_UNIQUE : UniqueMatchFinder.cpp:44-58 -- genomes with more than one copy are dropped, >= 2 stay
 // hit_pos[h*nseq+g] = global window index | strand << 31, 0xFFFFFFFF = absent.
 // ------------------------------------------------------------------------------------------------
-constexpr int JOIN_ITEMS = 8;
-constexpr int JOIN_TILE = 256 * JOIN_ITEMS;
-
 // block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix, *total
-// receives the block sum.  One global atomic per block instead of one per wave keeps the single output
+// receives the block sum.  One global atomic per block instead of one per wave keeps a single output
 // counter far below its ~12 ns-per-atomic serial rate (MI355X_MICROARCH.md "fanin").
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *lds /*[8]*/)
 {
@@ -278,195 +275,172 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total,
     return wbase + inc - v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// mum_join: one thread per sorted entry; the thread at the first entry of a run of identical mers decides
+// the hit by the finder's rule and scatters the hit into the dense HIT TABLE, indexed by the global
+// window index of the hit's anchor (lowest genome of its component set):
+//   tmask[p]    = component set (0 = no hit anchored at p)
+//   tpos[g*P+p] = component g's window: global index | strand << 31
+//   MODE_MEM    : MemHash -- a genome with more than one copy kills the seed
+//   MODE_UNIQUE : UniqueMatchFinder.cpp:44-58 -- genomes with more than one copy are dropped, >= 2 stay
+// A position carries at most one mer, so at most one hit is anchored at it: no atomics, no compaction.
+// ------------------------------------------------------------------------------------------------
 template <typename KeyT, bool SEG>
-__device__ __forceinline__ uint32_t run_hit_mask(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                 uint32_t n, uint32_t i, const GenomeTab &tab, int mode,
-                                                 uint32_t want_mask)
+__global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                uint32_t n, GenomeTab tab, int mode, uint32_t want_mask,
+                                                uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos, uint32_t P)
 {
-    if (i >= n) return 0;
-    KeyT k = keys[i];
-    if (SEG && k == (KeyT)~0ULL) return 0;
-    if (i > 0 && keys[i - 1] == k) return 0;
-    if (i + 1 >= n || keys[i + 1] != k) return 0;        // singleton run
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const KeyT k = keys[i];
+    if (SEG && k == (KeyT)~0ULL) return;
+    if (i > 0 && keys[i - 1] == k) return;
+    if (i + 1 >= n || keys[i + 1] != k) return;        // singleton run
     uint32_t once = 0, multi = 0, j = i;
     while (j < n && keys[j] == k) {
         uint32_t bit = 1u << genome_of(vals[j] & 0x7fffffffu, tab);
         multi |= once & bit; once |= bit; j++;
     }
-    uint32_t m = once & ~multi;
-    if (mode == MAUVE_MODE_MEM && multi) return 0;
-    if (__popc(m) < 2) return 0;
-    if (want_mask && m != want_mask) return 0;
-    return m;
-}
-
-template <typename KeyT, bool SEG>
-__global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                uint32_t n, GenomeTab tab, int mode, uint32_t want_mask,
-                                                uint32_t *__restrict__ posmask, uint32_t *__restrict__ hit_mask,
-                                                uint32_t *__restrict__ hit_pos, uint32_t *__restrict__ hit_seg,
-                                                int key_shift, uint32_t *__restrict__ counters)
-{
-    __shared__ uint32_t lds[8];
-    __shared__ uint32_t s_base;
-    const uint32_t base = blockIdx.x * JOIN_TILE;
-    uint32_t m[JOIN_ITEMS];
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int k = 0; k < JOIN_ITEMS; k++) {
-        m[k] = run_hit_mask<KeyT, SEG>(keys, vals, n, base + k * 256 + threadIdx.x, tab, mode, want_mask);
-        cnt += m[k] != 0;
-    }
-    uint32_t total;
-    uint32_t off = block_excl_scan(cnt, &total, lds);
-    if (threadIdx.x == 0) s_base = total ? atomicAdd(&counters[0], total) : 0u;
-    __syncthreads();
-    uint32_t h = s_base + off;
-#pragma unroll
-    for (int k = 0; k < JOIN_ITEMS; k++) {
-        if (!m[k]) continue;
-        const uint32_t i = base + k * 256 + threadIdx.x;
-        const KeyT key = keys[i];
-        hit_mask[h] = m[k];
-        if (SEG) hit_seg[h] = (uint32_t)((uint64_t)key >> key_shift);
-        uint32_t *hp = hit_pos + (size_t)h * tab.nseq;
-        for (int g = 0; g < tab.nseq; g++) hp[g] = 0xFFFFFFFFu;
-        for (uint32_t t = i; t < n && keys[t] == key; t++) {
-            uint32_t v = vals[t], gp = v & 0x7fffffffu;
-            int g = genome_of(gp, tab);
-            if (m[k] >> g & 1) { hp[g] = v; posmask[gp] = m[k]; }
-        }
-        h++;
+    const uint32_t m = once & ~multi;
+    if (mode == MAUVE_MODE_MEM && multi) return;
+    if (__popc(m) < 2) return;
+    if (want_mask && m != want_mask) return;
+    // entries of a run are in ascending global position (stable sort), so the anchor comes first
+    uint32_t ap = 0xFFFFFFFFu;
+    for (uint32_t t = i; t < j; t++) {
+        const uint32_t v = vals[t], gp = v & 0x7fffffffu;
+        const int g = genome_of(gp, tab);
+        if (!(m >> g & 1)) continue;
+        if (ap == 0xFFFFFFFFu) { ap = gp; tmask[ap] = m; }
+        tpos[(size_t)g * P + ap] = v;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// extension.  A hit fixes a generalized diagonal: component c moves +k (same strand
-// as the anchor) or -k (opposite strand) when the anchor moves +k.  Offset k "agrees" when the masked
-// windows of all components are equal there.  Agreeing offsets at most `span` apart chain into a
-// cluster; the match is the cluster through the hit, emitted by its leftmost same-mask hit.
+// extension.  A hit fixes a generalized diagonal: component c moves +k (same strand as the
+// anchor) or -k (opposite strand) when the anchor moves +k.  Offset k "agrees" when the masked windows of
+// all components are equal there.  Agreeing offsets at most `span` apart chain into a cluster; the match
+// is the cluster through the hit, emitted by its leftmost same-mask hit.
 // ------------------------------------------------------------------------------------------------
-struct HitView {
-    uint32_t mask; int anchor;
-    uint32_t apos;       // anchor local window index
-    uint32_t agpos;      // anchor global window index
-};
+struct HitRec { uint32_t mask; int anchor; uint32_t v[MAUVE_MAX_SEQ]; };
 
 template <bool SEG>
 __device__ __forceinline__ bool agree_at(const uint64_t *__restrict__ packed, const GenomeTab &tab,
-                                         const SeedShape &sh, const uint32_t *__restrict__ hp, uint32_t mask,
-                                         int anchor, int64_t k, const uint32_t *__restrict__ seg, uint32_t nseg,
-                                         uint32_t segid)
+                                         const SeedShape &sh, const uint32_t *__restrict__ tpos, uint32_t P,
+                                         uint32_t ap, uint32_t mask, int anchor, int64_t k,
+                                         const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t segid)
 {
-    uint32_t va = hp[anchor];
-    int64_t qa = (int64_t)((va & 0x7fffffffu) - tab.gpos_off[anchor]) + k;
+    const uint32_t va = tpos[(size_t)anchor * P + ap];
+    int64_t qa = (int64_t)(ap - tab.gpos_off[anchor]) + k;
     int64_t lo = 0, hi = (int64_t)tab.nwin[anchor] - 1;
     if (SEG) { const uint32_t *sg = seg + (size_t)anchor * (nseg + 1) + segid; lo = sg[0]; hi = (int64_t)sg[1] - sh.span; }
     if (qa < lo || qa > hi) return false;
-    uint64_t ka = kprime_at(packed + tab.word_off[anchor], (uint32_t)qa, sh);
-    uint64_t ka_rev = digit_reverse(ka, sh.weight);
-    uint32_t sa = va >> 31;
+    const uint64_t ka = kprime_at(packed + tab.word_off[anchor], (uint32_t)qa, sh);
+    const uint64_t ka_rev = digit_reverse(ka, sh.weight);
+    const uint32_t sa = va >> 31;
     bool ok = true;
     for (int g = anchor + 1; g < tab.nseq; g++) {
         if (!(mask >> g & 1)) continue;
-        uint32_t vg = hp[g];
-        uint32_t o = (vg >> 31) ^ sa;
-        int64_t pg = (int64_t)((vg & 0x7fffffffu) - tab.gpos_off[g]);
-        int64_t qg = o ? pg - k : pg + k;
+        const uint32_t vg = tpos[(size_t)g * P + ap];
+        const uint32_t o = (vg >> 31) ^ sa;
+        const int64_t pg = (int64_t)((vg & 0x7fffffffu) - tab.gpos_off[g]);
+        const int64_t qg = o ? pg - k : pg + k;
         lo = 0; hi = (int64_t)tab.nwin[g] - 1;
         if (SEG) { const uint32_t *sg = seg + (size_t)g * (nseg + 1) + segid; lo = sg[0]; hi = (int64_t)sg[1] - sh.span; }
         if (qg < lo || qg > hi) { ok = false; break; }
-        uint64_t kg = kprime_at(packed + tab.word_off[g], (uint32_t)qg, sh);
+        const uint64_t kg = kprime_at(packed + tab.word_off[g], (uint32_t)qg, sh);
         if (o ? (((~kg) & sh.keymask) != ka_rev) : (kg != ka)) { ok = false; break; }
     }
     return ok;
 }
 
-// phase A: thread per hit.  A hit whose nearest agreeing offset to the left (within span) is a
-// same-mask hit is certainly not the leftmost hit of its cluster; everything else is a candidate.
-constexpr int CAND_ITEMS = 4;
-
+// phase A (streaming, no genome access): one thread per window position.  A hit anchored at p that has a
+// same-mask hit on the same diagonal at p-d, d <= span, cannot be the leftmost hit of its cluster (the
+// left walk of S4 never jumps over an agreeing offset, and that hit agrees).  Everything else is a
+// candidate for phase B.  all != 0 (no extension): every hit is a candidate.
 template <bool SEG>
-__global__ void __launch_bounds__(256) mum_candidates(const uint64_t *__restrict__ packed, GenomeTab tab,
-                                                      SeedShape sh, const uint32_t *__restrict__ hit_mask,
-                                                      const uint32_t *__restrict__ hit_pos,
-                                                      const uint32_t *__restrict__ posmask, uint32_t nhit,
-                                                      uint32_t *__restrict__ cand, uint32_t *__restrict__ counters,
-                                                      const uint32_t *__restrict__ seg, uint32_t nseg,
-                                                      const uint32_t *__restrict__ hit_seg)
+__global__ void __launch_bounds__(256) mum_runs(GenomeTab tab, int span, const uint32_t *__restrict__ tmask,
+                                                const uint32_t *__restrict__ tpos, uint32_t P, int all,
+                                                uint32_t *__restrict__ cand, uint32_t *__restrict__ counters,
+                                                const uint32_t *__restrict__ seg, uint32_t nseg)
 {
     __shared__ uint32_t lds[8];
     __shared__ uint32_t s_base;
-    const uint32_t base = blockIdx.x * (256 * CAND_ITEMS);
-    uint32_t flags = 0, cnt = 0;
-#pragma unroll
-    for (int k = 0; k < CAND_ITEMS; k++) {
-        const uint32_t h = base + k * 256 + threadIdx.x;
-        if (h >= nhit) continue;
-        const uint32_t mask = hit_mask[h];
-        const uint32_t *hp = hit_pos + (size_t)h * tab.nseq;
-        const int anchor = __ffs(mask) - 1;
-        const uint32_t agpos = hp[anchor] & 0x7fffffffu;
-        const uint32_t segid = SEG ? hit_seg[h] : 0u;
-        bool is_cand = true;
-        for (int d = 1; d <= sh.span; d++) {
-            if (agree_at<SEG>(packed, tab, sh, hp, mask, anchor, -(int64_t)d, seg, nseg, segid)) {
-                if (posmask[agpos - d] == mask) is_cand = false;
-                break;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    bool is_cand = false;
+    if (p < P) {
+        const uint32_t m = tmask[p];
+        if (m) {
+            is_cand = true;
+            if (!all) {
+                const int a = __ffs(m) - 1;
+                uint32_t g0 = tab.gpos_off[a];
+                if (SEG) {      // a predecessor only counts inside the same gap segment
+                    const uint32_t *sg = seg + (size_t)a * (nseg + 1);
+                    g0 += sg[seg_of(sg, nseg, p - g0)];
+                }
+                const uint32_t sa = tpos[(size_t)a * P + p] >> 31;
+                for (int d = 1; d <= span && is_cand; d++) {
+                    if (p < g0 + (uint32_t)d) break;
+                    const uint32_t q = p - d;
+                    if (tmask[q] != m) continue;
+                    const uint32_t sq = tpos[(size_t)a * P + q] >> 31;
+                    bool same = true;
+                    for (int g = a + 1; g < tab.nseq && same; g++) {
+                        if (!(m >> g & 1)) continue;
+                        const uint32_t vp = tpos[(size_t)g * P + p], vq = tpos[(size_t)g * P + q];
+                        const uint32_t o = (vp >> 31) ^ sa;
+                        if (((vq >> 31) ^ sq) != o) { same = false; break; }
+                        const uint32_t pp = vp & 0x7fffffffu, pq = vq & 0x7fffffffu;
+                        same = o ? (pq == pp + (uint32_t)d) : (pq + (uint32_t)d == pp);
+                    }
+                    if (same) is_cand = false;
+                }
             }
         }
-        if (is_cand) { flags |= 1u << k; cnt++; }
     }
     uint32_t total;
-    uint32_t off = block_excl_scan(cnt, &total, lds);
+    const uint32_t off = block_excl_scan(is_cand ? 1u : 0u, &total, lds);
     if (threadIdx.x == 0) s_base = total ? atomicAdd(&counters[1], total) : 0u;
     __syncthreads();
-    uint32_t o = s_base + off;
-#pragma unroll
-    for (int k = 0; k < CAND_ITEMS; k++)
-        if (flags >> k & 1) cand[o++] = base + k * 256 + threadIdx.x;
+    if (is_cand) cand[s_base + off] = p;
 }
 
-// phase B: one wave per candidate; the 64 lanes test 64 consecutive offsets at a time and the
-// resulting agreement bitmap is walked with scalar bit operations.
+// phase B: one wave per candidate; the 64 lanes test 64 consecutive offsets at a time and the resulting
+// agreement bitmap is walked with scalar bit operations.  Record slot = candidate index; length 0 marks a
+// candidate that turned out not to be the leftmost hit of its cluster.
 template <bool SEG>
 __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ packed, GenomeTab tab, SeedShape sh,
-                                                  const uint32_t *__restrict__ hit_mask,
-                                                  const uint32_t *__restrict__ hit_pos,
-                                                  const uint32_t *__restrict__ posmask,
-                                                  const uint32_t *__restrict__ cand, uint32_t ncand, int extend,
-                                                  int32_t *__restrict__ mlen, int32_t *__restrict__ mstart,
-                                                  uint32_t *__restrict__ counters, const uint32_t *__restrict__ seg,
-                                                  uint32_t nseg, const uint32_t *__restrict__ hit_seg)
+                                                  const uint32_t *__restrict__ tmask, const uint32_t *__restrict__ tpos,
+                                                  uint32_t P, const uint32_t *__restrict__ cand, uint32_t ncand,
+                                                  int extend, int32_t *__restrict__ mlen, int32_t *__restrict__ mstart,
+                                                  const uint32_t *__restrict__ seg, uint32_t nseg)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint64_t spanmask = (sh.span >= 64) ? ~0ULL : ((1ULL << sh.span) - 1ULL);
     for (uint32_t ci = wave_global; ci < ncand; ci += nwaves) {
-        uint32_t h = cand[ci];
-        uint32_t mask = hit_mask[h];
-        const uint32_t *hp = hit_pos + (size_t)h * tab.nseq;
-        int anchor = __ffs(mask) - 1;
-        uint32_t agpos = hp[anchor] & 0x7fffffffu;
-        const uint32_t segid = SEG ? hit_seg[h] : 0u;
+        const uint32_t ap = cand[ci];
+        const uint32_t mask = tmask[ap];
+        const int anchor = __ffs(mask) - 1;
+        const uint32_t segid = SEG ? seg_of(seg + (size_t)anchor * (nseg + 1), nseg, ap - tab.gpos_off[anchor]) : 0u;
         int64_t klo = 0, khi = 0;
         bool leftmost = true;
         if (extend) {
             // ---- left walk: offsets cur-1 .. cur-64 per round ----
             int64_t cur = 0;
             for (bool done = false; !done;) {
-                int64_t k = cur - 1 - lane;
-                bool a = agree_at<SEG>(packed, tab, sh, hp, mask, anchor, k, seg, nseg, segid);
-                bool hh = a && (posmask[(int64_t)agpos + k] == mask);
-                uint64_t A = __ballot(a), H = __ballot(hh);
+                const int64_t k = cur - 1 - lane;
+                const bool a = agree_at<SEG>(packed, tab, sh, tpos, P, ap, mask, anchor, k, seg, nseg, segid);
+                const bool hh = a && (tmask[(int64_t)ap + k] == mask);
+                const uint64_t A = __ballot(a), H = __ballot(hh);
                 int p = 0;                      // offsets consumed in this round
                 for (;;) {
                     if (p + sh.span > 64) break;                       // need a fresh round from cur-p
-                    uint64_t x = (A >> p) & spanmask;
+                    const uint64_t x = (A >> p) & spanmask;
                     if (x == 0) { done = true; break; }
-                    int d = __ffsll((unsigned long long)x) - 1;
-                    p += d + 1;
+                    p += __ffsll((unsigned long long)x);
                     if (H >> (p - 1) & 1) { leftmost = false; done = true; break; }
                 }
                 cur -= p;
@@ -476,13 +450,13 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
             // ---- right walk ----
             cur = 0;
             for (bool done = false; !done;) {
-                int64_t k = cur + 1 + lane;
-                bool a = agree_at<SEG>(packed, tab, sh, hp, mask, anchor, k, seg, nseg, segid);
-                uint64_t A = __ballot(a);
+                const int64_t k = cur + 1 + lane;
+                const bool a = agree_at<SEG>(packed, tab, sh, tpos, P, ap, mask, anchor, k, seg, nseg, segid);
+                const uint64_t A = __ballot(a);
                 int p = 0;
                 for (;;) {
                     if (p + sh.span > 64) break;
-                    uint64_t x = (A >> p) & spanmask;
+                    const uint64_t x = (A >> p) & spanmask;
                     if (x == 0) { done = true; break; }
                     p += __ffsll((unsigned long long)x);
                 }
@@ -490,18 +464,17 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
             }
             khi = cur;
         }
-        if (lane == 0) {          // record slot = candidate index (length 0 = not the leftmost hit): no atomics
-            const uint32_t m = ci;
-            mlen[m] = (int32_t)(khi - klo) + sh.span;
-            uint32_t sa = hp[anchor] >> 31;
+        if (lane == 0) {
+            mlen[ci] = (int32_t)(khi - klo) + sh.span;
+            const uint32_t sa = tpos[(size_t)anchor * P + ap] >> 31;
             for (int g = 0; g < tab.nseq; g++) {
                 int32_t s = 0;
                 if (mask >> g & 1) {
-                    uint32_t vg = hp[g];
-                    int64_t pg = (int64_t)((vg & 0x7fffffffu) - tab.gpos_off[g]);
+                    const uint32_t vg = tpos[(size_t)g * P + ap];
+                    const int64_t pg = (int64_t)((vg & 0x7fffffffu) - tab.gpos_off[g]);
                     s = ((vg >> 31) ^ sa) ? (int32_t)(-(pg - khi + 1)) : (int32_t)(pg + klo + 1);
                 }
-                mstart[(size_t)m * tab.nseq + g] = s;
+                mstart[(size_t)ci * tab.nseq + g] = s;
             }
         }
     }
@@ -624,59 +597,42 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         return MAUVE_OK;
     }
 
-    // ---- join ----
+    // ---- join: scatter the hits into the dense hit table ----
     const int N = tab.nseq;
-    const size_t hit_cap = (size_t)n / 2 + 1;
-    HIPCHK(ctx, ctx->posmask.ensure((size_t)n * 4));
-    HIPCHK(ctx, ctx->hit_mask.ensure(hit_cap * 4));
-    HIPCHK(ctx, ctx->hit_pos.ensure(hit_cap * 4 * N));
-    if (SEG) HIPCHK(ctx, ctx->hit_seg.ensure(hit_cap * 4));
-    HIPCHK(ctx, hipMemsetAsync(ctx->posmask.p, 0, (size_t)n * 4, ctx->stream));
+    const uint32_t P = n;
+    HIPCHK(ctx, ctx->posmask.ensure((size_t)P * 4));             // tmask
+    HIPCHK(ctx, ctx->hit_pos.ensure((size_t)P * 4 * N));         // tpos [N][P]
+    HIPCHK(ctx, ctx->cand.ensure((size_t)(P / 2 + 1) * 4));      // a hit needs >= 2 entries
+    HIPCHK(ctx, hipMemsetAsync(ctx->posmask.p, 0, (size_t)P * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+    uint32_t *tmask = ctx->posmask.as<uint32_t>(), *tpos = ctx->hit_pos.as<uint32_t>();
     { KernelTimer t(ctx, MAUVE_K_JOIN, n);
-      hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((n + JOIN_TILE - 1) / JOIN_TILE), dim3(256), 0, ctx->stream, keys, vals, n, tab, mode,
-                         (uint32_t)mask, ctx->posmask.as<uint32_t>(), ctx->hit_mask.as<uint32_t>(),
-                         ctx->hit_pos.as<uint32_t>(), ctx->hit_seg.as<uint32_t>(), 2 * sh.weight,
-                         ctx->counters.as<uint32_t>()); }
+      hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, n, tab, mode,
+                         (uint32_t)mask, tmask, tpos, P); }
+    HIPCHK(ctx, hipGetLastError());
+    TRACE(ctx, "join");
+    // ---- extension phase A: run starts from the table ----
+    { KernelTimer t(ctx, MAUVE_K_RUNS, P);
+      hipLaunchKernelGGL((mum_runs<SEG>), dim3((P + 255) / 256), dim3(256), 0, ctx->stream, tab, sh.span, tmask, tpos, P,
+                         extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg, nseg); }
     HIPCHK(ctx, hipGetLastError());
     uint32_t hc[4] = {0, 0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t nhit = hc[0];
-    TRACE(ctx, "join");
+    const uint32_t ncand = hc[1];
+    TRACE(ctx, "runs");
     ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear();
     if (n_matches) *n_matches = 0;
-    if (nhit == 0) return MAUVE_OK;
-
-    // ---- extension ----
-    HIPCHK(ctx, ctx->cand.ensure((size_t)nhit * 4));
-    uint32_t ncand = nhit;
-    if (extend) {
-        KernelTimer t(ctx, MAUVE_K_EXTEND, nhit);
-        hipLaunchKernelGGL((mum_candidates<SEG>), dim3((nhit + 256 * CAND_ITEMS - 1) / (256 * CAND_ITEMS)), dim3(256), 0, ctx->stream, packed, tab, sh,
-                           ctx->hit_mask.as<uint32_t>(), ctx->hit_pos.as<uint32_t>(), ctx->posmask.as<uint32_t>(), nhit,
-                           ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg, nseg, ctx->hit_seg.as<uint32_t>());
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        ncand = hc[1];
-        TRACE(ctx, "candidates");
-    } else {
-        // every hit is its own match: candidate list = identity
-        std::vector<uint32_t> ident(nhit);
-        for (uint32_t i = 0; i < nhit; i++) ident[i] = i;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->cand.p, ident.data(), (size_t)nhit * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    if (ncand == 0) return MAUVE_OK;
+    // ---- extension phase B ----
     HIPCHK(ctx, ctx->mlen.ensure((size_t)ncand * 4 + 4));
     HIPCHK(ctx, ctx->mstart.ensure((size_t)ncand * 4 * N + 4));
-    if (ncand) {
+    {
         uint32_t blocks = std::min<uint32_t>((ncand + 3) / 4, 256 * 8);
         KernelTimer t(ctx, MAUVE_K_EXTEND, ncand);
-        hipLaunchKernelGGL((mum_extend<SEG>), dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh,
-                           ctx->hit_mask.as<uint32_t>(), ctx->hit_pos.as<uint32_t>(), ctx->posmask.as<uint32_t>(),
-                           ctx->cand.as<uint32_t>(), ncand, extend, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(),
-                           ctx->counters.as<uint32_t>(), seg, nseg, ctx->hit_seg.as<uint32_t>());
+        hipLaunchKernelGGL((mum_extend<SEG>), dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh, tmask, tpos, P,
+                           ctx->cand.as<uint32_t>(), ncand, extend, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(), seg,
+                           nseg);
         HIPCHK(ctx, hipGetLastError());
     }
     // ---- copy out (one record slot per candidate; length 0 = the candidate was not a leftmost hit) ----

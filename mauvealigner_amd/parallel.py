@@ -1,0 +1,101 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU).
+
+The hot path shards at the level the reference itself names (mauveAligner.cpp:130-131 `--realign-lcb`, "for
+parallelization of LCB alignment"): inter-anchor intervals are independent units.  Two shapes are provided:
+
+* weak scaling (bench.py): every rank aligns its own genome set, no data-path collective; only the timing is
+  reduced (MAX over ranks) and the aligned base pairs are summed.
+* interval sharding: the DP intervals of one alignment are LPT-partitioned over the ranks by estimated cells,
+  each rank runs its share through the GappedAligner seam (mauve_dp_batch) and the ragged results are
+  exchanged with ONE all_gather (messages are small, latency-bound; no ring all-reduce anywhere).
+"""
+import numpy as np
+
+
+def lpt_partition(costs, world):
+    """Longest-processing-time-first packing of `costs` into `world` bins.  Deterministic: ties go to the lower
+    index / lower bin.  Returns a list of sorted index arrays, one per rank."""
+    costs = np.asarray(costs, dtype=np.int64)
+    order = np.lexsort((np.arange(len(costs)), -costs))
+    load = np.zeros(world, dtype=np.int64)
+    bins = [[] for _ in range(world)]
+    for i in order.tolist():
+        b = int(np.argmin(load))
+        bins[b].append(i)
+        load[b] += int(costs[i])
+    return [np.array(sorted(b), dtype=np.int64) for b in bins]
+
+
+def interval_cost(interval):
+    """DP cells of the progressive alignment of one interval (same count as the kernel reports)."""
+    m, cells = 0, 0
+    for s in interval:
+        n = len(s)
+        if n == 0:
+            continue
+        if m == 0:
+            m = n
+            continue
+        cells += m * n
+        m += n           # upper bound of the merged profile length
+    return cells
+
+
+def all_gather_ragged(arr, dist, group=None):
+    """all_gather of one 1-D numpy array per rank with different lengths: one size exchange + one padded
+    all_gather.  Returns the list of arrays by rank."""
+    import torch
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    arr = np.ascontiguousarray(arr)
+    n = torch.tensor([arr.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(max(sizes), 1)
+    buf = torch.zeros(mx, dtype=torch.from_numpy(arr[:0].copy()).dtype, device=dev)
+    if arr.size:
+        buf[:arr.size] = torch.from_numpy(arr.reshape(-1)).to(dev)
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    return [o[:s].cpu().numpy() for o, s in zip(outs, sizes)]
+
+
+def dp_sharded(dp_fn, intervals, dist=None, group=None):
+    """Align `intervals` (list of lists of code arrays) with the per-rank worker `dp_fn(list) -> (cols list,
+    scores)`, sharded over the ranks of `dist`.  Every rank returns the full (cols list, scores) in input order."""
+    n = len(intervals)
+    if dist is None or dist.get_world_size(group) == 1:
+        return dp_fn(intervals)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    parts = lpt_partition([interval_cost(iv) for iv in intervals], world)
+    mine = parts[rank]
+    cols, score = dp_fn([intervals[i] for i in mine.tolist()]) if len(mine) else ([], np.zeros(0, np.int64))
+    lens = np.array([len(c) for c in cols], dtype=np.int64)
+    flat = np.concatenate(cols).astype(np.int64) if len(cols) and lens.sum() else np.zeros(0, np.int64)
+    g_lens = all_gather_ragged(lens, dist, group)
+    g_flat = all_gather_ragged(flat, dist, group)
+    g_score = all_gather_ragged(np.asarray(score, dtype=np.int64), dist, group)
+    out_cols = [None] * n
+    out_score = np.zeros(n, dtype=np.int64)
+    for r in range(world):
+        off = 0
+        for k, i in enumerate(parts[r].tolist()):
+            ln = int(g_lens[r][k])
+            out_cols[i] = g_flat[r][off:off + ln].astype(np.uint32)
+            out_score[i] = g_score[r][k]
+            off += ln
+    return out_cols, out_score
+
+
+def reduce_throughput(elapsed_s, base_pairs, dist=None, group=None):
+    """bench.py contract: MAX of the elapsed time over ranks, SUM of the aligned base pairs."""
+    if dist is None or dist.get_world_size(group) == 1:
+        return elapsed_s, float(base_pairs)
+    import torch
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
+    b = torch.tensor([float(base_pairs)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item()), float(b.item())

@@ -1,0 +1,117 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/mauve_hip.h declares, its
+host-side entry points (seeds, packing, chaining) agree with the oracle, and -- without a GPU -- it fails loudly
+instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from mauvealigner_amd import _lib, synth
+from oracle import pyoracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_match_header():
+    L = _lib.load()
+    with open(os.path.join(ROOT, "include", "mauve_hip.h")) as f:
+        hdr = f.read()
+    declared = set(re.findall(r"\b(mauve_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"mauve_ctx"}
+    assert declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_struct_layouts_match_oracle_side():
+    # the ctypes mirrors of mauve_params / orc_params must stay field-for-field compatible
+    assert [f[0] for f in _lib.Params._fields_] == [f[0] for f in O.Params._fields_]
+    assert C.sizeof(_lib.Params) == C.sizeof(O.Params)
+    p, q = _lib.default_params(), O.default_params()
+    for name, _ in _lib.Params._fields_:
+        if name != "scoring":
+            assert getattr(p, name) == getattr(q, name), name
+    assert [list(r) for r in p.scoring.matrix] == [list(r) for r in q.scoring.matrix]
+    assert (p.scoring.gap_open, p.scoring.gap_extend) == (-400, -30)
+
+
+def test_seed_helpers_and_packing():
+    for w in range(0, 34):
+        for r in (0, 1, 2, 3, _lib.SOLID_SEED, 7, -1):
+            assert _lib.get_seed(w, r) == O.get_seed(w, r)
+    for L in (0, 1, 2, 49, 200, 1000, 123456, 5_000_000, 10**8, 2**40):
+        assert _lib.default_seed_weight(L) == O.default_seed_weight(L)
+    pat = _lib.get_seed(15, 0)
+    assert _lib.seed_length(pat) == 21 and _lib.seed_weight(pat) == 15
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 31, 32, 33, 1000):
+        c = rng.integers(0, 4, n, dtype=np.uint8)
+        w64 = _lib.pack_codes(c)
+        assert len(w64) == (n + 31) // 32 + 3
+        for i in range(n):
+            assert (int(w64[i // 32]) >> (2 * (i % 32))) & 3 == c[i]
+        assert np.array_equal(_lib.pack_ascii(synth.to_ascii(c)), w64)
+    assert np.array_equal(_lib.pack_ascii(b"acgtNnXA"), _lib.pack_codes(np.array([0, 1, 2, 3, 0, 0, 0, 0], np.uint8)))
+
+
+@pytest.mark.parametrize("cfg,scale,w", [("C3", 0.02, 11), ("C2", 0.04, 11), ("C4", 0.03, 9)])
+def test_host_chaining_equals_oracle(cfg, scale, w):
+    gs = synth.make_config(cfg, scale=scale)
+    N = len(gs)
+    ln, st = O.find_matches(gs, O.get_seed(w, 0))
+    ln, st = O.multiplicity_filter(ln, st, N)
+    a = O.eliminate_overlaps(ln, st)
+    b = _lib.eliminate_overlaps(ln, st)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for mw, col in ((0, False), (3 * w * N, False), (2000, False), (10**7, False), (0, True)):
+        d1 = O.compute_lcbs(a[0], a[1], mw, col)
+        d2 = _lib.lcb_chain(a[0], a[1], mw, col)
+        for k in ("n_lcb", "match_lcb", "left_end", "right_end", "weight", "left_adj", "right_adj"):
+            assert np.array_equal(d1[k], d2[k]), (mw, col, k)
+
+
+def test_host_chaining_handmade_cases():
+    length = np.array([100, 100, 10, 100, 100], dtype=np.int64)
+    start = np.array([[1, 1], [201, 201], [401, -5000], [601, 601], [801, 801]], dtype=np.int64)
+    d = _lib.lcb_chain(length, start, 50)
+    assert d["n_lcb"] == 1 and d["match_lcb"].tolist() == [0, 0, -1, 0, 0] and d["weight"].tolist() == [800]
+    d = _lib.lcb_chain(length, start, 10)
+    assert d["n_lcb"] == 3 and d["left_end"].tolist() == [[1, 1], [401, -5000], [601, 601]]
+    # overlap elimination: shorter match gives way, reverse components crop at the other end
+    length = np.array([50, 30], dtype=np.int64)
+    start = np.array([[1, 1], [41, -100]], dtype=np.int64)
+    l2, s2 = _lib.eliminate_overlaps(length, start)
+    e = O.eliminate_overlaps(length, start)
+    assert np.array_equal(l2, e[0]) and np.array_equal(s2, e[1])
+    assert l2.tolist() == [50, 20] and s2.tolist() == [[1, 1], [51, -100]]
+    # empty input
+    d = _lib.lcb_chain(np.zeros(0, np.int64), np.zeros((0, 3), np.int64), 10)
+    assert d["n_lcb"] == 0
+    # a component with NO_MATCH is rejected (N-way input required)
+    with pytest.raises(RuntimeError):
+        _lib.lcb_chain(np.array([5], np.int64), np.array([[1, 0]], np.int64), 1)
+
+
+def test_no_silent_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError) as ei:
+        _lib.Context(0)
+    assert "no CPU fallback" in str(ei.value) or "HIP" in str(ei.value)
+
+
+def test_product_never_touches_the_oracle():
+    """The product tree must not include, link or import anything under oracle/."""
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "mauvealigner_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".hpp", ".h", "Makefile")):
+                with open(os.path.join(dp, fn), errors="ignore") as f:
+                    txt = f.read()
+                if re.search(r'#include\s*[<"][^>"]*oracle|pyoracle|liboracle|mauve_oracle\.h|^\s*(from|import)\s+oracle|\borc_[a-z_]+\(',
+                             txt, re.M):
+                    bad.append(fn)
+    assert not bad, bad
