@@ -1,0 +1,56 @@
+// mauve_hip_align.cpp -- the hot section of doAlignment (src/mauveAligner.cpp:453-466,523-531,585,648-698,
+// 746-760) written against the libMems-shaped headers in include/libMems, i.e. what a reference maintainer's
+// call site looks like after switching the path to libmauve_hip.so.  Not a CLI: positional FastA files in, XMFA
+// on stdout.  Optional first argument "-u" uses UniqueMatchFinder as progressiveMauve.cpp:490-495 does.
+#include <iostream>
+#include <memory>
+
+#include "libGenome/gnSequence.h"
+#include "libMems/Aligner.h"
+#include "libMems/MaskedMemHash.h"
+#include "libMems/MatchList.h"
+
+using namespace mems;
+using namespace genome;
+
+int main(int argc, char **argv)
+{
+    try {
+        int a = 1;
+        bool unique = argc > 1 && std::string(argv[1]) == "-u";
+        if (unique) a++;
+        if (argc - a < 2) { std::cerr << "usage: mauve_hip_align [-u] <seq1.fa> <seq2.fa> [...]\n"; return -1; }
+        MatchList match_list;
+        for (; a < argc; a++) {
+            gnSequence *s = new gnSequence();
+            s->LoadSource(argv[a]);                                  // LoadSequences, mauveAligner.cpp:463
+            match_list.seq_table.push_back(s);
+            match_list.seq_filename.push_back(argv[a]);
+        }
+        uint seed_size = 0, seed_rank = 0;
+        match_list.CreateMemorySMLs(seed_size, &std::cerr, seed_rank);   // :456
+        const uint N = (uint)match_list.seq_table.size();
+
+        std::unique_ptr<MatchFinder> finder;
+        if (unique) finder.reset(new UniqueMatchFinder());               // progressiveMauve.cpp:490-495
+        else { finder.reset(new MaskedMemHash()); finder->SetMask((1ull << N) - 1); }   // mauveAligner.cpp:523-531
+        finder->LogProgress(&std::cerr);
+        finder->FindMatches(match_list);                                 // :585
+        std::cerr << match_list.size() << " multi-MUMs\n";
+
+        seed_size = MatchList::GetDefaultMerSize(match_list.seq_table);  // :650-651
+        int64 LCB_size = (int64)seed_size * 3 * N;                       // :652
+        Aligner aligner(N);                                              // :668
+        aligner.SetGappedAligner(HipGappedAligner::getInterface());      // :674
+        IntervalList interval_list;
+        aligner.align(match_list, interval_list, 0, LCB_size, true, true, true, "");   // :698
+        interval_list.WriteStandardAlignment(std::cout);                 // :746-760
+        match_list.Clear();
+        for (auto *s : match_list.sml_table) delete s;
+        for (auto *s : match_list.seq_table) delete s;
+        return 0;
+    } catch (gnException &gne) {
+        std::cerr << gne << std::endl;                                   // :852-864
+        return -10;
+    }
+}

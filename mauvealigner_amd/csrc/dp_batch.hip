@@ -38,7 +38,7 @@ __device__ __forceinline__ void max3(int32_t a, int32_t b, int32_t c, int32_t &b
     if (c > best) { best = c; p = 2; }
 }
 
-__global__ void __launch_bounds__(256) dp_step(int g, int nseq, int64_t n_iv, const uint8_t *__restrict__ codes,
+__global__ void __launch_bounds__(256) dp_step(int nseq, int64_t n_iv, const uint8_t *__restrict__ codes,
                                                const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
                                                uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
                                                uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
@@ -52,17 +52,20 @@ __global__ void __launch_bounds__(256) dp_step(int g, int nseq, int64_t n_iv, co
     const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
 
     for (int64_t iv = wave_global; iv < n_iv; iv += nwaves) {
+      // all progressive steps of one interval run back to back in this wave (they only depend on each other)
+      DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
+      const int64_t base = seq_off[iv * nseq];
+      for (int g = 0; g < nseq; g++) {
         const int64_t so = seq_off[iv * nseq + g];
         const int32_t n = (int32_t)(seq_off[iv * nseq + g + 1] - so);
         if (n == 0) continue;
         const uint8_t *seq = codes + so;
-        const int64_t base = seq_off[iv * nseq];
-        DpMeta mt = meta[iv];
         uint32_t *Pc = (mt.cur ? cntB : cntA) + base, *Pm = (mt.cur ? maskB : maskA) + base;
         uint32_t *Qc = (mt.cur ? cntA : cntB) + base, *Qm = (mt.cur ? maskA : maskB) + base;
         if (mt.krows == 0) {           // first non-empty sequence becomes the profile
             for (int32_t c = lane; c < n; c += 64) { Pc[c] = 1u << (8 * seq[c]); Pm[c] = 1u << g; }
-            if (lane == 0) { mt.m = n; mt.krows = 1; meta[iv] = mt; }
+            mt.m = n; mt.krows = 1;
+            __threadfence_block();      // the next step's lanes read what other lanes just wrote
             continue;
         }
         const int32_t m = mt.m;
@@ -171,10 +174,10 @@ __global__ void __launch_bounds__(256) dp_step(int g, int nseq, int64_t n_iv, co
             }
             carry_p += (int32_t)__popcll(bp); carry_s += (int32_t)__popcll(bs);
         }
-        if (lane == 0) {
-            mt.cells += (int64_t)m * n; mt.score += best; mt.m = len; mt.krows += 1; mt.cur ^= 1;
-            meta[iv] = mt;
-        }
+        mt.cells += (int64_t)m * n; mt.score += best; mt.m = len; mt.krows += 1; mt.cur ^= 1;
+        __threadfence_block();
+      }
+      if (lane == 0) meta[iv] = mt;
     }
 }
 
@@ -263,7 +266,6 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     HIPCHK(ctx, hipMemcpyAsync(d_seq_off, seq_off, (size_t)(n_iv * nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_tb_off, tb_off.data(), (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_rows_off, rows_off.data(), (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->dp_meta.p, 0, (size_t)n_iv * sizeof(DpMeta), ctx->stream));
     const uint32_t blocks = (uint32_t)std::min<int64_t>((n_iv + 3) / 4, 256 * 8);
     if (desc) {
         const int64_t nd = n_iv * nseq;
@@ -278,9 +280,9 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
         HIPCHK(ctx, hipMemcpyAsync(ctx->dp_codes.p, codes, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
     }
     DpScoring sc; sc.go = scoring->gap_open; sc.ge = scoring->gap_extend; memcpy(sc.s, scoring->matrix, sizeof sc.s);
-    for (int g = 0; g < nseq; g++) {
+    {
         KernelTimer t(ctx, MAUVE_K_DP, n_iv);
-        hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, g, nseq, n_iv, ctx->dp_codes.as<uint8_t>(),
+        hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, nseq, n_iv, ctx->dp_codes.as<uint8_t>(),
                            d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
                            ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
                            ctx->dp_prof2_mask.as<uint32_t>(), ctx->dp_tb.as<uint8_t>(), d_tb_off, ctx->dp_rows.as<int32_t>(),

@@ -39,7 +39,12 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     const int N = c->nseq;
     const double t0 = now_ms();
     AlignResult &R = c->res;
-    R = AlignResult();
+    // keep the capacity of the result vectors across calls (a fresh 20 MB column buffer per call costs more in
+    // page faults than the whole seed pass)
+    R.sz = mauve_align_sizes();
+    R.mum_length.clear(); R.mum_start.clear(); R.lcb_left.clear(); R.lcb_right.clear(); R.lcb_weight.clear();
+    R.anchor_length.clear(); R.anchor_start.clear(); R.anchor_lcb.clear(); R.iv_left.clear(); R.iv_right.clear();
+    R.iv_reverse.clear(); R.col_off.clear(); R.cols.clear(); R.dp_score.clear();
     memset(&c->stage, 0, sizeof c->stage);
 
     int64_t sum = 0; for (int g = 0; g < N; g++) sum += c->lens[g];
@@ -64,6 +69,7 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
         std::copy(&c->match_start[(size_t)i * N], &c->match_start[(size_t)i * N] + N, m.st((size_t)i));
     }
     host_eliminate_overlaps(m);
+    const double t1b = now_ms();
     const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight : (int64_t)3 * w * N;
     std::vector<int64_t> match_lcb; int64_t nl = 0;
     host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl);
@@ -76,6 +82,7 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     }
     const double t2 = now_ms();
     c->stage.chain_ms = t2 - t1;
+    if (getenv("MAUVE_TRACE")) fprintf(stderr, "[trace] chain: eliminate_overlaps %.3f ms, lcb %.3f ms\n", t1b - t1, t2 - t1b);
 
     // ---- recursive anchoring ----
     if (p->recursive) {

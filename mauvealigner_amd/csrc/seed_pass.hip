@@ -655,15 +655,34 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         k1[i] = ((uint64_t)f << 40) | a;
     }
     const uint32_t nm = (uint32_t)order.size();
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        if (k1[x] != k1[y]) return k1[x] < k1[y];
-        const int32_t *a = &hs[(size_t)x * N], *b = &hs[(size_t)y * N];
-        uint32_t ma = 0, mb = 0;
-        for (int g = 0; g < N; g++) { if (a[g]) ma |= 1u << g; if (b[g]) mb |= 1u << g; }
-        if (ma != mb) return ma < mb;
-        for (int g = 0; g < N; g++) if (a[g] != b[g]) return a[g] < b[g];
-        return hl[x] < hl[y];
-    });
+    {   // LSD radix sort of the record indices by k1 (first component << 40 | start): 4 passes of 12 bits,
+        // then the rare equal-k1 groups are ordered with the full comparator
+        std::vector<uint32_t> tmp(nm);
+        uint32_t *src = order.data(), *dst = tmp.data();
+        for (int pass = 0; pass < 4; pass++) {
+            const int sh = 12 * pass;
+            uint32_t cnt[4097] = {0};
+            for (uint32_t i = 0; i < nm; i++) cnt[(((k1[src[i]] & 0xffffffffULL) | ((k1[src[i]] >> 40) << 32)) >> sh & 4095) + 1]++;
+            for (int b = 0; b < 4096; b++) cnt[b + 1] += cnt[b];
+            for (uint32_t i = 0; i < nm; i++) dst[cnt[((k1[src[i]] & 0xffffffffULL) | ((k1[src[i]] >> 40) << 32)) >> sh & 4095]++] = src[i];
+            std::swap(src, dst);
+        }
+        if (src != order.data()) std::copy(src, src + nm, order.data());
+        auto full_less = [&](uint32_t x, uint32_t y) {
+            const int32_t *a = &hs[(size_t)x * N], *b = &hs[(size_t)y * N];
+            uint32_t ma = 0, mb = 0;
+            for (int g = 0; g < N; g++) { if (a[g]) ma |= 1u << g; if (b[g]) mb |= 1u << g; }
+            if (ma != mb) return ma < mb;
+            for (int g = 0; g < N; g++) if (a[g] != b[g]) return a[g] < b[g];
+            return hl[x] < hl[y];
+        };
+        for (uint32_t i = 0; i < nm;) {
+            uint32_t j = i + 1;
+            while (j < nm && k1[order[j]] == k1[order[i]]) j++;
+            if (j - i > 1) std::sort(order.begin() + i, order.begin() + j, full_less);
+            i = j;
+        }
+    }
     ctx->match_len.resize(nm); ctx->match_start.resize((size_t)nm * N);
     for (uint32_t i = 0; i < nm; i++) {
         uint32_t o = order[i];

@@ -1,0 +1,97 @@
+"""The libMems-shaped C++ mirror (include/libMems) compiles with plain g++ against the C-ABI, its host-only
+classes behave like the in-tree call sites expect, and -- on the GPU box -- the example call site
+(examples/mauve_hip_align.cpp, shaped like mauveAligner.cpp:453-760) produces the same XMFA as mauve_align."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from mauvealigner_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+MATCH_UNIT = r'''
+#include <cassert>
+#include <sstream>
+#include "libMems/Match.h"
+#include "libMems/MatchList.h"
+#include "libMems/MemHash.h"
+#include "libMems/SortedMerList.h"
+#include "libGenome/gnSequence.h"
+using namespace mems;
+int main() {
+    Match m(3);
+    m.SetLength(100); m.SetStart(0, 11); m.SetStart(1, -501); m.SetStart(2, NO_MATCH);
+    assert(m.SeqCount() == 3 && m.Multiplicity() == 2 && m.FirstStart() == 0);
+    assert(m.LeftEnd(1) == 501 && m.RightEnd(1) == 600 && m.Orientation(1) == AbstractMatch::reverse);
+    assert(m.Orientation(2) == AbstractMatch::undefined && m[0] == 11);
+    m.CropStart(10);            /* first columns: forward start moves, reverse left end stays */
+    assert(m.Length() == 90 && m.Start(0) == 21 && m.Start(1) == -501 && m.RightEnd(1) == 590);
+    m.CropEnd(5);               /* last columns: reverse left end moves */
+    assert(m.Length() == 85 && m.Start(0) == 21 && m.Start(1) == -506);
+    m.CropLeft(5, 1);           /* left side of a reverse component = last columns */
+    assert(m.Length() == 80 && m.Start(1) == -511 && m.Start(0) == 21);
+    m.CropRight(5, 0);
+    assert(m.Length() == 75 && m.Start(0) == 21 && m.Start(1) == -516);
+    Match *c = m.Copy(); c->Invert(); assert(c->Start(0) == -21 && c->Start(1) == 516); c->Free();
+    std::ostringstream os; os << m; assert(os.str() == "75\t21\t-516\t0");
+    MatchList ml; ml.push_back(m.Copy()); Match full(3); full.SetLength(5); full.SetStart(0,1); full.SetStart(1,2); full.SetStart(2,3);
+    ml.push_back(full.Copy()); ml.MultiplicityFilter(3); assert(ml.size() == 1 && ml[0]->Length() == 5); ml.Clear();
+    assert(getSeedLength(getSeed(15, 0)) == 21 && getDefaultSeedWeight(5000000) == 15 && getSeed(15, SOLID_SEED) == 0x7fff);
+    genome::gnSequence s("ACGTACGT"); assert(s.length() == 8 && s.ToString(3, 2) == "CGT" && s.ToString() == "ACGTACGT");
+    PairwiseScoringScheme pss; assert(pss.gap_open == -400 && pss.gap_extend == -30 && pss.matrix[0][0] == 91);
+    UniqueMatchFinder umf; MatchFinder *cl = umf.Clone(); delete cl;
+    return 0;
+}
+'''
+
+
+def _compile(src_text, out, extra=()):
+    src = out + ".cpp"
+    with open(src, "w") as f:
+        f.write(src_text)
+    cmd = ["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", out, src,
+           "-L" + os.path.join(ROOT, "mauvealigner_amd"), "-lmauve_hip",
+           "-Wl,-rpath," + os.path.join(ROOT, "mauvealigner_amd")] + list(extra)
+    subprocess.check_call(cmd)
+
+
+def test_mirror_compiles_and_host_classes_work():
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "match_unit")
+        _compile(MATCH_UNIT, exe)
+        subprocess.check_call([exe])
+
+
+def test_example_call_site_compiles():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-B"], stdout=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(ROOT, "examples", "mauve_hip_align"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flag", [None, "-u"])
+def test_example_matches_c_abi(flag):
+    from mauvealigner_amd import _lib
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    gs = synth.make_config("C3", scale=0.01)
+    with tempfile.TemporaryDirectory() as td:
+        paths = []
+        for i, g in enumerate(gs):
+            p = os.path.join(td, "g%d.fa" % i)
+            with open(p, "w") as f:
+                f.write(">g%d\n" % i)
+                a = synth.to_ascii(g).decode()
+                for k in range(0, len(a), 70):
+                    f.write(a[k:k + 70] + "\n")
+            paths.append(p)
+        cmd = [os.path.join(ROOT, "examples", "mauve_hip_align")] + ([flag] if flag else []) + paths
+        out = subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_genomes(gs)
+            r = ctx.align(_lib.default_params(), names=paths, want_xmfa=True)
+        finally:
+            ctx.close()
+        assert out == r["xmfa"]
