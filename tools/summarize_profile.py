@@ -28,7 +28,8 @@ def short(name):
 
 def read_pmc(dirname, counter):
     out = {}
-    for f in glob.glob(os.path.join(SRC, dirname, "*", "*counter_collection.csv")):
+    files = sorted(glob.glob(os.path.join(SRC, dirname, "*", "*counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:            # newest run only
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 if row["Counter_Name"] != counter:
@@ -44,7 +45,7 @@ def avg(v):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     os.makedirs(DST, exist_ok=True)
-    stats = glob.glob(os.path.join(SRC, "trace", "*", "*kernel_stats.csv"))[0]
+    stats = sorted(glob.glob(os.path.join(SRC, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1]
     rows = list(csv.DictReader(open(stats)))
     with open(os.path.join(SRC, "bench.json")) as f:
         bench = json.loads(f.read().strip().splitlines()[-1])
