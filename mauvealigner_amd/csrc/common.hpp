@@ -46,6 +46,7 @@ struct SeedShape {
     uint8_t run_src[32];       // bit offset of the run in the window (2 * first care offset)
     uint8_t run_bits[32];      // 2 * run length
     uint8_t run_dst[32];       // bit offset in K'
+    uint64_t care_lo, care_hi; // 2-bit-expanded care mask of the window (offset t -> bits 2t, 2t+1)
 };
 
 // The genomes as the kernels see them: one packed buffer, windows numbered globally.
@@ -98,7 +99,7 @@ struct mauve_ctx {
     int64_t n_matches = 0;
 
     // DP workspace
-    DevBuf dp_desc, dp_codes, dp_off, dp_prof_cnt, dp_prof_mask, dp_prof2_cnt, dp_prof2_mask, dp_tb, dp_meta, dp_score,
+    DevBuf dp_desc, dp_list, dp_codes, dp_off, dp_prof_cnt, dp_prof_mask, dp_prof2_cnt, dp_prof2_mask, dp_tb, dp_meta, dp_score,
         dp_cols, dp_rows;
 
     // profiling

@@ -19,6 +19,8 @@
 #include <cstring>
 
 #define DP_NEG_INF (-(1 << 29))
+constexpr int DP_LDS_TB = 12288;
+constexpr int DP_LDS_OPS = 256;
 
 struct DpMeta {
     int32_t m;        // current profile length
@@ -31,6 +33,9 @@ struct DpMeta {
 
 struct DpScoring { int32_t go, ge; int32_t s[4][4]; };
 
+// lane l receives lane l-1's value, lane 0 keeps its own (gfx9 DPP wave_shr:1)
+__device__ __forceinline__ int32_t wave_shr1(int32_t v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+
 __device__ __forceinline__ void max3(int32_t a, int32_t b, int32_t c, int32_t &best, uint32_t &p)
 {
     best = a; p = 0;
@@ -38,7 +43,7 @@ __device__ __forceinline__ void max3(int32_t a, int32_t b, int32_t c, int32_t &b
     if (c > best) { best = c; p = 2; }
 }
 
-__global__ void __launch_bounds__(256) dp_step(int nseq, int64_t n_iv, const uint8_t *__restrict__ codes,
+__global__ void __launch_bounds__(256) dp_step(int nseq, const int64_t *__restrict__ list, int64_t n_iv, const uint8_t *__restrict__ codes,
                                                const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
                                                uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
                                                uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
@@ -46,12 +51,17 @@ __global__ void __launch_bounds__(256) dp_step(int nseq, int64_t n_iv, const uin
                                                int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
                                                uint8_t *__restrict__ ops, DpScoring sc)
 {
-    const int lane = threadIdx.x & 63;
+    // Small steps (one stripe, m + n <= 192) keep their traceback bytes and reversed ops in LDS: the traceback
+    // walk is a chain of dependent 1-byte loads, ~100 cycles each from LDS against >1000 from L2/HBM.
+    __shared__ uint8_t s_tb[4][DP_LDS_TB];
+    __shared__ uint8_t s_ops[4][DP_LDS_OPS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
 
-    for (int64_t iv = wave_global; iv < n_iv; iv += nwaves) {
+    for (int64_t li = wave_global; li < n_iv; li += nwaves) {
+      const int64_t iv = list[li];
       // all progressive steps of one interval run back to back in this wave (they only depend on each other)
       DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
       const int64_t base = seq_off[iv * nseq];
@@ -71,7 +81,8 @@ __global__ void __launch_bounds__(256) dp_step(int nseq, int64_t n_iv, const uin
         const int32_t m = mt.m;
         const int32_t gyo = sc.go * mt.krows, gye = sc.ge * mt.krows;
         const int32_t T = n + 64;                          // traceback stride per stripe (steps)
-        uint8_t *tbp = tb + tb_off[iv];
+        const bool in_lds = m <= 64 && (size_t)(m + n) * 64 <= DP_LDS_TB && m + n <= DP_LDS_OPS;
+        uint8_t *tbp = in_lds ? s_tb[wv] : tb + tb_off[iv];
         int32_t *rowbuf = rows + rows_off[iv];             // 2 x 3 x (n+1)
         const int32_t nstripes = (m + 63) / 64;
         int32_t fM = DP_NEG_INF, fX = DP_NEG_INF, fY = DP_NEG_INF;   // values at (m, n)
@@ -97,21 +108,42 @@ __global__ void __launch_bounds__(256) dp_step(int nseq, int64_t n_iv, const uin
             int32_t Mc = DP_NEG_INF, Xc = DP_NEG_INF, Yc = DP_NEG_INF;   // (i, j) just computed
             int32_t Md = DP_NEG_INF, Xd = DP_NEG_INF, Yd = DP_NEG_INF;   // (i-1, j-1)
             uint32_t bcur = 0;
+            // What lane 0 consumes every step -- the next base and, below the first stripe, the parked boundary
+            // row -- is fetched 64 columns at a time by the whole wave (one coalesced load, a chunk ahead) and
+            // handed to lane 0 with v_readlane: no memory latency inside the systolic step.
+            uint32_t sq_cur = (lane < n) ? (uint32_t)seq[lane] : 0u;
+            uint32_t sq_nxt = (64 + lane < n) ? (uint32_t)seq[64 + lane] : 0u;
+            int32_t bM_cur = DP_NEG_INF, bX_cur = DP_NEG_INF, bY_cur = DP_NEG_INF, bM_nxt = DP_NEG_INF, bX_nxt = DP_NEG_INF,
+                    bY_nxt = DP_NEG_INF;
+            if (s > 0) {
+                if (lane <= n) { bM_cur = rin[lane]; bX_cur = rin[(n + 1) + lane]; bY_cur = rin[2 * (n + 1) + lane]; }
+                if (64 + lane <= n) { bM_nxt = rin[64 + lane]; bX_nxt = rin[(n + 1) + 64 + lane]; bY_nxt = rin[2 * (n + 1) + 64 + lane]; }
+            }
             const int32_t steps = n + rows_here;                         // t = 0 .. n + rows_here - 1
             for (int32_t t = 0; t < steps; t++) {
                 const int32_t j = t - lane;
-                // (i-1, j): lane-1's newest values; lane 0 reads the stripe's upper boundary row
-                int32_t Mu = __shfl_up(Mc, 1), Xu = __shfl_up(Xc, 1), Yu = __shfl_up(Yc, 1);
-                uint32_t bnext = __shfl_up(bcur, 1);
-                if (lane == 0) {
-                    if (j <= n) {
-                        if (s == 0) {
-                            Mu = (j == 0) ? 0 : DP_NEG_INF; Xu = DP_NEG_INF;
-                            Yu = (j == 0) ? DP_NEG_INF : gyo + (j - 1) * gye;
-                        } else { Mu = rin[j]; Xu = rin[(n + 1) + j]; Yu = rin[2 * (n + 1) + j]; }
-                    }
-                    bnext = (j >= 1 && j <= n) ? seq[j - 1] : 0u;
+                if (t > 1 && ((t - 1) & 63) == 0) {                      // column t needs seq[t-1]: next chunk
+                    sq_cur = sq_nxt;
+                    sq_nxt = (t - 1 + 64 + lane < n) ? (uint32_t)seq[t - 1 + 64 + lane] : 0u;
                 }
+                if (s > 0 && t > 0 && (t & 63) == 0) {
+                    bM_cur = bM_nxt; bX_cur = bX_nxt; bY_cur = bY_nxt;
+                    const int32_t jj = t + 64 + lane;
+                    if (jj <= n) { bM_nxt = rin[jj]; bX_nxt = rin[(n + 1) + jj]; bY_nxt = rin[2 * (n + 1) + jj]; }
+                }
+                // (i-1, j): lane-1's newest values (DPP wave shift); lane 0 takes the stripe's upper boundary row
+                int32_t Mu = wave_shr1(Mc), Xu = wave_shr1(Xc), Yu = wave_shr1(Yc);
+                uint32_t bnext = (uint32_t)wave_shr1((int32_t)bcur);
+                const uint32_t b0 = (t >= 1 && t <= n) ? (uint32_t)__builtin_amdgcn_readlane((int32_t)sq_cur, (t - 1) & 63) : 0u;
+                int32_t M0, X0, Y0;
+                if (s == 0) {
+                    M0 = (t == 0) ? 0 : DP_NEG_INF; X0 = DP_NEG_INF;
+                    Y0 = (t == 0) ? DP_NEG_INF : gyo + (t - 1) * gye;
+                } else {
+                    M0 = __builtin_amdgcn_readlane(bM_cur, t & 63); X0 = __builtin_amdgcn_readlane(bX_cur, t & 63);
+                    Y0 = __builtin_amdgcn_readlane(bY_cur, t & 63);
+                }
+                if (lane == 0) { if (t <= n) { Mu = M0; Xu = X0; Yu = Y0; } bnext = b0; }
                 bcur = bnext;
                 const bool on = active && j >= 0 && j <= n;
                 int32_t Ml = Mc, Xl = Xc, Yl = Yc;           // (i, j-1): own previous column
@@ -139,7 +171,7 @@ __global__ void __launch_bounds__(256) dp_step(int nseq, int64_t n_iv, const uin
         if (fY > best) { best = fY; state = 2; }
 
         // ---- traceback (wave-uniform walk; bytes were written by this wave) ----
-        uint8_t *opr = ops + base;                  // reversed ops, capacity m + n
+        uint8_t *opr = in_lds ? s_ops[wv] : ops + base;   // reversed ops, capacity m + n
         int32_t ti = m, tj = n, len = 0;
         while (ti > 0 || tj > 0) {
             uint32_t op, nstate;
@@ -280,10 +312,21 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
         HIPCHK(ctx, hipMemcpyAsync(ctx->dp_codes.p, codes, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
     }
     DpScoring sc; sc.go = scoring->gap_open; sc.ge = scoring->gap_extend; memcpy(sc.s, scoring->matrix, sizeof sc.s);
+    // longest intervals first: one wave per interval, so the tail of the launch is its longest interval
+    std::vector<int64_t> lst((size_t)n_iv);
+    {   // counting sort by size class (log2 of the traceback footprint), largest class first
+        int64_t cnt[66] = {0};
+        auto cls = [&](int64_t iv) { int64_t f = tb_off[iv + 1] - tb_off[iv]; int c = 0; while (f > 1) { f >>= 1; c++; } return 63 - c; };
+        for (int64_t iv = 0; iv < n_iv; iv++) cnt[cls(iv) + 1]++;
+        for (int c = 0; c < 65; c++) cnt[c + 1] += cnt[c];
+        for (int64_t iv = 0; iv < n_iv; iv++) lst[(size_t)cnt[cls(iv)]++] = iv;
+    }
+    HIPCHK(ctx, ctx->dp_list.ensure((size_t)n_iv * 8));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dp_list.p, lst.data(), (size_t)n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
     {
         KernelTimer t(ctx, MAUVE_K_DP, n_iv);
-        hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, nseq, n_iv, ctx->dp_codes.as<uint8_t>(),
-                           d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
+        hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, nseq, ctx->dp_list.as<int64_t>(), n_iv,
+                           ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
                            ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
                            ctx->dp_prof2_mask.as<uint32_t>(), ctx->dp_tb.as<uint8_t>(), d_tb_off, ctx->dp_rows.as<int32_t>(),
                            d_rows_off, ctx->dp_score.as<uint8_t>(), sc);

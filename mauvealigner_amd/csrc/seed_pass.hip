@@ -43,6 +43,31 @@ __device__ __forceinline__ uint64_t kprime_at(const uint64_t *__restrict__ G, ui
     return k;
 }
 
+// the 2-bit window of `span` bases starting at base p, as a 128-bit little-endian digit string
+__device__ __forceinline__ void window_at(const uint64_t *__restrict__ G, uint32_t p, uint64_t &lo, uint64_t &hi)
+{
+    uint32_t q = p >> 5; int r = (p & 31) * 2;
+    uint64_t w0 = G[q], w1 = G[q + 1], w2 = G[q + 2];
+    lo = r ? ((w0 >> r) | (w1 << (64 - r))) : w0;
+    hi = r ? ((w1 >> r) | (w2 << (64 - r))) : w1;
+}
+
+__device__ __forceinline__ uint64_t digit_reverse64(uint64_t x)
+{
+    x = __brevll(x);
+    return ((x & 0xAAAAAAAAAAAAAAAAULL) >> 1) | ((x & 0x5555555555555555ULL) << 1);
+}
+
+// reverse complement of a span-base window (digits reversed, complemented); bits above 2*span are garbage
+// that the care mask removes
+__device__ __forceinline__ void window_revcomp(uint64_t lo, uint64_t hi, int span, uint64_t &rlo, uint64_t &rhi)
+{
+    const uint64_t nlo = digit_reverse64(~hi), nhi = digit_reverse64(~lo);   // 128-bit digit reversal
+    const int s = 128 - 2 * span;                                            // 30 <= s <= 126 (span 1..49)
+    if (s >= 64) { rlo = nhi >> (s - 64); rhi = 0; }
+    else { rlo = (nlo >> s) | (nhi << (64 - s)); rhi = nhi >> s; }
+}
+
 // reverse the order of the 2-bit digits of a 2*weight-bit value
 __device__ __forceinline__ uint64_t digit_reverse(uint64_t k, int weight)
 {
@@ -335,8 +360,11 @@ __device__ __forceinline__ bool agree_at(const uint64_t *__restrict__ packed, co
     int64_t lo = 0, hi = (int64_t)tab.nwin[anchor] - 1;
     if (SEG) { const uint32_t *sg = seg + (size_t)anchor * (nseg + 1) + segid; lo = sg[0]; hi = (int64_t)sg[1] - sh.span; }
     if (qa < lo || qa > hi) return false;
-    const uint64_t ka = kprime_at(packed + tab.word_off[anchor], (uint32_t)qa, sh);
-    const uint64_t ka_rev = digit_reverse(ka, sh.weight);
+    // masked windows are compared in place (XOR under the 2-bit care mask) -- equal care digits <=> equal
+    // masked mers; a reverse component is compared with the reverse complement of the anchor window
+    uint64_t alo, ahi, rlo = 0, rhi = 0;
+    window_at(packed + tab.word_off[anchor], (uint32_t)qa, alo, ahi);
+    bool have_rc = false;
     const uint32_t sa = va >> 31;
     bool ok = true;
     for (int g = anchor + 1; g < tab.nseq; g++) {
@@ -348,8 +376,14 @@ __device__ __forceinline__ bool agree_at(const uint64_t *__restrict__ packed, co
         lo = 0; hi = (int64_t)tab.nwin[g] - 1;
         if (SEG) { const uint32_t *sg = seg + (size_t)g * (nseg + 1) + segid; lo = sg[0]; hi = (int64_t)sg[1] - sh.span; }
         if (qg < lo || qg > hi) { ok = false; break; }
-        const uint64_t kg = kprime_at(packed + tab.word_off[g], (uint32_t)qg, sh);
-        if (o ? (((~kg) & sh.keymask) != ka_rev) : (kg != ka)) { ok = false; break; }
+        uint64_t clo, chi;
+        window_at(packed + tab.word_off[g], (uint32_t)qg, clo, chi);
+        if (o) {
+            if (!have_rc) { window_revcomp(alo, ahi, sh.span, rlo, rhi); have_rc = true; }
+            if (((clo ^ rlo) & sh.care_lo) | ((chi ^ rhi) & sh.care_hi)) { ok = false; break; }
+        } else {
+            if (((clo ^ alo) & sh.care_lo) | ((chi ^ ahi) & sh.care_hi)) { ok = false; break; }
+        }
     }
     return ok;
 }
@@ -504,6 +538,10 @@ bool make_seed_shape(uint64_t pattern, SeedShape *sh)
         nr++; j += len;
     }
     sh->nruns = nr;
+    for (int t = 0; t < span; t++) {
+        if (!((pattern >> (span - 1 - t)) & 1)) continue;
+        if (2 * t < 64) sh->care_lo |= 3ULL << (2 * t); else sh->care_hi |= 3ULL << (2 * t - 64);
+    }
     return true;
 }
 
