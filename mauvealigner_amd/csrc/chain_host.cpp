@@ -52,43 +52,61 @@ void host_eliminate_overlaps(MatchVec &m)
     const size_t n = m.size();
     if (n < 2) return;
     std::vector<uint8_t> alive(n, 1);
-    std::vector<uint64_t> key, tmp; key.reserve(n);
-    std::vector<int64_t> cf(n), cl(n), lenv(n), leftv(n);
+    std::vector<uint64_t> key, key2, tmp; key.reserve(n); key2.reserve(n);
+    std::vector<int64_t> cf(n, 0), cl(n, 0), lenv(n), leftv(n);
     std::vector<int8_t> fwd(n);
+    std::vector<uint32_t> touched;
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     for (int g = 0; g < N; g++) {
-        for (;;) {
-            key.clear();
-            for (size_t i = 0; i < n; i++) {
-                if (!alive[i]) continue;
-                leftv[i] = std::llabs(m.st(i)[g]); lenv[i] = m.len(i); fwd[i] = m.st(i)[g] > 0;
-                key.push_back(((uint64_t)leftv[i] << 32) | (uint64_t)i);
-            }
+        // order of the alive matches in genome g; later passes keep it (crops and deletions rarely disturb it,
+        // sort_by_left re-sorts only when they do)
+        key.clear();
+        for (size_t i = 0; i < n; i++) {
+            if (!alive[i]) continue;
+            leftv[i] = std::llabs(m.st(i)[g]); lenv[i] = m.len(i); fwd[i] = m.st(i)[g] > 0;
+            key.push_back(((uint64_t)leftv[i] << 32) | (uint64_t)i);
+        }
+        for (int pass = 0;; pass++) {
+            const double tp0 = trace ? now_ms() : 0;
             sort_by_left(key, tmp);
-            bool any = false;
+            touched.clear();
             for (size_t r = 0; r + 1 < key.size(); r++) {
                 const uint32_t A = (uint32_t)key[r], B = (uint32_t)key[r + 1];
                 const int64_t ov = leftv[A] + lenv[A] - leftv[B];
                 if (ov <= 0) continue;
-                if (!any) { std::fill(cf.begin(), cf.end(), 0); std::fill(cl.begin(), cl.end(), 0); any = true; }
                 if (lenv[A] < lenv[B]) {              // A gives up its right side in g
+                    if (!cf[A] && !cl[A]) touched.push_back(A);
                     int64_t &c = fwd[A] ? cl[A] : cf[A];
                     c = std::max(c, ov);
                 } else {                               // B gives up its left side in g
+                    if (!cf[B] && !cl[B]) touched.push_back(B);
                     int64_t &c = fwd[B] ? cf[B] : cl[B];
                     c = std::max(c, ov);
                 }
             }
-            if (!any) break;
-            for (uint64_t kk : key) {
-                const uint32_t i = (uint32_t)kk;
-                if (!cf[i] && !cl[i]) continue;
-                int64_t nl = m.len(i) - cf[i] - cl[i];
-                if (nl <= 0) { alive[i] = 0; continue; }
-                for (int c = 0; c < N; c++) {
-                    if (m.st(i)[c] > 0) m.st(i)[c] += cf[i];
-                    else m.st(i)[c] -= cl[i];
+            if (trace) fprintf(stderr, "[trace] eliminate g=%d pass=%d n=%zu overlaps=%zu %.3f ms\n", g, pass, key.size(), touched.size(), now_ms() - tp0);
+            if (touched.empty()) break;
+            bool died = false;
+            for (uint32_t i : touched) {
+                const int64_t nl = m.len(i) - cf[i] - cl[i];
+                if (nl <= 0) { alive[i] = 0; died = true; }
+                else {
+                    for (int c = 0; c < N; c++) {
+                        if (m.st(i)[c] > 0) m.st(i)[c] += cf[i];
+                        else m.st(i)[c] -= cl[i];
+                    }
+                    m.len(i) = nl;
+                    leftv[i] = std::llabs(m.st(i)[g]); lenv[i] = nl;
                 }
-                m.len(i) = nl;
+                cf[i] = 0; cl[i] = 0;
+            }
+            // refresh the keys of the touched matches in place, drop the dead ones
+            if (died) {
+                key2.clear();
+                for (uint64_t kk : key) { const uint32_t i = (uint32_t)kk; if (alive[i]) key2.push_back(((uint64_t)leftv[i] << 32) | i); }
+                key.swap(key2);
+            } else {
+                for (uint64_t &kk : key) { const uint32_t i = (uint32_t)kk; kk = ((uint64_t)leftv[i] << 32) | i; }
             }
         }
     }
