@@ -43,6 +43,24 @@ __device__ __forceinline__ uint64_t kprime_at(const uint64_t *__restrict__ G, ui
     return k;
 }
 
+// narrow form (span <= 32, weight <= 16): the window is one 64-bit word and K' fits 32 bits
+__device__ __forceinline__ uint32_t kprime_narrow(const uint64_t *__restrict__ G, uint32_t p, const SeedShape &sh)
+{
+    const uint32_t q = p >> 5; const int r = (p & 31) * 2;
+    const uint64_t w0 = G[q], w1 = G[q + 1];
+    const uint64_t lo = r ? ((w0 >> r) | (w1 << (64 - r))) : w0;
+    uint32_t k = 0;
+    for (int i = 0; i < sh.nruns; i++)
+        k |= ((uint32_t)(lo >> sh.run_src[i]) & ((1u << sh.run_bits[i]) - 1u)) << sh.run_dst[i];
+    return k;
+}
+
+__device__ __forceinline__ uint32_t digit_reverse32(uint32_t k, int weight)
+{
+    uint32_t x = __brev(k) >> (32 - 2 * weight);
+    return ((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1);
+}
+
 // the 2-bit window of `span` bases starting at base p, as a 128-bit little-endian digit string
 __device__ __forceinline__ void window_at(const uint64_t *__restrict__ G, uint32_t p, uint64_t &lo, uint64_t &hi)
 {
@@ -119,6 +137,47 @@ __global__ void __launch_bounds__(256) seed_extract(const uint64_t *__restrict__
         keys[out_base + p] = (KeyT)key;
         vals[out_base + p] = (tab.gpos_off[g] + p) | (s << 31);
     }
+}
+
+// All genomes in one launch, tiled exactly like the radix sort (4096 windows per workgroup), with the digit
+// histogram of the first sort pass accumulated on the way out: saves two launches and one re-read of the keys.
+template <typename KeyT, bool SEG, bool NARROW>
+__global__ void __launch_bounds__(256) seed_extract_all(const uint64_t *__restrict__ packed, GenomeTab tab, SeedShape sh,
+                                                        KeyT *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t P,
+                                                        const uint32_t *__restrict__ seg, uint32_t nseg,
+                                                        uint32_t *__restrict__ hist, uint32_t nblk)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * 4096u;
+#pragma unroll 4
+    for (int i = 0; i < 16; i++) {
+        const uint32_t gp = base + i * 256 + threadIdx.x;
+        if (gp >= P) break;
+        const int g = genome_of(gp, tab);
+        const uint32_t p = gp - tab.gpos_off[g];
+        uint64_t key; uint32_t s;
+        if (NARROW) {
+            const uint32_t kp = kprime_narrow(packed + tab.word_off[g], p, sh);
+            const uint32_t f = digit_reverse32(kp, sh.weight), r = (~kp) & (uint32_t)sh.keymask;
+            s = r < f; key = s ? r : f;
+        } else {
+            const uint64_t kp = kprime_at(packed + tab.word_off[g], p, sh);
+            const uint64_t f = digit_reverse(kp, sh.weight), r = (~kp) & sh.keymask;
+            s = r < f; key = s ? r : f;
+        }
+        if (SEG) {
+            const uint32_t *sg = seg + (size_t)g * (nseg + 1);
+            const uint32_t k = seg_of(sg, nseg, p);
+            key = (p + sh.span <= sg[k + 1]) ? (((uint64_t)k << (2 * sh.weight)) | key) : ~0ULL;
+        }
+        keys[gp] = (KeyT)key;
+        vals[gp] = gp | (s << 31);
+        atomicAdd(&h[(uint32_t)key & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -563,14 +622,14 @@ static int build_tab(mauve_ctx *ctx, const GenomeSet &gs, int span, GenomeTab *t
 
 template <typename KeyT>
 static int sort_pairs(mauve_ctx *ctx, uint32_t n, int key_bits, KeyT **keys_io, uint32_t **vals_io, KeyT *keys_alt,
-                      uint32_t *vals_alt)
+                      uint32_t *vals_alt, bool have_hist0)
 {
     uint32_t nblk = (n + RS_TILE - 1) / RS_TILE;
     HIPCHK(ctx, ctx->hist.ensure((size_t)nblk * 256 * sizeof(uint32_t)));
     HIPCHK(ctx, ctx->totals.ensure(256 * sizeof(uint32_t)));
     KeyT *kin = *keys_io, *kout = keys_alt; uint32_t *vin = *vals_io, *vout = vals_alt;
     for (int shift = 0; shift < key_bits; shift += 8) {
-        { KernelTimer t(ctx, MAUVE_K_SORT_HIST, n);
+        if (!(shift == 0 && have_hist0)) { KernelTimer t(ctx, MAUVE_K_SORT_HIST, n);
           hipLaunchKernelGGL(rs_hist<KeyT>, dim3(nblk), dim3(RS_THREADS), 0, ctx->stream, kin, n, shift,
                              ctx->hist.as<uint32_t>(), nblk); }
         { KernelTimer t(ctx, MAUVE_K_SORT_SCAN, n);
@@ -604,23 +663,35 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     const uint64_t *packed = gs.buf->as<uint64_t>();
 
     uint32_t sorted_n = 0;
-    for (int g = 0; g < tab.nseq; g++) {
-        if (only_seq >= 0 && g != only_seq) continue;
+    bool have_hist0 = false;
+    if (only_seq < 0) {
+        const uint32_t nblk = (n + RS_TILE - 1) / RS_TILE;
+        HIPCHK(ctx, ctx->hist.ensure((size_t)nblk * 256 * sizeof(uint32_t)));
+        KernelTimer t(ctx, MAUVE_K_EXTRACT, n);
+        if (sh.span <= 32 && sh.weight <= 15)
+            hipLaunchKernelGGL((seed_extract_all<KeyT, SEG, true>), dim3(nblk), dim3(256), 0, ctx->stream, packed, tab, sh, keys,
+                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk);
+        else
+            hipLaunchKernelGGL((seed_extract_all<KeyT, SEG, false>), dim3(nblk), dim3(256), 0, ctx->stream, packed, tab, sh, keys,
+                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk);
+        sorted_n = n; have_hist0 = true;
+    } else {
+        const int g = only_seq;
         uint32_t nw = tab.nwin[g];
-        if (!nw) continue;
-        uint32_t base = only_seq >= 0 ? 0u : tab.gpos_off[g];
-        uint32_t blocks = std::min<uint32_t>((nw + 255) / 256, 256 * 16);
-        KernelTimer t(ctx, MAUVE_K_EXTRACT, nw);
-        hipLaunchKernelGGL((seed_extract<KeyT, SEG>), dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh, g, keys,
-                           vals, base, seg, nseg);
-        sorted_n += nw;
+        if (nw) {
+            uint32_t blocks = std::min<uint32_t>((nw + 255) / 256, 256 * 16);
+            KernelTimer t(ctx, MAUVE_K_EXTRACT, nw);
+            hipLaunchKernelGGL((seed_extract<KeyT, SEG>), dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh, g, keys,
+                               vals, 0u, seg, nseg);
+            sorted_n = nw;
+        }
     }
     HIPCHK(ctx, hipGetLastError());
     TRACE(ctx, "extract");
     if (sorted_n == 0) { if (n_matches) *n_matches = 0; return MAUVE_OK; }
     // segmented keys: segment id above the mer; the all-ones invalid key needs every bit, so sort all 64
     const int key_bits = SEG ? 64 : 2 * sh.weight;
-    int rc = sort_pairs<KeyT>(ctx, sorted_n, key_bits, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>());
+    int rc = sort_pairs<KeyT>(ctx, sorted_n, key_bits, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>(), have_hist0);
     if (rc) return rc;
     TRACE(ctx, "sort");
 
