@@ -451,6 +451,8 @@ __device__ __forceinline__ bool agree_at(const uint64_t *__restrict__ packed, co
 // same-mask hit on the same diagonal at p-d, d <= span, cannot be the leftmost hit of its cluster (the
 // left walk of S4 never jumps over an agreeing offset, and that hit agrees).  Everything else is a
 // candidate for phase B.  all != 0 (no extension): every hit is a candidate.
+constexpr int RUNS_ITEMS = 16;
+
 template <bool SEG>
 __global__ void __launch_bounds__(256) mum_runs(GenomeTab tab, int span, const uint32_t *__restrict__ tmask,
                                                 const uint32_t *__restrict__ tpos, uint32_t P, int all,
@@ -459,44 +461,51 @@ __global__ void __launch_bounds__(256) mum_runs(GenomeTab tab, int span, const u
 {
     __shared__ uint32_t lds[8];
     __shared__ uint32_t s_base;
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    bool is_cand = false;
-    if (p < P) {
+    // 4096 windows per workgroup: one block scan and ONE global atomic per 4096 windows
+    const uint32_t base = blockIdx.x * (256u * RUNS_ITEMS);
+    uint32_t flags = 0, cnt = 0;
+#pragma unroll 4
+    for (int it = 0; it < RUNS_ITEMS; it++) {
+        const uint32_t p = base + it * 256 + threadIdx.x;
+        if (p >= P) break;
         const uint32_t m = tmask[p];
-        if (m) {
-            is_cand = true;
-            if (!all) {
-                const int a = __ffs(m) - 1;
-                uint32_t g0 = tab.gpos_off[a];
-                if (SEG) {      // a predecessor only counts inside the same gap segment
-                    const uint32_t *sg = seg + (size_t)a * (nseg + 1);
-                    g0 += sg[seg_of(sg, nseg, p - g0)];
+        if (!m) continue;
+        bool is_cand = true;
+        if (!all) {
+            const int a = __ffs(m) - 1;
+            uint32_t g0 = tab.gpos_off[a];
+            if (SEG) {      // a predecessor only counts inside the same gap segment
+                const uint32_t *sg = seg + (size_t)a * (nseg + 1);
+                g0 += sg[seg_of(sg, nseg, p - g0)];
+            }
+            const uint32_t sa = tpos[(size_t)a * P + p] >> 31;
+            for (int d = 1; d <= span && is_cand; d++) {
+                if (p < g0 + (uint32_t)d) break;
+                const uint32_t q = p - d;
+                if (tmask[q] != m) continue;
+                const uint32_t sq = tpos[(size_t)a * P + q] >> 31;
+                bool same = true;
+                for (int g = a + 1; g < tab.nseq && same; g++) {
+                    if (!(m >> g & 1)) continue;
+                    const uint32_t vp = tpos[(size_t)g * P + p], vq = tpos[(size_t)g * P + q];
+                    const uint32_t o = (vp >> 31) ^ sa;
+                    if (((vq >> 31) ^ sq) != o) { same = false; break; }
+                    const uint32_t pp = vp & 0x7fffffffu, pq = vq & 0x7fffffffu;
+                    same = o ? (pq == pp + (uint32_t)d) : (pq + (uint32_t)d == pp);
                 }
-                const uint32_t sa = tpos[(size_t)a * P + p] >> 31;
-                for (int d = 1; d <= span && is_cand; d++) {
-                    if (p < g0 + (uint32_t)d) break;
-                    const uint32_t q = p - d;
-                    if (tmask[q] != m) continue;
-                    const uint32_t sq = tpos[(size_t)a * P + q] >> 31;
-                    bool same = true;
-                    for (int g = a + 1; g < tab.nseq && same; g++) {
-                        if (!(m >> g & 1)) continue;
-                        const uint32_t vp = tpos[(size_t)g * P + p], vq = tpos[(size_t)g * P + q];
-                        const uint32_t o = (vp >> 31) ^ sa;
-                        if (((vq >> 31) ^ sq) != o) { same = false; break; }
-                        const uint32_t pp = vp & 0x7fffffffu, pq = vq & 0x7fffffffu;
-                        same = o ? (pq == pp + (uint32_t)d) : (pq + (uint32_t)d == pp);
-                    }
-                    if (same) is_cand = false;
-                }
+                if (same) is_cand = false;
             }
         }
+        if (is_cand) { flags |= 1u << it; cnt++; }
     }
     uint32_t total;
-    const uint32_t off = block_excl_scan(is_cand ? 1u : 0u, &total, lds);
+    const uint32_t off = block_excl_scan(cnt, &total, lds);
     if (threadIdx.x == 0) s_base = total ? atomicAdd(&counters[1], total) : 0u;
     __syncthreads();
-    if (is_cand) cand[s_base + off] = p;
+    uint32_t o = s_base + off;
+#pragma unroll
+    for (int it = 0; it < RUNS_ITEMS; it++)
+        if (flags >> it & 1) cand[o++] = base + it * 256 + threadIdx.x;
 }
 
 // phase B: one wave per candidate; the 64 lanes test 64 consecutive offsets at a time and the resulting
@@ -722,7 +731,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     TRACE(ctx, "join");
     // ---- extension phase A: run starts from the table ----
     { KernelTimer t(ctx, MAUVE_K_RUNS, P);
-      hipLaunchKernelGGL((mum_runs<SEG>), dim3((P + 255) / 256), dim3(256), 0, ctx->stream, tab, sh.span, tmask, tpos, P,
+      hipLaunchKernelGGL((mum_runs<SEG>), dim3((P + 256 * RUNS_ITEMS - 1) / (256 * RUNS_ITEMS)), dim3(256), 0, ctx->stream, tab, sh.span, tmask, tpos, P,
                          extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg, nseg); }
     HIPCHK(ctx, hipGetLastError());
     uint32_t hc[4] = {0, 0, 0, 0};
