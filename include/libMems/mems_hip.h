@@ -325,6 +325,13 @@ class MaskedMemHash : public MemHash {
 public:
     virtual MaskedMemHash *Clone() const { return new MaskedMemHash(*this); }
 };
+// progressiveMauve.cpp:496-501: "PairwiseMatchFinder pmf; pmf.FindMatches(pairwise_match_list)" for <= 4 genomes
+class PairwiseMatchFinder : public MemHash {
+public:
+    virtual PairwiseMatchFinder *Clone() const { return new PairwiseMatchFinder(*this); }
+protected:
+    virtual int seedRule() const { return MAUVE_MODE_PAIRWISE; }
+};
 
 }  // namespace mems
 

@@ -37,6 +37,8 @@ extern "C" {
 /* seed-hit rule = which MatchFinder subclass's EnumerateMatches is in force */
 #define MAUVE_MODE_MEM 0      /* mems::MemHash / MaskedMemHash (mauveAligner.cpp:523-531) */
 #define MAUVE_MODE_UNIQUE 1   /* UniqueMatchFinder::EnumerateMatches (UniqueMatchFinder.cpp:36-60) */
+#define MAUVE_MODE_PAIRWISE 2 /* mems::PairwiseMatchFinder (progressiveMauve.cpp:496-501): MemHash on every genome
+                                pair separately; matches have exactly two components; mask is ignored */
 
 typedef struct mauve_ctx mauve_ctx;
 

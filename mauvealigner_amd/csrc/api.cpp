@@ -113,7 +113,7 @@ int mauve_set_genomes(mauve_ctx *c, int nseq, const uint64_t *const *packed, con
 int mauve_seed_mums(mauve_ctx *c, uint64_t pattern, int mode, uint64_t mask, int extend, int64_t *n_matches)
 {
     if (!c) return MAUVE_ERR_ARG;
-    if (mode != MAUVE_MODE_MEM && mode != MAUVE_MODE_UNIQUE) { c->err = "seed_mums: unknown mode"; return MAUVE_ERR_ARG; }
+    if (mode != MAUVE_MODE_MEM && mode != MAUVE_MODE_UNIQUE && mode != MAUVE_MODE_PAIRWISE) { c->err = "seed_mums: unknown mode"; return MAUVE_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     return seedpass_run(c, main_genome_set(c), pattern, mode, mask, extend, nullptr, 0, n_matches);
 }

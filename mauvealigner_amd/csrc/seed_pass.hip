@@ -372,7 +372,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total,
 template <typename KeyT, bool SEG>
 __global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                 uint32_t n, GenomeTab tab, int mode, uint32_t want_mask,
-                                                uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos, uint32_t P)
+                                                uint32_t consider, uint32_t *__restrict__ tmask,
+                                                uint32_t *__restrict__ tpos, uint32_t P)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -380,10 +381,13 @@ __global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, c
     if (SEG && k == (KeyT)~0ULL) return;
     if (i > 0 && keys[i - 1] == k) return;
     if (i + 1 >= n || keys[i + 1] != k) return;        // singleton run
+    // `consider` restricts the finder to a subset of the genomes (PairwiseMatchFinder: one pair at a time);
+    // entries of the other genomes are invisible to it
     uint32_t once = 0, multi = 0, j = i;
     while (j < n && keys[j] == k) {
-        uint32_t bit = 1u << genome_of(vals[j] & 0x7fffffffu, tab);
+        uint32_t bit = (1u << genome_of(vals[j] & 0x7fffffffu, tab)) & consider;
         multi |= once & bit; once |= bit; j++;
+        if (mode == MAUVE_MODE_MEM && multi) return;   // MemHash: a repeat kills the seed, no need to finish the run
     }
     const uint32_t m = once & ~multi;
     if (mode == MAUVE_MODE_MEM && multi) return;
@@ -715,52 +719,61 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         return MAUVE_OK;
     }
 
-    // ---- join: scatter the hits into the dense hit table ----
+    // ---- join + extension, once per finder pass (one pass, or one per genome pair for PairwiseMatchFinder) ----
     const int N = tab.nseq;
     const uint32_t P = n;
     HIPCHK(ctx, ctx->posmask.ensure((size_t)P * 4));             // tmask
     HIPCHK(ctx, ctx->hit_pos.ensure((size_t)P * 4 * N));         // tpos [N][P]
     HIPCHK(ctx, ctx->cand.ensure((size_t)(P / 2 + 1) * 4));      // a hit needs >= 2 entries
-    HIPCHK(ctx, hipMemsetAsync(ctx->posmask.p, 0, (size_t)P * 4, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
     uint32_t *tmask = ctx->posmask.as<uint32_t>(), *tpos = ctx->hit_pos.as<uint32_t>();
-    { KernelTimer t(ctx, MAUVE_K_JOIN, n);
-      hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, n, tab, mode,
-                         (uint32_t)mask, tmask, tpos, P); }
-    HIPCHK(ctx, hipGetLastError());
-    TRACE(ctx, "join");
-    // ---- extension phase A: run starts from the table ----
-    { KernelTimer t(ctx, MAUVE_K_RUNS, P);
-      hipLaunchKernelGGL((mum_runs<SEG>), dim3((P + 256 * RUNS_ITEMS - 1) / (256 * RUNS_ITEMS)), dim3(256), 0, ctx->stream, tab, sh.span, tmask, tpos, P,
-                         extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg, nseg); }
-    HIPCHK(ctx, hipGetLastError());
-    uint32_t hc[4] = {0, 0, 0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t ncand = hc[1];
-    TRACE(ctx, "runs");
+    struct FinderPass { uint32_t consider, want; int rule; };
+    std::vector<FinderPass> passes;
+    if (mode == MAUVE_MODE_PAIRWISE) {
+        for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++) passes.push_back({(1u << i) | (1u << j), (1u << i) | (1u << j), MAUVE_MODE_MEM});
+    } else passes.push_back({0xffffffffu, (uint32_t)mask, mode});
     ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear();
     if (n_matches) *n_matches = 0;
-    if (ncand == 0) return MAUVE_OK;
-    // ---- extension phase B ----
-    HIPCHK(ctx, ctx->mlen.ensure((size_t)ncand * 4 + 4));
-    HIPCHK(ctx, ctx->mstart.ensure((size_t)ncand * 4 * N + 4));
-    {
-        uint32_t blocks = std::min<uint32_t>((ncand + 3) / 4, 256 * 8);
-        KernelTimer t(ctx, MAUVE_K_EXTEND, ncand);
-        hipLaunchKernelGGL((mum_extend<SEG>), dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh, tmask, tpos, P,
-                           ctx->cand.as<uint32_t>(), ncand, extend, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(), seg,
-                           nseg);
+    std::vector<int32_t> hl, hs;       // one record slot per candidate of every pass; length 0 = not a leftmost hit
+    for (const FinderPass &fp : passes) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->posmask.p, 0, (size_t)P * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+        { KernelTimer t(ctx, MAUVE_K_JOIN, n);
+          hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, n, tab, fp.rule,
+                             fp.want, fp.consider, tmask, tpos, P); }
         HIPCHK(ctx, hipGetLastError());
-    }
-    // ---- copy out (one record slot per candidate; length 0 = the candidate was not a leftmost hit) ----
-    std::vector<int32_t> hl(ncand), hs((size_t)ncand * N);
-    if (ncand) {
-        HIPCHK(ctx, hipMemcpyAsync(hl.data(), ctx->mlen.p, (size_t)ncand * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(hs.data(), ctx->mstart.p, (size_t)ncand * 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+        TRACE(ctx, "join");
+        // extension phase A: run starts from the table
+        { KernelTimer t(ctx, MAUVE_K_RUNS, P);
+          hipLaunchKernelGGL((mum_runs<SEG>), dim3((P + 256 * RUNS_ITEMS - 1) / (256 * RUNS_ITEMS)), dim3(256), 0, ctx->stream, tab,
+                             sh.span, tmask, tpos, P, extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg,
+                             nseg); }
+        HIPCHK(ctx, hipGetLastError());
+        uint32_t hc[4] = {0, 0, 0, 0};
+        HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        const uint32_t nc = hc[1];
+        TRACE(ctx, "runs");
+        if (nc == 0) continue;
+        // extension phase B
+        HIPCHK(ctx, ctx->mlen.ensure((size_t)nc * 4 + 4));
+        HIPCHK(ctx, ctx->mstart.ensure((size_t)nc * 4 * N + 4));
+        {
+            uint32_t blocks = std::min<uint32_t>((nc + 3) / 4, 256 * 8);
+            KernelTimer t(ctx, MAUVE_K_EXTEND, nc);
+            hipLaunchKernelGGL((mum_extend<SEG>), dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh, tmask, tpos, P,
+                               ctx->cand.as<uint32_t>(), nc, extend, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(), seg,
+                               nseg);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        const size_t old = hl.size();
+        hl.resize(old + nc); hs.resize((old + nc) * N);
+        HIPCHK(ctx, hipMemcpyAsync(hl.data() + old, ctx->mlen.p, (size_t)nc * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hs.data() + old * N, ctx->mstart.p, (size_t)nc * 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        TRACE(ctx, "extend+copy");
     }
-    TRACE(ctx, "extend+copy");
+    const uint32_t ncand = (uint32_t)hl.size();
+    if (ncand == 0) return MAUVE_OK;
     // ---- canonical order (first component, |start|, mask, starts, length) ----
     std::vector<uint32_t> order; order.reserve(ncand);
     std::vector<uint64_t> k1(ncand);   // (first component, |start|) packed for a fast first-level compare

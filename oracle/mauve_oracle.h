@@ -26,6 +26,7 @@ extern "C" {
 /* seed-hit rule (who calls HashMatch) */
 #define ORC_MODE_MEM 0        /* MemHash default: a mer repeated in any genome is dropped entirely */
 #define ORC_MODE_UNIQUE 1     /* UniqueMatchFinder.cpp:36-60: drop only the genomes with repeats */
+#define ORC_MODE_PAIRWISE 2   /* PairwiseMatchFinder (progressiveMauve.cpp:496-501): MemHash on each pair alone */
 
 typedef struct {
     int32_t gap_open;         /* cost of the first gap column of a run (negative) */

@@ -14,6 +14,7 @@ _LIB = None
 
 MODE_MEM = 0
 MODE_UNIQUE = 1
+MODE_PAIRWISE = 2
 CODING_SEED = 3
 SOLID_SEED = 0x7FFFFFFF
 MAX_SEQ = 32

@@ -155,3 +155,14 @@ def test_full_size_properties(ctx):
     assert np.array_equal(ln, ln3) and np.array_equal(st[:, :2], st3[:, :2])
     expect = -(L2 - (np.abs(st[:, 2]) + ln - 1) + 1) * np.sign(st[:, 2])
     assert np.array_equal(st3[:, 2], expect)
+
+
+def test_pairwise_match_finder(ctx):
+    """PairwiseMatchFinder (progressiveMauve.cpp:496-501): MemHash on every genome pair, sorted mer list built once."""
+    from mauvealigner_amd import _lib
+    for cfg, scale, w in (("C3", 0.02, 11), ("C4", 0.02, 9), ("C1", 0.2, 13)):
+        gs = synth.make_config(cfg, scale=scale)
+        pat = O.get_seed(w, 0)
+        ln, st = _same(ctx, gs, pat, mode=_lib.MODE_PAIRWISE)
+        assert np.all(np.count_nonzero(st, axis=1) == 2)
+        _same(ctx, gs, pat, mode=_lib.MODE_PAIRWISE, extend=False)

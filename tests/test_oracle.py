@@ -129,6 +129,22 @@ def test_matches_equal_bruteforce(seed, n, w, mode, inv):
     assert gotm == B.brute_matches([_asc(g) for g in gs], pat, mode=mode, mask=full)
 
 
+def test_pairwise_finder_is_memhash_per_pair():
+    """PairwiseMatchFinder = the MemHash search of each pair alone (brute force on the pair's two strings)."""
+    gs = _tiny_set(11, 4, 240, 0.05, inv=True)
+    pat = O.get_seed(5, 0)
+    ln, st = O.find_matches(gs, pat, mode=O.MODE_PAIRWISE)
+    got = set((int(l), tuple(int(x) for x in s)) for l, s in zip(ln, st))
+    want = set()
+    for i in range(4):
+        for j in range(i + 1, 4):
+            for l, (a, b) in B.brute_matches([_asc(gs[i]), _asc(gs[j])], pat, mode="mem"):
+                row = [0, 0, 0, 0]
+                row[i], row[j] = a, b
+                want.add((l, tuple(row)))
+    assert got == want and len(got) == len(ln)
+
+
 def test_matches_canonical_order_and_content():
     gs = synth.make_config("C1", scale=0.05)
     pat = O.get_seed(11, 0)
