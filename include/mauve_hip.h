@@ -154,6 +154,20 @@ int mauve_align_fetch(mauve_ctx *ctx,
                       int64_t *anchor_length, int64_t *anchor_start, int64_t *anchor_lcb,
                       int64_t *iv_left, int64_t *iv_right, int8_t *iv_reverse,   /* [n_iv*nseq] */
                       int64_t *col_off, uint32_t *cols, int64_t *dp_score);     /* [n_iv+1],[n_cols],[n_iv] */
+/* ---- the same path in three phases, for sharding the gapped alignment of ONE alignment over several GPUs
+        (mauveAligner.cpp:130-131 --realign-lcb "for parallelization of LCB alignment").  Every rank
+        calls mauve_align_begin (deterministic: identical anchors and interval table everywhere), aligns its
+        share of the n_dp intervals with mauve_align_dp (indices into the interval table; outputs compact, in
+        idx order: cols needs sum of max_cols over idx, col_off n+1, score n), exchanges the columns (one
+        all_gather, mauvealigner_amd/parallel.py) and calls mauve_align_finish with the columns of ALL
+        intervals in table order.  mauve_align_dp_cost gives per-interval DP cells (for LPT packing) and the
+        column capacity each interval needs. ------------------------------------------------------------- */
+int mauve_align_begin(mauve_ctx *ctx, const mauve_params *p, int64_t *n_dp, int64_t *n_codes);
+int mauve_align_dp_cost(mauve_ctx *ctx, int64_t *cost, int64_t *max_cols);
+int mauve_align_dp(mauve_ctx *ctx, const int64_t *idx, int64_t n, uint32_t *cols, int64_t *col_off,
+                   int64_t *score, int64_t *cells);
+int mauve_align_finish(mauve_ctx *ctx, const uint32_t *cols, const int64_t *col_off, const int64_t *score,
+                       int64_t cells, mauve_align_sizes *sizes);
 /* IntervalList::WriteStandardAlignment (mauveAligner.cpp:746-760; format mfa2xmfa.cpp:64-115).
    Two-phase: buf == NULL returns the needed size (including NUL) in *len. */
 int mauve_write_xmfa(mauve_ctx *ctx, const char *const *names, char *buf, int64_t *len);

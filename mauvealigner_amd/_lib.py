@@ -23,6 +23,7 @@ EXPORTS = [
     "mauve_default_params", "mauve_packed_words", "mauve_pack_ascii", "mauve_pack_codes", "mauve_set_genomes",
     "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_seed_match_enumerate",
     "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_align", "mauve_align_fetch",
+    "mauve_align_begin", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
     "mauve_write_xmfa", "mauve_profile_enable", "mauve_profile_reset", "mauve_profile_get", "mauve_last_stage_times",
 ]
 
@@ -263,7 +264,11 @@ class Context:
         out = {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
         if not fetch:
             return out
+        return self._fetch(sz, names, want_xmfa)
+
+    def _fetch(self, sz, names=None, want_xmfa=False):
         N = self.nseq
+        out = {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
         a = {
             "mum_length": np.zeros(sz.n_mums, np.int64), "mum_start": np.zeros((sz.n_mums, N), np.int64),
             "lcb_left": np.zeros((sz.n_lcb, N), np.int64), "lcb_right": np.zeros((sz.n_lcb, N), np.int64),
@@ -290,6 +295,41 @@ class Context:
             self._chk(self.L.mauve_write_xmfa(self.h, narr, buf, C.byref(ln)), "mauve_write_xmfa")
             out["xmfa"] = buf.value.decode()
         return out
+
+    # ---- sharded form: begin / dp on a subset / finish (include/mauve_hip.h) ----
+    def align_begin(self, params=None):
+        p = params or default_params()
+        n_dp, n_codes = C.c_int64(), C.c_int64()
+        self._chk(self.L.mauve_align_begin(self.h, C.byref(p), C.byref(n_dp), C.byref(n_codes)), "mauve_align_begin")
+        cost = np.zeros(max(n_dp.value, 1), np.int64)
+        cap = np.zeros(max(n_dp.value, 1), np.int64)
+        self._chk(self.L.mauve_align_dp_cost(self.h, _p(cost, C.c_int64), _p(cap, C.c_int64)), "mauve_align_dp_cost")
+        return n_dp.value, cost[:n_dp.value], cap[:n_dp.value]
+
+    def align_dp(self, idx, cap):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        n = len(idx)
+        cols = np.zeros(max(int(cap[idx].sum()) if n else 0, 1), np.uint32)
+        col_off = np.zeros(n + 1, np.int64)
+        score = np.zeros(max(n, 1), np.int64)
+        cells = C.c_int64()
+        self._chk(self.L.mauve_align_dp(self.h, _p(idx, C.c_int64), C.c_int64(n), _p(cols, C.c_uint32), _p(col_off, C.c_int64),
+                                        _p(score, C.c_int64), C.byref(cells)), "mauve_align_dp")
+        return [cols[col_off[i]:col_off[i + 1]] for i in range(n)], score[:n], cells.value
+
+    def align_finish(self, cols_list, scores, cells, fetch=True, names=None, want_xmfa=False):
+        n = len(cols_list)
+        col_off = np.zeros(n + 1, np.int64)
+        for i, c in enumerate(cols_list):
+            col_off[i + 1] = col_off[i] + len(c)
+        flat = np.concatenate(cols_list).astype(np.uint32) if n and col_off[n] else np.zeros(1, np.uint32)
+        scores = np.ascontiguousarray(scores, dtype=np.int64) if n else np.zeros(1, np.int64)
+        sz = AlignSizes()
+        self._chk(self.L.mauve_align_finish(self.h, _p(flat, C.c_uint32), _p(col_off, C.c_int64), _p(scores, C.c_int64),
+                                            C.c_int64(cells), C.byref(sz)), "mauve_align_finish")
+        if not fetch:
+            return {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
+        return self._fetch(sz, names, want_xmfa)
 
     def stage_times(self):
         t = StageTimes()

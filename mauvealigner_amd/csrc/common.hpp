@@ -78,6 +78,41 @@ struct AlignResult {
     std::vector<int64_t> dp_score;
 };
 
+// N-way match list in flat records of (1 + N) int64: length, signed 1-based starts (libMems Match layout).
+struct MatchVec {
+    int N = 0;
+    std::vector<int64_t> d;
+    explicit MatchVec(int n = 0) : N(n) {}
+    size_t size() const { return d.size() / (size_t)(1 + N); }
+    bool empty() const { return d.empty(); }
+    int64_t &len(size_t i) { return d[i * (1 + N)]; }
+    int64_t len(size_t i) const { return d[i * (1 + N)]; }
+    int64_t *st(size_t i) { return &d[i * (1 + N) + 1]; }
+    const int64_t *st(size_t i) const { return &d[i * (1 + N) + 1]; }
+    const int64_t *rec(size_t i) const { return &d[i * (1 + N)]; }
+    void push(const int64_t *r) { d.insert(d.end(), r, r + 1 + N); }
+    void push(int64_t l, const int64_t *starts) { d.push_back(l); d.insert(d.end(), starts, starts + N); }
+    void resize(size_t n) { d.resize(n * (1 + N)); }
+    void move(size_t dst, size_t src) { if (dst != src) std::copy(d.begin() + src * (1 + N), d.begin() + (src + 1) * (1 + N), d.begin() + dst * (1 + N)); }
+    void reserve(size_t n) { d.reserve(n * (1 + N)); }
+    void sort_by_start0();
+};
+struct DpSeqDesc { int32_t genome; int32_t rev; int64_t lo0; int64_t len; };   // lo0: 0-based left end in the genome
+
+// state of an alignment between its begin and finish phases (pipeline.cpp)
+struct AlignState {
+    struct GapRef { int64_t lcb, idx; bool dp; int64_t dp_slot; int64_t tot; };
+    bool open = false;
+    mauve_params p{};
+    int N = 0; uint32_t full = 0;
+    int64_t sum = 0, nm = 0, nl = 0, n_dp = 0, code_total = 0, n_anchor = 0, anchor_cols = 0;
+    double t0 = 0, t_dp0 = 0;
+    std::vector<MatchVec> chains;
+    std::vector<GapRef> gaps;
+    std::vector<DpSeqDesc> desc;
+    std::vector<uint32_t> dcols; std::vector<int64_t> dcol_off, dscore;
+};
+
 struct mauve_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -110,6 +145,7 @@ struct mauve_ctx {
     int64_t k_units[MAUVE_K_COUNT] = {0};
 
     AlignResult res;
+    AlignState ast;
     mauve_stage_times stage{};
 };
 
@@ -146,30 +182,10 @@ int seedpass_sorted_list(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t 
                          std::vector<uint32_t> *vals, int *weight);
 
 // host chaining (chain_host.cpp)
-// N-way match list in flat records of (1 + N) int64: length, signed 1-based starts (libMems Match layout).
-struct MatchVec {
-    int N = 0;
-    std::vector<int64_t> d;
-    explicit MatchVec(int n = 0) : N(n) {}
-    size_t size() const { return d.size() / (size_t)(1 + N); }
-    bool empty() const { return d.empty(); }
-    int64_t &len(size_t i) { return d[i * (1 + N)]; }
-    int64_t len(size_t i) const { return d[i * (1 + N)]; }
-    int64_t *st(size_t i) { return &d[i * (1 + N) + 1]; }
-    const int64_t *st(size_t i) const { return &d[i * (1 + N) + 1]; }
-    const int64_t *rec(size_t i) const { return &d[i * (1 + N)]; }
-    void push(const int64_t *r) { d.insert(d.end(), r, r + 1 + N); }
-    void push(int64_t l, const int64_t *starts) { d.push_back(l); d.insert(d.end(), starts, starts + N); }
-    void resize(size_t n) { d.resize(n * (1 + N)); }
-    void move(size_t dst, size_t src) { if (dst != src) std::copy(d.begin() + src * (1 + N), d.begin() + (src + 1) * (1 + N), d.begin() + dst * (1 + N)); }
-    void reserve(size_t n) { d.reserve(n * (1 + N)); }
-    void sort_by_start0();
-};
 void host_eliminate_overlaps(MatchVec &m);
 void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb);
 
 // DP (dp_batch.hip)
-struct DpSeqDesc { int32_t genome; int32_t rev; int64_t lo0; int64_t len; };   // lo0: 0-based left end in the genome
 int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *sc,
                       uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells);
 int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,

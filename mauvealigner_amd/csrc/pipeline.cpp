@@ -29,15 +29,16 @@ inline void gap_of(const int64_t *a, const int64_t *b, int g, int64_t &lo, int64
 
 int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector<MatchVec> &chains);
 
-extern "C" {
-
-int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
+// ---- the whole path in three phases, so that the DP intervals of one alignment can be sharded over ranks ----
+// begin : seed pass, chaining, recursive anchoring, interval descriptors        (every rank, deterministic)
+// dp    : gapped alignment of a subset of the intervals                         (each rank its share)
+// finish: assembly of the interval table from the columns of ALL intervals      (every rank)
+static int align_begin(mauve_ctx *c, const mauve_params *p)
 {
-    if (!c || !p || !sizes) return MAUVE_ERR_ARG;
-    if (c->nseq < 2) { c->err = "align: at least two genomes required"; return MAUVE_ERR_STATE; }
-    HIPCHK(c, hipSetDevice(c->device));
     const int N = c->nseq;
-    const double t0 = now_ms();
+    AlignState &S = c->ast;
+    S = AlignState();
+    S.p = *p; S.N = N; S.t0 = now_ms();
     AlignResult &R = c->res;
     // keep the capacity of the result vectors across calls (a fresh 20 MB column buffer per call costs more in
     // page faults than the whole seed pass)
@@ -48,19 +49,22 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     memset(&c->stage, 0, sizeof c->stage);
 
     int64_t sum = 0; for (int g = 0; g < N; g++) sum += c->lens[g];
+    S.sum = sum;
     int w = p->seed_weight > 0 ? p->seed_weight : mauve_default_seed_weight(sum / N);
     uint64_t pat = p->seed_pattern ? p->seed_pattern : mauve_get_seed(w, p->seed_rank);
     if (!pat) { c->err = "align: no seed pattern for this weight/rank"; return MAUVE_ERR_ARG; }
     w = mauve_seed_weight(pat);
     const uint32_t full = N >= 32 ? 0xffffffffu : ((1u << N) - 1);
+    S.full = full;
 
     // ---- seed pass: N-way multi-MUMs (the multiplicity filter is pushed into the join) ----
     int64_t nm = 0;
     int rc = seedpass_run(c, main_genome_set(c), pat, p->mode, full, 1, nullptr, 0, &nm);
     if (rc) return rc;
+    S.nm = nm;
     R.mum_length = c->match_len; R.mum_start = c->match_start;
     const double t1 = now_ms();
-    c->stage.seed_ms = t1 - t0;
+    c->stage.seed_ms = t1 - S.t0;
 
     // ---- chaining ----
     MatchVec m(N); m.resize((size_t)nm);
@@ -73,7 +77,9 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight : (int64_t)3 * w * N;
     std::vector<int64_t> match_lcb; int64_t nl = 0;
     host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl);
-    std::vector<MatchVec> chains((size_t)nl, MatchVec(N));
+    S.nl = nl;
+    std::vector<MatchVec> &chains = S.chains;
+    chains.assign((size_t)nl, MatchVec(N));
     R.lcb_weight.assign((size_t)nl, 0);
     for (size_t i = 0; i < m.size(); i++) {
         int64_t l = match_lcb[i]; if (l < 0) continue;
@@ -92,17 +98,13 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     const double t3 = now_ms();
     c->stage.recurse_ms = t3 - t2;
 
-    // ---- gapped alignment of every inter-anchor interval ----
-    // Interval descriptors only: the bases are gathered from the resident packed genomes on the device.
-    struct GapRef { int64_t lcb, idx; bool dp; int64_t dp_slot; int64_t tot; };
-    std::vector<GapRef> gaps;
-    std::vector<DpSeqDesc> desc;
-    int64_t n_dp = 0, code_total = 0, n_anchor = 0, anchor_cols = 0;
+    // ---- inter-anchor intervals.  Descriptors only: the bases are gathered from the resident packed genomes on
+    // the device. ----
     for (int64_t l = 0; l < nl; l++) {
         const MatchVec &ch = chains[(size_t)l];
-        n_anchor += (int64_t)ch.size();
+        S.n_anchor += (int64_t)ch.size();
         for (size_t i = 0; i < ch.size(); i++) {
-            anchor_cols += ch.len(i);
+            S.anchor_cols += ch.len(i);
             if (i + 1 == ch.size()) break;
             int64_t tot = 0, mx = 0; int nonempty = 0;
             int64_t lo[MAUVE_MAX_SEQ], ln[MAUVE_MAX_SEQ]; bool rv[MAUVE_MAX_SEQ];
@@ -111,32 +113,54 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
                 tot += ln[g]; mx = std::max(mx, ln[g]); nonempty += ln[g] > 0;
             }
             if (tot == 0) continue;
-            GapRef gr; gr.lcb = l; gr.idx = (int64_t)i; gr.dp = false; gr.dp_slot = -1; gr.tot = tot;
+            AlignState::GapRef gr; gr.lcb = l; gr.idx = (int64_t)i; gr.dp = false; gr.dp_slot = -1; gr.tot = tot;
             if (p->gapped && nonempty >= 2 && mx <= p->max_gapped_len) {
-                gr.dp = true; gr.dp_slot = n_dp++;
+                gr.dp = true; gr.dp_slot = S.n_dp++;
                 for (int g = 0; g < N; g++) {
                     DpSeqDesc d; d.genome = g; d.rev = rv[g]; d.lo0 = lo[g] - 1; d.len = ln[g];
-                    desc.push_back(d);
+                    S.desc.push_back(d);
                 }
-                code_total += tot;
+                S.code_total += tot;
             }
-            gaps.push_back(gr);
+            S.gaps.push_back(gr);
         }
     }
-    std::vector<uint32_t> dcols((size_t)code_total + 1);
-    std::vector<int64_t> dcol_off((size_t)n_dp + 1, 0), dscore((size_t)n_dp + 1, 0);
-    int64_t cells = 0;
-    rc = dp_batch_run_desc(c, N, n_dp, desc.data(), &p->scoring, dcols.data(), dcol_off.data(), dscore.data(), &cells);
-    if (rc) return rc;
+    S.t_dp0 = now_ms();
+    S.open = true;
+    return MAUVE_OK;
+}
+
+// DP of the intervals idx[0..n) (slots of the descriptor table); outputs are compact, in idx order
+static int align_dp(mauve_ctx *c, const int64_t *idx, int64_t n, uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells)
+{
+    AlignState &S = c->ast;
+    const int N = S.N;
+    if (!idx) return dp_batch_run_desc(c, N, S.n_dp, S.desc.data(), &S.p.scoring, cols, col_off, score, cells);
+    std::vector<DpSeqDesc> sub((size_t)n * N);
+    for (int64_t k = 0; k < n; k++) {
+        if (idx[k] < 0 || idx[k] >= S.n_dp) { c->err = "align_dp: interval index out of range"; return MAUVE_ERR_ARG; }
+        std::copy(S.desc.begin() + idx[k] * N, S.desc.begin() + (idx[k] + 1) * N, sub.begin() + k * N);
+    }
+    return dp_batch_run_desc(c, N, n, sub.data(), &S.p.scoring, cols, col_off, score, cells);
+}
+
+static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol_off, const int64_t *dscore, int64_t cells,
+                        mauve_align_sizes *sizes)
+{
+    AlignState &S = c->ast;
+    AlignResult &R = c->res;
+    const int N = S.N; const int64_t nl = S.nl, n_dp = S.n_dp; const uint32_t full = S.full;
+    const mauve_params *p = &S.p;
+    std::vector<MatchVec> &chains = S.chains;
     const double t4 = now_ms();
-    c->stage.dp_ms = t4 - t3;
+    c->stage.dp_ms = t4 - S.t_dp0;
 
     // ---- assemble the interval table ----
     int64_t unaligned_cols = 0;
-    for (const GapRef &gr : gaps) if (!gr.dp) unaligned_cols += gr.tot;
+    for (const AlignState::GapRef &gr : S.gaps) if (!gr.dp) unaligned_cols += gr.tot;
     R.col_off.clear(); R.cols.clear();
-    R.cols.reserve((size_t)(anchor_cols + dcol_off[(size_t)n_dp] + unaligned_cols + (p->add_unaligned ? sum : 0)));
-    R.anchor_length.reserve((size_t)n_anchor); R.anchor_start.reserve((size_t)n_anchor * N); R.anchor_lcb.reserve((size_t)n_anchor);
+    R.cols.reserve((size_t)(S.anchor_cols + dcol_off[(size_t)n_dp] + unaligned_cols + (p->add_unaligned ? S.sum : 0)));
+    R.anchor_length.reserve((size_t)S.n_anchor); R.anchor_start.reserve((size_t)S.n_anchor * N); R.anchor_lcb.reserve((size_t)S.n_anchor);
     R.lcb_left.assign((size_t)nl * N, 0); R.lcb_right.assign((size_t)nl * N, 0);
     R.dp_score.assign((size_t)nl, 0);
     size_t gi = 0;
@@ -148,10 +172,10 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
             R.anchor_length.push_back(alen); R.anchor_lcb.push_back(l);
             R.anchor_start.insert(R.anchor_start.end(), ast, ast + N);
             R.cols.insert(R.cols.end(), (size_t)alen, full);
-            if (gi < gaps.size() && gaps[gi].lcb == l && gaps[gi].idx == (int64_t)i) {
-                const GapRef &gr = gaps[gi++];
+            if (gi < S.gaps.size() && S.gaps[gi].lcb == l && S.gaps[gi].idx == (int64_t)i) {
+                const AlignState::GapRef &gr = S.gaps[gi++];
                 if (gr.dp) {
-                    R.cols.insert(R.cols.end(), dcols.begin() + dcol_off[(size_t)gr.dp_slot], dcols.begin() + dcol_off[(size_t)gr.dp_slot + 1]);
+                    R.cols.insert(R.cols.end(), dcols + dcol_off[(size_t)gr.dp_slot], dcols + dcol_off[(size_t)gr.dp_slot + 1]);
                     R.dp_score[(size_t)l] += dscore[(size_t)gr.dp_slot];
                 } else {
                     for (int g = 0; g < N; g++) {
@@ -202,13 +226,80 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
         }
     }
     R.col_off.push_back((int64_t)R.cols.size());
-    R.sz.n_mums = nm; R.sz.n_lcb = nl; R.sz.n_anchor = n_anchor; R.sz.n_iv = niv; R.sz.n_cols = (int64_t)R.cols.size();
+    R.sz.n_mums = S.nm; R.sz.n_lcb = nl; R.sz.n_anchor = S.n_anchor; R.sz.n_iv = niv; R.sz.n_cols = (int64_t)R.cols.size();
     R.sz.n_gap_dp = n_dp; R.sz.n_dp_cells = cells;
     *sizes = R.sz;
     const double t5 = now_ms();
     c->stage.assemble_ms = t5 - t4;
-    c->stage.total_ms = t5 - t0;
+    c->stage.total_ms = t5 - S.t0;
+    S.open = false;
     return MAUVE_OK;
+}
+
+extern "C" {
+
+int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
+{
+    if (!c || !p || !sizes) return MAUVE_ERR_ARG;
+    if (c->nseq < 2) { c->err = "align: at least two genomes required"; return MAUVE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = align_begin(c, p);
+    if (rc) return rc;
+    AlignState &S = c->ast;
+    S.dcols.resize((size_t)S.code_total + 1);
+    S.dcol_off.assign((size_t)S.n_dp + 1, 0); S.dscore.assign((size_t)S.n_dp + 1, 0);
+    int64_t cells = 0;
+    rc = align_dp(c, nullptr, S.n_dp, S.dcols.data(), S.dcol_off.data(), S.dscore.data(), &cells);
+    if (rc) return rc;
+    return align_finish(c, S.dcols.data(), S.dcol_off.data(), S.dscore.data(), cells, sizes);
+}
+
+// ---- sharded form of mauve_align: see the phase comment above -------------------------------------------------
+int mauve_align_begin(mauve_ctx *c, const mauve_params *p, int64_t *n_dp, int64_t *n_codes)
+{
+    if (!c || !p || !n_dp) return MAUVE_ERR_ARG;
+    if (c->nseq < 2) { c->err = "align: at least two genomes required"; return MAUVE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = align_begin(c, p);
+    if (rc) return rc;
+    *n_dp = c->ast.n_dp;
+    if (n_codes) *n_codes = c->ast.code_total;
+    return MAUVE_OK;
+}
+
+int mauve_align_dp_cost(mauve_ctx *c, int64_t *cost, int64_t *max_cols)
+{
+    if (!c || !c->ast.open) { if (c) c->err = "align_dp_cost: no alignment in progress"; return c ? MAUVE_ERR_STATE : MAUVE_ERR_ARG; }
+    const AlignState &S = c->ast;
+    for (int64_t k = 0; k < S.n_dp; k++) {
+        int64_t m = 0, cells = 0, tot = 0;
+        for (int g = 0; g < S.N; g++) {
+            const int64_t n = S.desc[(size_t)(k * S.N + g)].len;
+            tot += n;
+            if (!n) continue;
+            if (!m) { m = n; continue; }
+            cells += m * n; m += n;
+        }
+        if (cost) cost[k] = cells;
+        if (max_cols) max_cols[k] = tot;
+    }
+    return MAUVE_OK;
+}
+
+int mauve_align_dp(mauve_ctx *c, const int64_t *idx, int64_t n, uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells)
+{
+    if (!c || !col_off || (n && (!idx || !cols))) return MAUVE_ERR_ARG;
+    if (!c->ast.open) { c->err = "align_dp: no alignment in progress"; return MAUVE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    return align_dp(c, idx, n, cols, col_off, score, cells);
+}
+
+int mauve_align_finish(mauve_ctx *c, const uint32_t *cols, const int64_t *col_off, const int64_t *score, int64_t cells,
+                       mauve_align_sizes *sizes)
+{
+    if (!c || !sizes || !col_off) return MAUVE_ERR_ARG;
+    if (!c->ast.open) { c->err = "align_finish: no alignment in progress"; return MAUVE_ERR_STATE; }
+    return align_finish(c, cols, col_off, score, cells, sizes);
 }
 
 #define CPY(dst, vec) do { if ((dst) && !(vec).empty()) memcpy((dst), (vec).data(), (vec).size() * sizeof((vec)[0])); } while (0)

@@ -99,3 +99,41 @@ def reduce_throughput(elapsed_s, base_pairs, dist=None, group=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
     return float(t.item()), float(b.item())
+
+
+def align_sharded(ctx, params=None, dist=None, group=None, names=None, want_xmfa=False, fetch=True):
+    """One alignment, its gapped-alignment intervals sharded over the ranks (LCB sharding).
+
+    Every rank holds the same genomes (ctx.set_genomes) and runs the deterministic front of the path
+    (mauve_align_begin: seed pass, chaining, recursive anchoring).  The DP intervals are LPT-partitioned by cells,
+    each rank aligns its share on its own GPU (mauve_align_dp), the ragged column lists are exchanged with one
+    all_gather and every rank assembles the full result (mauve_align_finish).
+    """
+    n_dp, cost, cap = ctx.align_begin(params)
+    world = 1 if dist is None else dist.get_world_size(group)
+    rank = 0 if dist is None else dist.get_rank(group)
+    parts = lpt_partition(cost, world) if n_dp else [np.zeros(0, np.int64) for _ in range(world)]
+    mine = parts[rank]
+    cols, score, cells = ctx.align_dp(mine, cap) if len(mine) else ([], np.zeros(0, np.int64), 0)
+    if world == 1:
+        all_cols, all_score, all_cells = [None] * n_dp, np.zeros(n_dp, np.int64), cells
+        for k, i in enumerate(mine.tolist()):
+            all_cols[i] = cols[k]
+            all_score[i] = score[k]
+    else:
+        lens = np.array([len(c) for c in cols], dtype=np.int64)
+        flat = np.concatenate(cols).astype(np.int64) if len(cols) and lens.sum() else np.zeros(0, np.int64)
+        g_lens = all_gather_ragged(lens, dist, group)
+        g_flat = all_gather_ragged(flat, dist, group)
+        g_score = all_gather_ragged(np.asarray(score, dtype=np.int64), dist, group)
+        g_cells = all_gather_ragged(np.array([cells], dtype=np.int64), dist, group)
+        all_cols, all_score = [None] * n_dp, np.zeros(n_dp, np.int64)
+        for r in range(world):
+            off = 0
+            for k, i in enumerate(parts[r].tolist()):
+                ln = int(g_lens[r][k])
+                all_cols[i] = g_flat[r][off:off + ln].astype(np.uint32)
+                all_score[i] = g_score[r][k]
+                off += ln
+        all_cells = int(sum(int(x[0]) for x in g_cells))
+    return ctx.align_finish(all_cols, all_score, all_cells, fetch=fetch, names=names, want_xmfa=want_xmfa)

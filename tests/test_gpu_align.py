@@ -195,3 +195,37 @@ def test_full_size_c2_properties(ctx):
     lcb_cols = cols[off[0]:off[1]]
     assert np.mean(lcb_cols == 7) > 0.9
     assert r["n_dp_cells"] > 0
+
+
+def test_sharded_align_equals_whole(ctx):
+    """The begin / dp / finish phases (LCB-sharded form of mauve_align): a single rank and a simulated two-rank
+    split of the DP intervals both reproduce mauve_align bit for bit."""
+    from mauvealigner_amd import _lib, parallel
+    gs = synth.make_config("C3", scale=0.03)
+    ctx.set_genomes(gs)
+    names = ["g%d" % i for i in range(len(gs))]
+    whole = ctx.align(_lib.default_params(), names=names, want_xmfa=True)
+    one = parallel.align_sharded(ctx, _lib.default_params(), None, names=names, want_xmfa=True)
+    keys = ("cols", "col_off", "left", "right", "reverse", "dp_score", "anchor_start", "anchor_length", "lcb_weight")
+    for k in keys:
+        assert np.array_equal(whole[k], one[k]), k
+    assert whole["xmfa"] == one["xmfa"] and whole["n_dp_cells"] == one["n_dp_cells"]
+    # two simulated ranks on one GPU: each aligns its LPT share, the shares are merged, every rank finishes
+    n_dp, cost, cap = ctx.align_begin(_lib.default_params())
+    assert n_dp == whole["n_gap_dp"] and int(cost.sum()) >= whole["n_dp_cells"]
+    parts = parallel.lpt_partition(cost, 2)
+    assert abs(int(cost[parts[0]].sum()) - int(cost[parts[1]].sum())) <= int(cost.max())
+    all_cols, all_score, cells = [None] * n_dp, np.zeros(n_dp, np.int64), 0
+    for part in parts:
+        cols, score, c = ctx.align_dp(part, cap)
+        cells += c
+        for k, i in enumerate(part.tolist()):
+            all_cols[i] = cols[k].copy()
+            all_score[i] = score[k]
+    two = ctx.align_finish(all_cols, all_score, cells, names=names, want_xmfa=True)
+    for k in keys:
+        assert np.array_equal(whole[k], two[k]), k
+    assert whole["xmfa"] == two["xmfa"] and whole["n_dp_cells"] == two["n_dp_cells"]
+    # phase order is enforced
+    with pytest.raises(RuntimeError):
+        ctx.align_dp(np.array([0], np.int64), cap)
