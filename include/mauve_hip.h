@@ -168,6 +168,17 @@ int mauve_align_dp(mauve_ctx *ctx, const int64_t *idx, int64_t n, uint32_t *cols
                    int64_t *score, int64_t *cells);
 int mauve_align_finish(mauve_ctx *ctx, const uint32_t *cols, const int64_t *col_off, const int64_t *score,
                        int64_t cells, mauve_align_sizes *sizes);
+/* ---- progressiveMauve path: guide tree + ProgressiveAligner::align(seq_table, interval_list)
+        (progressiveMauve.cpp:575-710; distance matrix / guide tree mauveAligner.cpp:616-623).  Frozen replacement
+        ("guide-tree recursive anchoring"): UPGMA over pairwise-match coverage; the root aligns
+        what all genomes share, every node below aligns -- among its own genomes -- the bases no ancestor has
+        placed.  tree_left/right: [2*nseq-1] child ids (-1 for leaves, internal ids nseq.. in merge order);
+        dist: [nseq*nseq] distances in parts per million; any of them may be NULL.  The result is fetched with
+        mauve_align_fetch / mauve_write_xmfa: intervals with >= 2 genomes first (n_lcb of them), then the
+        single-genome leftovers; absent genomes have left = right = 0. ------------------------------------- */
+int mauve_guide_tree(mauve_ctx *ctx, uint64_t pattern, int64_t *dist, int32_t *tree_left, int32_t *tree_right);
+int mauve_progressive_align(mauve_ctx *ctx, const mauve_params *p, mauve_align_sizes *sizes,
+                            int32_t *tree_left, int32_t *tree_right, int64_t *dist);
 /* IntervalList::WriteStandardAlignment (mauveAligner.cpp:746-760; format mfa2xmfa.cpp:64-115).
    Two-phase: buf == NULL returns the needed size (including NUL) in *len. */
 int mauve_write_xmfa(mauve_ctx *ctx, const char *const *names, char *buf, int64_t *len);

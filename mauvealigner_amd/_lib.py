@@ -24,6 +24,7 @@ EXPORTS = [
     "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_seed_match_enumerate",
     "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_align", "mauve_align_fetch",
     "mauve_align_begin", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
+    "mauve_guide_tree", "mauve_progressive_align",
     "mauve_write_xmfa", "mauve_profile_enable", "mauve_profile_reset", "mauve_profile_get", "mauve_last_stage_times",
 ]
 
@@ -330,6 +331,29 @@ class Context:
         if not fetch:
             return {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
         return self._fetch(sz, names, want_xmfa)
+
+    def guide_tree(self, pattern):
+        N = self.nseq
+        dist = np.zeros((N, N), np.int64)
+        left = np.zeros(2 * N - 1, np.int32)
+        right = np.zeros(2 * N - 1, np.int32)
+        self._chk(self.L.mauve_guide_tree(self.h, C.c_uint64(pattern), _p(dist, C.c_int64), _p(left, C.c_int32),
+                                          _p(right, C.c_int32)), "mauve_guide_tree")
+        return dist, left, right
+
+    def progressive_align(self, params=None, fetch=True, names=None, want_xmfa=False):
+        p = params or default_params()
+        N = self.nseq
+        sz = AlignSizes()
+        dist = np.zeros((N, N), np.int64)
+        left = np.zeros(2 * N - 1, np.int32)
+        right = np.zeros(2 * N - 1, np.int32)
+        self._chk(self.L.mauve_progressive_align(self.h, C.byref(p), C.byref(sz), _p(left, C.c_int32), _p(right, C.c_int32),
+                                                 _p(dist, C.c_int64)), "mauve_progressive_align")
+        out = self._fetch(sz, names, want_xmfa) if fetch else {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
+        out["tree"] = (left, right)
+        out["dist"] = dist
+        return out
 
     def stage_times(self):
         t = StageTimes()

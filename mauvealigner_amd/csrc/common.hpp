@@ -55,6 +55,7 @@ struct GenomeTab {
     uint32_t gpos_off[MAUVE_MAX_SEQ + 1];   // first global window index of genome g
     uint32_t nwin[MAUVE_MAX_SEQ];           // valid window starts of genome g
     uint64_t word_off[MAUVE_MAX_SEQ];       // first 64-bit word of genome g in the packed buffer
+    uint64_t mask_off[MAUVE_MAX_SEQ];       // first 64-bit word of genome g in the placed-base bitmap (S9), if any
 };
 
 // A set of packed genomes resident on the device (the main genomes, or the gap sub-sequences of one
@@ -64,6 +65,10 @@ struct GenomeSet {
     int nseq = 0;
     std::vector<int64_t> lens;
     std::vector<uint64_t> word_off;
+    // guide-tree recursive anchoring: 1 bit per base, set = already placed by an ancestor node;
+    // windows touching a set bit are invalid for seeding and extension.  nullptr = no mask.
+    DevBuf *vmask = nullptr;
+    std::vector<uint64_t> mask_off;
 };
 
 struct AlignResult {
@@ -129,6 +134,7 @@ struct mauve_ctx {
     // seed-pass workspace
     DevBuf keysA, keysB, valsA, valsB, hist, totals, posmask, hit_mask, hit_pos, hit_seg, cand, mlen, mstart, counters;
     DevBuf rec_genomes, rec_seg;         // recursive anchoring: gap sub-sequences + segment table
+    DevBuf placed_mask;                  // guide-tree recursive anchoring: placed-base bitmap
     // last match list (canonical order, host) + nseq it refers to
     std::vector<int64_t> match_len, match_start;
     int64_t n_matches = 0;

@@ -27,7 +27,7 @@ inline void gap_of(const int64_t *a, const int64_t *b, int g, int64_t &lo, int64
 
 }  // namespace
 
-int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector<MatchVec> &chains);
+int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector<MatchVec> &chains, int N, const int *gmap);
 
 // ---- the whole path in three phases, so that the DP intervals of one alignment can be sharded over ranks ----
 // begin : seed pass, chaining, recursive anchoring, interval descriptors        (every rank, deterministic)
@@ -92,7 +92,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p)
 
     // ---- recursive anchoring ----
     if (p->recursive) {
-        rc = recursive_anchoring(c, p, w, chains);
+        rc = recursive_anchoring(c, p, w, chains, N, nullptr);
         if (rc) return rc;
     }
     const double t3 = now_ms();

@@ -1,0 +1,331 @@
+// progressive.cpp -- guide tree and guide-tree recursive anchoring behind mauve_progressive_align():
+// the stand-in for ProgressiveAligner::align(seq_table, interval_list) [EXT] (progressiveMauve.cpp:575-710) and
+// for the distance matrix / guide tree of mauveAligner.cpp:616-623.  Frozen spec: DESIGN.md S9.
+//
+//   1. pairwise matches of every genome pair (PairwiseMatchFinder rule, one sorted mer list on the device),
+//      similarity = matched bases / shorter genome, integer distance in ppm, UPGMA with integer averaging;
+//   2. the root of the tree aligns what all genomes share (the Aligner::align path); every internal node below
+//      aligns, among its own genomes only, the bases no ancestor has placed.  Placed bases are a 1-bit-per-base
+//      mask on the device: windows touching them are invalid for seeding and extension (seed_pass.hip), chains
+//      are cut where the stretch between two anchors touches a placed base or is too long for the gapped
+//      aligner, so those bases flow down to the subtree that shares them;
+//   3. what is left at the leaves becomes single-genome intervals.
+// Every node is one pass of the same device pipeline (seed pass, batched recursive anchoring, batched DP).
+#include "common.hpp"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector<MatchVec> &chains, int N, const int *gmap);
+
+namespace {
+
+struct IvList {                       // 1-based inclusive, sorted, disjoint, non-adjacent
+    std::vector<int64_t> lo, hi;
+    void push(int64_t l, int64_t h)
+    {
+        if (h < l) return;
+        if (!lo.empty() && hi.back() + 1 >= l) { hi.back() = std::max(hi.back(), h); return; }
+        lo.push_back(l); hi.push_back(h);
+    }
+    int64_t find(int64_t pos) const    // index of the interval holding pos, -1 = placed already
+    {
+        size_t k = std::upper_bound(lo.begin(), lo.end(), pos) - lo.begin();
+        if (k == 0) return -1;
+        return pos <= hi[k - 1] ? (int64_t)k - 1 : -1;
+    }
+    void subtract(std::vector<std::pair<int64_t, int64_t>> r)      // minus the union of the ranges
+    {
+        std::sort(r.begin(), r.end());
+        IvList out; size_t k = 0;
+        for (size_t i = 0; i < lo.size(); i++) {
+            int64_t cur = lo[i];
+            while (k < r.size() && r[k].second < cur) k++;
+            for (size_t q = k; q < r.size() && r[q].first <= hi[i]; q++) {
+                if (r[q].first > cur) out.push(cur, r[q].first - 1);
+                cur = std::max(cur, r[q].second + 1);
+            }
+            if (cur <= hi[i]) out.push(cur, hi[i]);
+        }
+        *this = out;
+    }
+};
+
+inline void gap_of(const int64_t *a, const int64_t *b, int g, int64_t &lo, int64_t &len, bool &rev)
+{
+    const int64_t sa = a[1 + g], sb = b[1 + g];
+    int64_t hi;
+    if (sa > 0) { lo = sa + a[0]; hi = sb - 1; rev = false; }
+    else { lo = -sb + b[0]; hi = -sa - 1; rev = true; }
+    len = hi - lo + 1; if (len < 0) len = 0;
+}
+
+struct Prog {
+    mauve_ctx *c; const mauve_params *p; int N;
+    std::vector<int32_t> left, right;
+    std::vector<IvList> rest;          // per genome: bases not placed in any block yet
+    AlignResult *R;
+    int64_t n_gap_dp = 0, n_cells = 0, n_anchor = 0, n_multi = 0;
+};
+
+int leaves_of(const Prog &P, int node, std::vector<int> &out)
+{
+    if (P.left[node] < 0) { out.push_back(node); return 1; }
+    return leaves_of(P, P.left[node], out) + leaves_of(P, P.right[node], out);
+}
+
+// upload the placed-base bitmap of the node's genomes (bit set = placed)
+int upload_mask(Prog &P, const std::vector<int> &gm, GenomeSet &gs)
+{
+    mauve_ctx *c = P.c;
+    gs.mask_off.assign(gm.size(), 0);
+    size_t words = 0;
+    for (size_t j = 0; j < gm.size(); j++) { gs.mask_off[j] = words; words += (size_t)((c->lens[gm[j]] + 63) / 64) + 2; }
+    std::vector<uint64_t> bits(words, ~0ULL);
+    for (size_t j = 0; j < gm.size(); j++) {
+        uint64_t *M = bits.data() + gs.mask_off[j];
+        const IvList &L = P.rest[gm[j]];
+        for (size_t k = 0; k < L.lo.size(); k++)
+            for (int64_t b = L.lo[k] - 1; b < L.hi[k];) {           // clear [lo-1, hi) word-wise
+                const int64_t w = b >> 6, e = std::min<int64_t>(L.hi[k], (w + 1) << 6);
+                const int n = (int)(e - b), sh = (int)(b & 63);
+                const uint64_t m = (n == 64 ? ~0ULL : ((1ULL << n) - 1ULL)) << sh;
+                M[w] &= ~m; b = e;
+            }
+    }
+    HIPCHK(c, c->placed_mask.ensure(words * 8));
+    HIPCHK(c, hipMemcpyAsync(c->placed_mask.p, bits.data(), words * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    gs.vmask = &c->placed_mask;
+    return MAUVE_OK;
+}
+
+int prog_node(Prog &P, int node)
+{
+    if (P.left[node] < 0) return MAUVE_OK;
+    mauve_ctx *c = P.c; const mauve_params *p = P.p;
+    std::vector<int> gm; leaves_of(P, node, gm);
+    std::sort(gm.begin(), gm.end());
+    const int n = (int)gm.size();
+    AlignResult &R = *P.R;
+
+    int64_t rest_len = 0;
+    for (int j = 0; j < n; j++) for (size_t k = 0; k < P.rest[gm[j]].lo.size(); k++) rest_len += P.rest[gm[j]].hi[k] - P.rest[gm[j]].lo[k] + 1;
+    int w = p->seed_weight > 0 ? p->seed_weight : mauve_default_seed_weight(rest_len / n);
+    uint64_t pat = p->seed_pattern ? p->seed_pattern : mauve_get_seed(w, p->seed_rank);
+    if (!pat) { c->err = "progressive_align: no seed pattern for this weight/rank"; return MAUVE_ERR_ARG; }
+    w = mauve_seed_weight(pat);
+    const uint32_t full = n >= 32 ? 0xffffffffu : ((1u << n) - 1);
+
+    GenomeSet gs; gs.buf = &c->genomes; gs.nseq = n;
+    for (int j = 0; j < n; j++) { gs.lens.push_back(c->lens[gm[j]]); gs.word_off.push_back(c->word_off[gm[j]]); }
+    bool any_placed = false;
+    for (int j = 0; j < n; j++) { const IvList &L = P.rest[gm[j]]; if (!(L.lo.size() == 1 && L.lo[0] == 1 && L.hi[0] == c->lens[gm[j]])) any_placed = true; }
+    if (any_placed) { int rc = upload_mask(P, gm, gs); if (rc) return rc; }
+
+    int64_t nm = 0;
+    int rc = seedpass_run(c, gs, pat, p->mode, full, 1, nullptr, 0, &nm);
+    if (rc) return rc;
+    MatchVec m(n); m.resize((size_t)nm);
+    for (int64_t i = 0; i < nm; i++) {
+        m.len((size_t)i) = c->match_len[(size_t)i];
+        std::copy(&c->match_start[(size_t)i * n], &c->match_start[(size_t)i * n] + n, m.st((size_t)i));
+    }
+    host_eliminate_overlaps(m);
+    const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight * n / P.N : (int64_t)3 * w * n;
+    std::vector<int64_t> match_lcb; int64_t nl = 0;
+    host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl);
+    // chains, cut wherever the stretch between two consecutive anchors touches an already placed base
+    std::vector<MatchVec> pieces; int64_t cur_lcb = -1;
+    for (size_t i = 0; i < m.size(); i++) {
+        const int64_t l = match_lcb[i]; if (l < 0) continue;
+        bool newp = l != cur_lcb;
+        if (!newp) {
+            const MatchVec &last = pieces.back();
+            const int64_t *a = last.st(last.size() - 1);
+            for (int j = 0; j < n && !newp; j++)
+                if (P.rest[gm[j]].find(std::llabs(a[j])) != P.rest[gm[j]].find(std::llabs(m.st(i)[j]))) newp = true;
+        }
+        if (newp) { pieces.emplace_back(n); cur_lcb = l; }
+        pieces.back().push(m.rec(i));
+    }
+    if (p->recursive) { rc = recursive_anchoring(c, p, w, pieces, n, gm.data()); if (rc) return rc; }
+    // a stretch shared by >= 2 genomes that is too long for the gapped aligner ends the block: its bases stay
+    // in the pool for the nodes below
+    if (p->gapped) {
+        std::vector<MatchVec> np2;
+        for (const MatchVec &pc : pieces)
+            for (size_t i = 0; i < pc.size(); i++) {
+                bool split = i == 0;
+                if (!split) {
+                    int64_t mx = 0; int nonempty = 0;
+                    for (int j = 0; j < n; j++) { int64_t lo, ln; bool rv; gap_of(pc.rec(i - 1), pc.rec(i), j, lo, ln, rv); mx = std::max(mx, ln); nonempty += ln > 0; }
+                    split = nonempty >= 2 && mx > p->max_gapped_len;
+                }
+                if (split) np2.emplace_back(n);
+                np2.back().push(pc.rec(i));
+            }
+        pieces.swap(np2);
+    }
+    // ---- gapped alignment of the inter-anchor intervals of this node (descriptors carry GLOBAL genome ids) ----
+    struct GapRef { size_t piece, idx; bool dp; int64_t slot; };
+    std::vector<GapRef> gaps; std::vector<DpSeqDesc> desc; int64_t n_dp = 0, code_total = 0;
+    for (size_t q = 0; q < pieces.size(); q++) {
+        const MatchVec &ch = pieces[q];
+        for (size_t i = 0; i + 1 < ch.size(); i++) {
+            int64_t tot = 0, mx = 0; int nonempty = 0; int64_t lo[MAUVE_MAX_SEQ], ln[MAUVE_MAX_SEQ]; bool rv[MAUVE_MAX_SEQ];
+            for (int j = 0; j < n; j++) { gap_of(ch.rec(i), ch.rec(i + 1), j, lo[j], ln[j], rv[j]); tot += ln[j]; mx = std::max(mx, ln[j]); nonempty += ln[j] > 0; }
+            if (!tot) continue;
+            GapRef gr{q, i, false, -1};
+            if (p->gapped && nonempty >= 2 && mx <= p->max_gapped_len) {
+                gr.dp = true; gr.slot = n_dp++;
+                for (int j = 0; j < n; j++) { DpSeqDesc d; d.genome = gm[j]; d.rev = rv[j]; d.lo0 = lo[j] - 1; d.len = ln[j]; desc.push_back(d); }
+                code_total += tot;
+            }
+            gaps.push_back(gr);
+        }
+    }
+    std::vector<uint32_t> dcols((size_t)code_total + 1); std::vector<int64_t> dcol_off((size_t)n_dp + 1, 0), dscore((size_t)n_dp + 1, 0);
+    int64_t cells = 0;
+    rc = dp_batch_run_desc(c, n, n_dp, desc.data(), &p->scoring, dcols.data(), dcol_off.data(), dscore.data(), &cells);
+    if (rc) return rc;
+    P.n_gap_dp += n_dp; P.n_cells += cells;
+    // ---- blocks ----
+    uint32_t gfull = 0; for (int j = 0; j < n; j++) gfull |= 1u << gm[j];
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> placed((size_t)n);
+    size_t gi = 0;
+    const int N = P.N;
+    for (size_t q = 0; q < pieces.size(); q++) {
+        const MatchVec &ch = pieces[q];
+        R.col_off.push_back((int64_t)R.cols.size());
+        R.dp_score.push_back(0);
+        P.n_anchor += (int64_t)ch.size(); P.n_multi++;
+        for (size_t i = 0; i < ch.size(); i++) {
+            R.cols.insert(R.cols.end(), (size_t)ch.len(i), gfull);
+            if (gi < gaps.size() && gaps[gi].piece == q && gaps[gi].idx == i) {
+                const GapRef &gr = gaps[gi++];
+                if (gr.dp) {
+                    for (int64_t k = dcol_off[(size_t)gr.slot]; k < dcol_off[(size_t)gr.slot + 1]; k++) {
+                        const uint32_t mloc = dcols[(size_t)k]; uint32_t o = 0;         // local genome bits -> global
+                        for (int j = 0; j < n; j++) if (mloc >> j & 1) o |= 1u << gm[j];
+                        R.cols.push_back(o);
+                    }
+                    R.dp_score.back() += dscore[(size_t)gr.slot];
+                } else {
+                    for (int j = 0; j < n; j++) { int64_t lo, ln; bool rv; gap_of(ch.rec(i), ch.rec(i + 1), j, lo, ln, rv); R.cols.insert(R.cols.end(), (size_t)ln, 1u << gm[j]); }
+                }
+            }
+        }
+        const size_t base = R.iv_left.size();
+        R.iv_left.resize(base + N, 0); R.iv_right.resize(base + N, 0); R.iv_reverse.resize(base + N, 0);
+        const size_t last = ch.size() - 1;
+        for (int j = 0; j < n; j++) {
+            const int64_t s0 = ch.st(0)[j], s1 = ch.st(last)[j];
+            int64_t le, re;
+            if (s0 > 0) { le = s0; re = s1 + ch.len(last) - 1; } else { le = -s1; re = -s0 + ch.len(0) - 1; }
+            R.iv_left[base + gm[j]] = le; R.iv_right[base + gm[j]] = re; R.iv_reverse[base + gm[j]] = s0 < 0;
+            placed[(size_t)j].push_back({le, re});
+        }
+    }
+    for (int j = 0; j < n; j++) P.rest[gm[j]].subtract(placed[(size_t)j]);
+    rc = prog_node(P, P.left[node]);
+    if (rc) return rc;
+    return prog_node(P, P.right[node]);
+}
+
+}  // namespace
+
+extern "C" {
+
+// guide tree only (distance matrix in ppm, UPGMA merge order); dist may be NULL
+int mauve_guide_tree(mauve_ctx *c, uint64_t pattern, int64_t *dist, int32_t *left, int32_t *right)
+{
+    if (!c || !left || !right) return MAUVE_ERR_ARG;
+    if (c->nseq < 2) { c->err = "guide_tree: at least two genomes required"; return MAUVE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int N = c->nseq, M = 2 * N - 1;
+    int64_t nm = 0;
+    int rc = seedpass_run(c, main_genome_set(c), pattern, MAUVE_MODE_PAIRWISE, 0, 1, nullptr, 0, &nm);
+    if (rc) return rc;
+    std::vector<int64_t> S((size_t)N * N, 0);
+    for (int64_t k = 0; k < nm; k++) {
+        int a = -1, b = -1;
+        for (int g = 0; g < N; g++) if (c->match_start[(size_t)k * N + g]) { if (a < 0) a = g; else b = g; }
+        S[(size_t)a * N + b] += c->match_len[(size_t)k]; S[(size_t)b * N + a] += c->match_len[(size_t)k];
+    }
+    std::vector<int64_t> D((size_t)M * M, 0), size((size_t)M, 0);
+    std::vector<char> active((size_t)M, 0);
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) {
+        const int64_t mn = std::min(c->lens[i], c->lens[j]); int64_t d = 1000000;
+        if (i == j) d = 0;
+        else if (mn > 0) d = 1000000 - std::min<int64_t>(1000000, S[(size_t)i * N + j] * 1000000 / mn);
+        D[(size_t)i * M + j] = d; if (dist) dist[(size_t)i * N + j] = d;
+    }
+    for (int i = 0; i < N; i++) { active[i] = 1; size[i] = 1; left[i] = right[i] = -1; }
+    for (int k = N; k < M; k++) {
+        int ba = -1, bb = -1; int64_t bd = 0;
+        for (int a = 0; a < k; a++) if (active[a]) for (int b = a + 1; b < k; b++) if (active[b])
+            if (ba < 0 || D[(size_t)a * M + b] < bd) { ba = a; bb = b; bd = D[(size_t)a * M + b]; }
+        left[k] = ba; right[k] = bb; size[k] = size[ba] + size[bb];
+        for (int x = 0; x < k; x++) if (active[x] && x != ba && x != bb)
+            D[(size_t)k * M + x] = D[(size_t)x * M + k] = (size[ba] * D[(size_t)ba * M + x] + size[bb] * D[(size_t)bb * M + x]) / size[k];
+        active[ba] = active[bb] = 0; active[k] = 1;
+    }
+    return MAUVE_OK;
+}
+
+int mauve_progressive_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes, int32_t *tree_left,
+                            int32_t *tree_right, int64_t *dist)
+{
+    if (!c || !p || !sizes) return MAUVE_ERR_ARG;
+    if (c->nseq < 2) { c->err = "progressive_align: at least two genomes required"; return MAUVE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const double t0 = now_ms();
+    const int N = c->nseq;
+    int64_t sum = 0; for (int g = 0; g < N; g++) sum += c->lens[g];
+    int w = p->seed_weight > 0 ? p->seed_weight : mauve_default_seed_weight(sum / N);
+    uint64_t pat = p->seed_pattern ? p->seed_pattern : mauve_get_seed(w, p->seed_rank);
+    if (!pat) { c->err = "progressive_align: no seed pattern for this weight/rank"; return MAUVE_ERR_ARG; }
+    Prog P; P.c = c; P.p = p; P.N = N;
+    P.left.assign((size_t)(2 * N - 1), -1); P.right.assign((size_t)(2 * N - 1), -1);
+    int rc = mauve_guide_tree(c, pat, dist, P.left.data(), P.right.data());
+    if (rc) return rc;
+    if (tree_left) std::copy(P.left.begin(), P.left.end(), tree_left);
+    if (tree_right) std::copy(P.right.begin(), P.right.end(), tree_right);
+    AlignResult &R = c->res;
+    R.sz = mauve_align_sizes();
+    R.mum_length.clear(); R.mum_start.clear(); R.lcb_left.clear(); R.lcb_right.clear(); R.lcb_weight.clear();
+    R.anchor_length.clear(); R.anchor_start.clear(); R.anchor_lcb.clear(); R.iv_left.clear(); R.iv_right.clear();
+    R.iv_reverse.clear(); R.col_off.clear(); R.cols.clear(); R.dp_score.clear();
+    P.R = &R;
+    P.rest.assign((size_t)N, IvList());
+    for (int g = 0; g < N; g++) P.rest[(size_t)g].push(1, c->lens[g]);
+    rc = prog_node(P, 2 * N - 2);
+    if (rc) return rc;
+    const int64_t n_multi = P.n_multi;
+    if (p->add_unaligned)
+        for (int g = 0; g < N; g++)
+            for (size_t k = 0; k < P.rest[(size_t)g].lo.size(); k++) {
+                const int64_t lo = P.rest[(size_t)g].lo[k], hi = P.rest[(size_t)g].hi[k];
+                R.col_off.push_back((int64_t)R.cols.size());
+                R.cols.insert(R.cols.end(), (size_t)(hi - lo + 1), 1u << g);
+                for (int h = 0; h < N; h++) { R.iv_left.push_back(h == g ? lo : 0); R.iv_right.push_back(h == g ? hi : 0); R.iv_reverse.push_back(0); }
+                R.dp_score.push_back(0);
+            }
+    R.col_off.push_back((int64_t)R.cols.size());
+    // the multi-genome blocks double as the "LCB" table of the result (signed ends, weight unused)
+    R.lcb_left.assign((size_t)n_multi * N, 0); R.lcb_right.assign((size_t)n_multi * N, 0); R.lcb_weight.assign((size_t)n_multi, 0);
+    for (int64_t b = 0; b < n_multi; b++) for (int g = 0; g < N; g++) {
+        const int64_t le = R.iv_left[(size_t)b * N + g], re = R.iv_right[(size_t)b * N + g];
+        const bool rv = R.iv_reverse[(size_t)b * N + g] != 0;
+        R.lcb_left[(size_t)b * N + g] = rv ? -le : le; R.lcb_right[(size_t)b * N + g] = rv ? -re : re;
+    }
+    R.sz.n_mums = 0; R.sz.n_lcb = n_multi; R.sz.n_anchor = 0; R.sz.n_iv = (int64_t)R.dp_score.size();
+    R.sz.n_cols = (int64_t)R.cols.size(); R.sz.n_gap_dp = P.n_gap_dp; R.sz.n_dp_cells = P.n_cells;
+    *sizes = R.sz;
+    memset(&c->stage, 0, sizeof c->stage);
+    c->stage.total_ms = now_ms() - t0;
+    return MAUVE_OK;
+}
+
+}  // extern "C"

@@ -59,9 +59,8 @@ inline int gap_weight(int N, const int64_t *a, const int64_t *b, int prev_w, int
 
 }  // namespace
 
-int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector<MatchVec> &chains)
+int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector<MatchVec> &chains, int N, const int *gmap)
 {
-    const int N = c->nseq;
     const uint32_t full = N >= 32 ? 0xffffffffu : ((1u << N) - 1);
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     WorkList work(N);
@@ -102,7 +101,7 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                 if (tot >= (1LL << 31)) { c->err = "recursive anchoring: gap set too large"; return MAUVE_ERR_LIMIT; }
                 vs.lens[g] = tot;
                 std::vector<uint8_t> codes((size_t)tot + 1);
-                const auto &hw = c->host_packed[g];
+                const auto &hw = c->host_packed[gmap ? gmap[g] : g];
                 for (uint32_t k = 0; k < K; k++) {
                     uint8_t *out = codes.data() + seg[(size_t)g * (K + 1) + k];
                     const int64_t lo0 = glo[(size_t)g * K + k] - 1, n = glen[(size_t)g * K + k];

@@ -43,6 +43,15 @@ __device__ __forceinline__ uint64_t kprime_at(const uint64_t *__restrict__ G, ui
     return k;
 }
 
+// placed-base bitmap: is any of the `span` bases from p on already placed?
+__device__ __forceinline__ bool window_masked(const uint64_t *__restrict__ M, uint32_t p, int span)
+{
+    const uint32_t q = p >> 6; const int r = p & 63;
+    const uint64_t m0 = M[q], m1 = M[q + 1];
+    const uint64_t v = r ? ((m0 >> r) | (m1 << (64 - r))) : m0;
+    return (v & ((span >= 64) ? ~0ULL : ((1ULL << span) - 1ULL))) != 0;
+}
+
 // narrow form (span <= 32, weight <= 16): the window is one 64-bit word and K' fits 32 bits
 __device__ __forceinline__ uint32_t kprime_narrow(const uint64_t *__restrict__ G, uint32_t p, const SeedShape &sh)
 {
@@ -145,7 +154,8 @@ template <typename KeyT, bool SEG, bool NARROW>
 __global__ void __launch_bounds__(256) seed_extract_all(const uint64_t *__restrict__ packed, GenomeTab tab, SeedShape sh,
                                                         KeyT *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t P,
                                                         const uint32_t *__restrict__ seg, uint32_t nseg,
-                                                        uint32_t *__restrict__ hist, uint32_t nblk)
+                                                        uint32_t *__restrict__ hist, uint32_t nblk,
+                                                        const uint64_t *__restrict__ vmask)
 {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
@@ -172,6 +182,7 @@ __global__ void __launch_bounds__(256) seed_extract_all(const uint64_t *__restri
             const uint32_t k = seg_of(sg, nseg, p);
             key = (p + sh.span <= sg[k + 1]) ? (((uint64_t)k << (2 * sh.weight)) | key) : ~0ULL;
         }
+        if (vmask && window_masked(vmask + tab.mask_off[g], p, sh.span)) key = ~0ULL;
         keys[gp] = (KeyT)key;
         vals[gp] = gp | (s << 31);
         atomicAdd(&h[(uint32_t)key & 255u], 1u);
@@ -373,12 +384,12 @@ template <typename KeyT, bool SEG>
 __global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                 uint32_t n, GenomeTab tab, int mode, uint32_t want_mask,
                                                 uint32_t consider, uint32_t *__restrict__ tmask,
-                                                uint32_t *__restrict__ tpos, uint32_t P)
+                                                uint32_t *__restrict__ tpos, uint32_t P, int has_invalid)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const KeyT k = keys[i];
-    if (SEG && k == (KeyT)~0ULL) return;
+    if ((SEG || has_invalid) && k == (KeyT)~0ULL) return;
     if (i > 0 && keys[i - 1] == k) return;
     if (i + 1 >= n || keys[i + 1] != k) return;        // singleton run
     // `consider` restricts the finder to a subset of the genomes (PairwiseMatchFinder: one pair at a time);
@@ -416,13 +427,15 @@ template <bool SEG>
 __device__ __forceinline__ bool agree_at(const uint64_t *__restrict__ packed, const GenomeTab &tab,
                                          const SeedShape &sh, const uint32_t *__restrict__ tpos, uint32_t P,
                                          uint32_t ap, uint32_t mask, int anchor, int64_t k,
-                                         const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t segid)
+                                         const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t segid,
+                                         const uint64_t *__restrict__ vmask)
 {
     const uint32_t va = tpos[(size_t)anchor * P + ap];
     int64_t qa = (int64_t)(ap - tab.gpos_off[anchor]) + k;
     int64_t lo = 0, hi = (int64_t)tab.nwin[anchor] - 1;
     if (SEG) { const uint32_t *sg = seg + (size_t)anchor * (nseg + 1) + segid; lo = sg[0]; hi = (int64_t)sg[1] - sh.span; }
     if (qa < lo || qa > hi) return false;
+    if (vmask && window_masked(vmask + tab.mask_off[anchor], (uint32_t)qa, sh.span)) return false;
     // masked windows are compared in place (XOR under the 2-bit care mask) -- equal care digits <=> equal
     // masked mers; a reverse component is compared with the reverse complement of the anchor window
     uint64_t alo, ahi, rlo = 0, rhi = 0;
@@ -439,6 +452,7 @@ __device__ __forceinline__ bool agree_at(const uint64_t *__restrict__ packed, co
         lo = 0; hi = (int64_t)tab.nwin[g] - 1;
         if (SEG) { const uint32_t *sg = seg + (size_t)g * (nseg + 1) + segid; lo = sg[0]; hi = (int64_t)sg[1] - sh.span; }
         if (qg < lo || qg > hi) { ok = false; break; }
+        if (vmask && window_masked(vmask + tab.mask_off[g], (uint32_t)qg, sh.span)) { ok = false; break; }
         uint64_t clo, chi;
         window_at(packed + tab.word_off[g], (uint32_t)qg, clo, chi);
         if (o) {
@@ -520,7 +534,8 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
                                                   const uint32_t *__restrict__ tmask, const uint32_t *__restrict__ tpos,
                                                   uint32_t P, const uint32_t *__restrict__ cand, uint32_t ncand,
                                                   int extend, int32_t *__restrict__ mlen, int32_t *__restrict__ mstart,
-                                                  const uint32_t *__restrict__ seg, uint32_t nseg)
+                                                  const uint32_t *__restrict__ seg, uint32_t nseg,
+                                                  const uint64_t *__restrict__ vmask)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -538,7 +553,7 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
             int64_t cur = 0;
             for (bool done = false; !done;) {
                 const int64_t k = cur - 1 - lane;
-                const bool a = agree_at<SEG>(packed, tab, sh, tpos, P, ap, mask, anchor, k, seg, nseg, segid);
+                const bool a = agree_at<SEG>(packed, tab, sh, tpos, P, ap, mask, anchor, k, seg, nseg, segid, vmask);
                 const bool hh = a && (tmask[(int64_t)ap + k] == mask);
                 const uint64_t A = __ballot(a), H = __ballot(hh);
                 int p = 0;                      // offsets consumed in this round
@@ -557,7 +572,7 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
             cur = 0;
             for (bool done = false; !done;) {
                 const int64_t k = cur + 1 + lane;
-                const bool a = agree_at<SEG>(packed, tab, sh, tpos, P, ap, mask, anchor, k, seg, nseg, segid);
+                const bool a = agree_at<SEG>(packed, tab, sh, tpos, P, ap, mask, anchor, k, seg, nseg, segid, vmask);
                 const uint64_t A = __ballot(a);
                 int p = 0;
                 for (;;) {
@@ -625,6 +640,7 @@ static int build_tab(mauve_ctx *ctx, const GenomeSet &gs, int span, GenomeTab *t
     for (int g = 0; g < gs.nseq; g++) {
         int64_t nw = gs.lens[g] - span + 1; if (nw < 0) nw = 0;
         tab->gpos_off[g] = (uint32_t)tot; tab->nwin[g] = (uint32_t)nw; tab->word_off[g] = gs.word_off[g];
+        tab->mask_off[g] = gs.vmask ? gs.mask_off[g] : 0;
         tot += nw;
         if (tot >= (1LL << 31)) { ctx->err = "total genome length exceeds 2^31 windows"; return MAUVE_ERR_LIMIT; }
     }
@@ -674,6 +690,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     HIPCHK(ctx, ctx->counters.ensure(64));
     KeyT *keys = ctx->keysA.as<KeyT>(); uint32_t *vals = ctx->valsA.as<uint32_t>();
     const uint64_t *packed = gs.buf->as<uint64_t>();
+    const uint64_t *vmask = gs.vmask ? gs.vmask->as<uint64_t>() : nullptr;
 
     uint32_t sorted_n = 0;
     bool have_hist0 = false;
@@ -683,10 +700,10 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         KernelTimer t(ctx, MAUVE_K_EXTRACT, n);
         if (sh.span <= 32 && sh.weight <= 15)
             hipLaunchKernelGGL((seed_extract_all<KeyT, SEG, true>), dim3(nblk), dim3(256), 0, ctx->stream, packed, tab, sh, keys,
-                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk);
+                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk, vmask);
         else
             hipLaunchKernelGGL((seed_extract_all<KeyT, SEG, false>), dim3(nblk), dim3(256), 0, ctx->stream, packed, tab, sh, keys,
-                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk);
+                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk, vmask);
         sorted_n = n; have_hist0 = true;
     } else {
         const int g = only_seq;
@@ -703,7 +720,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     TRACE(ctx, "extract");
     if (sorted_n == 0) { if (n_matches) *n_matches = 0; return MAUVE_OK; }
     // segmented keys: segment id above the mer; the all-ones invalid key needs every bit, so sort all 64
-    const int key_bits = SEG ? 64 : 2 * sh.weight;
+    const int key_bits = SEG ? 64 : (vmask ? (int)sizeof(KeyT) * 8 : 2 * sh.weight);
     int rc = sort_pairs<KeyT>(ctx, sorted_n, key_bits, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>(), have_hist0);
     if (rc) return rc;
     TRACE(ctx, "sort");
@@ -739,7 +756,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
         { KernelTimer t(ctx, MAUVE_K_JOIN, n);
           hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, n, tab, fp.rule,
-                             fp.want, fp.consider, tmask, tpos, P); }
+                             fp.want, fp.consider, tmask, tpos, P, vmask != nullptr); }
         HIPCHK(ctx, hipGetLastError());
         TRACE(ctx, "join");
         // extension phase A: run starts from the table
@@ -762,7 +779,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             KernelTimer t(ctx, MAUVE_K_EXTEND, nc);
             hipLaunchKernelGGL((mum_extend<SEG>), dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh, tmask, tpos, P,
                                ctx->cand.as<uint32_t>(), nc, extend, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(), seg,
-                               nseg);
+                               nseg, vmask);
             HIPCHK(ctx, hipGetLastError());
         }
         const size_t old = hl.size();

@@ -91,6 +91,27 @@ def star_genomes(n, length, divergence, seed_key, inversions=0, inv_min=5000, in
     return genomes
 
 
+def tree_genomes(n_leaves, length, branch_div, seed_key, inv_per_branch=2, insert_per_branch=1, insert_len=(2000, 12000)):
+    """Balanced binary tree (BASELINE config C4): every branch mutates at `branch_div`, adds `inv_per_branch`
+    inversions and `insert_per_branch` clade-specific insertions, so sister genomes share sequence the rest lacks."""
+    def grow(seq, depth, key):
+        rng = _rng(seed_key, key)
+        x = mutate(seq, branch_div, rng)
+        if inv_per_branch:
+            x, _ = invert_segments(x, inv_per_branch, rng, max(200, length // 200), max(400, length // 20))
+        for _ in range(insert_per_branch):
+            ln = int(rng.integers(min(insert_len[0], max(50, length // 40)), min(insert_len[1], max(100, length // 10))))
+            at = int(rng.integers(0, len(x)))
+            x = np.concatenate([x[:at], rng.integers(0, 4, size=ln, dtype=np.uint8), x[at:]])
+        if depth == 0:
+            return [x]
+        return grow(x, depth - 1, key * 2) + grow(x, depth - 1, key * 2 + 1)
+    depth = int(np.ceil(np.log2(n_leaves)))
+    anc = random_genome(length, _rng(seed_key, 0))
+    leaves = grow(anc, depth - 1, 2) + grow(anc, depth - 1, 3)
+    return leaves[:n_leaves]
+
+
 def make_config(name, scale=1.0):
     """BASELINE.json configs.  `scale` < 1 shrinks genome lengths (parity tests, bounded CPU baselines)."""
     name = name.upper()
@@ -102,7 +123,7 @@ def make_config(name, scale=1.0):
         L = int(5_000_000 * scale)
         return star_genomes(5, L, 0.03, 3, inversions=max(1, int(round(50 * min(1.0, scale * 4)))) if scale < 0.25 else 50)
     if name == "C4":
-        return star_genomes(8, int(2_000_000 * scale), 0.06, 4, inversions=14)
+        return tree_genomes(8, int(2_000_000 * scale), 0.01, 4)
     if name == "C5":
         L = int(100_000_000 * scale)
         gs = star_genomes(2, L, 0.03, 5)

@@ -106,6 +106,11 @@ int64_t orc_sorted_mer_list(const uint8_t *codes, int64_t len, uint64_t pattern,
 /* ---- multi-MUM enumeration + ungapped extension ---------------------------------------------- */
 int orc_find_matches(int nseq, const uint8_t *const *codes, const int64_t *lens, uint64_t pattern,
                      int mode, uint64_t mask, int extend, orc_matches *out);
+/* the same search restricted to the bases inside the given intervals (1-based inclusive, sorted, disjoint,
+   CSR by genome: iv_off[nseq+1]); a window is valid only if it holds no base outside them */
+int orc_find_matches_masked(int nseq, const uint8_t *const *codes, const int64_t *lens, uint64_t pattern,
+                            int mode, uint64_t mask, int extend, const int64_t *iv_off, const int64_t *iv_lo,
+                            const int64_t *iv_hi, orc_matches *out);
 /* SeedMatchEnumerator (SeedMatchEnumerator.h:19-141): single genome, every repeated seed -> Match */
 int orc_seed_match_enumerate(const uint8_t *codes, int64_t len, uint64_t pattern, int64_t min_multi,
                              int64_t max_multi, int direct_only, int64_t *n_out, int64_t **mult_out,
@@ -134,6 +139,12 @@ int64_t orc_profile_dp(int64_t m, const uint8_t *cnt, int k_rows, int64_t n, con
 int orc_align(int nseq, const uint8_t *const *codes, const int64_t *lens, const orc_params *p,
               orc_matches *mums_out, orc_lcbs *lcbs_out, orc_alignment *aln_out);
 void orc_free_alignment(orc_alignment *a);
+/* guide tree + guide-tree recursive anchoring (ProgressiveAligner::align stand-in);
+   dist: [nseq*nseq] ppm distances (may be NULL), tree_left/right: [2*nseq-1] */
+int orc_guide_tree(int nseq, const uint8_t *const *codes, const int64_t *lens, uint64_t pattern,
+                   int64_t *dist, int32_t *left, int32_t *right);
+int orc_progressive_align(int nseq, const uint8_t *const *codes, const int64_t *lens, const orc_params *p,
+                          int32_t *tree_left, int32_t *tree_right, int64_t *dist, orc_alignment *aln);
 /* XMFA text (format pinned by mfa2xmfa.cpp:64,89-91,104-115); returns malloc'd NUL-terminated text */
 char *orc_write_xmfa(int nseq, const uint8_t *const *codes, const int64_t *lens,
                      const char *const *names, const orc_alignment *a, int64_t *text_len);

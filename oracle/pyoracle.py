@@ -188,6 +188,28 @@ def find_matches(codes, pattern, mode=MODE_MEM, mask=0, extend=True):
     return out
 
 
+def find_matches_masked(codes, pattern, valid, mode=MODE_MEM, mask=0, extend=True):
+    """valid: per genome a list of (lo, hi) 1-based inclusive intervals (sorted, disjoint)."""
+    codes, arr, lens = _seq_args(codes)
+    off = np.zeros(len(codes) + 1, np.int64)
+    lo, hi = [], []
+    for g, ivs in enumerate(valid):
+        off[g + 1] = off[g] + len(ivs)
+        lo += [a for a, _ in ivs]
+        hi += [b for _, b in ivs]
+    lo = np.array(lo + [0], np.int64)
+    hi = np.array(hi + [0], np.int64)
+    m = Matches()
+    rc = lib().orc_find_matches_masked(len(codes), arr, lens, C.c_uint64(pattern), mode, C.c_uint64(mask), int(bool(extend)),
+                                       off.ctypes.data_as(C.POINTER(C.c_int64)), lo.ctypes.data_as(C.POINTER(C.c_int64)),
+                                       hi.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(m))
+    if rc:
+        raise RuntimeError("orc_find_matches_masked failed: %d" % rc)
+    out = _matches_to_np(m)
+    lib().orc_free_matches(C.byref(m))
+    return out
+
+
 def seed_match_enumerate(codes, pattern, min_multi=2, max_multi=1000, direct_only=False):
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     n = C.c_int64()
@@ -320,3 +342,59 @@ def align(codes, params=None, names=None, want_xmfa=False):
     lib().orc_free_lcbs(C.byref(lc))
     lib().orc_free_alignment(C.byref(al))
     return {"mums": mums, "n_nway": nway, "lcbs": lcbs, "aln": aln, "xmfa": xmfa}
+
+
+def guide_tree(codes, pattern):
+    codes, arr, lens = _seq_args(codes)
+    N = len(codes)
+    dist = np.zeros((N, N), np.int64)
+    left = np.zeros(2 * N - 1, np.int32)
+    right = np.zeros(2 * N - 1, np.int32)
+    rc = lib().orc_guide_tree(N, arr, lens, C.c_uint64(pattern), dist.ctypes.data_as(C.POINTER(C.c_int64)),
+                              left.ctypes.data_as(C.POINTER(C.c_int32)), right.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc:
+        raise RuntimeError("orc_guide_tree failed: %d" % rc)
+    return dist, left, right
+
+
+def progressive_align(codes, params=None, names=None, want_xmfa=False):
+    """Guide-tree recursive anchoring.  -> dict(aln={...}, tree=(left,right), dist, xmfa)"""
+    p = params or default_params()
+    codes, arr, lens = _seq_args(codes)
+    N = len(codes)
+    al = Alignment()
+    dist = np.zeros((N, N), np.int64)
+    left = np.zeros(2 * N - 1, np.int32)
+    right = np.zeros(2 * N - 1, np.int32)
+    rc = lib().orc_progressive_align(N, arr, lens, C.byref(p), left.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     right.ctypes.data_as(C.POINTER(C.c_int32)), dist.ctypes.data_as(C.POINTER(C.c_int64)),
+                                     C.byref(al))
+    if rc:
+        raise RuntimeError("orc_progressive_align failed: %d" % rc)
+    niv = int(al.n_iv)
+
+    def arr64(ptr, n):
+        return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].copy()
+    col_off = np.ctypeslib.as_array(al.col_off, shape=(niv + 1,)).copy()
+    ncol = int(col_off[niv])
+    aln = {
+        "n_iv": niv,
+        "left": arr64(al.left, niv * N).reshape(niv, N),
+        "right": arr64(al.right, niv * N).reshape(niv, N),
+        "reverse": np.ctypeslib.as_array(al.reverse, shape=(max(niv * N, 1),))[:niv * N].copy().reshape(niv, N),
+        "col_off": col_off,
+        "cols": np.ctypeslib.as_array(al.cols, shape=(max(ncol, 1),))[:ncol].copy(),
+        "dp_score": arr64(al.dp_score, niv),
+        "n_gap_dp": int(al.n_gap_dp),
+        "n_dp_cells": int(al.n_dp_cells),
+    }
+    xmfa = None
+    if want_xmfa:
+        nm = names or ["seq%d" % i for i in range(N)]
+        narr = (C.c_char_p * N)(*[s.encode() for s in nm])
+        tl = C.c_int64()
+        ptr = lib().orc_write_xmfa(N, arr, lens, narr, C.byref(al), C.byref(tl))
+        xmfa = C.string_at(ptr, tl.value).decode()
+        lib().orc_free(C.c_void_p(ptr))
+    lib().orc_free_alignment(C.byref(al))
+    return {"aln": aln, "tree": (left, right), "dist": dist, "xmfa": xmfa}

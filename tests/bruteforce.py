@@ -19,14 +19,21 @@ def rc(s):
     return "".join(COMP[c] for c in reversed(s))
 
 
-def brute_matches(seqs, pattern, mode="mem", mask=0, extend=True):
-    """seqs: list of ACGT strings.  Returns a set of (length, (signed 1-based starts...))."""
+def brute_matches(seqs, pattern, mode="mem", mask=0, extend=True, valid=None):
+    """seqs: list of ACGT strings.  Returns a set of (length, (signed 1-based starts...)).
+    valid: optional per-genome list of (lo, hi) 1-based inclusive intervals; a window counts only if it lies
+    inside one of them."""
     offs, span = pattern_offsets(pattern)
     N = len(seqs)
     fw = [[masked(s, p, offs) for p in range(len(s) - span + 1)] for s in seqs]
+
+    def wvalid(g, p):
+        return valid is None or any(lo - 1 <= p and p + span <= hi for lo, hi in valid[g])
     groups = {}
     for g in range(N):
         for p, f in enumerate(fw[g]):
+            if not wvalid(g, p):
+                continue
             r = rc(f)
             canon, strand = (r, 1) if r < f else (f, 0)
             groups.setdefault(canon, []).append((g, p, strand))
@@ -53,14 +60,14 @@ def brute_matches(seqs, pattern, mode="mem", mask=0, extend=True):
         a = comps[0]
         pa, sa = pos[a]
         qa = pa + k
-        if qa < 0 or qa >= len(fw[a]):
+        if qa < 0 or qa >= len(fw[a]) or not wvalid(a, qa):
             return False
         fa = fw[a][qa]
         for g in comps[1:]:
             pg, sg = pos[g]
             o = sg ^ sa
             qg = pg - k if o else pg + k
-            if qg < 0 or qg >= len(fw[g]):
+            if qg < 0 or qg >= len(fw[g]) or not wvalid(g, qg):
                 return False
             f = fw[g][qg]
             if o:

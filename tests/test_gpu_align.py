@@ -229,3 +229,45 @@ def test_sharded_align_equals_whole(ctx):
     # phase order is enforced
     with pytest.raises(RuntimeError):
         ctx.align_dp(np.array([0], np.int64), cap)
+
+
+def _same_progressive(ctx, gs, **kw):
+    from mauvealigner_amd import _lib
+    ctx.set_genomes(gs)
+    names = ["g%d" % i for i in range(len(gs))]
+    r = ctx.progressive_align(_lib.default_params(**kw), names=names, want_xmfa=True)
+    e = O.progressive_align(gs, O.default_params(**kw), names=names, want_xmfa=True)
+    assert np.array_equal(r["dist"], e["dist"])
+    assert np.array_equal(r["tree"][0], e["tree"][0]) and np.array_equal(r["tree"][1], e["tree"][1])
+    a = e["aln"]
+    assert r["n_iv"] == a["n_iv"]
+    for k in ("left", "right", "reverse", "col_off", "cols", "dp_score"):
+        assert np.array_equal(r[k], a[k]), k
+    assert r["n_gap_dp"] == a["n_gap_dp"] and r["n_dp_cells"] == a["n_dp_cells"]
+    assert r["xmfa"] == e["xmfa"]
+    return r
+
+
+def test_guide_tree_and_progressive_align(ctx):
+    """ProgressiveAligner stand-in: guide tree + guide-tree recursive anchoring, bit-exact vs oracle."""
+    gs = synth.make_config("C4", scale=0.02)
+    r = _same_progressive(ctx, gs)
+    N = len(gs)
+    # the UPGMA tree recovers the balanced topology the generator used: sisters (0,1), (2,3), (4,5), (6,7)
+    left, right = r["tree"]
+    first = sorted(tuple(sorted((int(left[k]), int(right[k])))) for k in range(N, N + 4))
+    assert first == [(0, 1), (2, 3), (4, 5), (6, 7)]
+    # clade-specific insertions are aligned below the root: some blocks hold a proper subset of >= 2 genomes
+    multi = np.count_nonzero(r["left"][:r["n_lcb"]], axis=1)
+    assert (multi == N).any() and ((multi >= 2) & (multi < N)).any()
+    # every base of every genome appears in exactly one interval
+    for g in range(N):
+        cover = np.zeros(len(gs[g]), np.int32)
+        for iv in range(r["n_iv"]):
+            if r["left"][iv, g]:
+                cover[r["left"][iv, g] - 1:r["right"][iv, g]] += 1
+        assert np.all(cover == 1)
+    _same_progressive(ctx, gs, max_gapped_len=500)
+    _same_progressive(ctx, gs, recursive=0)
+    _same_progressive(ctx, synth.make_config("C3", scale=0.02))
+    _same_progressive(ctx, synth.make_config("C1", scale=0.1))

@@ -145,6 +145,60 @@ def test_pairwise_finder_is_memhash_per_pair():
     assert got == want and len(got) == len(ln)
 
 
+def test_masked_matches_equal_bruteforce():
+    """S9: windows touching a base outside the valid intervals are invisible to seeding and extension."""
+    gs = _tiny_set(21, 3, 300, 0.04, inv=True)
+    pat = O.get_seed(5, 0)
+    valid = [[(1, 120), (160, 300)], [(10, 290)], [(1, 99), (101, 180), (200, len(gs[2]))]]
+    ln, st = O.find_matches_masked(gs, pat, valid)
+    got = set((int(l), tuple(int(x) for x in s)) for l, s in zip(ln, st))
+    want = B.brute_matches([_asc(g) for g in gs], pat, mode="mem", valid=valid)
+    assert got == want and len(got) == len(ln)
+    # no match may touch a masked base
+    for l, row in got:
+        for g, s0 in enumerate(row):
+            if s0:
+                le, re = abs(s0), abs(s0) + l - 1
+                assert any(lo <= le and re <= hi for lo, hi in valid[g])
+    # an all-valid mask changes nothing
+    ln2, st2 = O.find_matches_masked(gs, pat, [[(1, len(g))] for g in gs])
+    ln3, st3 = O.find_matches(gs, pat)
+    assert np.array_equal(ln2, ln3) and np.array_equal(st2, st3)
+
+
+def test_guide_tree_upgma():
+    gs = synth.tree_genomes(4, 20000, 0.02, 77, inv_per_branch=0, insert_per_branch=0)
+    dist, left, right = O.guide_tree(gs, O.get_seed(11, 0))
+    assert np.array_equal(dist, dist.T) and np.all(np.diag(dist) == 0)
+    assert dist[0, 1] < dist[0, 2] and dist[2, 3] < dist[1, 2]
+    assert sorted([(int(left[4]), int(right[4])), (int(left[5]), int(right[5]))]) == [(0, 1), (2, 3)]
+    assert (int(left[6]), int(right[6])) == (4, 5)
+    assert left[:4].tolist() == [-1] * 4
+
+
+def test_progressive_align_properties():
+    """Guide-tree recursive anchoring: every base in exactly one block, rows reproduce the genomes, clade-specific
+    sequence is aligned below the root, and with nothing clade-specific the result equals the plain N-way path."""
+    rng = np.random.default_rng(5)
+    anc = rng.integers(0, 4, 30000, dtype=np.uint8)
+    Lc, Rc = synth.mutate(anc, 0.02, rng), synth.mutate(anc, 0.02, rng)
+    Lc = np.concatenate([Lc[:10000], rng.integers(0, 4, 3000, dtype=np.uint8), Lc[10000:]])
+    Rc = np.concatenate([Rc[:20000], rng.integers(0, 4, 2500, dtype=np.uint8), Rc[20000:]])
+    gs = [synth.mutate(Lc, 0.005, rng), synth.mutate(Lc, 0.005, rng), synth.mutate(Rc, 0.005, rng), synth.mutate(Rc, 0.005, rng)]
+    r = O.progressive_align(gs, O.default_params(max_gapped_len=1000), want_xmfa=True)
+    _check_xmfa(r["xmfa"], gs)
+    a = r["aln"]
+    sets = [tuple(np.flatnonzero(a["left"][b]).tolist()) for b in range(a["n_iv"])]
+    assert (0, 1, 2, 3) in sets and (0, 1) in sets and (2, 3) in sets
+    b01 = sets.index((0, 1))
+    assert a["right"][b01, 0] - a["left"][b01, 0] + 1 >= 2900          # the clade insert is aligned at node (0,1)
+    # two genomes: the tree is trivial and the path is the plain one
+    two = gs[:2]
+    rp = O.progressive_align(two, want_xmfa=True)
+    ra = O.align(two, want_xmfa=True)
+    assert rp["xmfa"] == ra["xmfa"]
+
+
 def test_matches_canonical_order_and_content():
     gs = synth.make_config("C1", scale=0.05)
     pat = O.get_seed(11, 0)
