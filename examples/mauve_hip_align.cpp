@@ -1,7 +1,8 @@
 // mauve_hip_align.cpp -- the hot section of doAlignment (src/mauveAligner.cpp:453-466,523-531,585,648-698,
 // 746-760) written against the libMems-shaped headers in include/libMems, i.e. what a reference maintainer's
 // call site looks like after switching the path to libmauve_hip.so.  Not a CLI: positional FastA files in, XMFA
-// on stdout.  Optional first argument "-u" uses UniqueMatchFinder as progressiveMauve.cpp:490-495 does.
+// on stdout.  Optional first argument "-u" uses UniqueMatchFinder as progressiveMauve.cpp:490-495 does; "-p" runs
+// the progressiveMauve alignment stage instead (ProgressiveAligner, progressiveMauve.cpp:575-722).
 #include <iostream>
 #include <memory>
 
@@ -9,6 +10,7 @@
 #include "libMems/Aligner.h"
 #include "libMems/MaskedMemHash.h"
 #include "libMems/MatchList.h"
+#include "libMems/ProgressiveAligner.h"
 
 using namespace mems;
 using namespace genome;
@@ -18,7 +20,8 @@ int main(int argc, char **argv)
     try {
         int a = 1;
         bool unique = argc > 1 && std::string(argv[1]) == "-u";
-        if (unique) a++;
+        bool progressive = argc > 1 && std::string(argv[1]) == "-p";
+        if (unique || progressive) a++;
         if (argc - a < 2) { std::cerr << "usage: mauve_hip_align [-u] <seq1.fa> <seq2.fa> [...]\n"; return -1; }
         MatchList match_list;
         for (; a < argc; a++) {
@@ -26,6 +29,18 @@ int main(int argc, char **argv)
             s->LoadSource(argv[a]);                                  // LoadSequences, mauveAligner.cpp:463
             match_list.seq_table.push_back(s);
             match_list.seq_filename.push_back(argv[a]);
+        }
+        if (progressive) {
+            const uint n = (uint)match_list.seq_table.size();
+            ProgressiveAligner aligner(n);                               // progressiveMauve.cpp:575
+            PairwiseScoringScheme pss;                                   // :666-687 (hoxd_matrix, -400, -30)
+            aligner.setPairwiseScoringScheme(pss);
+            IntervalList interval_list;
+            interval_list.seq_filename = match_list.seq_filename;
+            aligner.align(match_list.seq_table, interval_list);          // :710
+            interval_list.WriteStandardAlignment(std::cout);             // :722
+            for (auto *s : match_list.seq_table) delete s;
+            return 0;
         }
         uint seed_size = 0, seed_rank = 0;
         match_list.CreateMemorySMLs(seed_size, &std::cerr, seed_rank);   // :456

@@ -71,7 +71,7 @@ def test_example_call_site_compiles():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flag", [None, "-u"])
+@pytest.mark.parametrize("flag", [None, "-u", "-p"])
 def test_example_matches_c_abi(flag):
     from mauvealigner_amd import _lib
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
@@ -91,7 +91,10 @@ def test_example_matches_c_abi(flag):
         ctx = _lib.Context(0)
         try:
             ctx.set_genomes(gs)
-            r = ctx.align(_lib.default_params(), names=paths, want_xmfa=True)
+            if flag == "-p":
+                r = ctx.progressive_align(_lib.default_params(), names=paths, want_xmfa=True)
+            else:
+                r = ctx.align(_lib.default_params(), names=paths, want_xmfa=True)
         finally:
             ctx.close()
         assert out == r["xmfa"]
