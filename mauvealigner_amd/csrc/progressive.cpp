@@ -123,9 +123,12 @@ int prog_node(Prog &P, int node)
     for (int j = 0; j < n; j++) { const IvList &L = P.rest[gm[j]]; if (!(L.lo.size() == 1 && L.lo[0] == 1 && L.hi[0] == c->lens[gm[j]])) any_placed = true; }
     if (any_placed) { int rc = upload_mask(P, gm, gs); if (rc) return rc; }
 
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    const double tn0 = now_ms();
     int64_t nm = 0;
     int rc = seedpass_run(c, gs, pat, p->mode, full, 1, nullptr, 0, &nm);
     if (rc) return rc;
+    const double tn1 = now_ms();
     MatchVec m(n); m.resize((size_t)nm);
     for (int64_t i = 0; i < nm; i++) {
         m.len((size_t)i) = c->match_len[(size_t)i];
@@ -149,18 +152,21 @@ int prog_node(Prog &P, int node)
         if (newp) { pieces.emplace_back(n); cur_lcb = l; }
         pieces.back().push(m.rec(i));
     }
+    const double tn2 = now_ms();
     if (p->recursive) { rc = recursive_anchoring(c, p, w, pieces, n, gm.data()); if (rc) return rc; }
-    // a stretch shared by >= 2 genomes that is too long for the gapped aligner ends the block: its bases stay
-    // in the pool for the nodes below
+    const double tn3 = now_ms();
+    // a stretch shared by >= 2 genomes that is too long for the gapped aligner, or that only a proper subset of
+    // this node's genomes has (and that is long enough to be anchored), ends the block: its bases stay in the
+    // pool for the subtree that shares them
     if (p->gapped) {
         std::vector<MatchVec> np2;
         for (const MatchVec &pc : pieces)
             for (size_t i = 0; i < pc.size(); i++) {
                 bool split = i == 0;
                 if (!split) {
-                    int64_t mx = 0; int nonempty = 0;
-                    for (int j = 0; j < n; j++) { int64_t lo, ln; bool rv; gap_of(pc.rec(i - 1), pc.rec(i), j, lo, ln, rv); mx = std::max(mx, ln); nonempty += ln > 0; }
-                    split = nonempty >= 2 && mx > p->max_gapped_len;
+                    int64_t mx = 0; int nonempty = 0, big = 0;
+                    for (int j = 0; j < n; j++) { int64_t lo, ln; bool rv; gap_of(pc.rec(i - 1), pc.rec(i), j, lo, ln, rv); mx = std::max(mx, ln); nonempty += ln > 0; big += ln > p->min_recursive_gap; }
+                    split = nonempty >= 2 && (mx > p->max_gapped_len || (big >= 2 && big < n));
                 }
                 if (split) np2.emplace_back(n);
                 np2.back().push(pc.rec(i));
@@ -190,6 +196,11 @@ int prog_node(Prog &P, int node)
     rc = dp_batch_run_desc(c, n, n_dp, desc.data(), &p->scoring, dcols.data(), dcol_off.data(), dscore.data(), &cells);
     if (rc) return rc;
     P.n_gap_dp += n_dp; P.n_cells += cells;
+    if (trace) {
+        int64_t big = 0; for (int64_t k = 0; k < n_dp; k++) { int64_t mx = 0; for (int j = 0; j < n; j++) mx = std::max(mx, desc[(size_t)(k * n + j)].len); big = std::max(big, mx); }
+        fprintf(stderr, "[trace] node %d (n=%d, pool %lld): seed %.1f ms (%lld mums), chain %.1f, recursion %.1f, dp %.1f ms (%lld intervals, %lld cells, longest side %lld)\n",
+                node, n, (long long)rest_len, tn1 - tn0, (long long)nm, tn2 - tn1, tn3 - tn2, now_ms() - tn3, (long long)n_dp, (long long)cells, (long long)big);
+    }
     // ---- blocks ----
     uint32_t gfull = 0; for (int j = 0; j < n; j++) gfull |= 1u << gm[j];
     std::vector<std::vector<std::pair<int64_t, int64_t>>> placed((size_t)n);
