@@ -194,6 +194,25 @@ __global__ void __launch_bounds__(256) seed_extract_all(const uint64_t *__restri
 // ------------------------------------------------------------------------------------------------
 // radix sort (LSD, 8-bit digits, stable): histogram / row scan / scatter per pass
 // ------------------------------------------------------------------------------------------------
+// block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix, *total
+// receives the block sum.  One global atomic per block instead of one per wave keeps a single output
+// counter far below its ~12 ns-per-atomic serial rate (MI355X_MICROARCH.md "fanin").
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *lds /*[8]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { uint32_t c = lds[w]; if (w < wave) wbase += c; tot += c; }
+    __syncthreads();
+    *total = tot;
+    return wbase + inc - v;
+}
+
 constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;   // 4096 keys per workgroup
@@ -220,24 +239,16 @@ __global__ void __launch_bounds__(RS_THREADS) rs_hist(const KeyT *__restrict__ k
 __global__ void __launch_bounds__(256) rs_rowscan(uint32_t *__restrict__ hist, uint32_t nblk,
                                                   uint32_t *__restrict__ totals)
 {
-    __shared__ uint32_t part[256];
+    __shared__ uint32_t part[8];
     uint32_t *row = hist + (size_t)blockIdx.x * nblk;
     uint32_t chunk = (nblk + 255) / 256;
     uint32_t lo = threadIdx.x * chunk, hi = min(lo + chunk, nblk);
     uint32_t s = 0;
     for (uint32_t i = lo; i < hi; i++) s += row[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 256 partials
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t v = threadIdx.x >= (uint32_t)off ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - s;
+    uint32_t total;
+    uint32_t run = block_excl_scan(s, &total, part);
     for (uint32_t i = lo; i < hi; i++) { uint32_t v = row[i]; row[i] = run; run += v; }
-    if (threadIdx.x == 255) totals[blockIdx.x] = part[255];
+    if (threadIdx.x == 255) totals[blockIdx.x] = total;
 }
 
 template <typename KeyT>
@@ -261,16 +272,11 @@ __global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict_
 
     for (int w = 0; w < RS_WAVES; w++) wcount[w][tid] = 0;
     // digit base = exclusive scan of the digit totals
-    uint32_t tot = totals[tid];
-    scan[tid] = tot;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t v = tid >= off ? scan[tid - off] : 0;
-        __syncthreads();
-        scan[tid] += v;
-        __syncthreads();
+    {
+        uint32_t dummy;
+        const uint32_t tot = totals[tid];
+        gbase[tid] = block_excl_scan(tot, &dummy, scan) + hist[(size_t)tid * nblk + blockIdx.x];
     }
-    gbase[tid] = scan[tid] - tot + hist[(size_t)tid * nblk + blockIdx.x];
     __syncthreads();
 
     // load (wave-striped: wave w owns [w*1024, (w+1)*1024), item i of lane l is index i*64+l)
@@ -310,15 +316,10 @@ __global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict_
     for (int w = 0; w < RS_WAVES; w++) { c[w] = wcount[w][tid]; }
 #pragma unroll
     for (int w = 0; w < RS_WAVES; w++) { uint32_t t = c[w]; wcount[w][tid] = sum; sum += t; }
-    scan[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t t = tid >= off ? scan[tid - off] : 0;
-        __syncthreads();
-        scan[tid] += t;
-        __syncthreads();
+    {
+        uint32_t dummy;
+        tstart[tid] = block_excl_scan(sum, &dummy, scan);
     }
-    tstart[tid] = scan[tid] - sum;
     __syncthreads();
     // stage in LDS at the tile-sorted position
 #pragma unroll
@@ -342,32 +343,6 @@ __global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict_
             keys_out[dst] = kk; vals_out[dst] = s_vals[pos];
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// mum_join: one thread per sorted entry; the thread at the first entry of a run of identical mers
-// decides the hit by the finder's rule and writes the hit record + the per-position component mask.
-//   MODE_MEM    : MemHash -- a genome with more than one copy kills the seed
-//   MODE_UNIQUE : UniqueMatchFinder.cpp:44-58 -- genomes with more than one copy are dropped, >= 2 stay
-// hit_pos[h*nseq+g] = global window index | strand << 31, 0xFFFFFFFF = absent.
-// ------------------------------------------------------------------------------------------------
-// block-wide exclusive scan of one value per thread (256 threads); returns the exclusive prefix, *total
-// receives the block sum.  One global atomic per block instead of one per wave keeps a single output
-// counter far below its ~12 ns-per-atomic serial rate (MI355X_MICROARCH.md "fanin").
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *lds /*[8]*/)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    if (lane == 63) lds[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) { uint32_t c = lds[w]; if (w < wave) wbase += c; tot += c; }
-    __syncthreads();
-    *total = tot;
-    return wbase + inc - v;
 }
 
 // ------------------------------------------------------------------------------------------------
