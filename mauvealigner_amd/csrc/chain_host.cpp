@@ -134,8 +134,8 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
     // per-genome order of the matches
     std::vector<std::vector<uint32_t>> order(N, std::vector<uint32_t>(n)), rank(N, std::vector<uint32_t>(n));
     {
-        std::vector<uint64_t> key(n), tmp;
         for (int g = 0; g < N; g++) {
+            std::vector<uint64_t> key(n), tmp;
             for (size_t i = 0; i < n; i++) key[i] = ((uint64_t)std::llabs(m.st(i)[g]) << 32) | (uint64_t)i;
             sort_by_left(key, tmp);
             for (uint32_t r = 0; r < n; r++) { order[g][r] = (uint32_t)key[r]; rank[g][order[g][r]] = r; }

@@ -79,7 +79,8 @@ struct AlignResult {
     std::vector<int64_t> iv_left, iv_right;
     std::vector<int8_t> iv_reverse;
     std::vector<int64_t> col_off;
-    std::vector<uint32_t> cols;
+    std::vector<uint32_t> cols;        // capacity buffer: the first n_cols entries are the result (see pipeline.cpp)
+    size_t n_cols = 0;
     std::vector<int64_t> dp_score;
 };
 

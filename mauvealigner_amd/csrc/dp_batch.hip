@@ -17,6 +17,7 @@
 #include "common.hpp"
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 
 #define DP_NEG_INF (-(1 << 29))
 constexpr int DP_LDS_TB = 12288;
@@ -261,6 +262,8 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     if (cells) *cells = 0;
     col_off[0] = 0;
     if (n_iv == 0) return MAUVE_OK;
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    const double td0 = now_ms();
     const int64_t total = seq_off[n_iv * nseq];
     // per-interval scratch: traceback (worst profile length before each step) and parked rows
     std::vector<int64_t> tb_off(n_iv + 1), rows_off(n_iv + 1);
@@ -311,6 +314,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     } else if (total) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->dp_codes.p, codes, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
     }
+    const double td1 = now_ms();
     DpScoring sc; sc.go = scoring->gap_open; sc.ge = scoring->gap_extend; memcpy(sc.s, scoring->matrix, sizeof sc.s);
     // longest intervals first: one wave per interval, so the tail of the launch is its longest interval
     std::vector<int64_t> lst((size_t)n_iv);
@@ -333,8 +337,10 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     }
     HIPCHK(ctx, hipGetLastError());
     std::vector<DpMeta> hm(n_iv);
+    const double td2 = now_ms();
     HIPCHK(ctx, hipMemcpyAsync(hm.data(), ctx->dp_meta.p, (size_t)n_iv * sizeof(DpMeta), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const double td3 = now_ms();
     int64_t tc = 0, cl = 0;
     for (int64_t iv = 0; iv < n_iv; iv++) {
         col_off[iv] = tc; tc += hm[iv].m; cl += hm[iv].cells;
@@ -351,6 +357,8 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
         HIPCHK(ctx, hipMemcpyAsync(cols, ctx->dp_cols.p, (size_t)tc * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
+    if (trace) fprintf(stderr, "[trace] dp_core: sizing+H2D %.3f ms, order+launch %.3f, kernel+meta D2H %.3f, gather+cols D2H %.3f\n",
+                       td1 - td0, td2 - td1, td3 - td2, now_ms() - td3);
     return MAUVE_OK;
 }
 

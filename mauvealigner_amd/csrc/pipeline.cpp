@@ -45,7 +45,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p)
     R.sz = mauve_align_sizes();
     R.mum_length.clear(); R.mum_start.clear(); R.lcb_left.clear(); R.lcb_right.clear(); R.lcb_weight.clear();
     R.anchor_length.clear(); R.anchor_start.clear(); R.anchor_lcb.clear(); R.iv_left.clear(); R.iv_right.clear();
-    R.iv_reverse.clear(); R.col_off.clear(); R.cols.clear(); R.dp_score.clear();
+    R.iv_reverse.clear(); R.col_off.clear(); R.n_cols = 0; R.dp_score.clear();
     memset(&c->stage, 0, sizeof c->stage);
 
     int64_t sum = 0; for (int g = 0; g < N; g++) sum += c->lens[g];
@@ -126,6 +126,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p)
         }
     }
     S.t_dp0 = now_ms();
+    if (getenv("MAUVE_TRACE")) fprintf(stderr, "[trace] interval table: %.3f ms (%lld gaps, %lld dp)\n", S.t_dp0 - t3, (long long)S.gaps.size(), (long long)S.n_dp);
     S.open = true;
     return MAUVE_OK;
 }
@@ -156,49 +157,72 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
     c->stage.dp_ms = t4 - S.t_dp0;
 
     // ---- assemble the interval table ----
-    int64_t unaligned_cols = 0;
-    for (const AlignState::GapRef &gr : S.gaps) if (!gr.dp) unaligned_cols += gr.tot;
-    R.col_off.clear(); R.cols.clear();
-    R.cols.reserve((size_t)(S.anchor_cols + dcol_off[(size_t)n_dp] + unaligned_cols + (p->add_unaligned ? S.sum : 0)));
-    R.anchor_length.reserve((size_t)S.n_anchor); R.anchor_start.reserve((size_t)S.n_anchor * N); R.anchor_lcb.reserve((size_t)S.n_anchor);
+    // pass 1 (sequential, light): where every anchor and every stretch goes in the column array
+    struct Item { int64_t lcb; uint32_t idx; int64_t col0; int64_t gap; };
+    std::vector<Item> items((size_t)S.n_anchor);
+    R.col_off.clear();
     R.lcb_left.assign((size_t)nl * N, 0); R.lcb_right.assign((size_t)nl * N, 0);
     R.dp_score.assign((size_t)nl, 0);
-    size_t gi = 0;
-    for (int64_t l = 0; l < nl; l++) {
-        const MatchVec &ch = chains[(size_t)l];
-        R.col_off.push_back((int64_t)R.cols.size());
-        for (size_t i = 0; i < ch.size(); i++) {
-            const int64_t alen = ch.len(i); const int64_t *ast = ch.st(i);
-            R.anchor_length.push_back(alen); R.anchor_lcb.push_back(l);
-            R.anchor_start.insert(R.anchor_start.end(), ast, ast + N);
-            R.cols.insert(R.cols.end(), (size_t)alen, full);
-            if (gi < S.gaps.size() && S.gaps[gi].lcb == l && S.gaps[gi].idx == (int64_t)i) {
-                const AlignState::GapRef &gr = S.gaps[gi++];
-                if (gr.dp) {
-                    R.cols.insert(R.cols.end(), dcols + dcol_off[(size_t)gr.dp_slot], dcols + dcol_off[(size_t)gr.dp_slot + 1]);
-                    R.dp_score[(size_t)l] += dscore[(size_t)gr.dp_slot];
-                } else {
-                    for (int g = 0; g < N; g++) {
-                        int64_t lo, ln; bool rv;
-                        gap_of(ch.rec(i), ch.rec(i + 1), g, lo, ln, rv);
-                        R.cols.insert(R.cols.end(), (size_t)ln, 1u << g);
-                    }
+    int64_t col = 0;
+    {
+        size_t gi = 0, ai = 0;
+        for (int64_t l = 0; l < nl; l++) {
+            const MatchVec &ch = chains[(size_t)l];
+            R.col_off.push_back(col);
+            for (size_t i = 0; i < ch.size(); i++) {
+                Item it; it.lcb = l; it.idx = (uint32_t)i; it.col0 = col; it.gap = -1;
+                col += ch.len(i);
+                if (gi < S.gaps.size() && S.gaps[gi].lcb == l && S.gaps[gi].idx == (int64_t)i) {
+                    const AlignState::GapRef &gr = S.gaps[gi];
+                    it.gap = (int64_t)gi++;
+                    if (gr.dp) { col += dcol_off[(size_t)gr.dp_slot + 1] - dcol_off[(size_t)gr.dp_slot]; R.dp_score[(size_t)l] += dscore[(size_t)gr.dp_slot]; }
+                    else col += gr.tot;
+                }
+                items[ai++] = it;
+            }
+            // LCB extent: anchors are ordered, so the ends come from the first and last anchor
+            if (ch.size()) {
+                const size_t last = ch.size() - 1;
+                for (int g = 0; g < N; g++) {
+                    const int64_t s0 = ch.st(0)[g], s1 = ch.st(last)[g];
+                    int64_t le, re;
+                    if (s0 > 0) { le = s0; re = s1 + ch.len(last) - 1; }
+                    else { le = -s1; re = -s0 + ch.len(0) - 1; }
+                    R.lcb_left[(size_t)l * N + g] = s0 < 0 ? -le : le;
+                    R.lcb_right[(size_t)l * N + g] = s0 < 0 ? -re : re;
                 }
             }
         }
-        // LCB extent: anchors are ordered, so the ends come from the first and last anchor
-        if (ch.size()) {
-            const size_t last = ch.size() - 1;
-            for (int g = 0; g < N; g++) {
-                const int64_t s0 = ch.st(0)[g], s1 = ch.st(last)[g];
-                int64_t le, re;
-                if (s0 > 0) { le = s0; re = s1 + ch.len(last) - 1; }
-                else { le = -s1; re = -s0 + ch.len(0) - 1; }
-                R.lcb_left[(size_t)l * N + g] = s0 < 0 ? -le : le;
-                R.lcb_right[(size_t)l * N + g] = s0 < 0 ? -re : re;
+    }
+    // the column array is a capacity buffer kept across calls (no zero fill of 20 MB per call)
+    const size_t need = (size_t)col + (size_t)(p->add_unaligned ? S.sum : 0);
+    if (R.cols.size() < need) R.cols.resize(need);
+    R.anchor_length.resize((size_t)S.n_anchor); R.anchor_start.resize((size_t)S.n_anchor * N); R.anchor_lcb.resize((size_t)S.n_anchor);
+    // pass 2: every anchor writes its own columns and the stretch that follows it (independent writes; a thread
+    // pool did not pay here: waking it costs more than the 0.7 ms of fills)
+    {
+        uint32_t *out = R.cols.data();
+        for (int64_t a = 0; a < S.n_anchor; a++) {
+            const Item &it = items[(size_t)a];
+            const MatchVec &ch = chains[(size_t)it.lcb];
+            const int64_t alen = ch.len(it.idx); const int64_t *ast = ch.st(it.idx);
+            R.anchor_length[(size_t)a] = alen; R.anchor_lcb[(size_t)a] = it.lcb;
+            std::copy(ast, ast + N, &R.anchor_start[(size_t)a * N]);
+            uint32_t *o = out + it.col0;
+            std::fill(o, o + alen, full);
+            o += alen;
+            if (it.gap >= 0) {
+                const AlignState::GapRef &gr = S.gaps[(size_t)it.gap];
+                if (gr.dp) std::copy(dcols + dcol_off[(size_t)gr.dp_slot], dcols + dcol_off[(size_t)gr.dp_slot + 1], o);
+                else for (int g = 0; g < N; g++) {
+                    int64_t lo, ln; bool rv;
+                    gap_of(ch.rec(it.idx), ch.rec(it.idx + 1), g, lo, ln, rv);
+                    std::fill(o, o + ln, 1u << g); o += ln;
+                }
             }
         }
     }
+    size_t ncols = (size_t)col;
     int64_t niv = nl;
     R.iv_left.assign((size_t)nl * N, 0); R.iv_right.assign((size_t)nl * N, 0); R.iv_reverse.assign((size_t)nl * N, 0);
     for (int64_t i = 0; i < nl * N; i++) {
@@ -215,8 +239,9 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
             for (size_t i = 0; i <= sp.size(); i++) {
                 int64_t lo = cur, hi = i < sp.size() ? sp[i].first - 1 : c->lens[g];
                 if (hi >= lo) {
-                    R.col_off.push_back((int64_t)R.cols.size());
-                    R.cols.insert(R.cols.end(), (size_t)(hi - lo + 1), 1u << g);
+                    R.col_off.push_back((int64_t)ncols);
+                    std::fill(R.cols.begin() + ncols, R.cols.begin() + ncols + (size_t)(hi - lo + 1), 1u << g);
+                    ncols += (size_t)(hi - lo + 1);
                     for (int h = 0; h < N; h++) { R.iv_left.push_back(h == g ? lo : 0); R.iv_right.push_back(h == g ? hi : 0); R.iv_reverse.push_back(0); }
                     R.dp_score.push_back(0);
                     niv++;
@@ -225,8 +250,9 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
             }
         }
     }
-    R.col_off.push_back((int64_t)R.cols.size());
-    R.sz.n_mums = S.nm; R.sz.n_lcb = nl; R.sz.n_anchor = S.n_anchor; R.sz.n_iv = niv; R.sz.n_cols = (int64_t)R.cols.size();
+    R.col_off.push_back((int64_t)ncols);
+    R.n_cols = ncols;
+    R.sz.n_mums = S.nm; R.sz.n_lcb = nl; R.sz.n_anchor = S.n_anchor; R.sz.n_iv = niv; R.sz.n_cols = (int64_t)ncols;
     R.sz.n_gap_dp = n_dp; R.sz.n_dp_cells = cells;
     *sizes = R.sz;
     const double t5 = now_ms();
@@ -315,7 +341,8 @@ int mauve_align_fetch(mauve_ctx *c, int64_t *mum_length, int64_t *mum_start, int
     CPY(lcb_left, R.lcb_left); CPY(lcb_right, R.lcb_right); CPY(lcb_weight, R.lcb_weight);
     CPY(anchor_length, R.anchor_length); CPY(anchor_start, R.anchor_start); CPY(anchor_lcb, R.anchor_lcb);
     CPY(iv_left, R.iv_left); CPY(iv_right, R.iv_right); CPY(iv_reverse, R.iv_reverse);
-    CPY(col_off, R.col_off); CPY(cols, R.cols); CPY(dp_score, R.dp_score);
+    CPY(col_off, R.col_off); CPY(dp_score, R.dp_score);
+    if (cols && R.n_cols) memcpy(cols, R.cols.data(), R.n_cols * sizeof(uint32_t));
     return MAUVE_OK;
 }
 
@@ -328,7 +355,7 @@ int mauve_write_xmfa(mauve_ctx *c, const char *const *names, char *buf, int64_t 
     const int N = c->nseq;
     static const char B[4] = {'A', 'C', 'G', 'T'};
     std::string out;
-    out.reserve((size_t)R.cols.size() * (size_t)N / 2 + 4096);
+    out.reserve(R.n_cols * (size_t)N / 2 + 4096);
     char line[600];
     out += "#FormatVersion Mauve1\n";
     for (int g = 0; g < N; g++) {

@@ -332,6 +332,7 @@ int mauve_progressive_align(mauve_ctx *c, const mauve_params *p, mauve_align_siz
         R.lcb_left[(size_t)b * N + g] = rv ? -le : le; R.lcb_right[(size_t)b * N + g] = rv ? -re : re;
     }
     R.sz.n_mums = 0; R.sz.n_lcb = n_multi; R.sz.n_anchor = 0; R.sz.n_iv = (int64_t)R.dp_score.size();
+    R.n_cols = R.cols.size();
     R.sz.n_cols = (int64_t)R.cols.size(); R.sz.n_gap_dp = P.n_gap_dp; R.sz.n_dp_cells = P.n_cells;
     *sizes = R.sz;
     memset(&c->stage, 0, sizeof c->stage);
