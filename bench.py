@@ -77,7 +77,7 @@ def main():
     # ---- workload: C2-shaped genome set, one per rank ----
     weight = 15
     L = int(5_000_000 * args.scale)
-    genomes = synth.star_genomes(3, L, 0.03, 2 + 1000 * rank)
+    genomes, origins = synth.star_genomes(3, L, 0.03, 2 + 1000 * rank, track=True)   # origins: truth, for accuracy only
     total_bp = sum(len(g) for g in genomes)
     ctx = _lib.Context(local_rank)
     t_up0 = time.perf_counter()
@@ -159,6 +159,13 @@ def main():
                                  "achieved_GBs": round(tot_b * P / (seed_ms * 1e-3) / 1e9, 1) if seed_ms else None,
                                  "frac": round(tot_b * P / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if seed_ms else None}
 
+    # ---- accuracy of the bench workload's alignment against the generator's truth (not timed) ----
+    acc = None
+    if rank == 0 and world == 1:
+        from mauvealigner_amd import accuracy
+        acc = accuracy.score_alignment(ctx.align(params), origins)
+        acc = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in acc.items()}
+
     # ---- CPU baseline: the oracle on the same workload, host cores of this box ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -182,7 +189,7 @@ def main():
                                    "recursive anchoring + gapped DP on" % L,
                        "genomes_per_gpu": 3, "genome_length": L, "seed_weight": weight,
                        "parallelism": "independent genome sets per GPU (no data-path collective)"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "accuracy_vs_truth": acc,
             "stages_ms": {k: round(v / args.steps, 3) for k, v in stage_acc.items()},
             "kernels_ms": {k: round(v["ms"] / 3, 4) for k, v in kernels.items()},
             "result_sizes": sizes, "upload_ms": round(t_upload * 1e3, 2), "device": ctx.device_name(),

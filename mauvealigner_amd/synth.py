@@ -22,11 +22,13 @@ def random_genome(length, rng):
     return rng.integers(0, 4, size=int(length), dtype=np.uint8)
 
 
-def mutate(codes, rate, rng, indel_frac=0.10, mean_indel=3.0, cap=50):
-    """Point-mutate `codes` at per-base event rate `rate`."""
+def mutate(codes, rate, rng, indel_frac=0.10, mean_indel=3.0, cap=50, origin=None):
+    """Point-mutate `codes` at per-base event rate `rate`.  With `origin` (signed 1-based ancestor coordinate per
+    base, 0 = no ancestor) the same draws are made and (codes, origin) of the descendant is returned: the truth
+    used by accuracy.py."""
     L = len(codes)
     if rate <= 0 or L == 0:
-        return codes.copy()
+        return codes.copy() if origin is None else (codes.copy(), origin.copy())
     ev = rng.random(L) < rate
     pos = np.flatnonzero(ev)
     kind = rng.random(len(pos))
@@ -35,32 +37,42 @@ def mutate(codes, rate, rng, indel_frac=0.10, mean_indel=3.0, cap=50):
     out[sub] = (out[sub] + rng.integers(1, 4, size=len(sub), dtype=np.uint8)) & 3
     ind = pos[kind < indel_frac]
     if len(ind) == 0:
-        return out
+        return out if origin is None else (out, origin.copy())
     lens = np.minimum(rng.geometric(1.0 / mean_indel, size=len(ind)), cap)
     is_ins = rng.random(len(ind)) < 0.5
-    pieces = []
+    pieces, opieces = [], []
     cur = 0
     for p, ln, ins in zip(ind.tolist(), lens.tolist(), is_ins.tolist()):
         if p < cur:
             continue
         pieces.append(out[cur:p])
+        if origin is not None:
+            opieces.append(origin[cur:p])
         if ins:
             pieces.append(rng.integers(0, 4, size=ln, dtype=np.uint8))
+            if origin is not None:
+                opieces.append(np.zeros(ln, dtype=np.int64))
             cur = p
         else:
             cur = min(L, p + ln)
     pieces.append(out[cur:])
-    return np.concatenate(pieces)
+    if origin is None:
+        return np.concatenate(pieces)
+    opieces.append(origin[cur:])
+    return np.concatenate(pieces), np.concatenate(opieces)
 
 
 def revcomp(codes):
     return (3 - codes[::-1]).astype(np.uint8)
 
 
-def invert_segments(codes, n_inv, rng, min_len, max_len):
-    """Reverse-complement n_inv non-overlapping segments (log-uniform lengths)."""
+def invert_segments(codes, n_inv, rng, min_len, max_len, origin=None):
+    """Reverse-complement n_inv non-overlapping segments (log-uniform lengths).  `origin` (if given) is updated in
+    place on a copy: an inverted base keeps its ancestor coordinate with the sign flipped."""
     L = len(codes)
     out = codes.copy()
+    if origin is not None:
+        origin[:] = origin          # caller passes a private copy
     if n_inv <= 0:
         return out, []
     slot = L // n_inv
@@ -70,25 +82,34 @@ def invert_segments(codes, n_inv, rng, min_len, max_len):
         ln = max(1, min(ln, slot - 2))
         st = i * slot + int(rng.integers(0, max(1, slot - ln)))
         out[st:st + ln] = revcomp(out[st:st + ln])
+        if origin is not None:
+            origin[st:st + ln] = -origin[st:st + ln][::-1]
         segs.append((st, ln))
     return out, segs
 
 
-def star_genomes(n, length, divergence, seed_key, inversions=0, inv_min=5000, inv_max=500000):
-    """n descendants of one random ancestor; `inversions` total, spread over genomes 1..n-1."""
+def star_genomes(n, length, divergence, seed_key, inversions=0, inv_min=5000, inv_max=500000, track=False):
+    """n descendants of one random ancestor; `inversions` total, spread over genomes 1..n-1.  track=True also
+    returns, per genome, the signed ancestor coordinate of every base (the truth alignment)."""
     anc = random_genome(length, _rng(seed_key, 0))
-    genomes = []
+    genomes, origins = [], []
     per = [0] * n
     for i in range(inversions):
         per[1 + i % (n - 1)] += 1
     for g in range(n):
         rng = _rng(seed_key, 1 + g)
         x = anc
+        o = np.arange(1, length + 1, dtype=np.int64) if track else None
         if per[g]:
             x, _ = invert_segments(x, per[g], rng, min(inv_min, max(50, length // 400)),
-                                   min(inv_max, max(100, length // (2 * max(1, per[g])))))
-        genomes.append(mutate(x, divergence / 2.0, rng))
-    return genomes
+                                   min(inv_max, max(100, length // (2 * max(1, per[g])))), origin=o)
+        if track:
+            x, o = mutate(x, divergence / 2.0, rng, origin=o)
+            genomes.append(x)
+            origins.append(o)
+        else:
+            genomes.append(mutate(x, divergence / 2.0, rng))
+    return (genomes, origins) if track else genomes
 
 
 def tree_genomes(n_leaves, length, branch_div, seed_key, inv_per_branch=2, insert_per_branch=1, insert_len=(2000, 12000)):
