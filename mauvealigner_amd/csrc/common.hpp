@@ -122,6 +122,8 @@ struct AlignState {
 struct mauve_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           // dp_step_big runs here, beside dp_step on `stream`
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     char devname[256] = {0};
 

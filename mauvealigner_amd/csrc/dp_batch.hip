@@ -44,7 +44,238 @@ __device__ __forceinline__ void max3(int32_t a, int32_t b, int32_t c, int32_t &b
     if (c > best) { best = c; p = 2; }
 }
 
-__global__ void __launch_bounds__(256) dp_step(int nseq, const int64_t *__restrict__ list, int64_t n_iv, const uint8_t *__restrict__ codes,
+// One 64-row stripe of a DP step as a wave sees it: the lane's row constants, the rolling cell state and the two
+// 64-column chunks (current, next) of what lane 0 consumes -- the sequence bases and the boundary row above the
+// stripe.  Chunks are fetched by the whole wave one round (64 steps) ahead, from clamped addresses so the load is
+// unconditional and its wait lands a round later, and handed to lane 0 with v_readlane.
+struct DpStripe {
+    int32_t s, i, m, n, steps, gyo, gye, gxo, gxe, sub0, sub1, sub2, sub3;
+    bool active, park;
+    const uint8_t *seq; const int32_t *rin; int32_t *rout; uint8_t *tbs;
+    int32_t Mc, Xc, Yc, Md, Xd, Yd;
+    uint32_t bcur, sq_cur, sq_nxt;
+    int32_t bM_cur, bX_cur, bY_cur, bM_nxt, bX_nxt, bY_nxt;
+};
+
+__device__ __forceinline__ void dp_stripe_begin(DpStripe &S, int32_t s, int lane, int32_t m, int32_t n, int32_t nstripes,
+                                                const uint32_t *Pc, const uint8_t *seq, const DpScoring &sc, int32_t krows,
+                                                int32_t *rowbuf, uint8_t *tbp, int32_t T)
+{
+    S.s = s; S.m = m; S.n = n; S.seq = seq;
+    S.i = s * 64 + lane + 1;
+    S.active = S.i <= m;
+    const uint32_t cn = S.active ? Pc[S.i - 1] : 0u;
+    const int32_t c0 = cn & 255, c1 = (cn >> 8) & 255, c2 = (cn >> 16) & 255, c3 = cn >> 24;
+    const int32_t r = c0 + c1 + c2 + c3;
+    // sum-of-pairs substitution score of this profile column against each base (named registers: a
+    // runtime-indexed array would go to scratch)
+    S.sub0 = c0 * sc.s[0][0] + c1 * sc.s[1][0] + c2 * sc.s[2][0] + c3 * sc.s[3][0];
+    S.sub1 = c0 * sc.s[0][1] + c1 * sc.s[1][1] + c2 * sc.s[2][1] + c3 * sc.s[3][1];
+    S.sub2 = c0 * sc.s[0][2] + c1 * sc.s[1][2] + c2 * sc.s[2][2] + c3 * sc.s[3][2];
+    S.sub3 = c0 * sc.s[0][3] + c1 * sc.s[1][3] + c2 * sc.s[2][3] + c3 * sc.s[3][3];
+    S.gxo = sc.go * r; S.gxe = sc.ge * r;
+    S.gyo = sc.go * krows; S.gye = sc.ge * krows;
+    S.rin = rowbuf + (size_t)((s & 1) ^ 1) * 3 * (n + 1);      // written by stripe s-1
+    S.rout = rowbuf + (size_t)(s & 1) * 3 * (n + 1);
+    S.park = s + 1 < nstripes;
+    S.steps = n + min(64, m - s * 64);                          // t = 0 .. n + rows_here - 1
+    S.tbs = tbp + (size_t)s * T * 64 + lane;
+    S.Mc = S.Xc = S.Yc = S.Md = S.Xd = S.Yd = DP_NEG_INF;
+    S.bcur = 0;
+}
+
+// chunk k of lane 0's inputs: base t-1 and boundary column t for t = 64k + lane
+__device__ __forceinline__ void dp_stripe_chunk(const DpStripe &S, int32_t k, int lane, uint32_t &sq, int32_t &bM, int32_t &bX, int32_t &bY)
+{
+    const int32_t col = 64 * k + lane;
+    sq = (uint32_t)S.seq[min(max(col - 1, 0), S.n - 1)];
+    if (S.s == 0) {
+        bM = col == 0 ? 0 : DP_NEG_INF; bX = DP_NEG_INF;
+        bY = col == 0 ? DP_NEG_INF : S.gyo + (col - 1) * S.gye;
+    } else {
+        const int32_t cc = min(col, S.n);
+        bM = S.rin[cc]; bX = S.rin[(S.n + 1) + cc]; bY = S.rin[2 * (S.n + 1) + cc];
+    }
+}
+
+// round c: steps t = 64c .. min(64c + 63, steps - 1).  Branch-free cell update; (fM, fX, fY) catch cell (m, n).
+__device__ __forceinline__ void dp_stripe_round(DpStripe &S, int32_t c, int lane, int32_t &fM, int32_t &fX, int32_t &fY)
+{
+    if (c == 0) dp_stripe_chunk(S, 0, lane, S.sq_cur, S.bM_cur, S.bX_cur, S.bY_cur);
+    else { S.sq_cur = S.sq_nxt; S.bM_cur = S.bM_nxt; S.bX_cur = S.bX_nxt; S.bY_cur = S.bY_nxt; }
+    dp_stripe_chunk(S, c + 1, lane, S.sq_nxt, S.bM_nxt, S.bX_nxt, S.bY_nxt);
+    const int32_t t_end = min(64 * c + 64, S.steps);
+    const bool lane0 = lane == 0, last_lane = S.park && lane == 63;
+    for (int32_t t = 64 * c; t < t_end; t++) {
+        const int32_t j = t - lane;
+        // (i-1, j): lane-1's newest values (DPP wave shift); lane 0 takes the stripe's upper boundary row
+        int32_t Mu = wave_shr1(S.Mc), Xu = wave_shr1(S.Xc), Yu = wave_shr1(S.Yc);
+        uint32_t bnext = (uint32_t)wave_shr1((int32_t)S.bcur);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int32_t)S.sq_cur, t & 63);
+        const int32_t M0 = __builtin_amdgcn_readlane(S.bM_cur, t & 63), X0 = __builtin_amdgcn_readlane(S.bX_cur, t & 63),
+                      Y0 = __builtin_amdgcn_readlane(S.bY_cur, t & 63);
+        Mu = lane0 ? M0 : Mu; Xu = lane0 ? X0 : Xu; Yu = lane0 ? Y0 : Yu; bnext = lane0 ? b0 : bnext;
+        S.bcur = bnext;
+        const bool on = S.active && (uint32_t)j <= (uint32_t)S.n, j1 = j >= 1;
+        int32_t best; uint32_t pm, px, py;
+        max3(S.Md, S.Xd, S.Yd, best, pm);
+        const int32_t sa = (bnext & 1) ? S.sub1 : S.sub0, sb = (bnext & 1) ? S.sub3 : S.sub2;
+        int32_t Mn = max(best + ((bnext & 2) ? sb : sa), DP_NEG_INF);
+        max3(Mu + S.gxo, Xu + S.gxe, Yu + S.gxo, best, px);
+        const int32_t Xn = max(best, DP_NEG_INF);
+        max3(S.Mc + S.gyo, S.Xc + S.gyo, S.Yc + S.gye, best, py);    // (i, j-1): own previous column
+        int32_t Yn = max(best, DP_NEG_INF);
+        Mn = j1 ? Mn : DP_NEG_INF; Yn = j1 ? Yn : DP_NEG_INF; pm = j1 ? pm : 0u; py = j1 ? py : 0u;
+        if (on) {
+            S.Mc = Mn; S.Xc = Xn; S.Yc = Yn;
+            S.tbs[(size_t)t * 64] = (uint8_t)(pm | (px << 2) | (py << 4));
+            if (last_lane) { S.rout[j] = Mn; S.rout[(S.n + 1) + j] = Xn; S.rout[2 * (S.n + 1) + j] = Yn; }
+            if (S.i == S.m && j == S.n) { fM = Mn; fX = Xn; fY = Yn; }
+        }
+        S.Md = Mu; S.Xd = Xu; S.Yd = Yu;
+    }
+}
+
+// ---- big intervals: one workgroup (DP_MW_WAVES waves) per interval ---------------------------------------------------------
+// The 64-row stripes of a long profile go round-robin to the waves and run as a software pipeline: stripe s
+// follows stripe s-1 three 64-step rounds behind, which is when the columns of the parked boundary row it is about to
+// consume (and the chunk it prefetches) are final.  Progress is published per wave in LDS between two barriers per
+// round; a wave whose dependency is not met sits the round out.  Same recurrences, same traceback bytes, same
+// results as the one-wave path -- only the schedule differs.
+constexpr int DP_MW_LAG = 3;
+constexpr int DP_MW_WAVES = 16;            // 1024 threads: four waves per SIMD of one CU
+
+__device__ void dp_interval_mw(int nseq, int64_t iv, const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
+                               DpMeta *__restrict__ meta, uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
+                               uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB, uint8_t *__restrict__ tb,
+                               const int64_t *__restrict__ tb_off, int32_t *__restrict__ rows,
+                               const int64_t *__restrict__ rows_off, uint8_t *__restrict__ ops, const DpScoring &sc)
+{
+    __shared__ int32_t s_stripe[DP_MW_WAVES], s_round[DP_MW_WAVES], s_fin[3];
+    constexpr int W = DP_MW_WAVES;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
+    const int64_t base = seq_off[iv * nseq];
+    for (int g = 0; g < nseq; g++) {
+        const int64_t so = seq_off[iv * nseq + g];
+        const int32_t n = (int32_t)(seq_off[iv * nseq + g + 1] - so);
+        if (n == 0) continue;
+        const uint8_t *seq = codes + so;
+        uint32_t *Pc = (mt.cur ? cntB : cntA) + base, *Pm = (mt.cur ? maskB : maskA) + base;
+        uint32_t *Qc = (mt.cur ? cntA : cntB) + base, *Qm = (mt.cur ? maskA : maskB) + base;
+        if (mt.krows == 0) {
+            for (int32_t c = threadIdx.x; c < n; c += 64 * W) { Pc[c] = 1u << (8 * seq[c]); Pm[c] = 1u << g; }
+            mt.m = n; mt.krows = 1;
+            __threadfence_block();
+            __syncthreads();
+            continue;
+        }
+        const int32_t m = mt.m;
+        const int32_t T = n + 64;
+        uint8_t *tbp = tb + tb_off[iv];
+        int32_t *rowbuf = rows + rows_off[iv];
+        const int32_t nstripes = (m + 63) / 64;
+
+        // ---- pipeline over stripes ----
+        int32_t my_s = wv, my_c = 0;
+        if (lane == 0) { s_stripe[wv] = wv; s_round[wv] = 0; }
+        __syncthreads();
+        DpStripe S;                                       // the stripe this wave is in the middle of
+        int32_t nrounds = 0;
+        int32_t fM = DP_NEG_INF, fX = DP_NEG_INF, fY = DP_NEG_INF;
+        // every stripe runs at most (n + 64) / 64 + 1 rounds; a fully serial schedule is the upper bound
+        const int64_t guard_max = (int64_t)nstripes * ((n + 64) / 64 + 2) + 16;
+        for (int64_t guard = 0; guard < guard_max; guard++) {
+            int32_t lo = s_stripe[0];
+#pragma unroll
+            for (int w = 1; w < W; w++) lo = min(lo, s_stripe[w]);
+            if (lo >= nstripes) break;
+            bool can = my_s < nstripes;
+            if (can && my_s > 0) {
+                const int pw = (my_s - 1) % W;
+                const int32_t ps = s_stripe[pw], pr = s_round[pw];
+                can = ps > my_s - 1 || (ps == my_s - 1 && pr >= my_c + DP_MW_LAG);
+            }
+            __syncthreads();               // every wave has read this round's state before anyone updates it
+            if (can) {
+                if (my_c == 0) {
+                    dp_stripe_begin(S, my_s, lane, m, n, nstripes, Pc, seq, sc, mt.krows, rowbuf, tbp, T);
+                    nrounds = (S.steps + 63) / 64;
+                }
+                dp_stripe_round(S, my_c, lane, fM, fX, fY);
+                my_c++;
+                if (my_c == nrounds) {
+                    if (my_s == nstripes - 1 && lane == ((m - 1) & 63)) { s_fin[0] = fM; s_fin[1] = fX; s_fin[2] = fY; }
+                    my_s += W; my_c = 0;
+                }
+                __threadfence_block();     // parked row and traceback bytes before the progress counters
+                if (lane == 0) { s_stripe[wv] = my_s; s_round[wv] = my_c; }
+            }
+            __syncthreads();
+        }
+        fM = s_fin[0]; fX = s_fin[1]; fY = s_fin[2];
+        int32_t best = fM; int state = 0;
+        if (fX > best) { best = fX; state = 1; }
+        if (fY > best) { best = fY; state = 2; }
+
+        // ---- traceback: every wave walks the same path (uniform control flow), wave 0 records it ----
+        uint8_t *opr = ops + base;
+        int32_t ti = m, tj = n, len = 0;
+        while (ti > 0 || tj > 0) {
+            uint32_t op, nstate;
+            if (ti == 0) { op = 2; nstate = (tj == 1) ? 0 : 2; }
+            else {
+                const int32_t s = (ti - 1) >> 6, l = (ti - 1) & 63;
+                const uint8_t bt = tbp[((size_t)s * T + (tj + l)) * 64 + l];
+                if (state == 0) { op = 3; nstate = bt & 3; }
+                else if (state == 1) { op = 1; nstate = (bt >> 2) & 3; }
+                else { op = 2; nstate = (bt >> 4) & 3; }
+            }
+            if (threadIdx.x == 0) opr[len] = (uint8_t)op;
+            len++;
+            if (op & 1) ti--;
+            if (op & 2) tj--;
+            state = (int)nstate;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // ---- new profile: every wave keeps the running source counts, chunk k is written by wave k mod W ----
+        int32_t carry_p = 0, carry_s = 0;
+        for (int32_t c0i = 0, k = 0; c0i < len; c0i += 64, k++) {
+            const int32_t c = c0i + lane;
+            const bool ok = c < len;
+            const uint32_t op = ok ? opr[len - 1 - c] : 0u;
+            const uint64_t bp = __ballot(ok && (op & 1)), bs = __ballot(ok && (op & 2));
+            if (ok && (k % W) == wv) {
+                const int32_t pi = carry_p + (int32_t)__popcll(bp & lt), sj = carry_s + (int32_t)__popcll(bs & lt);
+                uint32_t cv = 0, mv = 0;
+                if (op & 1) { cv = Pc[pi]; mv = Pm[pi]; }
+                if (op & 2) { cv += 1u << (8 * seq[sj]); mv |= 1u << g; }
+                Qc[c] = cv; Qm[c] = mv;
+            }
+            carry_p += (int32_t)__popcll(bp); carry_s += (int32_t)__popcll(bs);
+        }
+        mt.cells += (int64_t)m * n; mt.score += best; mt.m = len; mt.krows += 1; mt.cur ^= 1;
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) meta[iv] = mt;
+}
+
+
+__global__ void __launch_bounds__(64 * DP_MW_WAVES) dp_step_big(int nseq, const int64_t *__restrict__ list, const uint8_t *__restrict__ codes,
+                                               const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
+                                               uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
+                                               uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
+                                               uint8_t *__restrict__ tb, const int64_t *__restrict__ tb_off,
+                                               int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
+                                               uint8_t *__restrict__ ops, DpScoring sc)
+{
+    dp_interval_mw(nseq, list[blockIdx.x], codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, sc);
+}
+
+__global__ void __launch_bounds__(256) dp_step(int nseq, const int64_t *__restrict__ list, int64_t n_iv, int n_big, const uint8_t *__restrict__ codes,
                                                const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
                                                uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
                                                uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
@@ -56,12 +287,13 @@ __global__ void __launch_bounds__(256) dp_step(int nseq, const int64_t *__restri
     // walk is a chain of dependent 1-byte loads, ~100 cycles each from LDS against >1000 from L2/HBM.
     __shared__ uint8_t s_tb[4][DP_LDS_TB];
     __shared__ uint8_t s_ops[4][DP_LDS_OPS];
+    // the first n_big entries of the list belong to dp_step_big
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
 
-    for (int64_t li = wave_global; li < n_iv; li += nwaves) {
+    for (int64_t li = n_big + wave_global; li < n_iv; li += nwaves) {
       const int64_t iv = list[li];
       // all progressive steps of one interval run back to back in this wave (they only depend on each other)
       DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
@@ -80,7 +312,6 @@ __global__ void __launch_bounds__(256) dp_step(int nseq, const int64_t *__restri
             continue;
         }
         const int32_t m = mt.m;
-        const int32_t gyo = sc.go * mt.krows, gye = sc.ge * mt.krows;
         const int32_t T = n + 64;                          // traceback stride per stripe (steps)
         const bool in_lds = m <= 64 && (size_t)(m + n) * 64 <= DP_LDS_TB && m + n <= DP_LDS_OPS;
         uint8_t *tbp = in_lds ? s_tb[wv] : tb + tb_off[iv];
@@ -89,79 +320,10 @@ __global__ void __launch_bounds__(256) dp_step(int nseq, const int64_t *__restri
         int32_t fM = DP_NEG_INF, fX = DP_NEG_INF, fY = DP_NEG_INF;   // values at (m, n)
 
         for (int32_t s = 0; s < nstripes; s++) {
-            const int32_t i = s * 64 + lane + 1;
-            const bool active = i <= m;
-            const int32_t rows_here = min(64, m - s * 64);
-            uint32_t cn = active ? Pc[i - 1] : 0u;
-            const int32_t c0 = cn & 255, c1 = (cn >> 8) & 255, c2 = (cn >> 16) & 255, c3 = cn >> 24;
-            const int32_t r = c0 + c1 + c2 + c3;
-            // sum-of-pairs substitution score of this column against each base (kept in named registers:
-            // a runtime-indexed array would go to scratch)
-            const int32_t sub0 = c0 * sc.s[0][0] + c1 * sc.s[1][0] + c2 * sc.s[2][0] + c3 * sc.s[3][0];
-            const int32_t sub1 = c0 * sc.s[0][1] + c1 * sc.s[1][1] + c2 * sc.s[2][1] + c3 * sc.s[3][1];
-            const int32_t sub2 = c0 * sc.s[0][2] + c1 * sc.s[1][2] + c2 * sc.s[2][2] + c3 * sc.s[3][2];
-            const int32_t sub3 = c0 * sc.s[0][3] + c1 * sc.s[1][3] + c2 * sc.s[2][3] + c3 * sc.s[3][3];
-            const int32_t gxo = sc.go * r, gxe = sc.ge * r;
-            const int32_t *rin = rowbuf + (size_t)((s & 1) ^ 1) * 3 * (n + 1);   // written by stripe s-1
-            int32_t *rout = rowbuf + (size_t)(s & 1) * 3 * (n + 1);
-            const bool park = s + 1 < nstripes;
-
-            int32_t Mc = DP_NEG_INF, Xc = DP_NEG_INF, Yc = DP_NEG_INF;   // (i, j) just computed
-            int32_t Md = DP_NEG_INF, Xd = DP_NEG_INF, Yd = DP_NEG_INF;   // (i-1, j-1)
-            uint32_t bcur = 0;
-            // What lane 0 consumes every step -- the next base and, below the first stripe, the parked boundary
-            // row -- is fetched 64 columns at a time by the whole wave (one coalesced load, a chunk ahead) and
-            // handed to lane 0 with v_readlane: no memory latency inside the systolic step.
-            uint32_t sq_cur = (lane < n) ? (uint32_t)seq[lane] : 0u;
-            uint32_t sq_nxt = (64 + lane < n) ? (uint32_t)seq[64 + lane] : 0u;
-            int32_t bM_cur = DP_NEG_INF, bX_cur = DP_NEG_INF, bY_cur = DP_NEG_INF, bM_nxt = DP_NEG_INF, bX_nxt = DP_NEG_INF,
-                    bY_nxt = DP_NEG_INF;
-            if (s > 0) {
-                if (lane <= n) { bM_cur = rin[lane]; bX_cur = rin[(n + 1) + lane]; bY_cur = rin[2 * (n + 1) + lane]; }
-                if (64 + lane <= n) { bM_nxt = rin[64 + lane]; bX_nxt = rin[(n + 1) + 64 + lane]; bY_nxt = rin[2 * (n + 1) + 64 + lane]; }
-            }
-            const int32_t steps = n + rows_here;                         // t = 0 .. n + rows_here - 1
-            for (int32_t t = 0; t < steps; t++) {
-                const int32_t j = t - lane;
-                if (t > 1 && ((t - 1) & 63) == 0) {                      // column t needs seq[t-1]: next chunk
-                    sq_cur = sq_nxt;
-                    sq_nxt = (t - 1 + 64 + lane < n) ? (uint32_t)seq[t - 1 + 64 + lane] : 0u;
-                }
-                if (s > 0 && t > 0 && (t & 63) == 0) {
-                    bM_cur = bM_nxt; bX_cur = bX_nxt; bY_cur = bY_nxt;
-                    const int32_t jj = t + 64 + lane;
-                    if (jj <= n) { bM_nxt = rin[jj]; bX_nxt = rin[(n + 1) + jj]; bY_nxt = rin[2 * (n + 1) + jj]; }
-                }
-                // (i-1, j): lane-1's newest values (DPP wave shift); lane 0 takes the stripe's upper boundary row
-                int32_t Mu = wave_shr1(Mc), Xu = wave_shr1(Xc), Yu = wave_shr1(Yc);
-                uint32_t bnext = (uint32_t)wave_shr1((int32_t)bcur);
-                const uint32_t b0 = (t >= 1 && t <= n) ? (uint32_t)__builtin_amdgcn_readlane((int32_t)sq_cur, (t - 1) & 63) : 0u;
-                int32_t M0, X0, Y0;
-                if (s == 0) {
-                    M0 = (t == 0) ? 0 : DP_NEG_INF; X0 = DP_NEG_INF;
-                    Y0 = (t == 0) ? DP_NEG_INF : gyo + (t - 1) * gye;
-                } else {
-                    M0 = __builtin_amdgcn_readlane(bM_cur, t & 63); X0 = __builtin_amdgcn_readlane(bX_cur, t & 63);
-                    Y0 = __builtin_amdgcn_readlane(bY_cur, t & 63);
-                }
-                if (lane == 0) { if (t <= n) { Mu = M0; Xu = X0; Yu = Y0; } bnext = b0; }
-                bcur = bnext;
-                const bool on = active && j >= 0 && j <= n;
-                int32_t Ml = Mc, Xl = Xc, Yl = Yc;           // (i, j-1): own previous column
-                if (on) {
-                    int32_t best; uint32_t pm = 0, px, py = 0;
-                    if (j >= 1) { max3(Md, Xd, Yd, best, pm); best += (bcur == 0 ? sub0 : bcur == 1 ? sub1 : bcur == 2 ? sub2 : sub3); Mc = best < DP_NEG_INF ? DP_NEG_INF : best; }
-                    else Mc = DP_NEG_INF;
-                    max3(Mu + gxo, Xu + gxe, Yu + gxo, best, px);
-                    Xc = best < DP_NEG_INF ? DP_NEG_INF : best;
-                    if (j >= 1) { max3(Ml + gyo, Xl + gyo, Yl + gye, best, py); Yc = best < DP_NEG_INF ? DP_NEG_INF : best; }
-                    else Yc = DP_NEG_INF;
-                    tbp[((size_t)s * T + t) * 64 + lane] = (uint8_t)(pm | (px << 2) | (py << 4));
-                    if (park && lane == 63) { rout[j] = Mc; rout[(n + 1) + j] = Xc; rout[2 * (n + 1) + j] = Yc; }
-                    if (i == m && j == n) { fM = Mc; fX = Xc; fY = Yc; }
-                }
-                Md = Mu; Xd = Xu; Yd = Yu;
-            }
+            DpStripe S;
+            dp_stripe_begin(S, s, lane, m, n, nstripes, Pc, seq, sc, mt.krows, rowbuf, tbp, T);
+            const int32_t nrounds = (S.steps + 63) / 64;
+            for (int32_t c = 0; c < nrounds; c++) dp_stripe_round(S, c, lane, fM, fX, fY);
             __threadfence_block();   // the parked row / traceback bytes are read back by this wave
         }
         // result lives in the lane that owns row m
@@ -267,6 +429,10 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     const int64_t total = seq_off[n_iv * nseq];
     // per-interval scratch: traceback (worst profile length before each step) and parked rows
     std::vector<int64_t> tb_off(n_iv + 1), rows_off(n_iv + 1);
+    std::vector<uint8_t> is_big((size_t)n_iv, 0);
+    std::vector<int64_t> est((size_t)n_iv, 0);
+    int64_t est_total = 0;
+    static const bool no_mw = getenv("MAUVE_DP_ONE_WAVE") != nullptr;     // A/B switch for the workgroup path
     int64_t tbt = 0, rwt = 0;
     for (int64_t iv = 0; iv < n_iv; iv++) {
         int64_t mmax = 0, need = 0, nmax = 0; bool first = true;
@@ -276,8 +442,12 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
             if (first) { first = false; mmax = n; continue; }
             need = std::max(need, ((mmax + 63) / 64) * (n + 64) * 64);
             nmax = std::max(nmax, n);
+            // a step with >= 3 stripes against >= 256 columns pipelines over several waves
+            if (mmax > 128 && n >= 256 && !no_mw) is_big[(size_t)iv] = 1;
+            est[(size_t)iv] += ((mmax + 63) / 64) * (n + 64);       // systolic steps of a single wave
             mmax += n;
         }
+        est_total += est[(size_t)iv];
         tb_off[iv] = tbt; rows_off[iv] = rwt;
         tbt += need; rwt += 6 * (nmax + 1);
     }
@@ -301,7 +471,6 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     HIPCHK(ctx, hipMemcpyAsync(d_seq_off, seq_off, (size_t)(n_iv * nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_tb_off, tb_off.data(), (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_rows_off, rows_off.data(), (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    const uint32_t blocks = (uint32_t)std::min<int64_t>((n_iv + 3) / 4, 256 * 8);
     if (desc) {
         const int64_t nd = n_iv * nseq;
         HIPCHK(ctx, ctx->dp_desc.ensure((size_t)nd * sizeof(DpSeqDesc)));
@@ -325,15 +494,42 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
         for (int c = 0; c < 65; c++) cnt[c + 1] += cnt[c];
         for (int64_t iv = 0; iv < n_iv; iv++) lst[(size_t)cnt[cls(iv)]++] = iv;
     }
+    // workgroup-per-interval entries first (still largest first), one-wave entries after them
+    // A 16-wave workgroup fills a CU, so it only pays for the tail: intervals well above what a balanced one-wave
+    // schedule (3072 resident waves) would take, and at most half the CUs' worth of them.
+    int64_t n_big = 0;
+    {
+        const int64_t balanced = est_total / 3072;
+        for (int64_t k = 0; k < n_iv; k++) {          // lst is largest first
+            uint8_t &b = is_big[(size_t)lst[(size_t)k]];
+            if (b && (n_big >= 128 || est[(size_t)lst[(size_t)k]] <= 4 * balanced)) b = 0;
+            n_big += b;
+        }
+    }
+    if (n_big) std::stable_partition(lst.begin(), lst.end(), [&](int64_t iv) { return is_big[(size_t)iv] != 0; });
+    const int64_t n_small = n_iv - n_big;
+    const uint32_t blocks = (uint32_t)std::min<int64_t>((n_small + 3) / 4, 256 * 8);
     HIPCHK(ctx, ctx->dp_list.ensure((size_t)n_iv * 8));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dp_list.p, lst.data(), (size_t)n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
     {
         KernelTimer t(ctx, MAUVE_K_DP, n_iv);
-        hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, nseq, ctx->dp_list.as<int64_t>(), n_iv,
-                           ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
-                           ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
-                           ctx->dp_prof2_mask.as<uint32_t>(), ctx->dp_tb.as<uint8_t>(), d_tb_off, ctx->dp_rows.as<int32_t>(),
-                           d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
+        if (n_big) {   // the workgroup-per-interval launch runs beside the one-wave launch on a second stream
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            hipLaunchKernelGGL(dp_step_big, dim3((uint32_t)n_big), dim3(64 * DP_MW_WAVES), 0, ctx->stream2, nseq,
+                               ctx->dp_list.as<int64_t>(), ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(),
+                               ctx->dp_prof_cnt.as<uint32_t>(), ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
+                               ctx->dp_prof2_mask.as<uint32_t>(), ctx->dp_tb.as<uint8_t>(), d_tb_off, ctx->dp_rows.as<int32_t>(),
+                               d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+        }
+        if (n_small)
+            hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, nseq, ctx->dp_list.as<int64_t>(), n_iv, (int)n_big,
+                               ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
+                               ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
+                               ctx->dp_prof2_mask.as<uint32_t>(), ctx->dp_tb.as<uint8_t>(), d_tb_off, ctx->dp_rows.as<int32_t>(),
+                               d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
+        if (n_big) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     HIPCHK(ctx, hipGetLastError());
     std::vector<DpMeta> hm(n_iv);
@@ -350,7 +546,8 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     if (cells) *cells = cl;
     if (tc) {
         HIPCHK(ctx, hipMemcpyAsync(d_col_off, col_off, (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(dp_gather, dim3(blocks), dim3(256), 0, ctx->stream, nseq, n_iv, d_seq_off, ctx->dp_meta.as<DpMeta>(),
+        const uint32_t gblocks = (uint32_t)std::min<int64_t>((n_iv + 3) / 4, 256 * 8);
+        hipLaunchKernelGGL(dp_gather, dim3(gblocks), dim3(256), 0, ctx->stream, nseq, n_iv, d_seq_off, ctx->dp_meta.as<DpMeta>(),
                            ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_mask.as<uint32_t>(), d_col_off,
                            ctx->dp_cols.as<uint32_t>());
         HIPCHK(ctx, hipGetLastError());

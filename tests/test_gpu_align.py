@@ -88,6 +88,29 @@ def test_dp_long_interval(ctx):
     _check_dp(ctx, [_rand_interval(rng, 3, 1500, 0.25, 0.0), _rand_interval(rng, 3, 700, 0.1, 0.0)])
 
 
+def test_dp_workgroup_pipeline(ctx):
+    """Tail intervals run as a 16-wave stripe pipeline (dp_step_big); same bytes as the one-wave path and the
+    oracle.  Shapes around the pipeline's edges: fewer stripes than waves, more stripes than waves, n just above
+    the 256-column threshold (waves wait for their predecessor to finish), a short last stripe, and big + small
+    intervals in one launch (both kernels run side by side)."""
+    rng = np.random.default_rng(7)
+    def pair(m, n, related=True):
+        a = rng.integers(0, 4, m, dtype=np.uint8)
+        if related and n <= m:
+            b = synth.mutate(a, 0.15, rng, indel_frac=0.3)[:n]
+            if len(b) < n:
+                b = np.concatenate([b, rng.integers(0, 4, n - len(b), dtype=np.uint8)])
+        else:
+            b = rng.integers(0, 4, n, dtype=np.uint8)
+        return [a, b]
+    ivs = [pair(2500, 2300), pair(129, 256), pair(1100, 257), pair(300, 4000, related=False), pair(64 * 17 + 1, 700),
+           pair(64 * 40, 300), pair(4000, 4000, related=False)]
+    ivs += [_rand_interval(rng, 2, int(rng.integers(1, 60)), 0.1, 0.0) for _ in range(200)]
+    _check_dp(ctx, ivs)
+    # three sequences: the second step's profile is the merged first two
+    _check_dp(ctx, [_rand_interval(rng, 3, 1200, 0.2, 0.0)] + [_rand_interval(rng, 3, 30, 0.1, 0.0) for _ in range(50)])
+
+
 def _same_align(ctx, gs, **kw):
     from mauvealigner_amd import _lib
     ctx.set_genomes(gs)
