@@ -46,186 +46,272 @@ void MatchVec::sort_by_start0()
     d.swap(nd);
 }
 
-void host_eliminate_overlaps(MatchVec &m)
+namespace {
+// one alive match as genome g sees it; kept sorted by left end, so the overlap scan is a sequential sweep
+struct Ent { uint32_t left, len, idx, flag; };     // flag: 1 = forward in g, 0 = reverse, 2 = died this pass
+
+// stable LSD radix sort by left end (3 x 11 bits); returns at once when the order already holds
+void sort_ents(std::vector<Ent> &e, std::vector<Ent> &tmp, bool nearly_sorted)
+{
+    const size_t n = e.size();
+    if (n < 2) return;
+    // Nearly sorted input (a pass of crops moves a few entries a few places) is repaired by a stable insertion
+    // sort on a shift budget; whatever is left when the budget runs out goes through the radix passes, which are
+    // stable on top of the partly repaired order.
+    size_t budget = nearly_sorted ? 4 * n : 0, i = 1;
+    for (; i < n; i++) {
+        if (e[i - 1].left <= e[i].left) continue;
+        const Ent x = e[i];
+        size_t j = i;
+        while (j > 0 && e[j - 1].left > x.left && budget) { e[j] = e[j - 1]; j--; budget--; }
+        e[j] = x;
+        if (!budget && j > 0 && e[j - 1].left > x.left) break;
+    }
+    if (i >= n) return;
+    tmp.resize(n);
+    Ent *src = e.data(), *dst = tmp.data();
+    for (int pass = 0; pass < 3; pass++) {
+        const int sh = 11 * pass;
+        uint32_t cnt[2049] = {0};
+        for (size_t i = 0; i < n; i++) cnt[((src[i].left >> sh) & 2047) + 1]++;
+        for (int b = 0; b < 2048; b++) cnt[b + 1] += cnt[b];
+        for (size_t i = 0; i < n; i++) dst[cnt[(src[i].left >> sh) & 2047]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != e.data()) std::copy(src, src + n, e.data());
+}
+
+// buffers kept per thread across calls: fresh multi-hundred-KB vectors cost page faults on every call
+struct ElimScratch {
+    std::vector<uint8_t> alive;
+    std::vector<Ent> ents, tmp;
+    std::vector<uint32_t> cf, cl, touched, newidx;
+    std::vector<std::vector<uint32_t>> ordg;
+};
+}  // namespace
+
+// EliminateOverlaps.  Per genome: sweep the matches in left-end order; of two overlapping
+// neighbours the shorter one gives up the overlap (ties: the right one), crops are collected per pass and
+// applied together, and the sweep repeats until the genome is overlap free.  `orders` (optional) receives
+// the per-genome order of the survivors -- the (left end, index) order host_lcb_chain needs: once a genome
+// is overlap free, later crops and deaths cannot reorder it.
+void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders)
 {
     const int N = m.N;
     const size_t n = m.size();
-    if (n < 2) return;
-    std::vector<uint8_t> alive(n, 1);
-    std::vector<uint64_t> key, key2, tmp; key.reserve(n); key2.reserve(n);
-    std::vector<int64_t> cf(n, 0), cl(n, 0), lenv(n), leftv(n);
-    std::vector<int8_t> fwd(n);
-    std::vector<uint32_t> touched;
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    const double te0 = trace ? now_ms() : 0;
+    static thread_local ElimScratch S;
+    if (orders) orders->ord.assign((size_t)N, std::vector<uint32_t>());
+    if (n < 2) {
+        if (orders) for (int g = 0; g < N; g++) orders->ord[(size_t)g].assign(n, 0u);
+        return;
+    }
+    S.alive.assign(n, 1);
+    if (S.cf.size() < n) { S.cf.assign(n, 0); S.cl.assign(n, 0); }     // all-zero between passes
+    S.ordg.resize((size_t)N);
+    std::vector<Ent> &ents = S.ents;
     for (int g = 0; g < N; g++) {
-        // order of the alive matches in genome g; later passes keep it (crops and deletions rarely disturb it,
-        // sort_by_left re-sorts only when they do)
-        key.clear();
+        ents.clear();
         for (size_t i = 0; i < n; i++) {
-            if (!alive[i]) continue;
-            leftv[i] = std::llabs(m.st(i)[g]); lenv[i] = m.len(i); fwd[i] = m.st(i)[g] > 0;
-            key.push_back(((uint64_t)leftv[i] << 32) | (uint64_t)i);
+            if (!S.alive[i]) continue;
+            const int64_t s = m.st(i)[g];
+            ents.push_back({(uint32_t)std::llabs(s), (uint32_t)m.len(i), (uint32_t)i, s > 0 ? 1u : 0u});
         }
         for (int pass = 0;; pass++) {
             const double tp0 = trace ? now_ms() : 0;
-            sort_by_left(key, tmp);
-            touched.clear();
-            for (size_t r = 0; r + 1 < key.size(); r++) {
-                const uint32_t A = (uint32_t)key[r], B = (uint32_t)key[r + 1];
-                const int64_t ov = leftv[A] + lenv[A] - leftv[B];
+            sort_ents(ents, S.tmp, pass > 0);
+            S.touched.clear();
+            const size_t k = ents.size();
+            for (size_t r = 0; r + 1 < k; r++) {
+                const Ent &A = ents[r], &B = ents[r + 1];
+                const int64_t ov = (int64_t)A.left + A.len - B.left;
                 if (ov <= 0) continue;
-                if (lenv[A] < lenv[B]) {              // A gives up its right side in g
-                    if (!cf[A] && !cl[A]) touched.push_back(A);
-                    int64_t &c = fwd[A] ? cl[A] : cf[A];
-                    c = std::max(c, ov);
+                if (A.len < B.len) {                  // A gives up its right side in g
+                    if (!S.cf[r] && !S.cl[r]) S.touched.push_back((uint32_t)r);
+                    uint32_t &c = A.flag ? S.cl[r] : S.cf[r];
+                    c = std::max(c, (uint32_t)ov);
                 } else {                               // B gives up its left side in g
-                    if (!cf[B] && !cl[B]) touched.push_back(B);
-                    int64_t &c = fwd[B] ? cf[B] : cl[B];
-                    c = std::max(c, ov);
+                    if (!S.cf[r + 1] && !S.cl[r + 1]) S.touched.push_back((uint32_t)(r + 1));
+                    uint32_t &c = B.flag ? S.cf[r + 1] : S.cl[r + 1];
+                    c = std::max(c, (uint32_t)ov);
                 }
             }
-            if (trace) fprintf(stderr, "[trace] eliminate g=%d pass=%d n=%zu overlaps=%zu %.3f ms\n", g, pass, key.size(), touched.size(), now_ms() - tp0);
-            if (touched.empty()) break;
+            if (trace) fprintf(stderr, "[trace] eliminate g=%d pass=%d n=%zu overlaps=%zu %.3f ms\n", g, pass, k, S.touched.size(), now_ms() - tp0);
+            if (S.touched.empty()) break;
             bool died = false;
-            for (uint32_t i : touched) {
-                const int64_t nl = m.len(i) - cf[i] - cl[i];
-                if (nl <= 0) { alive[i] = 0; died = true; }
+            for (uint32_t r : S.touched) {
+                Ent &e = ents[r];
+                const size_t i = e.idx;
+                const int64_t cf = S.cf[r], cl = S.cl[r];
+                const int64_t nl = m.len(i) - cf - cl;
+                if (nl <= 0) { S.alive[i] = 0; e.flag = 2; died = true; }
                 else {
                     for (int c = 0; c < N; c++) {
-                        if (m.st(i)[c] > 0) m.st(i)[c] += cf[i];
-                        else m.st(i)[c] -= cl[i];
+                        if (m.st(i)[c] > 0) m.st(i)[c] += cf;
+                        else m.st(i)[c] -= cl;
                     }
                     m.len(i) = nl;
-                    leftv[i] = std::llabs(m.st(i)[g]); lenv[i] = nl;
+                    e.left = (uint32_t)std::llabs(m.st(i)[g]); e.len = (uint32_t)nl;
                 }
-                cf[i] = 0; cl[i] = 0;
+                S.cf[r] = 0; S.cl[r] = 0;
             }
-            // refresh the keys of the touched matches in place, drop the dead ones
             if (died) {
-                key2.clear();
-                for (uint64_t kk : key) { const uint32_t i = (uint32_t)kk; if (alive[i]) key2.push_back(((uint64_t)leftv[i] << 32) | i); }
-                key.swap(key2);
-            } else {
-                for (uint64_t &kk : key) { const uint32_t i = (uint32_t)kk; kk = ((uint64_t)leftv[i] << 32) | i; }
+                size_t w = 0;
+                for (size_t r = 0; r < k; r++) if (ents[r].flag != 2) ents[w++] = ents[r];
+                ents.resize(w);
             }
         }
+        std::vector<uint32_t> &og = S.ordg[(size_t)g];
+        og.resize(ents.size());
+        for (size_t r = 0; r < ents.size(); r++) og[r] = ents[r].idx;
     }
+    const double te1 = trace ? now_ms() : 0;
+    S.newidx.resize(n);
     size_t k = 0;
-    for (size_t i = 0; i < n; i++) if (alive[i]) m.move(k++, i);
+    for (size_t i = 0; i < n; i++) if (S.alive[i]) { S.newidx[i] = (uint32_t)k; m.move(k++, i); }
     m.resize(k);
+    if (orders) {
+        for (int g = 0; g < N; g++) {
+            std::vector<uint32_t> &o = orders->ord[(size_t)g];
+            o.clear(); o.reserve(k);
+            for (uint32_t i : S.ordg[(size_t)g]) if (S.alive[i]) o.push_back(S.newidx[i]);
+        }
+    }
+    if (trace) fprintf(stderr, "[trace] eliminate compaction %.3f ms, total %.3f\n", now_ms() - te1, now_ms() - te0);
 }
 
-namespace {
-struct Node {
-    int64_t weight = 0;
-    std::vector<int32_t> prev, next;    // per genome
-    bool alive = true;
-    int32_t merged_into = -1;
-};
-}
-
-void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb)
+// Greedy breakpoint elimination over the compact LCB graph.  `orders` (optional): the
+// per-genome (left end, index) order of m as produced by host_eliminate_overlaps; sorted here otherwise.
+void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb,
+                    const ChainOrders *orders)
 {
     const int N = m.N;
     const size_t n = m.size();
     match_lcb.assign(n, -1);
     n_lcb = 0;
     if (n == 0) return;
-    // per-genome order of the matches
-    std::vector<std::vector<uint32_t>> order(N, std::vector<uint32_t>(n)), rank(N, std::vector<uint32_t>(n));
-    {
-        for (int g = 0; g < N; g++) {
-            std::vector<uint64_t> key(n), tmp;
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    const double tl0 = trace ? now_ms() : 0;
+    // per-genome order of the matches and its inverse
+    static thread_local std::vector<uint32_t> order_s, rank_s;
+    static thread_local std::vector<uint64_t> key, tmp;
+    order_s.resize((size_t)N * n); rank_s.resize((size_t)N * n);
+    uint32_t *order = order_s.data(), *rank = rank_s.data();
+    const bool given = orders && (int)orders->ord.size() == N && orders->ord[0].size() == n;
+    for (int g = 0; g < N; g++) {
+        uint32_t *og = order + (size_t)g * n, *rg = rank + (size_t)g * n;
+        if (given) std::copy(orders->ord[(size_t)g].begin(), orders->ord[(size_t)g].end(), og);
+        else {
+            key.resize(n);
             for (size_t i = 0; i < n; i++) key[i] = ((uint64_t)std::llabs(m.st(i)[g]) << 32) | (uint64_t)i;
             sort_by_left(key, tmp);
-            for (uint32_t r = 0; r < n; r++) { order[g][r] = (uint32_t)key[r]; rank[g][order[g][r]] = r; }
+            for (size_t r = 0; r < n; r++) og[r] = (uint32_t)key[r];
         }
+        for (uint32_t r = 0; r < n; r++) rg[og[r]] = r;
     }
+    const double tl1 = trace ? now_ms() : 0;
     // initial nodes: maximal collinear runs in genome-0 order
-    std::vector<int32_t> node_of(n);
-    std::vector<Node> nodes;
+    static thread_local std::vector<int32_t> node_of;
+    node_of.resize(n);
+    std::vector<int64_t> weight;
     std::vector<uint32_t> node_first;     // first match (genome-0 order) of each node
     for (uint32_t k = 0; k < n; k++) {
-        uint32_t i = order[0][k];
+        const uint32_t i = order[k];
         bool join = k > 0;
         if (join) {
-            uint32_t p = order[0][k - 1];
+            const uint32_t p = order[k - 1];
             for (int g = 1; g < N && join; g++) {
-                bool oi = m.st(i)[g] < 0, op = m.st(p)[g] < 0;
+                const uint32_t *rg = rank + (size_t)g * n;
+                const bool oi = m.st(i)[g] < 0, op = m.st(p)[g] < 0;
                 if (oi != op) join = false;
-                else if (!oi) join = rank[g][i] == rank[g][p] + 1;
-                else join = rank[g][i] + 1 == rank[g][p];
+                else if (!oi) join = rg[i] == rg[p] + 1;
+                else join = rg[i] + 1 == rg[p];
             }
         }
-        if (!join) { nodes.emplace_back(); nodes.back().prev.assign(N, -1); nodes.back().next.assign(N, -1); node_first.push_back(i); }
-        node_of[i] = (int32_t)nodes.size() - 1;
-        nodes.back().weight += m.len(i) * N;
+        if (!join) { weight.push_back(0); node_first.push_back(i); }
+        node_of[i] = (int32_t)weight.size() - 1;
+        weight.back() += m.len(i) * N;
     }
-    const int32_t K = (int32_t)nodes.size();
-    // per-genome linked lists of nodes
+    const int32_t K = (int32_t)weight.size();
+    // per-genome doubly linked lists of nodes, flat [K][N]
+    std::vector<int32_t> prevv((size_t)K * N, -1), nextv((size_t)K * N, -1), merged_into((size_t)K, -1);
+    std::vector<uint8_t> alive((size_t)K, 1);
+    auto PREV = [&](int32_t x, int g) -> int32_t & { return prevv[(size_t)x * N + g]; };
+    auto NEXT = [&](int32_t x, int g) -> int32_t & { return nextv[(size_t)x * N + g]; };
     for (int g = 0; g < N; g++) {
+        const uint32_t *og = order + (size_t)g * n;
         int32_t last = -1;
         for (uint32_t r = 0; r < n; r++) {
-            int32_t nd = node_of[order[g][r]];
+            const int32_t nd = node_of[og[r]];
             if (nd == last) continue;
             // a node's matches are contiguous in every genome, so each node shows up exactly once here
-            nodes[nd].prev[g] = last;
-            if (last >= 0) nodes[last].next[g] = nd;
+            PREV(nd, g) = last;
+            if (last >= 0) NEXT(last, g) = nd;
             last = nd;
         }
     }
-    auto orient = [&](int32_t nd, int g) { return m.st(node_first[nd])[g] < 0; };
+    auto orient = [&](int32_t nd, int g) { return m.st(node_first[(size_t)nd])[g] < 0; };
     auto mergeable = [&](int32_t a, int32_t b) {   // b == next_0(a)
         for (int g = 1; g < N; g++) {
-            bool oa = orient(a, g);
+            const bool oa = orient(a, g);
             if (oa != orient(b, g)) return false;
-            if (!oa ? nodes[a].next[g] != b : nodes[a].prev[g] != b) return false;
+            if (!oa ? NEXT(a, g) != b : PREV(a, g) != b) return false;
         }
         return true;
     };
     auto unlink = [&](int32_t x, int g) {
-        int32_t p = nodes[x].prev[g], q = nodes[x].next[g];
-        if (p >= 0) nodes[p].next[g] = q;
-        if (q >= 0) nodes[q].prev[g] = p;
+        const int32_t p = PREV(x, g), q = NEXT(x, g);
+        if (p >= 0) NEXT(p, g) = q;
+        if (q >= 0) PREV(q, g) = p;
     };
+    const double tl2 = trace ? now_ms() : 0;
     std::set<std::pair<int64_t, int32_t>> heap;    // (weight, genome-0 order index): node ids are in that order
-    for (int32_t i = 0; i < K; i++) heap.insert({nodes[i].weight, i});
+    for (int32_t i = 0; i < K; i++) heap.insert({weight[(size_t)i], i});
     int32_t alive_cnt = K;
+    std::vector<std::pair<int32_t, int32_t>> cand;
     while (!heap.empty()) {
         auto it = heap.begin();
         if (collinear ? alive_cnt <= 1 : it->first >= min_weight) break;
-        int32_t x = it->second;
+        const int32_t x = it->second;
         heap.erase(it);
         // neighbours that may become mergeable once x is gone
-        std::vector<std::pair<int32_t, int32_t>> cand;
-        for (int g = 0; g < N; g++) cand.push_back({nodes[x].prev[g], nodes[x].next[g]});
+        cand.clear();
+        for (int g = 0; g < N; g++) cand.push_back({PREV(x, g), NEXT(x, g)});
         for (int g = 0; g < N; g++) unlink(x, g);
-        nodes[x].alive = false; alive_cnt--;
+        alive[(size_t)x] = 0; alive_cnt--;
         for (auto pr : cand) {
             int32_t a = pr.first, b = pr.second;
-            auto resolve = [&](int32_t v) { while (v >= 0 && !nodes[v].alive && nodes[v].merged_into >= 0) v = nodes[v].merged_into; return v; };
+            auto resolve = [&](int32_t v) { while (v >= 0 && !alive[(size_t)v] && merged_into[(size_t)v] >= 0) v = merged_into[(size_t)v]; return v; };
             a = resolve(a); b = resolve(b);
-            if (a < 0 || b < 0 || a == b || !nodes[a].alive || !nodes[b].alive) continue;
-            if (nodes[b].next[0] == a) std::swap(a, b);
-            if (nodes[a].next[0] != b) continue;
+            if (a < 0 || b < 0 || a == b || !alive[(size_t)a] || !alive[(size_t)b]) continue;
+            if (NEXT(b, 0) == a) std::swap(a, b);
+            if (NEXT(a, 0) != b) continue;
             if (!mergeable(a, b)) continue;
-            heap.erase({nodes[a].weight, a}); heap.erase({nodes[b].weight, b});
-            nodes[a].weight += nodes[b].weight;
+            heap.erase({weight[(size_t)a], a}); heap.erase({weight[(size_t)b], b});
+            weight[(size_t)a] += weight[(size_t)b];
             for (int g = 0; g < N; g++) unlink(b, g);
-            nodes[b].alive = false; nodes[b].merged_into = a; alive_cnt--;
-            heap.insert({nodes[a].weight, a});
+            alive[(size_t)b] = 0; merged_into[(size_t)b] = a; alive_cnt--;
+            heap.insert({weight[(size_t)a], a});
         }
     }
+    const double tl3 = trace ? now_ms() : 0;
     // final ids in genome-0 order
-    std::vector<int64_t> final_id(K, -1);
+    std::vector<int64_t> final_id((size_t)K, -1);
     int64_t id = 0;
-    for (int32_t i = 0; i < K; i++) if (nodes[i].alive) final_id[i] = id++;
-    n_lcb = id;
-    for (size_t i = 0; i < n; i++) {
-        int32_t v = node_of[i];
-        while (!nodes[v].alive && nodes[v].merged_into >= 0) v = nodes[v].merged_into;
-        match_lcb[i] = nodes[v].alive ? final_id[v] : -1;
+    for (int32_t i = 0; i < K; i++) {
+        if (alive[(size_t)i]) final_id[(size_t)i] = id++;
     }
+    n_lcb = id;
+    // a dead node resolves through its merge chain; memoised per node, matches just look their node up
+    for (int32_t i = 0; i < K; i++) {
+        if (alive[(size_t)i]) continue;
+        int32_t v = i;
+        while (!alive[(size_t)v] && merged_into[(size_t)v] >= 0) v = merged_into[(size_t)v];
+        final_id[(size_t)i] = alive[(size_t)v] ? final_id[(size_t)v] : -1;
+    }
+    for (size_t i = 0; i < n; i++) match_lcb[i] = final_id[(size_t)node_of[i]];
+    if (trace) fprintf(stderr, "[trace] lcb: orders %.3f ms, nodes+lists %.3f (K=%d), greedy %.3f, labels %.3f\n", tl1 - tl0, tl2 - tl1, K, tl3 - tl2, now_ms() - tl3);
 }
 
 extern "C" {

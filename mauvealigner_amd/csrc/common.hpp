@@ -81,6 +81,8 @@ struct AlignResult {
     std::vector<int64_t> col_off;
     std::vector<uint32_t> cols;        // capacity buffer: the first n_cols entries are the result (see pipeline.cpp)
     size_t n_cols = 0;
+    uint32_t cols_fill = 0;            // value every word outside cols_dirty holds (0 = no such invariant)
+    std::vector<std::pair<size_t, size_t>> cols_dirty;   // (offset, length) ranges holding gap columns
     std::vector<int64_t> dp_score;
 };
 
@@ -191,8 +193,10 @@ int seedpass_sorted_list(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t 
                          std::vector<uint32_t> *vals, int *weight);
 
 // host chaining (chain_host.cpp)
-void host_eliminate_overlaps(MatchVec &m);
-void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb);
+struct ChainOrders { std::vector<std::vector<uint32_t>> ord; };   // per genome: match indices in left-end order
+void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders = nullptr);
+void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb,
+                    const ChainOrders *orders = nullptr);
 
 // DP (dp_batch.hip)
 int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *sc,

@@ -72,11 +72,12 @@ static int align_begin(mauve_ctx *c, const mauve_params *p)
         m.len((size_t)i) = c->match_len[(size_t)i];
         std::copy(&c->match_start[(size_t)i * N], &c->match_start[(size_t)i * N] + N, m.st((size_t)i));
     }
-    host_eliminate_overlaps(m);
+    ChainOrders orders;
+    host_eliminate_overlaps(m, &orders);
     const double t1b = now_ms();
     const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight : (int64_t)3 * w * N;
     std::vector<int64_t> match_lcb; int64_t nl = 0;
-    host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl);
+    host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl, &orders);
     S.nl = nl;
     std::vector<MatchVec> &chains = S.chains;
     chains.assign((size_t)nl, MatchVec(N));
@@ -194,9 +195,20 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
             }
         }
     }
-    // the column array is a capacity buffer kept across calls (no zero fill of 20 MB per call)
+    const double ta1 = now_ms();
+    // The column array is a capacity buffer kept across calls in the "all anchors" state: every word outside the
+    // ranges the previous call wrote gap columns into equals `full`.  Anchors are >80 % of the columns, so a call
+    // restores the previous gap ranges and writes its own instead of filling tens of MB.
     const size_t need = (size_t)col + (size_t)(p->add_unaligned ? S.sum : 0);
-    if (R.cols.size() < need) R.cols.resize(need);
+    if (R.cols.size() < need || R.cols_fill != full) {
+        if (R.cols.size() < need) R.cols.resize(need);
+        std::fill(R.cols.begin(), R.cols.end(), full);
+        R.cols_fill = full; R.cols_dirty.clear();
+    } else {
+        for (const auto &d : R.cols_dirty) std::fill(R.cols.begin() + d.first, R.cols.begin() + d.first + d.second, full);
+        R.cols_dirty.clear();
+    }
+    const double ta2 = now_ms();
     R.anchor_length.resize((size_t)S.n_anchor); R.anchor_start.resize((size_t)S.n_anchor * N); R.anchor_lcb.resize((size_t)S.n_anchor);
     // pass 2: every anchor writes its own columns and the stretch that follows it (independent writes; a thread
     // pool did not pay here: waking it costs more than the 0.7 ms of fills)
@@ -208,11 +220,11 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
             const int64_t alen = ch.len(it.idx); const int64_t *ast = ch.st(it.idx);
             R.anchor_length[(size_t)a] = alen; R.anchor_lcb[(size_t)a] = it.lcb;
             std::copy(ast, ast + N, &R.anchor_start[(size_t)a * N]);
-            uint32_t *o = out + it.col0;
-            std::fill(o, o + alen, full);
-            o += alen;
+            uint32_t *o = out + it.col0 + alen;            // the anchor's own columns already hold `full`
             if (it.gap >= 0) {
                 const AlignState::GapRef &gr = S.gaps[(size_t)it.gap];
+                const size_t glen = (size_t)(gr.dp ? dcol_off[(size_t)gr.dp_slot + 1] - dcol_off[(size_t)gr.dp_slot] : gr.tot);
+                if (glen) R.cols_dirty.push_back({(size_t)(o - out), glen});
                 if (gr.dp) std::copy(dcols + dcol_off[(size_t)gr.dp_slot], dcols + dcol_off[(size_t)gr.dp_slot + 1], o);
                 else for (int g = 0; g < N; g++) {
                     int64_t lo, ln; bool rv;
@@ -222,6 +234,7 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
             }
         }
     }
+    const double ta3 = now_ms();
     size_t ncols = (size_t)col;
     int64_t niv = nl;
     R.iv_left.assign((size_t)nl * N, 0); R.iv_right.assign((size_t)nl * N, 0); R.iv_reverse.assign((size_t)nl * N, 0);
@@ -241,6 +254,7 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
                 if (hi >= lo) {
                     R.col_off.push_back((int64_t)ncols);
                     std::fill(R.cols.begin() + ncols, R.cols.begin() + ncols + (size_t)(hi - lo + 1), 1u << g);
+                    R.cols_dirty.push_back({ncols, (size_t)(hi - lo + 1)});
                     ncols += (size_t)(hi - lo + 1);
                     for (int h = 0; h < N; h++) { R.iv_left.push_back(h == g ? lo : 0); R.iv_right.push_back(h == g ? hi : 0); R.iv_reverse.push_back(0); }
                     R.dp_score.push_back(0);
@@ -256,6 +270,7 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
     R.sz.n_gap_dp = n_dp; R.sz.n_dp_cells = cells;
     *sizes = R.sz;
     const double t5 = now_ms();
+    if (getenv("MAUVE_TRACE")) fprintf(stderr, "[trace] assemble: layout %.3f ms, restore %.3f, anchors+gaps %.3f, unaligned+sizes %.3f\n", ta1 - t4, ta2 - ta1, ta3 - ta2, t5 - ta3);
     c->stage.assemble_ms = t5 - t4;
     c->stage.total_ms = t5 - S.t0;
     S.open = false;

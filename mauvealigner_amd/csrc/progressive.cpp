@@ -134,10 +134,11 @@ int prog_node(Prog &P, int node)
         m.len((size_t)i) = c->match_len[(size_t)i];
         std::copy(&c->match_start[(size_t)i * n], &c->match_start[(size_t)i * n] + n, m.st((size_t)i));
     }
-    host_eliminate_overlaps(m);
+    ChainOrders orders;
+    host_eliminate_overlaps(m, &orders);
     const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight * n / P.N : (int64_t)3 * w * n;
     std::vector<int64_t> match_lcb; int64_t nl = 0;
-    host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl);
+    host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl, &orders);
     // chains, cut wherever the stretch between two consecutive anchors touches an already placed base
     std::vector<MatchVec> pieces; int64_t cur_lcb = -1;
     for (size_t i = 0; i < m.size(); i++) {
@@ -308,6 +309,7 @@ int mauve_progressive_align(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     R.mum_length.clear(); R.mum_start.clear(); R.lcb_left.clear(); R.lcb_right.clear(); R.lcb_weight.clear();
     R.anchor_length.clear(); R.anchor_start.clear(); R.anchor_lcb.clear(); R.iv_left.clear(); R.iv_right.clear();
     R.iv_reverse.clear(); R.col_off.clear(); R.cols.clear(); R.dp_score.clear();
+    R.cols_fill = 0; R.cols_dirty.clear();           // mauve_align's prefilled-buffer invariant no longer holds
     P.R = &R;
     P.rest.assign((size_t)N, IvList());
     for (int g = 0; g < N; g++) P.rest[(size_t)g].push(1, c->lens[g]);

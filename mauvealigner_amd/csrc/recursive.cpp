@@ -143,9 +143,10 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                     i++;
                 }
                 if (loc.empty()) continue;
-                host_eliminate_overlaps(loc);
+                ChainOrders orders;
+                host_eliminate_overlaps(loc, &orders);
                 std::vector<int64_t> ml; int64_t nl = 0;
-                host_lcb_chain(loc, 0, true, ml, nl);
+                host_lcb_chain(loc, 0, true, ml, nl, &orders);
                 const size_t wi = ids[k];
                 const int64_t *A = work.a(wi);
                 MatchVec glob(N);
