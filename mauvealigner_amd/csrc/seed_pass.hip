@@ -225,11 +225,24 @@ __global__ void __launch_bounds__(RS_THREADS) rs_hist(const KeyT *__restrict__ k
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t base = blockIdx.x * RS_TILE;
+    const uint32_t base = blockIdx.x * RS_TILE;
+    if (base + RS_TILE <= n) {
+        // full tile: 16-byte loads, no predication (the order inside a tile does not matter for a histogram)
+        constexpr int KPV = 16 / (int)sizeof(KeyT);
+        struct alignas(16) Vec { KeyT k[KPV]; };
+        const Vec *src = reinterpret_cast<const Vec *>(keys + base);
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS; i++) {
-        uint32_t idx = base + i * RS_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & 255u], 1u);
+        for (int i = 0; i < RS_ITEMS / KPV; i++) {
+            const Vec q = src[i * RS_THREADS + threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < KPV; j++) atomicAdd(&h[(uint32_t)(q.k[j] >> shift) & 255u], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < RS_ITEMS; i++) {
+            const uint32_t idx = base + i * RS_THREADS + threadIdx.x;
+            if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & 255u], 1u);
+        }
     }
     __syncthreads();
     hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
@@ -251,63 +264,48 @@ __global__ void __launch_bounds__(256) rs_rowscan(uint32_t *__restrict__ hist, u
     if (threadIdx.x == 255) totals[blockIdx.x] = total;
 }
 
-template <typename KeyT>
-__global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict__ keys_in,
-                                                         const uint32_t *__restrict__ vals_in,
-                                                         KeyT *__restrict__ keys_out,
-                                                         uint32_t *__restrict__ vals_out, uint32_t n, int shift,
-                                                         const uint32_t *__restrict__ hist,
-                                                         const uint32_t *__restrict__ totals, uint32_t nblk)
+// One tile of the scatter.  FULL: the tile holds RS_TILE keys, so no lane is ever predicated off (all tiles but the
+// last) -- the loads, ballots and stores compile without exec-mask branches.
+template <typename KeyT, bool FULL>
+__device__ __forceinline__ void rs_scatter_tile(const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                uint32_t tile_base, uint32_t tile_n, int shift, KeyT *s_keys, uint32_t *s_vals,
+                                                uint32_t (*wcount)[256], const uint32_t *gbase, uint32_t *tstart, uint32_t *scan)
 {
-    __shared__ KeyT s_keys[RS_TILE];
-    __shared__ uint32_t s_vals[RS_TILE];
-    __shared__ uint32_t wcount[RS_WAVES][256];
-    __shared__ uint32_t gbase[256];       // global output index of this tile's first key of digit d
-    __shared__ uint32_t tstart[256];      // tile-local start of digit d
-    __shared__ uint32_t scan[256];
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile_base = blockIdx.x * RS_TILE;
-    const uint32_t tile_n = min((uint32_t)RS_TILE, n - tile_base);
-
-    for (int w = 0; w < RS_WAVES; w++) wcount[w][tid] = 0;
-    // digit base = exclusive scan of the digit totals
-    {
-        uint32_t dummy;
-        const uint32_t tot = totals[tid];
-        gbase[tid] = block_excl_scan(tot, &dummy, scan) + hist[(size_t)tid * nblk + blockIdx.x];
-    }
-    __syncthreads();
-
     // load (wave-striped: wave w owns [w*1024, (w+1)*1024), item i of lane l is index i*64+l)
     KeyT k[RS_ITEMS]; uint32_t v[RS_ITEMS]; uint32_t rank[RS_ITEMS];
     const uint32_t wbase = wave * (64 * RS_ITEMS);
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
-        uint32_t li = wbase + i * 64 + lane;
-        bool ok = li < tile_n;
+        const uint32_t li = wbase + i * 64 + lane;
+        const bool ok = FULL || li < tile_n;
         k[i] = ok ? keys_in[tile_base + li] : (KeyT)0;
         v[i] = ok ? vals_in[tile_base + li] : 0u;
     }
-    // wave-level multisplit ranking, stable in (i, lane) order
-    const uint64_t lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+    // wave-level multisplit ranking, stable in (i, lane) order.  peers = lanes of row i with the same digit, built
+    // as two 32-bit halves from eight ballots (one 3-input bit op per half and bit).  The wave owns
+    // wcount[wave][]: every peer reads the running count, then the first peer bumps it -- LDS operations of one
+    // wave stay in order, so no atomic and no broadcast is needed.
+    uint32_t *wc = wcount[wave];
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
-        uint32_t li = wbase + i * 64 + lane;
-        bool ok = li < tile_n;
-        uint32_t d = (uint32_t)(k[i] >> shift) & 255u;
-        uint64_t peers = __ballot(ok);
+        const uint32_t li = wbase + i * 64 + lane;
+        const bool ok = FULL || li < tile_n;
+        const uint32_t d = (uint32_t)(k[i] >> shift) & 255u;
+        uint32_t plo, phi;
+        if (FULL) { plo = 0xffffffffu; phi = 0xffffffffu; }
+        else { const uint64_t a = __ballot(ok); plo = (uint32_t)a; phi = (uint32_t)(a >> 32); }
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            uint64_t m = __ballot(ok && ((d >> b) & 1));
-            peers &= ((d >> b) & 1) ? m : ~m;
+            const uint64_t m = FULL ? __ballot((d >> b) & 1) : __ballot(ok && ((d >> b) & 1));
+            const uint32_t sb = (uint32_t)((int32_t)(d << (31 - b)) >> 31);     // all ones when bit b of d is set
+            plo &= ~((uint32_t)m ^ sb); phi &= ~((uint32_t)(m >> 32) ^ sb);
         }
-        // one atomic per distinct digit (its lowest lane), the old count broadcast to its peers
-        int leader = ok ? (__ffsll((unsigned long long)peers) - 1) : lane;
-        uint32_t old = 0;
-        if (ok && lane == leader) old = atomicAdd(&wcount[wave][d], (uint32_t)__popcll(peers));
-        old = __shfl(old, leader);
-        rank[i] = old + (uint32_t)__popcll(peers & lt);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        const uint32_t old = ok ? wc[d] : 0u;
+        if (ok && below == 0) wc[d] = old + (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
+        rank[i] = old + below;
     }
     __syncthreads();
     // per-digit prefix over the waves, then the tile-level digit starts
@@ -324,10 +322,10 @@ __global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict_
     // stage in LDS at the tile-sorted position
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
-        uint32_t li = wbase + i * 64 + lane;
-        if (li < tile_n) {
-            uint32_t d = (uint32_t)(k[i] >> shift) & 255u;
-            uint32_t pos = tstart[d] + wcount[wave][d] + rank[i];
+        const uint32_t li = wbase + i * 64 + lane;
+        if (FULL || li < tile_n) {
+            const uint32_t d = (uint32_t)(k[i] >> shift) & 255u;
+            const uint32_t pos = tstart[d] + wc[d] + rank[i];
             s_keys[pos] = k[i]; s_vals[pos] = v[i];
         }
     }
@@ -335,14 +333,47 @@ __global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict_
     // coalesced write-out: consecutive threads write consecutive addresses inside a digit's run
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
-        uint32_t pos = i * RS_THREADS + tid;
-        if (pos < tile_n) {
-            KeyT kk = s_keys[pos];
-            uint32_t d = (uint32_t)(kk >> shift) & 255u;
-            uint32_t dst = gbase[d] + (pos - tstart[d]);
+        const uint32_t pos = i * RS_THREADS + tid;
+        if (FULL || pos < tile_n) {
+            const KeyT kk = s_keys[pos];
+            const uint32_t d = (uint32_t)(kk >> shift) & 255u;
+            const uint32_t dst = gbase[d] + (pos - tstart[d]);
             keys_out[dst] = kk; vals_out[dst] = s_vals[pos];
         }
     }
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict__ keys_in,
+                                                         const uint32_t *__restrict__ vals_in,
+                                                         KeyT *__restrict__ keys_out,
+                                                         uint32_t *__restrict__ vals_out, uint32_t n, int shift,
+                                                         const uint32_t *__restrict__ hist,
+                                                         const uint32_t *__restrict__ totals, uint32_t nblk)
+{
+    __shared__ KeyT s_keys[RS_TILE];
+    __shared__ uint32_t s_vals[RS_TILE];
+    __shared__ uint32_t wcount[RS_WAVES][256];
+    __shared__ uint32_t gbase[256];       // global output index of this tile's first key of digit d
+    __shared__ uint32_t tstart[256];      // tile-local start of digit d
+    __shared__ uint32_t scan[256];
+
+    const int tid = threadIdx.x;
+    const uint32_t tile_base = blockIdx.x * RS_TILE;
+    const uint32_t tile_n = min((uint32_t)RS_TILE, n - tile_base);
+
+    for (int w = 0; w < RS_WAVES; w++) wcount[w][tid] = 0;
+    // digit base = exclusive scan of the digit totals
+    {
+        uint32_t dummy;
+        const uint32_t tot = totals[tid];
+        gbase[tid] = block_excl_scan(tot, &dummy, scan) + hist[(size_t)tid * nblk + blockIdx.x];
+    }
+    __syncthreads();
+    if (tile_n == RS_TILE)
+        rs_scatter_tile<KeyT, true>(keys_in, vals_in, keys_out, vals_out, tile_base, tile_n, shift, s_keys, s_vals, wcount, gbase, tstart, scan);
+    else
+        rs_scatter_tile<KeyT, false>(keys_in, vals_in, keys_out, vals_out, tile_base, tile_n, shift, s_keys, s_vals, wcount, gbase, tstart, scan);
 }
 
 // ------------------------------------------------------------------------------------------------
