@@ -381,7 +381,8 @@ __global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict_
 // the hit by the finder's rule and scatters the hit into the dense HIT TABLE, indexed by the global
 // window index of the hit's anchor (lowest genome of its component set):
 //   tmask[p]    = component set (0 = no hit anchored at p)
-//   tpos[g*P+p] = component g's window: global index | strand << 31
+//   tpos[p*N+g] = component g's window: global index | strand << 31   (one record of N words per anchor:
+//                 a hit is written, and later read, as one contiguous record instead of N scattered words)
 //   MODE_MEM    : MemHash -- a genome with more than one copy kills the seed
 //   MODE_UNIQUE : UniqueMatchFinder.cpp:44-58 -- genomes with more than one copy are dropped, >= 2 stay
 // A position carries at most one mer, so at most one hit is anchored at it: no atomics, no compaction.
@@ -417,7 +418,7 @@ __global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, c
         const int g = genome_of(gp, tab);
         if (!(m >> g & 1)) continue;
         if (ap == 0xFFFFFFFFu) { ap = gp; tmask[ap] = m; }
-        tpos[(size_t)g * P + ap] = v;
+        tpos[(size_t)ap * tab.nseq + g] = v;
     }
 }
 
@@ -427,45 +428,44 @@ __global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, c
 // all components are equal there.  Agreeing offsets at most `span` apart chain into a cluster; the match
 // is the cluster through the hit, emitted by its leftmost same-mask hit.
 // ------------------------------------------------------------------------------------------------
-struct HitRec { uint32_t mask; int anchor; uint32_t v[MAUVE_MAX_SEQ]; };
+// One component of the hit a wave is extending: where its windows live, the window index at offset 0, its walking
+// direction relative to the anchor and the window range it may use.  Built once per candidate (LDS, per wave).
+struct ExtComp { const uint64_t *G; const uint64_t *VM; int64_t pos, lo, hi; uint32_t rev, pad; };
 
-template <bool SEG>
-__device__ __forceinline__ bool agree_at(const uint64_t *__restrict__ packed, const GenomeTab &tab,
-                                         const SeedShape &sh, const uint32_t *__restrict__ tpos, uint32_t P,
-                                         uint32_t ap, uint32_t mask, int anchor, int64_t k,
-                                         const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t segid,
-                                         const uint64_t *__restrict__ vmask)
+// Does offset k agree?  Components are handled four at a time: the window loads of a batch are issued together from
+// clamped (always valid) addresses and compared afterwards, so a call costs one memory round trip per batch rather
+// than one per component.  Masked windows are compared in place (XOR under the 2-bit care mask) -- equal care
+// digits <=> equal masked mers; a reverse component is compared with the reverse complement of the anchor window.
+__device__ __forceinline__ bool agree_at(const ExtComp *__restrict__ comp, int nc, const SeedShape &sh, int64_t k)
 {
-    const uint32_t va = tpos[(size_t)anchor * P + ap];
-    int64_t qa = (int64_t)(ap - tab.gpos_off[anchor]) + k;
-    int64_t lo = 0, hi = (int64_t)tab.nwin[anchor] - 1;
-    if (SEG) { const uint32_t *sg = seg + (size_t)anchor * (nseg + 1) + segid; lo = sg[0]; hi = (int64_t)sg[1] - sh.span; }
-    if (qa < lo || qa > hi) return false;
-    if (vmask && window_masked(vmask + tab.mask_off[anchor], (uint32_t)qa, sh.span)) return false;
-    // masked windows are compared in place (XOR under the 2-bit care mask) -- equal care digits <=> equal
-    // masked mers; a reverse component is compared with the reverse complement of the anchor window
-    uint64_t alo, ahi, rlo = 0, rhi = 0;
-    window_at(packed + tab.word_off[anchor], (uint32_t)qa, alo, ahi);
-    bool have_rc = false;
-    const uint32_t sa = va >> 31;
-    bool ok = true;
-    for (int g = anchor + 1; g < tab.nseq; g++) {
-        if (!(mask >> g & 1)) continue;
-        const uint32_t vg = tpos[(size_t)g * P + ap];
-        const uint32_t o = (vg >> 31) ^ sa;
-        const int64_t pg = (int64_t)((vg & 0x7fffffffu) - tab.gpos_off[g]);
-        const int64_t qg = o ? pg - k : pg + k;
-        lo = 0; hi = (int64_t)tab.nwin[g] - 1;
-        if (SEG) { const uint32_t *sg = seg + (size_t)g * (nseg + 1) + segid; lo = sg[0]; hi = (int64_t)sg[1] - sh.span; }
-        if (qg < lo || qg > hi) { ok = false; break; }
-        if (vmask && window_masked(vmask + tab.mask_off[g], (uint32_t)qg, sh.span)) { ok = false; break; }
-        uint64_t clo, chi;
-        window_at(packed + tab.word_off[g], (uint32_t)qg, clo, chi);
-        if (o) {
-            if (!have_rc) { window_revcomp(alo, ahi, sh.span, rlo, rhi); have_rc = true; }
-            if (((clo ^ rlo) & sh.care_lo) | ((chi ^ rhi) & sh.care_hi)) { ok = false; break; }
-        } else {
-            if (((clo ^ alo) & sh.care_lo) | ((chi ^ ahi) & sh.care_hi)) { ok = false; break; }
+    bool ok = true, have_rc = false;
+    uint64_t alo = 0, ahi = 0, rlo = 0, rhi = 0;
+    for (int c0 = 0; c0 < nc; c0 += 4) {
+        uint64_t wl[4], wh[4]; uint32_t rv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            wl[i] = 0; wh[i] = 0; rv[i] = 0;
+            if (c0 + i < nc) {
+                const ExtComp &C = comp[c0 + i];
+                const int64_t q = C.rev ? C.pos - k : C.pos + k;
+                const bool inb = q >= C.lo && q <= C.hi;
+                const uint32_t qq = (uint32_t)(inb ? q : C.lo);
+                ok &= inb;
+                if (C.VM) ok &= !window_masked(C.VM, qq, sh.span);
+                window_at(C.G, qq, wl[i], wh[i]);
+                rv[i] = C.rev;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (c0 + i >= nc) continue;
+            if (c0 + i == 0) { alo = wl[0]; ahi = wh[0]; continue; }     // the anchor
+            if (rv[i]) {
+                if (!have_rc) { window_revcomp(alo, ahi, sh.span, rlo, rhi); have_rc = true; }
+                ok &= (((wl[i] ^ rlo) & sh.care_lo) | ((wh[i] ^ rhi) & sh.care_hi)) == 0;
+            } else {
+                ok &= (((wl[i] ^ alo) & sh.care_lo) | ((wh[i] ^ ahi) & sh.care_hi)) == 0;
+            }
         }
     }
     return ok;
@@ -477,6 +477,23 @@ __device__ __forceinline__ bool agree_at(const uint64_t *__restrict__ packed, co
 // candidate for phase B.  all != 0 (no extension): every hit is a candidate.
 constexpr int RUNS_ITEMS = 16;
 
+// same generalized diagonal: every component of hit p sits d windows after (forward) / before (reverse) the
+// corresponding component of hit q = p - d, with the same relative strands
+__device__ __forceinline__ bool same_diagonal(const uint32_t *__restrict__ rp, const uint32_t *__restrict__ rq, uint32_t m, int a,
+                                              int nseq, uint32_t d)
+{
+    const uint32_t sa = rp[a] >> 31, sq = rq[a] >> 31;
+    for (int g = a + 1; g < nseq; g++) {
+        if (!(m >> g & 1)) continue;
+        const uint32_t vp = rp[g], vq = rq[g];
+        const uint32_t o = (vp >> 31) ^ sa;
+        if (((vq >> 31) ^ sq) != o) return false;
+        const uint32_t pp = vp & 0x7fffffffu, pq = vq & 0x7fffffffu;
+        if (!(o ? (pq == pp + d) : (pq + d == pp))) return false;
+    }
+    return true;
+}
+
 template <bool SEG>
 __global__ void __launch_bounds__(256) mum_runs(GenomeTab tab, int span, const uint32_t *__restrict__ tmask,
                                                 const uint32_t *__restrict__ tpos, uint32_t P, int all,
@@ -487,38 +504,46 @@ __global__ void __launch_bounds__(256) mum_runs(GenomeTab tab, int span, const u
     __shared__ uint32_t s_base;
     // 4096 windows per workgroup: one block scan and ONE global atomic per 4096 windows
     const uint32_t base = blockIdx.x * (256u * RUNS_ITEMS);
+    const int N = tab.nseq;
     uint32_t flags = 0, cnt = 0;
-#pragma unroll 4
+    // Inside a conserved stretch nearly every hit has its predecessor right at p - 1, so that test runs first for
+    // all items as straight-line streaming loads (mask words, then the two records); only the few hits it does
+    // not settle -- cluster starts and hits just after a gap -- walk the offsets 2 .. span.
+    uint32_t mm[RUNS_ITEMS], mq[RUNS_ITEMS];
+#pragma unroll
     for (int it = 0; it < RUNS_ITEMS; it++) {
         const uint32_t p = base + it * 256 + threadIdx.x;
-        if (p >= P) break;
-        const uint32_t m = tmask[p];
+        mm[it] = p < P ? tmask[p] : 0u;
+        mq[it] = (p < P && p > 0) ? tmask[p - 1] : 0u;
+    }
+    uint32_t slow = 0;
+#pragma unroll
+    for (int it = 0; it < RUNS_ITEMS; it++) {
+        const uint32_t m = mm[it];
         if (!m) continue;
+        if (all) { flags |= 1u << it; cnt++; continue; }
+        const uint32_t p = base + it * 256 + threadIdx.x;
+        const int a = __ffs(m) - 1;
+        uint32_t g0 = tab.gpos_off[a];
+        if (SEG) {      // a predecessor only counts inside the same gap segment
+            const uint32_t *sg = seg + (size_t)a * (nseg + 1);
+            g0 += sg[seg_of(sg, nseg, p - g0)];
+        }
+        if (p >= g0 + 1 && mq[it] == m && same_diagonal(tpos + (size_t)p * N, tpos + (size_t)(p - 1) * N, m, a, N, 1u)) continue;
+        slow |= 1u << it;
+    }
+    while (slow) {
+        const int it = __ffs(slow) - 1; slow &= slow - 1;
+        const uint32_t p = base + it * 256 + threadIdx.x, m = mm[it];
+        const int a = __ffs(m) - 1;
+        uint32_t g0 = tab.gpos_off[a];
+        if (SEG) { const uint32_t *sg = seg + (size_t)a * (nseg + 1); g0 += sg[seg_of(sg, nseg, p - g0)]; }
         bool is_cand = true;
-        if (!all) {
-            const int a = __ffs(m) - 1;
-            uint32_t g0 = tab.gpos_off[a];
-            if (SEG) {      // a predecessor only counts inside the same gap segment
-                const uint32_t *sg = seg + (size_t)a * (nseg + 1);
-                g0 += sg[seg_of(sg, nseg, p - g0)];
-            }
-            const uint32_t sa = tpos[(size_t)a * P + p] >> 31;
-            for (int d = 1; d <= span && is_cand; d++) {
-                if (p < g0 + (uint32_t)d) break;
-                const uint32_t q = p - d;
-                if (tmask[q] != m) continue;
-                const uint32_t sq = tpos[(size_t)a * P + q] >> 31;
-                bool same = true;
-                for (int g = a + 1; g < tab.nseq && same; g++) {
-                    if (!(m >> g & 1)) continue;
-                    const uint32_t vp = tpos[(size_t)g * P + p], vq = tpos[(size_t)g * P + q];
-                    const uint32_t o = (vp >> 31) ^ sa;
-                    if (((vq >> 31) ^ sq) != o) { same = false; break; }
-                    const uint32_t pp = vp & 0x7fffffffu, pq = vq & 0x7fffffffu;
-                    same = o ? (pq == pp + (uint32_t)d) : (pq + (uint32_t)d == pp);
-                }
-                if (same) is_cand = false;
-            }
+        for (int d = 2; d <= span && is_cand; d++) {
+            if (p < g0 + (uint32_t)d) break;
+            const uint32_t q = p - d;
+            if (tmask[q] != m) continue;
+            if (same_diagonal(tpos + (size_t)p * N, tpos + (size_t)q * N, m, a, N, (uint32_t)d)) is_cand = false;
         }
         if (is_cand) { flags |= 1u << it; cnt++; }
     }
@@ -543,15 +568,34 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
                                                   const uint32_t *__restrict__ seg, uint32_t nseg,
                                                   const uint64_t *__restrict__ vmask)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ ExtComp s_comp[4][MAUVE_MAX_SEQ];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint64_t spanmask = (sh.span >= 64) ? ~0ULL : ((1ULL << sh.span) - 1ULL);
+    const int N = tab.nseq;
+    ExtComp *comp = s_comp[wv];
     for (uint32_t ci = wave_global; ci < ncand; ci += nwaves) {
         const uint32_t ap = cand[ci];
         const uint32_t mask = tmask[ap];
         const int anchor = __ffs(mask) - 1;
+        const int nc = __popc(mask);
         const uint32_t segid = SEG ? seg_of(seg + (size_t)anchor * (nseg + 1), nseg, ap - tab.gpos_off[anchor]) : 0u;
+        // component table: lane g fills the entry of genome g (entries in ascending genome order, anchor first)
+        const uint32_t sa = tpos[(size_t)ap * N + anchor] >> 31;
+        if (lane < N && (mask >> lane & 1)) {
+            const int g = lane;
+            const uint32_t vg = tpos[(size_t)ap * N + g];
+            ExtComp C;
+            C.G = packed + tab.word_off[g];
+            C.VM = vmask ? vmask + tab.mask_off[g] : nullptr;
+            C.pos = (int64_t)((vg & 0x7fffffffu) - tab.gpos_off[g]);
+            C.rev = (vg >> 31) ^ sa; C.pad = 0;
+            C.lo = 0; C.hi = (int64_t)tab.nwin[g] - 1;
+            if (SEG) { const uint32_t *sg = seg + (size_t)g * (nseg + 1) + segid; C.lo = sg[0]; C.hi = (int64_t)sg[1] - sh.span; }
+            comp[__popc(mask & ((1u << g) - 1u))] = C;
+        }
+        __threadfence_block();          // the table is read by every lane of this wave
         int64_t klo = 0, khi = 0;
         bool leftmost = true;
         if (extend) {
@@ -559,51 +603,57 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
             int64_t cur = 0;
             for (bool done = false; !done;) {
                 const int64_t k = cur - 1 - lane;
-                const bool a = agree_at<SEG>(packed, tab, sh, tpos, P, ap, mask, anchor, k, seg, nseg, segid, vmask);
-                const bool hh = a && (tmask[(int64_t)ap + k] == mask);
+                const int64_t hq = (int64_t)ap + k;
+                const uint32_t hm = (hq >= 0) ? tmask[hq] : 0u;       // issued beside the window loads
+                const bool a = agree_at(comp, nc, sh, k);
+                const bool hh = a && hm == mask;
                 const uint64_t A = __ballot(a), H = __ballot(hh);
                 int p = 0;                      // offsets consumed in this round
                 for (;;) {
                     if (p + sh.span > 64) break;                       // need a fresh round from cur-p
                     const uint64_t x = (A >> p) & spanmask;
                     if (x == 0) { done = true; break; }
-                    p += __ffsll((unsigned long long)x);
-                    if (H >> (p - 1) & 1) { leftmost = false; done = true; break; }
+                    // jump to the next agreeing offset and over the whole run of agreeing offsets behind it
+                    const int b = p + __ffsll((unsigned long long)x) - 1;
+                    const uint64_t y = ~(A >> b);
+                    const int run = y ? __ffsll((unsigned long long)y) - 1 : 64 - b;
+                    const uint64_t visited = (run >= 64 ? ~0ULL : ((1ULL << run) - 1ULL)) << b;
+                    if (H & visited) { leftmost = false; done = true; break; }
+                    p = b + run;
                 }
                 cur -= p;
             }
-            if (!leftmost) { if (lane == 0) mlen[ci] = 0; continue; }
+            if (!leftmost) { if (lane == 0) mlen[ci] = 0; __threadfence_block(); continue; }
             klo = cur;
             // ---- right walk ----
             cur = 0;
             for (bool done = false; !done;) {
                 const int64_t k = cur + 1 + lane;
-                const bool a = agree_at<SEG>(packed, tab, sh, tpos, P, ap, mask, anchor, k, seg, nseg, segid, vmask);
+                const bool a = agree_at(comp, nc, sh, k);
                 const uint64_t A = __ballot(a);
                 int p = 0;
                 for (;;) {
                     if (p + sh.span > 64) break;
                     const uint64_t x = (A >> p) & spanmask;
                     if (x == 0) { done = true; break; }
-                    p += __ffsll((unsigned long long)x);
+                    const int b = p + __ffsll((unsigned long long)x) - 1;
+                    const uint64_t y = ~(A >> b);
+                    p = b + (y ? __ffsll((unsigned long long)y) - 1 : 64 - b);
                 }
                 cur += p;
             }
             khi = cur;
         }
-        if (lane == 0) {
-            mlen[ci] = (int32_t)(khi - klo) + sh.span;
-            const uint32_t sa = tpos[(size_t)anchor * P + ap] >> 31;
-            for (int g = 0; g < tab.nseq; g++) {
-                int32_t s = 0;
-                if (mask >> g & 1) {
-                    const uint32_t vg = tpos[(size_t)g * P + ap];
-                    const int64_t pg = (int64_t)((vg & 0x7fffffffu) - tab.gpos_off[g]);
-                    s = ((vg >> 31) ^ sa) ? (int32_t)(-(pg - khi + 1)) : (int32_t)(pg + klo + 1);
-                }
-                mstart[(size_t)ci * tab.nseq + g] = s;
+        if (lane == 0) mlen[ci] = (int32_t)(khi - klo) + sh.span;
+        if (lane < N) {
+            int32_t st = 0;
+            if (mask >> lane & 1) {
+                const ExtComp &C = comp[__popc(mask & ((1u << lane) - 1u))];
+                st = C.rev ? (int32_t)(-(C.pos - khi + 1)) : (int32_t)(C.pos + klo + 1);
             }
+            mstart[(size_t)ci * N + lane] = st;
         }
+        __threadfence_block();          // the next candidate overwrites the table
     }
 }
 
@@ -776,6 +826,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t nc = hc[1];
         TRACE(ctx, "runs");
+        if (g_trace) fprintf(stderr, "[trace]   %u candidates of %u windows\n", nc, P);
         if (nc == 0) continue;
         // extension phase B
         HIPCHK(ctx, ctx->mlen.ensure((size_t)nc * 4 + 4));
