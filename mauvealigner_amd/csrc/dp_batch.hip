@@ -16,6 +16,7 @@
 // bound, not HBM and not MFMA.
 #include "common.hpp"
 #include <algorithm>
+#include <functional>
 #include <cstring>
 #include <cstdlib>
 
@@ -553,6 +554,13 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(cols, ctx->dp_cols.p, (size_t)tc * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (trace) {
+        std::vector<int64_t> e2(est); std::sort(e2.begin(), e2.end(), std::greater<int64_t>());
+        fprintf(stderr, "[trace] dp_core: %lld intervals, %lld on the workgroup path, single-wave steps: total %lld (balanced %lld), top", (long long)n_iv,
+                (long long)n_big, (long long)est_total, (long long)(est_total / 3072));
+        for (size_t i = 0; i < e2.size() && i < 8; i++) fprintf(stderr, " %lld", (long long)e2[i]);
+        fprintf(stderr, "\n");
     }
     if (trace) fprintf(stderr, "[trace] dp_core: sizing+H2D %.3f ms, order+launch %.3f, kernel+meta D2H %.3f, gather+cols D2H %.3f\n",
                        td1 - td0, td2 - td1, td3 - td2, now_ms() - td3);
