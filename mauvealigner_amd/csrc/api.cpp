@@ -42,6 +42,8 @@ int mauve_ctx_create(int device, mauve_ctx **out)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         snprintf(c->devname, sizeof c->devname, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     }
+    c->pool = new (std::nothrow) SpinPool(SpinPool::default_threads());
+    if (!c->pool) { g_create_err = "out of host memory"; mauve_ctx_destroy(c); return MAUVE_ERR_ARG; }
     *out = c;
     return MAUVE_OK;
 }
@@ -51,6 +53,7 @@ void mauve_ctx_destroy(mauve_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    delete c->pool; c->pool = nullptr;
     DevBuf *bufs[] = {&c->genomes, &c->keysA, &c->keysB, &c->valsA, &c->valsB, &c->hist, &c->totals, &c->posmask,
                       &c->hit_mask, &c->hit_pos, &c->hit_seg, &c->rec_genomes, &c->rec_seg, &c->placed_mask, &c->cand, &c->mlen, &c->mstart, &c->counters, &c->dp_desc, &c->dp_list, &c->dp_codes, &c->dp_off,
                       &c->dp_prof_cnt, &c->dp_prof_mask, &c->dp_prof2_cnt, &c->dp_prof2_mask, &c->dp_tb, &c->dp_meta,

@@ -38,10 +38,12 @@ void sort_by_left(std::vector<uint64_t> &k, std::vector<uint64_t> &tmp)
 void MatchVec::sort_by_start0()
 {
     const size_t n = size();
-    std::vector<uint64_t> key(n), tmp;
+    static thread_local std::vector<uint64_t> key, tmp;
+    static thread_local std::vector<int64_t> nd;        // swapped with d: both buffers live on, no fresh allocation
+    key.resize(n);
     for (size_t i = 0; i < n; i++) key[i] = ((uint64_t)std::llabs(st(i)[0]) << 32) | (uint64_t)i;
     sort_by_left(key, tmp);
-    std::vector<int64_t> nd(d.size());
+    nd.resize(d.size());
     for (size_t r = 0; r < n; r++) std::copy(rec((uint32_t)key[r]), rec((uint32_t)key[r]) + 1 + N, nd.begin() + r * (1 + N));
     d.swap(nd);
 }

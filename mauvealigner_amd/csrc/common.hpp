@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <string>
 #include <vector>
+#include "workers.hpp"
 #include <chrono>
 #include <algorithm>
 
@@ -110,6 +111,7 @@ struct DpSeqDesc { int32_t genome; int32_t rev; int64_t lo0; int64_t len; };   /
 // state of an alignment between its begin and finish phases (pipeline.cpp)
 struct AlignState {
     struct GapRef { int64_t lcb, idx; bool dp; int64_t dp_slot; int64_t tot; };
+    struct Item { int64_t lcb; uint32_t idx; int64_t col0; int64_t gap; };
     bool open = false;
     mauve_params p{};
     int N = 0; uint32_t full = 0;
@@ -119,6 +121,19 @@ struct AlignState {
     std::vector<GapRef> gaps;
     std::vector<DpSeqDesc> desc;
     std::vector<uint32_t> dcols; std::vector<int64_t> dcol_off, dscore;
+    // scratch of the host stages; like everything above it keeps its capacity from call to call -- a fresh
+    // megabyte-sized vector per stage and call costs more in page faults than the stage itself
+    MatchVec m;
+    std::vector<int64_t> match_lcb;
+    std::vector<Item> items;
+    // start a new alignment: scalars to zero, vectors emptied but not released
+    void reset()
+    {
+        open = false; p = mauve_params(); N = 0; full = 0;
+        sum = nm = nl = n_dp = code_total = n_anchor = anchor_cols = 0; t0 = t_dp0 = 0;
+        gaps.clear(); desc.clear(); dcols.clear(); dcol_off.clear(); dscore.clear();
+        match_lcb.clear(); items.clear();
+    }
 };
 
 struct mauve_ctx {
@@ -154,6 +169,20 @@ struct mauve_ctx {
     double k_ms[MAUVE_K_COUNT] = {0};
     int64_t k_launch[MAUVE_K_COUNT] = {0};
     int64_t k_units[MAUVE_K_COUNT] = {0};
+
+    // host scratch of dp_core, kept across calls (see AlignState)
+    struct DpHost {
+        std::vector<int64_t> tb_off, rows_off, est, need, nmax, lst, seq_off;
+        std::vector<uint8_t> is_big, meta;
+    } dph;
+    // host scratch of the seed pass (match records before the canonical sort)
+    struct SeedHost {
+        std::vector<int32_t> hl, hs;
+        std::vector<uint32_t> order, tmp;
+        std::vector<uint64_t> k1;
+    } sdh;
+
+    SpinPool *pool = nullptr;            // host helpers, armed for the duration of an align call (workers.hpp)
 
     AlignResult res;
     AlignState ast;

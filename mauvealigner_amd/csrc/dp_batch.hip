@@ -429,28 +429,38 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     const double td0 = now_ms();
     const int64_t total = seq_off[n_iv * nseq];
     // per-interval scratch: traceback (worst profile length before each step) and parked rows
-    std::vector<int64_t> tb_off(n_iv + 1), rows_off(n_iv + 1);
-    std::vector<uint8_t> is_big((size_t)n_iv, 0);
-    std::vector<int64_t> est((size_t)n_iv, 0);
+    mauve_ctx::DpHost &H = ctx->dph;
+    std::vector<int64_t> &tb_off = H.tb_off, &rows_off = H.rows_off, &est = H.est;
+    std::vector<uint8_t> &is_big = H.is_big;
+    tb_off.resize((size_t)n_iv + 1); rows_off.resize((size_t)n_iv + 1);
+    is_big.assign((size_t)n_iv, 0); est.assign((size_t)n_iv, 0);
     int64_t est_total = 0;
     static const bool no_mw = getenv("MAUVE_DP_ONE_WAVE") != nullptr;     // A/B switch for the workgroup path
     int64_t tbt = 0, rwt = 0;
-    for (int64_t iv = 0; iv < n_iv; iv++) {
-        int64_t mmax = 0, need = 0, nmax = 0; bool first = true;
-        for (int g = 0; g < nseq; g++) {
-            int64_t n = seq_off[iv * nseq + g + 1] - seq_off[iv * nseq + g];
-            if (n == 0) continue;
-            if (first) { first = false; mmax = n; continue; }
-            need = std::max(need, ((mmax + 63) / 64) * (n + 64) * 64);
-            nmax = std::max(nmax, n);
-            // a step with >= 3 stripes against >= 256 columns pipelines over several waves
-            if (mmax > 128 && n >= 256 && !no_mw) is_big[(size_t)iv] = 1;
-            est[(size_t)iv] += ((mmax + 63) / 64) * (n + 64);       // systolic steps of a single wave
-            mmax += n;
+    // per-interval figures on the host helpers, then one sequential prefix
+    std::vector<int64_t> &need_v = H.need, &nmax_v = H.nmax;
+    need_v.resize((size_t)n_iv); nmax_v.resize((size_t)n_iv);
+    ctx->pool->parallel_for(n_iv, 2048, [&](int64_t b, int64_t e) {
+        for (int64_t iv = b; iv < e; iv++) {
+            int64_t mmax = 0, need = 0, nmax = 0, es = 0; bool first = true; uint8_t big = 0;
+            for (int g = 0; g < nseq; g++) {
+                const int64_t n = seq_off[iv * nseq + g + 1] - seq_off[iv * nseq + g];
+                if (n == 0) continue;
+                if (first) { first = false; mmax = n; continue; }
+                need = std::max(need, ((mmax + 63) / 64) * (n + 64) * 64);
+                nmax = std::max(nmax, n);
+                // a step with >= 3 stripes against >= 256 columns pipelines over several waves
+                if (mmax > 128 && n >= 256 && !no_mw) big = 1;
+                es += ((mmax + 63) / 64) * (n + 64);                   // systolic steps of a single wave
+                mmax += n;
+            }
+            need_v[(size_t)iv] = need; nmax_v[(size_t)iv] = nmax; est[(size_t)iv] = es; is_big[(size_t)iv] = big;
         }
-        est_total += est[(size_t)iv];
+    });
+    for (int64_t iv = 0; iv < n_iv; iv++) {
         tb_off[iv] = tbt; rows_off[iv] = rwt;
-        tbt += need; rwt += 6 * (nmax + 1);
+        tbt += need_v[(size_t)iv]; rwt += 6 * (nmax_v[(size_t)iv] + 1);
+        est_total += est[(size_t)iv];
     }
     tb_off[n_iv] = tbt; rows_off[n_iv] = rwt;
 
@@ -487,7 +497,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     const double td1 = now_ms();
     DpScoring sc; sc.go = scoring->gap_open; sc.ge = scoring->gap_extend; memcpy(sc.s, scoring->matrix, sizeof sc.s);
     // longest intervals first: one wave per interval, so the tail of the launch is its longest interval
-    std::vector<int64_t> lst((size_t)n_iv);
+    std::vector<int64_t> &lst = H.lst; lst.resize((size_t)n_iv);
     {   // counting sort by size class (log2 of the traceback footprint), largest class first
         int64_t cnt[66] = {0};
         auto cls = [&](int64_t iv) { int64_t f = tb_off[iv + 1] - tb_off[iv]; int c = 0; while (f > 1) { f >>= 1; c++; } return 63 - c; };
@@ -533,9 +543,10 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
         if (n_big) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     HIPCHK(ctx, hipGetLastError());
-    std::vector<DpMeta> hm(n_iv);
+    H.meta.resize((size_t)n_iv * sizeof(DpMeta));
+    DpMeta *hm = reinterpret_cast<DpMeta *>(H.meta.data());
     const double td2 = now_ms();
-    HIPCHK(ctx, hipMemcpyAsync(hm.data(), ctx->dp_meta.p, (size_t)n_iv * sizeof(DpMeta), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hm, ctx->dp_meta.p, (size_t)n_iv * sizeof(DpMeta), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const double td3 = now_ms();
     int64_t tc = 0, cl = 0;
@@ -576,7 +587,7 @@ int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, c
 int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *scoring,
                       uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells)
 {
-    std::vector<int64_t> seq_off((size_t)(n_iv * nseq + 1));
+    std::vector<int64_t> &seq_off = ctx->dph.seq_off; seq_off.resize((size_t)(n_iv * nseq + 1));
     int64_t t = 0;
     for (int64_t i = 0; i < n_iv * nseq; i++) { seq_off[(size_t)i] = t; t += desc[i].len; }
     seq_off[(size_t)(n_iv * nseq)] = t;

@@ -37,7 +37,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p)
 {
     const int N = c->nseq;
     AlignState &S = c->ast;
-    S = AlignState();
+    S.reset();
     S.p = *p; S.N = N; S.t0 = now_ms();
     AlignResult &R = c->res;
     // keep the capacity of the result vectors across calls (a fresh 20 MB column buffer per call costs more in
@@ -67,7 +67,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p)
     c->stage.seed_ms = t1 - S.t0;
 
     // ---- chaining ----
-    MatchVec m(N); m.resize((size_t)nm);
+    MatchVec &m = S.m; m.N = N; m.resize((size_t)nm);
     for (int64_t i = 0; i < nm; i++) {
         m.len((size_t)i) = c->match_len[(size_t)i];
         std::copy(&c->match_start[(size_t)i * N], &c->match_start[(size_t)i * N] + N, m.st((size_t)i));
@@ -76,11 +76,12 @@ static int align_begin(mauve_ctx *c, const mauve_params *p)
     host_eliminate_overlaps(m, &orders);
     const double t1b = now_ms();
     const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight : (int64_t)3 * w * N;
-    std::vector<int64_t> match_lcb; int64_t nl = 0;
+    std::vector<int64_t> &match_lcb = S.match_lcb; int64_t nl = 0;
     host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl, &orders);
     S.nl = nl;
     std::vector<MatchVec> &chains = S.chains;
-    chains.assign((size_t)nl, MatchVec(N));
+    chains.resize((size_t)nl);                        // element buffers keep their capacity
+    for (auto &ch : chains) { ch.N = N; ch.d.clear(); }
     R.lcb_weight.assign((size_t)nl, 0);
     for (size_t i = 0; i < m.size(); i++) {
         int64_t l = match_lcb[i]; if (l < 0) continue;
@@ -101,6 +102,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p)
 
     // ---- inter-anchor intervals.  Descriptors only: the bases are gathered from the resident packed genomes on
     // the device. ----
+    S.gaps.reserve((size_t)R.mum_length.size() + 16);
     for (int64_t l = 0; l < nl; l++) {
         const MatchVec &ch = chains[(size_t)l];
         S.n_anchor += (int64_t)ch.size();
@@ -156,11 +158,13 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
     std::vector<MatchVec> &chains = S.chains;
     const double t4 = now_ms();
     c->stage.dp_ms = t4 - S.t_dp0;
+    // Host helpers (opt-in, MAUVE_HOST_THREADS > 1; workers.hpp) are only awake during the assembly.
+    SpinPool::Armed helpers(c->pool);
 
     // ---- assemble the interval table ----
     // pass 1 (sequential, light): where every anchor and every stretch goes in the column array
-    struct Item { int64_t lcb; uint32_t idx; int64_t col0; int64_t gap; };
-    std::vector<Item> items((size_t)S.n_anchor);
+    typedef AlignState::Item Item;
+    std::vector<Item> &items = S.items; items.resize((size_t)S.n_anchor);
     R.col_off.clear();
     R.lcb_left.assign((size_t)nl * N, 0); R.lcb_right.assign((size_t)nl * N, 0);
     R.dp_score.assign((size_t)nl, 0);
@@ -205,34 +209,42 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
         std::fill(R.cols.begin(), R.cols.end(), full);
         R.cols_fill = full; R.cols_dirty.clear();
     } else {
-        for (const auto &d : R.cols_dirty) std::fill(R.cols.begin() + d.first, R.cols.begin() + d.first + d.second, full);
+        c->pool->parallel_for((int64_t)R.cols_dirty.size(), 1024, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; i++) {
+                const auto &d = R.cols_dirty[(size_t)i];
+                std::fill(R.cols.begin() + d.first, R.cols.begin() + d.first + d.second, full);
+            }
+        });
         R.cols_dirty.clear();
     }
     const double ta2 = now_ms();
     R.anchor_length.resize((size_t)S.n_anchor); R.anchor_start.resize((size_t)S.n_anchor * N); R.anchor_lcb.resize((size_t)S.n_anchor);
-    // pass 2: every anchor writes its own columns and the stretch that follows it (independent writes; a thread
-    // pool did not pay here: waking it costs more than the 0.7 ms of fills)
+    // pass 2: every anchor writes its record and the stretch that follows it (independent writes, run on the host
+    // helpers).  Dirty ranges: one slot per anchor, length 0 where no gap follows.
     {
         uint32_t *out = R.cols.data();
-        for (int64_t a = 0; a < S.n_anchor; a++) {
-            const Item &it = items[(size_t)a];
-            const MatchVec &ch = chains[(size_t)it.lcb];
-            const int64_t alen = ch.len(it.idx); const int64_t *ast = ch.st(it.idx);
-            R.anchor_length[(size_t)a] = alen; R.anchor_lcb[(size_t)a] = it.lcb;
-            std::copy(ast, ast + N, &R.anchor_start[(size_t)a * N]);
-            uint32_t *o = out + it.col0 + alen;            // the anchor's own columns already hold `full`
-            if (it.gap >= 0) {
-                const AlignState::GapRef &gr = S.gaps[(size_t)it.gap];
-                const size_t glen = (size_t)(gr.dp ? dcol_off[(size_t)gr.dp_slot + 1] - dcol_off[(size_t)gr.dp_slot] : gr.tot);
-                if (glen) R.cols_dirty.push_back({(size_t)(o - out), glen});
-                if (gr.dp) std::copy(dcols + dcol_off[(size_t)gr.dp_slot], dcols + dcol_off[(size_t)gr.dp_slot + 1], o);
-                else for (int g = 0; g < N; g++) {
-                    int64_t lo, ln; bool rv;
-                    gap_of(ch.rec(it.idx), ch.rec(it.idx + 1), g, lo, ln, rv);
-                    std::fill(o, o + ln, 1u << g); o += ln;
+        R.cols_dirty.assign((size_t)S.n_anchor, std::pair<size_t, size_t>(0, 0));
+        c->pool->parallel_for(S.n_anchor, 1024, [&](int64_t ab, int64_t ae) {
+            for (int64_t a = ab; a < ae; a++) {
+                const Item &it = items[(size_t)a];
+                const MatchVec &ch = chains[(size_t)it.lcb];
+                const int64_t alen = ch.len(it.idx); const int64_t *ast = ch.st(it.idx);
+                R.anchor_length[(size_t)a] = alen; R.anchor_lcb[(size_t)a] = it.lcb;
+                std::copy(ast, ast + N, &R.anchor_start[(size_t)a * N]);
+                uint32_t *o = out + it.col0 + alen;            // the anchor's own columns already hold `full`
+                if (it.gap >= 0) {
+                    const AlignState::GapRef &gr = S.gaps[(size_t)it.gap];
+                    const size_t glen = (size_t)(gr.dp ? dcol_off[(size_t)gr.dp_slot + 1] - dcol_off[(size_t)gr.dp_slot] : gr.tot);
+                    R.cols_dirty[(size_t)a] = {(size_t)(o - out), glen};
+                    if (gr.dp) std::copy(dcols + dcol_off[(size_t)gr.dp_slot], dcols + dcol_off[(size_t)gr.dp_slot + 1], o);
+                    else for (int g = 0; g < N; g++) {
+                        int64_t lo, ln; bool rv;
+                        gap_of(ch.rec(it.idx), ch.rec(it.idx + 1), g, lo, ln, rv);
+                        std::fill(o, o + ln, 1u << g); o += ln;
+                    }
                 }
             }
-        }
+        });
     }
     const double ta3 = now_ms();
     size_t ncols = (size_t)col;

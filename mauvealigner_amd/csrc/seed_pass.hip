@@ -806,7 +806,8 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     } else passes.push_back({0xffffffffu, (uint32_t)mask, mode});
     ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear();
     if (n_matches) *n_matches = 0;
-    std::vector<int32_t> hl, hs;       // one record slot per candidate of every pass; length 0 = not a leftmost hit
+    // one record slot per candidate of every pass; length 0 = not a leftmost hit (host scratch kept across calls)
+    std::vector<int32_t> &hl = ctx->sdh.hl, &hs = ctx->sdh.hs; hl.clear(); hs.clear();
     for (const FinderPass &fp : passes) {
         HIPCHK(ctx, hipMemsetAsync(ctx->posmask.p, 0, (size_t)P * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
@@ -849,8 +850,8 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     const uint32_t ncand = (uint32_t)hl.size();
     if (ncand == 0) return MAUVE_OK;
     // ---- canonical order (first component, |start|, mask, starts, length) ----
-    std::vector<uint32_t> order; order.reserve(ncand);
-    std::vector<uint64_t> k1(ncand);   // (first component, |start|) packed for a fast first-level compare
+    std::vector<uint32_t> &order = ctx->sdh.order; order.clear(); order.reserve(ncand);
+    std::vector<uint64_t> &k1 = ctx->sdh.k1; k1.resize(ncand);   // (first component, |start|) packed for a fast first-level compare
     for (uint32_t i = 0; i < ncand; i++) {
         if (hl[i] == 0) continue;
         order.push_back(i);
@@ -862,7 +863,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     const uint32_t nm = (uint32_t)order.size();
     {   // LSD radix sort of the record indices by k1 (first component << 40 | start): 4 passes of 12 bits,
         // then the rare equal-k1 groups are ordered with the full comparator
-        std::vector<uint32_t> tmp(nm);
+        std::vector<uint32_t> &tmp = ctx->sdh.tmp; tmp.resize(nm);
         uint32_t *src = order.data(), *dst = tmp.data();
         for (int pass = 0; pass < 4; pass++) {
             const int sh = 12 * pass;

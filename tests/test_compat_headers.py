@@ -98,3 +98,14 @@ def test_example_matches_c_abi(flag):
         finally:
             ctx.close()
         assert out == r["xmfa"]
+
+
+def test_host_spin_pool():
+    """csrc/workers.hpp (the helpers behind the host loops of mauve_align): every index exactly once, over many
+    jobs, armed and disarmed, 1/2/4 threads.  Host-only C++, plain g++."""
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "workers_test")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "mauvealigner_amd", "csrc"),
+                        os.path.join(ROOT, "tests", "cpp", "workers_test.cpp"), "-o", exe], check=True)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.strip() == "OK", r.stdout + r.stderr
