@@ -2,7 +2,11 @@
 // 746-760) written against the libMems-shaped headers in include/libMems, i.e. what a reference maintainer's
 // call site looks like after switching the path to libmauve_hip.so.  Not a CLI: positional FastA files in, XMFA
 // on stdout.  Optional first argument "-u" uses UniqueMatchFinder as progressiveMauve.cpp:490-495 does; "-p" runs
-// the progressiveMauve alignment stage instead (ProgressiveAligner, progressiveMauve.cpp:575-722).
+// the progressiveMauve alignment stage instead (ProgressiveAligner, progressiveMauve.cpp:575-722).  With
+// MAUVE_MUMS_OUT / MAUVE_MLN_OUT set, the match list and the interval list are also written at the stage seams
+// (--mums / --output of the original, mauveAligner.cpp:603,702).
+#include <cstdlib>
+#include <fstream>
 #include <iostream>
 #include <memory>
 
@@ -52,6 +56,7 @@ int main(int argc, char **argv)
         finder->LogProgress(&std::cerr);
         finder->FindMatches(match_list);                                 // :585
         std::cerr << match_list.size() << " multi-MUMs\n";
+        if (const char *mp = getenv("MAUVE_MUMS_OUT")) { std::ofstream mo(mp); WriteList(match_list, mo); }   // :603
 
         seed_size = MatchList::GetDefaultMerSize(match_list.seq_table);  // :650-651
         int64 LCB_size = (int64)seed_size * 3 * N;                       // :652
@@ -59,6 +64,7 @@ int main(int argc, char **argv)
         aligner.SetGappedAligner(HipGappedAligner::getInterface());      // :674
         IntervalList interval_list;
         aligner.align(match_list, interval_list, 0, LCB_size, true, true, true, "");   // :698
+        if (const char *lp = getenv("MAUVE_MLN_OUT")) { std::ofstream lo(lp); interval_list.WriteList(lo); }  // :702
         interval_list.WriteStandardAlignment(std::cout);                 // :746-760
         match_list.Clear();
         for (auto *s : match_list.sml_table) delete s;

@@ -19,6 +19,9 @@
 #include <fstream>
 #include <iostream>
 #include <ostream>
+#include <sstream>
+#include <algorithm>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -418,26 +421,251 @@ private:
     PairwiseScoringScheme pss_;
 };
 
-// ---- IntervalList: the result of Aligner::align, written as XMFA ---------------------------------------
-class IntervalList {
+// ---- Interval / IntervalList: the result of Aligner::align, resident on the host ------------------------------
+// One Interval is one block of the alignment: for every genome its range and strand (absent: left = right = 0)
+// and, per alignment column, the set of genomes that have a base there.  The bases themselves stay in seq_table.
+class Interval {
+public:
+    Interval() {}
+    Interval(const std::vector<int64> &left, const std::vector<int64> &right, const std::vector<char> &reverse,
+             const std::vector<uint32_t> &cols) : left_(left), right_(right), rev_(reverse), cols_(cols) {}
+    uint SeqCount() const { return (uint)left_.size(); }
+    gnSeqI LeftEnd(uint seqI) const { return (gnSeqI)left_[seqI]; }                       // toGrimmFormat.cpp:62-77
+    gnSeqI RightEnd(uint seqI) const { return (gnSeqI)right_[seqI]; }
+    gnSeqI Length(uint seqI) const { return left_[seqI] ? (gnSeqI)(right_[seqI] - left_[seqI] + 1) : 0; }
+    int64 Start(uint seqI) const { return rev_[seqI] ? -left_[seqI] : left_[seqI]; }      // signed, NO_MATCH when absent
+    AbstractMatch::orientation Orientation(uint seqI) const
+    { return left_[seqI] == NO_MATCH ? AbstractMatch::undefined : (rev_[seqI] ? AbstractMatch::reverse : AbstractMatch::forward); }
+    uint Multiplicity() const { uint m = 0; for (int64 l : left_) m += l != NO_MATCH; return m; }
+    gnSeqI AlignmentLength() const { return (gnSeqI)cols_.size(); }
+    const std::vector<uint32_t> &Columns() const { return cols_; }
+    // rows of the block as '-'-gapped strings, one per genome (all gaps for an absent genome); a reverse
+    // component is written as the reverse complement (GetAlignment, repeatoire.cpp:1264-1265)
+    void GetAlignment(std::vector<std::string> &rows, const std::vector<genome::gnSequence *> &seq_table) const
+    {
+        const uint N = SeqCount();
+        rows.assign(N, std::string(cols_.size(), '-'));
+        for (uint g = 0; g < N; g++) {
+            if (!left_[g]) continue;
+            if (g >= seq_table.size() || (gnSeqI)right_[g] > seq_table[g]->length()) throw genome::gnException("Interval::GetAlignment: sequence table does not cover the interval");
+            const std::string &sq = seq_table[g]->str();
+            int64 nxt = rev_[g] ? right_[g] : left_[g];
+            for (size_t k = 0; k < cols_.size(); k++) {
+                if (!(cols_[k] >> g & 1)) continue;
+                rows[g][k] = base_char(sq[(size_t)nxt - 1], rev_[g] != 0);
+                nxt += rev_[g] ? -1 : 1;
+            }
+        }
+    }
+    // the letter the device path sees: upper case ACGT, everything else reads as A (mauve_pack_ascii)
+    static char base_char(char c, bool complement)
+    {
+        int code;
+        switch (c) { case 'C': case 'c': code = 1; break; case 'G': case 'g': code = 2; break; case 'T': case 't': code = 3; break; default: code = 0; }
+        return "ACGT"[complement ? 3 - code : code];
+    }
+private:
+    std::vector<int64> left_, right_;
+    std::vector<char> rev_;
+    std::vector<uint32_t> cols_;
+};
+
+class IntervalList : public std::vector<Interval> {
 public:
     std::vector<genome::gnSequence *> seq_table;
     std::vector<std::string> seq_filename;
     mauve_align_sizes sizes;
     IntervalList() { sizes = mauve_align_sizes(); }
-    size_t size() const { return (size_t)sizes.n_iv; }
-    void WriteStandardAlignment(std::ostream &os) const                    // mauveAligner.cpp:746-760
+
+    // pull the interval table of the last mauve_align / mauve_progressive_align off the context
+    void fetch(HipContext &hc, uint seq_count)
     {
-        HipContext &hc = HipContext::global();
-        std::vector<const char *> names;
-        for (size_t i = 0; i < seq_table.size(); i++) names.push_back(i < seq_filename.size() ? seq_filename[i].c_str() : "");
-        int64_t len = 0;
-        hc.check(mauve_write_xmfa(hc.get(), names.data(), nullptr, &len), "mauve_write_xmfa");
-        std::string buf((size_t)len, '\0');
-        hc.check(mauve_write_xmfa(hc.get(), names.data(), &buf[0], &len), "mauve_write_xmfa");
-        os.write(buf.data(), (std::streamsize)(len - 1));
+        clear();
+        const size_t K = (size_t)sizes.n_iv, N = seq_count;
+        std::vector<int64_t> left(K * N), right(K * N), col_off(K + 1);
+        std::vector<int8_t> rev(K * N);
+        std::vector<uint32_t> cols((size_t)sizes.n_cols);
+        hc.check(mauve_align_fetch(hc.get(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, left.data(),
+                                   right.data(), rev.data(), col_off.data(), cols.data(), nullptr), "mauve_align_fetch");
+        for (size_t i = 0; i < K; i++) {
+            std::vector<int64> l(left.begin() + i * N, left.begin() + (i + 1) * N), r(right.begin() + i * N, right.begin() + (i + 1) * N);
+            std::vector<char> rv(rev.begin() + i * N, rev.begin() + (i + 1) * N);
+            push_back(Interval(l, r, rv, std::vector<uint32_t>(cols.begin() + col_off[i], cols.begin() + col_off[i + 1])));
+        }
     }
+
+    // XMFA (mauveAligner.cpp:746-760; layout mfa2xmfa.cpp:64-115): byte-identical to mauve_write_xmfa
+    void WriteStandardAlignment(std::ostream &os) const
+    {
+        const uint N = (uint)seq_table.size();
+        os << "#FormatVersion Mauve1\n";
+        for (uint g = 0; g < N; g++)
+            os << "#Sequence" << g + 1 << "File\t" << name(g) << "\n#Sequence" << g + 1 << "Entry\t" << g + 1 << "\n#Sequence" << g + 1
+               << "Format\tFastA\n";
+        std::vector<std::string> rows;
+        for (const Interval &iv : *this) {
+            iv.GetAlignment(rows, seq_table);
+            for (uint g = 0; g < N && g < iv.SeqCount(); g++) {
+                if (!iv.LeftEnd(g)) continue;
+                os << "> " << g + 1 << ':' << iv.LeftEnd(g) << '-' << iv.RightEnd(g) << ' ' << (iv.Orientation(g) == AbstractMatch::reverse ? '-' : '+')
+                   << ' ' << name(g) << '\n';
+                for (size_t pos = 0; pos < rows[g].size(); pos += 80) os << rows[g].substr(pos, 80) << '\n';
+            }
+            os << "=\n";
+        }
+    }
+
+    // XMFA reader (ReadStandardAlignment, scoreProcrastAlignment.cpp:442): ranges, strands and gap pattern of every
+    // block; the number of genomes comes from the header (or the largest index seen).  seq_table is left alone:
+    // as with libMems the caller loads the sequences named in seq_filename.
+    void ReadStandardAlignment(std::istream &is)
+    {
+        clear(); seq_filename.clear();
+        std::string line;
+        struct Row { uint g; int64 lo, hi; bool rev; std::string txt; };
+        std::vector<std::vector<Row>> blocks(1);
+        uint N = 0;
+        while (std::getline(is, line)) {
+            if (!line.empty() && line[line.size() - 1] == '\r') line.erase(line.size() - 1);
+            if (line.empty()) continue;
+            if (line[0] == '#') {
+                unsigned idx = 0; char tag[32];
+                if (sscanf(line.c_str(), "#Sequence%u%31[A-Za-z]", &idx, tag) == 2 && std::string(tag) == "File" && idx >= 1) {
+                    if (seq_filename.size() < idx) seq_filename.resize(idx);
+                    const size_t tab = line.find('\t');
+                    seq_filename[idx - 1] = tab == std::string::npos ? "" : line.substr(tab + 1);
+                    N = std::max(N, (uint)idx);
+                }
+                continue;
+            }
+            if (line[0] == '=') { blocks.push_back(std::vector<Row>()); continue; }
+            if (line[0] == '>') {
+                Row r; unsigned g = 0; long long lo = 0, hi = 0; char strand = '+';
+                if (sscanf(line.c_str(), "> %u:%lld-%lld %c", &g, &lo, &hi, &strand) < 3 || g < 1) throw genome::gnException("ReadStandardAlignment: bad defline: " + line);
+                r.g = g - 1; r.lo = lo; r.hi = hi; r.rev = strand == '-';
+                N = std::max(N, (uint)g);
+                blocks.back().push_back(r);
+                continue;
+            }
+            if (blocks.back().empty()) throw genome::gnException("ReadStandardAlignment: sequence data before a defline");
+            blocks.back().back().txt += line;
+        }
+        for (const auto &blk : blocks) {
+            if (blk.empty()) continue;
+            const size_t len = blk[0].txt.size();
+            std::vector<int64> l(N, 0), r(N, 0); std::vector<char> rv(N, 0); std::vector<uint32_t> cols(len, 0);
+            for (const Row &row : blk) {
+                if (row.txt.size() != len) throw genome::gnException("ReadStandardAlignment: ragged block");
+                if (row.lo == 0 && row.hi == 0) continue;            // some writers list absent genomes as 0-0
+                l[row.g] = row.lo; r[row.g] = row.hi; rv[row.g] = row.rev;
+                int64 bases = 0;
+                for (size_t k = 0; k < len; k++) if (row.txt[k] != '-') { cols[k] |= 1u << row.g; bases++; }
+                if (bases != row.hi - row.lo + 1) throw genome::gnException("ReadStandardAlignment: range and residue count disagree");
+            }
+            push_back(Interval(l, r, rv, cols));
+        }
+        sizes = mauve_align_sizes(); sizes.n_iv = (int64_t)size();
+        for (const Interval &iv : *this) sizes.n_cols += (int64_t)iv.AlignmentLength();
+    }
+
+    // .mln (mauveAligner.cpp:702,715).  libMems owns the real layout [EXT]; this one is self-describing text in the
+    // same spirit (tab-separated header, then per interval the signed starts, lengths and the gap pattern
+    // run-length encoded per genome), and round-trips through ReadList.
+    void WriteList(std::ostream &os) const
+    {
+        const uint N = (uint)seq_table.size();
+        os << "FormatVersion\t4\nSequenceCount\t" << N << '\n';
+        for (uint g = 0; g < N; g++) os << "Sequence" << g << "File\t" << name(g) << "\nSequence" << g << "Length\t" << seq_table[g]->length() << '\n';
+        os << "IntervalCount\t" << size() << '\n';
+        for (size_t i = 0; i < size(); i++) {
+            const Interval &iv = (*this)[i];
+            os << "Interval\t" << i << '\t' << iv.AlignmentLength() << '\n';
+            for (uint g = 0; g < iv.SeqCount(); g++) {
+                os << iv.Start(g) << '\t' << iv.Length(g);
+                // runs: +n = n columns with a base, -n = n gap columns
+                const std::vector<uint32_t> &c = iv.Columns();
+                for (size_t k = 0; k < c.size();) {
+                    const bool on = c[k] >> g & 1; size_t j = k;
+                    while (j < c.size() && ((c[j] >> g & 1) != 0) == on) j++;
+                    os << '\t' << (on ? "" : "-") << (j - k);
+                    k = j;
+                }
+                os << '\n';
+            }
+        }
+    }
+    void ReadList(std::istream &is)
+    {
+        clear(); seq_filename.clear();
+        std::string key; uint N = 0; size_t K = 0; std::string line;
+        auto expect = [&](const std::string &k) { if (!(is >> key) || key != k) throw genome::gnException("IntervalList::ReadList: expected " + k); };
+        expect("FormatVersion"); int ver; is >> ver;
+        expect("SequenceCount"); is >> N;
+        for (uint g = 0; g < N; g++) {
+            is >> key; std::getline(is, line); seq_filename.push_back(line.empty() ? "" : line.substr(1));
+            is >> key; long long len; is >> len;
+        }
+        expect("IntervalCount"); is >> K;
+        for (size_t i = 0; i < K; i++) {
+            size_t idx, alen; expect("Interval"); is >> idx >> alen;
+            std::getline(is, line);
+            std::vector<int64> l(N, 0), r(N, 0); std::vector<char> rv(N, 0); std::vector<uint32_t> cols(alen, 0);
+            for (uint g = 0; g < N; g++) {
+                if (!std::getline(is, line)) throw genome::gnException("IntervalList::ReadList: truncated interval");
+                std::istringstream ls(line);
+                long long st, len; ls >> st >> len;
+                l[g] = std::llabs(st); r[g] = st ? l[g] + len - 1 : 0; rv[g] = st < 0;
+                long long run; size_t k = 0;
+                while (ls >> run) {
+                    const size_t n = (size_t)std::llabs(run);
+                    if (k + n > alen) throw genome::gnException("IntervalList::ReadList: runs exceed the alignment length");
+                    if (run > 0) for (size_t j = 0; j < n; j++) cols[k + j] |= 1u << g;
+                    k += n;
+                }
+            }
+            push_back(Interval(l, r, rv, cols));
+        }
+        sizes = mauve_align_sizes(); sizes.n_iv = (int64_t)size();
+        for (const Interval &iv : *this) sizes.n_cols += (int64_t)iv.AlignmentLength();
+    }
+private:
+    std::string name(uint g) const { return g < seq_filename.size() ? seq_filename[g] : std::string(); }
 };
+
+// ---- .mums: the match list at the seam between the seed stage and the aligner (mauveAligner.cpp:484,499,603;
+// progressiveMauve.cpp:476,552).  Header as libMems writes it [EXT, from Mauve's published files]: FormatVersion,
+// SequenceCount, Sequence<i>File / Sequence<i>Length, MatchCount; then one row per match in the layout of
+// operator<< above (length, signed starts; MatchRecord.h:350-355 prints the same row).
+inline void WriteList(const MatchList &ml, std::ostream &os)
+{
+    os << "FormatVersion\t3\nSequenceCount\t" << ml.seq_table.size() << '\n';
+    for (size_t g = 0; g < ml.seq_table.size(); g++)
+        os << "Sequence" << g << "File\t" << (g < ml.seq_filename.size() ? ml.seq_filename[g] : std::string()) << "\nSequence" << g << "Length\t"
+           << ml.seq_table[g]->length() << '\n';
+    os << "MatchCount\t" << ml.size() << '\n';
+    for (const Match *m : ml) os << *m << '\n';
+}
+inline void ReadList(MatchList &ml, std::istream &is)
+{
+    ml.Clear(); ml.seq_filename.clear();
+    std::string key, line; size_t N = 0, M = 0; int ver = 0;
+    auto expect = [&](const std::string &k) { if (!(is >> key) || key != k) throw genome::gnException("ReadList: expected " + k); };
+    expect("FormatVersion"); is >> ver;
+    expect("SequenceCount"); is >> N;
+    for (size_t g = 0; g < N; g++) {
+        is >> key; std::getline(is, line); ml.seq_filename.push_back(line.empty() ? "" : line.substr(1));
+        long long len; is >> key >> len;
+    }
+    expect("MatchCount"); is >> M;
+    for (size_t i = 0; i < M; i++) {
+        long long len, st;
+        if (!(is >> len)) throw genome::gnException("ReadList: truncated match list");
+        Match *m = new Match((uint)N);
+        m->SetLength((gnSeqI)len);
+        for (size_t g = 0; g < N; g++) { if (!(is >> st)) { m->Free(); throw genome::gnException("ReadList: truncated match row"); } m->SetStart((uint)g, st); }
+        ml.push_back(m);
+    }
+}
 
 // ---- Aligner: setters and align() as called at mauveAligner.cpp:668-698 -----------------------------------
 class Aligner {
@@ -467,6 +695,7 @@ public:
         p.recursive = recursive; p.gapped = gapped;
         hc.check(mauve_align(hc.get(), &p, &il.sizes), "mauve_align");
         il.seq_table = ml.seq_table; il.seq_filename = ml.seq_filename;
+        il.fetch(hc, seq_count_);
     }
 private:
     uint seq_count_;
@@ -513,6 +742,7 @@ public:
         tmp.upload(hc);
         hc.check(mauve_progressive_align(hc.get(), &p_, &il.sizes, tree_left_.data(), tree_right_.data(), nullptr), "mauve_progressive_align");
         il.seq_table = seq_table;
+        il.fetch(hc, seq_count_);
     }
     // guide tree of the last align(): child ids per node (leaves -1), nodes seq_count.. in merge order
     const std::vector<int32_t> &treeLeft() const { return tree_left_; }

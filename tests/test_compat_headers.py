@@ -48,6 +48,53 @@ int main() {
 '''
 
 
+IO_UNIT = r'''
+// usage: io_unit in.xmfa out.xmfa out.mln out2.xmfa seq0.fa seq1.fa ...
+#include <cassert>
+#include <fstream>
+#include <sstream>
+#include "libMems/IntervalList.h"
+#include "libMems/MatchList.h"
+using namespace mems;
+int main(int argc, char **argv) {
+    IntervalList il;
+    { std::ifstream in(argv[1]); il.ReadStandardAlignment(in); }
+    for (int i = 5; i < argc; i++) { genome::gnSequence *s = new genome::gnSequence(); s->LoadSource(argv[i]); il.seq_table.push_back(s); }
+    assert(il.seq_filename.size() == il.seq_table.size());
+    { std::ofstream out(argv[2]); il.WriteStandardAlignment(out); }           // XMFA -> XMFA
+    { std::ofstream out(argv[3]); il.WriteList(out); }                        // -> .mln
+    IntervalList il2;
+    { std::ifstream in(argv[3]); il2.ReadList(in); }
+    il2.seq_table = il.seq_table;
+    assert(il2.size() == il.size() && il2.seq_filename == il.seq_filename);
+    for (size_t i = 0; i < il.size(); i++) {
+        assert(il2[i].Columns() == il[i].Columns());
+        for (uint g = 0; g < il[i].SeqCount(); g++) assert(il2[i].Start(g) == il[i].Start(g) && il2[i].Length(g) == il[i].Length(g));
+    }
+    { std::ofstream out(argv[4]); il2.WriteStandardAlignment(out); }          // .mln -> XMFA
+    // .mums round trip
+    MatchList ml; ml.seq_table = il.seq_table; ml.seq_filename = il.seq_filename;
+    for (size_t i = 0; i < il.size(); i++) {
+        Match m((uint)il.seq_table.size()); m.SetLength(il[i].AlignmentLength());
+        for (uint g = 0; g < il[i].SeqCount(); g++) m.SetStart(g, il[i].Start(g));
+        ml.push_back(m.Copy());
+    }
+    std::stringstream ss; WriteList(ml, ss);
+    MatchList back; ReadList(back, ss);
+    assert(back.size() == ml.size() && back.seq_filename == ml.seq_filename);
+    for (size_t i = 0; i < ml.size(); i++) {
+        assert(back[i]->Length() == ml[i]->Length());
+        for (uint g = 0; g < ml[i]->SeqCount(); g++) assert(back[i]->Start(g) == ml[i]->Start(g));
+    }
+    back.seq_table = ml.seq_table;            // ReadList leaves loading the sequences to the caller
+    std::stringstream s2; WriteList(back, s2);
+    assert(s2.str() == ss.str());
+    ml.Clear(); back.Clear();
+    return 0;
+}
+'''
+
+
 def _compile(src_text, out, extra=()):
     src = out + ".cpp"
     with open(src, "w") as f:
@@ -63,6 +110,32 @@ def test_mirror_compiles_and_host_classes_work():
         exe = os.path.join(td, "match_unit")
         _compile(MATCH_UNIT, exe)
         subprocess.check_call([exe])
+
+
+@pytest.mark.parametrize("name", ["g2x2k", "g3x5k_inv", "g5x3k_unique"])
+def test_stage_seam_formats_round_trip(name):
+    """the text formats at the stage seams, host only.  A committed golden XMFA goes through
+    ReadStandardAlignment -> WriteStandardAlignment and through WriteList(.mln) -> ReadList -> WriteStandardAlignment
+    and must come back byte for byte; the match list goes through WriteList/ReadList(.mums)."""
+    golden = os.path.join(ROOT, "tests", "golden")
+    z = np.load(os.path.join(golden, name + ".npz"))
+    want = open(os.path.join(golden, name + ".xmfa")).read()
+    names = [ln.split("\t", 1)[1] for ln in want.splitlines() if ln.startswith("#Sequence") and "File\t" in ln]
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "io_unit")
+        _compile(IO_UNIT, exe)
+        fas = []
+        for g in range(int(z["nseq"])):
+            p = os.path.join(td, "s%d.fa" % g)
+            with open(p, "w") as f:
+                f.write(">s%d\n%s\n" % (g, synth.to_ascii(z["genome%d" % g]).decode()))
+            fas.append(p)
+        assert len(names) == len(fas)
+        out1, mln, out2 = (os.path.join(td, x) for x in ("a.xmfa", "a.mln", "b.xmfa"))
+        subprocess.check_call([exe, os.path.join(golden, name + ".xmfa"), out1, mln, out2] + fas)
+        assert open(out1).read() == want
+        assert open(out2).read() == want
+        assert open(mln).read().startswith("FormatVersion\t4\nSequenceCount\t%d\n" % len(fas))
 
 
 def test_example_call_site_compiles():
@@ -87,7 +160,14 @@ def test_example_matches_c_abi(flag):
                     f.write(a[k:k + 70] + "\n")
             paths.append(p)
         cmd = [os.path.join(ROOT, "examples", "mauve_hip_align")] + ([flag] if flag else []) + paths
-        out = subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+        env = dict(os.environ, MAUVE_MUMS_OUT=os.path.join(td, "o.mums"), MAUVE_MLN_OUT=os.path.join(td, "o.mln"))
+        out = subprocess.run(cmd, check=True, capture_output=True, text=True, env=env).stdout
+        if flag != "-p":        # the seam files of the mauveAligner path: match list and interval list
+            mums = open(env["MAUVE_MUMS_OUT"]).read().splitlines()
+            assert mums[0] == "FormatVersion\t3" and mums[1] == "SequenceCount\t%d" % len(gs)
+            n_m = int(mums[2 + 2 * len(gs)].split("\t")[1])
+            assert n_m > 0 and len(mums) == 3 + 2 * len(gs) + n_m
+            assert open(env["MAUVE_MLN_OUT"]).read().startswith("FormatVersion\t4\n")
         ctx = _lib.Context(0)
         try:
             ctx.set_genomes(gs)
