@@ -192,6 +192,38 @@ public:
         return n;
     }
     void Clear() { mer_.clear(); pos_.clear(); by_pos_.clear(); }
+    // .sslist cache of a device-built list (DNAFileSML::LoadFile, uniqueMerCount.cpp:30-39; file naming
+    // getDefaultSmlFileNames, progressiveMauve.cpp:215-224).  libMems' binary layout is [EXT]; this one is a small
+    // little-endian header ("MHSSLIST", version, seed pattern, entries) followed by the mers and the positions.
+    void WriteFile(const std::string &path) const
+    {
+        std::ofstream out(path.c_str(), std::ios::binary);
+        if (!out) throw genome::gnException("SortedMerList::WriteFile: cannot open " + path);
+        const char magic[8] = {'M', 'H', 'S', 'S', 'L', 'I', 'S', 'T'};
+        const uint64_t hdr[3] = {1, (uint64_t)seed_, (uint64_t)mer_.size()};
+        out.write(magic, 8); out.write((const char *)hdr, sizeof hdr);
+        out.write((const char *)mer_.data(), (std::streamsize)(mer_.size() * 8));
+        out.write((const char *)pos_.data(), (std::streamsize)(pos_.size() * 8));
+        if (!out) throw genome::gnException("SortedMerList::WriteFile: write failed: " + path);
+    }
+    void LoadFile(const std::string &path)
+    {
+        std::ifstream in(path.c_str(), std::ios::binary);
+        if (!in) throw genome::gnException("SortedMerList::LoadFile: cannot open " + path);
+        char magic[8]; uint64_t hdr[3];
+        in.read(magic, 8); in.read((char *)hdr, sizeof hdr);
+        if (!in || std::string(magic, 8) != "MHSSLIST" || hdr[0] != 1) throw genome::gnException("SortedMerList::LoadFile: not a sorted mer list: " + path);
+        seed_ = (int64)hdr[1]; seq_index_ = -1;
+        mer_.assign((size_t)hdr[2], 0); pos_.assign((size_t)hdr[2], 0);
+        in.read((char *)mer_.data(), (std::streamsize)(mer_.size() * 8));
+        in.read((char *)pos_.data(), (std::streamsize)(pos_.size() * 8));
+        if (!in) throw genome::gnException("SortedMerList::LoadFile: truncated file: " + path);
+        by_pos_.assign(mer_.size(), 0);
+        for (size_t i = 0; i < mer_.size(); i++) {
+            if (pos_[i] < 0 || (size_t)pos_[i] >= mer_.size()) throw genome::gnException("SortedMerList::LoadFile: position out of range");
+            by_pos_[(size_t)pos_[i]] = mer_[i];
+        }
+    }
     // filled by MatchList::CreateMemorySMLs
     void fill(HipContext &hc, int seq_index, int64 seed, gnSeqI seq_len)
     {
@@ -207,6 +239,23 @@ private:
     int64 seed_; int seq_index_;
     std::vector<uint64_t> mer_; std::vector<int64_t> pos_; std::vector<uint64_t> by_pos_;
 };
+
+typedef SortedMerList DNAFileSML;                 // uniqueMerCount.cpp:30: the file-backed list is the same object here
+
+// progressiveMauve.cpp:199-224: the seed pattern as a 0/1 string from its first set bit, and the default
+// <sequence file>.<pattern>.sslist names
+inline std::string getPatternText(int64 seed_pattern)
+{
+    std::string pat;
+    for (int i = 63; i >= 0; i--) if (!pat.empty() || ((uint64)seed_pattern >> i & 1)) pat.push_back(((uint64)seed_pattern >> i & 1) ? '1' : '0');
+    return pat;
+}
+inline void getDefaultSmlFileNames(const std::vector<std::string> &seq_files, std::vector<std::string> &sml_files, int seed_weight, int seed_rank)
+{
+    const std::string pattern = getPatternText(getSeed(seed_weight, seed_rank));
+    sml_files.resize(seq_files.size());
+    for (size_t i = 0; i < seq_files.size(); i++) sml_files[i] = seq_files[i] + "." + pattern + ".sslist";
+}
 
 // ---- MatchList: vector<Match*> + sequence and SML tables (mauveAligner.cpp:450-466,600,641-651) ----------
 class MatchList : public std::vector<Match *> {

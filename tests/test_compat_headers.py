@@ -43,6 +43,11 @@ int main() {
     genome::gnSequence s("ACGTACGT"); assert(s.length() == 8 && s.ToString(3, 2) == "CGT" && s.ToString() == "ACGTACGT");
     PairwiseScoringScheme pss; assert(pss.gap_open == -400 && pss.gap_extend == -30 && pss.matrix[0][0] == 91);
     UniqueMatchFinder umf; MatchFinder *cl = umf.Clone(); delete cl;
+    /* progressiveMauve.cpp:199-224: pattern text and default .sslist names */
+    assert(getPatternText(getSeed(15, 0)) == "111011010111010110111" && getPatternText(getSeed(5, SOLID_SEED)) == "11111");
+    std::vector<std::string> fn; fn.push_back("a.fa"); fn.push_back("b.gbk"); std::vector<std::string> sn;
+    getDefaultSmlFileNames(fn, sn, 15, 0);
+    assert(sn.size() == 2 && sn[0] == "a.fa.111011010111010110111.sslist" && sn[1] == "b.gbk.111011010111010110111.sslist");
     return 0;
 }
 '''
@@ -90,6 +95,32 @@ int main(int argc, char **argv) {
     std::stringstream s2; WriteList(back, s2);
     assert(s2.str() == ss.str());
     ml.Clear(); back.Clear();
+    return 0;
+}
+'''
+
+
+SML_UNIT = r'''
+// usage: sml_unit seq.fa  -- device-built sorted mer list -> .sslist -> reload (uniqueMerCount.cpp:30-39)
+#include <cassert>
+#include <iostream>
+#include "libMems/MatchList.h"
+#include "libMems/SortedMerList.h"
+using namespace mems;
+int main(int argc, char **argv) {
+    MatchList ml;
+    genome::gnSequence *s = new genome::gnSequence(); s->LoadSource(argv[1]);
+    ml.seq_table.push_back(s); ml.seq_filename.push_back(argv[1]);
+    ml.CreateMemorySMLs(11, nullptr, 0);
+    std::vector<std::string> names; getDefaultSmlFileNames(ml.seq_filename, names, 11, 0);
+    ml.sml_table[0]->WriteFile(names[0]);
+    DNAFileSML back; back.LoadFile(names[0]);
+    assert(back.Seed() == ml.sml_table[0]->Seed() && back.Length() == ml.sml_table[0]->Length());
+    for (gnSeqI i = 0; i < back.Length(); i++) {
+        assert(back.SortedMer(i) == ml.sml_table[0]->SortedMer(i) && back.SortedPosition(i) == ml.sml_table[0]->SortedPosition(i));
+        assert(back.GetMer(i) == ml.sml_table[0]->GetMer(i));
+    }
+    std::cout << back.UniqueMerCount() << std::endl;
     return 0;
 }
 '''
@@ -178,6 +209,24 @@ def test_example_matches_c_abi(flag):
         finally:
             ctx.close()
         assert out == r["xmfa"]
+
+
+@pytest.mark.gpu
+def test_sslist_cache_and_unique_mer_count():
+    """a device-built sorted mer list written as <seq>.<pattern>.sslist, reloaded, and counted
+    (uniqueMerCount.cpp:39) -- the count equals the oracle's number of distinct canonical mers."""
+    from oracle import pyoracle as O
+    g = synth.make_config("C1", scale=0.05)[0]
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "g.fa")
+        with open(fa, "w") as f:
+            f.write(">g\n%s\n" % synth.to_ascii(g).decode())
+        exe = os.path.join(td, "sml_unit")
+        _compile(SML_UNIT, exe)
+        out = subprocess.run([exe, fa], check=True, capture_output=True, text=True).stdout
+        assert os.path.exists(fa + "." + bin(O.get_seed(11, 0))[2:] + ".sslist")
+        mer, _ = O.sorted_mer_list(g, O.get_seed(11, 0))
+        assert int(out) == len(np.unique(mer >> 1))
 
 
 def test_host_spin_pool():
