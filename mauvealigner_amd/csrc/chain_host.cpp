@@ -101,7 +101,8 @@ void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders)
 {
     const int N = m.N;
     const size_t n = m.size();
-    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    static const bool trace_on = getenv("MAUVE_TRACE") != nullptr;
+    const bool trace = trace_on && n >= 1000;          // per-gap calls of the recursion stay quiet
     const double te0 = trace ? now_ms() : 0;
     static thread_local ElimScratch S;
     if (orders) orders->ord.assign((size_t)N, std::vector<uint32_t>());
@@ -193,7 +194,8 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
     match_lcb.assign(n, -1);
     n_lcb = 0;
     if (n == 0) return;
-    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    static const bool trace_on = getenv("MAUVE_TRACE") != nullptr;
+    const bool trace = trace_on && n >= 1000;
     const double tl0 = trace ? now_ms() : 0;
     // per-genome order of the matches and its inverse
     static thread_local std::vector<uint32_t> order_s, rank_s;
@@ -268,15 +270,26 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
         if (q >= 0) PREV(q, g) = p;
     };
     const double tl2 = trace ? now_ms() : 0;
-    std::set<std::pair<int64_t, int32_t>> heap;    // (weight, genome-0 order index): node ids are in that order
-    for (int32_t i = 0; i < K; i++) heap.insert({weight[(size_t)i], i});
+    // min-heap of (weight, node id) -- node ids are in genome-0 order, so ties resolve as the spec says -- with lazy
+    // deletion: an entry counts only while its node is alive and still has the weight recorded in the entry
+    // (weights only grow, by merges).  No per-node allocation: recursive anchoring calls this once per gap.
+    typedef std::pair<int64_t, int32_t> HeapEnt;
+    static thread_local std::vector<HeapEnt> heap;
+    heap.clear();
+    for (int32_t i = 0; i < K; i++) heap.push_back({weight[(size_t)i], i});
+    auto cmp = [](const HeapEnt &a, const HeapEnt &b) { return a > b; };          // min-heap
+    std::make_heap(heap.begin(), heap.end(), cmp);
     int32_t alive_cnt = K;
     std::vector<std::pair<int32_t, int32_t>> cand;
     while (!heap.empty()) {
-        auto it = heap.begin();
-        if (collinear ? alive_cnt <= 1 : it->first >= min_weight) break;
-        const int32_t x = it->second;
-        heap.erase(it);
+        const HeapEnt top = heap.front();
+        if (!alive[(size_t)top.second] || weight[(size_t)top.second] != top.first) {     // stale entry
+            std::pop_heap(heap.begin(), heap.end(), cmp); heap.pop_back();
+            continue;
+        }
+        if (collinear ? alive_cnt <= 1 : top.first >= min_weight) break;
+        const int32_t x = top.second;
+        std::pop_heap(heap.begin(), heap.end(), cmp); heap.pop_back();
         // neighbours that may become mergeable once x is gone
         cand.clear();
         for (int g = 0; g < N; g++) cand.push_back({PREV(x, g), NEXT(x, g)});
@@ -290,11 +303,10 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
             if (NEXT(b, 0) == a) std::swap(a, b);
             if (NEXT(a, 0) != b) continue;
             if (!mergeable(a, b)) continue;
-            heap.erase({weight[(size_t)a], a}); heap.erase({weight[(size_t)b], b});
-            weight[(size_t)a] += weight[(size_t)b];
+            weight[(size_t)a] += weight[(size_t)b];              // the old entries of a and b are stale from here on
             for (int g = 0; g < N; g++) unlink(b, g);
             alive[(size_t)b] = 0; merged_into[(size_t)b] = a; alive_cnt--;
-            heap.insert({weight[(size_t)a], a});
+            heap.push_back({weight[(size_t)a], a}); std::push_heap(heap.begin(), heap.end(), cmp);
         }
     }
     const double tl3 = trace ? now_ms() : 0;

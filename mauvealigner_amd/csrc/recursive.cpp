@@ -10,11 +10,51 @@
 #include "common.hpp"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 
 namespace {
 
-inline uint8_t base_at(const std::vector<uint64_t> &w, int64_t i) { return (uint8_t)((w[(size_t)(i >> 5)] >> (2 * (i & 31))) & 3); }
+// Virtual genomes of one recursion batch, built on the device from the resident packed genomes: thread (g, j)
+// writes packed word j of virtual genome g -- 32 bases, each looked up through the segment table (which gap it
+// belongs to) and the gap's source range; reverse gaps are read backwards and complemented.  Pad words are zero.
+struct RecGatherArgs {
+    uint64_t src_word_off[MAUVE_MAX_SEQ];   // genome g's words inside the resident genome buffer
+    uint64_t dst_word_off[MAUVE_MAX_SEQ];   // virtual genome g's words inside rec_genomes
+    uint64_t dst_words[MAUVE_MAX_SEQ];      // including the 3 pad words
+};
+
+__global__ void __launch_bounds__(256) rec_gather(const uint64_t *__restrict__ genomes, uint64_t *__restrict__ out, RecGatherArgs ga,
+                                                  const uint32_t *__restrict__ seg, const int64_t *__restrict__ glo0,
+                                                  const uint8_t *__restrict__ grev, uint32_t K)
+{
+    const int g = blockIdx.y;
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ga.dst_words[g]) return;
+    const uint32_t *sg = seg + (size_t)g * (K + 1);
+    const uint32_t tot = sg[K];
+    const uint64_t base0 = j * 32;
+    uint64_t word = 0;
+    if (base0 < tot) {
+        // last k with sg[k] <= base0: the (non-empty) gap that holds base0
+        uint32_t lo = 0, hi = K;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sg[mid] <= base0) lo = mid; else hi = mid; }
+        uint32_t k = lo;
+        const uint64_t *G = genomes + ga.src_word_off[g];
+        for (int b = 0; b < 32; b++) {
+            const uint64_t p = base0 + b;
+            if (p >= tot) break;
+            while (p >= sg[k + 1]) k++;                       // steps over empty gaps as well
+            const int64_t off = (int64_t)(p - sg[k]), len = (int64_t)(sg[k + 1] - sg[k]), s0 = glo0[(size_t)g * K + k];
+            const bool rev = grev[(size_t)g * K + k] != 0;
+            const int64_t src = rev ? s0 + len - 1 - off : s0 + off;
+            uint64_t code = (G[src >> 5] >> (2 * (src & 31))) & 3ULL;
+            if (rev) code = 3ULL - code;
+            word |= code << (2 * b);
+        }
+    }
+    out[ga.dst_word_off[g] + j] = word;
+}
 
 // A gap waiting for a recursive search: flat record [lcb, prev_w, a(1+N), b(1+N)] in `work`.
 struct WorkList {
@@ -63,6 +103,7 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
 {
     const uint32_t full = N >= 32 ? 0xffffffffu : ((1u << N) - 1);
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    const double t_stage0 = now_ms();
     WorkList work(N);
     for (size_t l = 0; l < chains.size(); l++)
         for (size_t i = 0; i + 1 < chains[l].size(); i++)
@@ -70,6 +111,7 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                 work.push((int64_t)l, w0, chains[l].rec(i), chains[l].rec(i + 1));
     std::vector<MatchVec> found(chains.size(), MatchVec(N));
     int level = 0;
+    if (trace) fprintf(stderr, "[trace] recursion: work list of %zu gaps built in %.3f ms\n", work.size(), now_ms() - t_stage0);
 
     while (work.size()) {
         std::map<int, std::vector<size_t>> classes;     // seed weight -> gaps of this level
@@ -89,42 +131,48 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
             GenomeSet vs; vs.buf = &c->rec_genomes; vs.nseq = N; vs.lens.assign(N, 0); vs.word_off.assign(N, 0);
             std::vector<uint32_t> seg((size_t)N * (K + 1));
             std::vector<int64_t> glo((size_t)N * K), glen((size_t)N * K);
-            std::vector<std::vector<uint64_t>> packed(N);
-            size_t words = 0;
+            std::vector<uint8_t> grev((size_t)N * K);
+            RecGatherArgs ga; memset(&ga, 0, sizeof ga);
+            size_t words = 0; uint64_t max_words = 0;
             for (int g = 0; g < N; g++) {
                 int64_t tot = 0;
                 for (uint32_t k = 0; k < K; k++) {
                     gap_of(work.a(ids[k]), work.b(ids[k]), g, glo[(size_t)g * K + k], glen[(size_t)g * K + k]);
                     seg[(size_t)g * (K + 1) + k] = (uint32_t)tot; tot += glen[(size_t)g * K + k];
+                    grev[(size_t)g * K + k] = work.a(ids[k])[1 + g] > 0 ? 0 : 1;
+                    glo[(size_t)g * K + k] -= 1;                  // 0-based for the gather; restored below
                 }
                 seg[(size_t)g * (K + 1) + K] = (uint32_t)tot;
                 if (tot >= (1LL << 31)) { c->err = "recursive anchoring: gap set too large"; return MAUVE_ERR_LIMIT; }
                 vs.lens[g] = tot;
-                std::vector<uint8_t> codes((size_t)tot + 1);
-                const auto &hw = c->host_packed[gmap ? gmap[g] : g];
-                for (uint32_t k = 0; k < K; k++) {
-                    uint8_t *out = codes.data() + seg[(size_t)g * (K + 1) + k];
-                    const int64_t lo0 = glo[(size_t)g * K + k] - 1, n = glen[(size_t)g * K + k];
-                    if (work.a(ids[k])[1 + g] > 0) for (int64_t i = 0; i < n; i++) out[i] = base_at(hw, lo0 + i);
-                    else for (int64_t i = 0; i < n; i++) out[i] = (uint8_t)(3 - base_at(hw, lo0 + n - 1 - i));
-                }
-                packed[g].assign(mauve_packed_words(tot), 0);
-                mauve_pack_codes(codes.data(), tot, packed[g].data());
-                vs.word_off[g] = words; words += packed[g].size();
+                const size_t nw = mauve_packed_words(tot);
+                vs.word_off[g] = words;
+                ga.src_word_off[g] = c->word_off[gmap ? gmap[g] : g]; ga.dst_word_off[g] = words; ga.dst_words[g] = nw;
+                max_words = std::max<uint64_t>(max_words, nw);
+                words += nw;
             }
             HIPCHK(c, c->rec_genomes.ensure((words + 4) * sizeof(uint64_t)));
-            HIPCHK(c, c->rec_seg.ensure(seg.size() * sizeof(uint32_t)));
-            for (int g = 0; g < N; g++)
-                HIPCHK(c, hipMemcpyAsync(c->rec_genomes.as<uint64_t>() + vs.word_off[g], packed[g].data(),
-                                         packed[g].size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->rec_seg.p, seg.data(), seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));    // packed[] must outlive the copies
+            // one side buffer: segment table, then the 0-based gap starts, then the strand flags
+            const size_t seg_bytes = (seg.size() * sizeof(uint32_t) + 7) & ~(size_t)7, glo_bytes = glo.size() * sizeof(int64_t);
+            HIPCHK(c, c->rec_seg.ensure(seg_bytes + glo_bytes + grev.size() + 8));
+            char *side = c->rec_seg.as<char>();
+            HIPCHK(c, hipMemcpyAsync(side, seg.data(), seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(side + seg_bytes, glo.data(), glo_bytes, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(side + seg_bytes + glo_bytes, grev.data(), grev.size(), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(rec_gather, dim3((uint32_t)((max_words + 255) / 256), (uint32_t)N), dim3(256), 0, c->stream,
+                               c->genomes.as<uint64_t>(), c->rec_genomes.as<uint64_t>(), ga, (const uint32_t *)side,
+                               (const int64_t *)(side + seg_bytes), (const uint8_t *)(side + seg_bytes + glo_bytes), K);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(c->stream));    // the host vectors must outlive the copies
+            for (auto &x : glo) x += 1;                    // back to 1-based for the coordinate mapping below
             int64_t nm = 0;
             int rc = seedpass_run(c, vs, pat, MAUVE_MODE_MEM, full, 1, c->rec_seg.as<uint32_t>(), K, &nm);
             if (rc) return rc;
             if (trace) fprintf(stderr, "[trace] recursion level %d weight %d: %u gaps, %lld bases, %lld matches, %.3f ms\n", level, w, K,
                                (long long)vs.lens[0], (long long)nm, now_ms() - tc0);
             // ---- per-gap chaining of the N-way forward matches ----
+            const double tch0 = now_ms();
+            double t_elim = 0, t_lcb = 0;
             const uint32_t *seg0 = seg.data();
             int64_t i = 0;
             while (i < nm) {
@@ -143,10 +191,13 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                     i++;
                 }
                 if (loc.empty()) continue;
+                const double te0 = trace ? now_ms() : 0;
                 ChainOrders orders;
                 host_eliminate_overlaps(loc, &orders);
+                const double te1 = trace ? now_ms() : 0;
                 std::vector<int64_t> ml; int64_t nl = 0;
                 host_lcb_chain(loc, 0, true, ml, nl, &orders);
+                if (trace) { t_elim += te1 - te0; t_lcb += now_ms() - te1; }
                 const size_t wi = ids[k];
                 const int64_t *A = work.a(wi);
                 MatchVec glob(N);
@@ -167,13 +218,16 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                     next.push(lcb, w, q == 0 ? work.a(wi) : glob.rec(q - 1), q == glob.size() ? work.b(wi) : glob.rec(q));
                 for (size_t q = 0; q < glob.size(); q++) found[(size_t)lcb].push(glob.rec(q));
             }
+            if (trace) fprintf(stderr, "[trace]   per-gap chaining %.3f ms (eliminate %.3f, lcb %.3f)\n", now_ms() - tch0, t_elim, t_lcb);
         }
         work.d.swap(next.d);
     }
+    const double tm0 = now_ms();
     for (size_t l = 0; l < chains.size(); l++) {
         if (found[l].empty()) continue;
         chains[l].d.insert(chains[l].d.end(), found[l].d.begin(), found[l].d.end());
         chains[l].sort_by_start0();
     }
+    if (trace) fprintf(stderr, "[trace] recursion: merge into chains %.3f ms, whole stage %.3f ms\n", now_ms() - tm0, now_ms() - t_stage0);
     return MAUVE_OK;
 }
