@@ -172,8 +172,8 @@ struct mauve_ctx {
 
     // host scratch of dp_core, kept across calls (see AlignState)
     struct DpHost {
-        std::vector<int64_t> tb_off, rows_off, est, need, nmax, lst, seq_off;
-        std::vector<uint8_t> is_big, meta;
+        std::vector<int64_t> tb_off, rows_off, est, need, nmax, lst, lst2, seq_off;
+        std::vector<uint8_t> is_big, cls, meta;
     } dph;
     // host scratch of the seed pass (match records before the canonical sort)
     struct SeedHost {

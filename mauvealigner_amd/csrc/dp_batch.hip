@@ -22,7 +22,7 @@
 
 #define DP_NEG_INF (-(1 << 29))
 constexpr int DP_LDS_TB = 12288;
-constexpr int DP_LDS_OPS = 256;
+constexpr int DP_LDS_OPS = 768;            // 4 groups x 192 reversed ops (dp_groups); >= 256 for the one-wave path
 
 struct DpMeta {
     int32_t m;        // current profile length
@@ -265,6 +265,151 @@ __device__ void dp_interval_mw(int nseq, int64_t iv, const uint8_t *__restrict__
 }
 
 
+// ---- small intervals: several per wave -------------------------------------------------------------------------
+// Most inter-anchor intervals of a closely related genome set are a handful of bases: a profile of m <= 16 rows
+// keeps 48 of a wave's 64 lanes idle in dp_step.  Here a wave is cut into 64/G groups of G lanes (G = 16 or 32) and
+// every group runs its own interval through the same systolic recurrence: the DPP wave shift still moves
+// (i-1, .) down the whole wave and each group's first lane overrides what it received with its own boundary row
+// (always the analytic first row: one stripe); the group leader's next base comes from the group's preloaded
+// chunk by ds_bpermute; traceback bytes and reversed ops live in the wave's LDS slice, cut per group; the
+// traceback walks are run by the group leaders side by side.  The step loop runs to the longest group of the wave
+// (the list is sorted by size, so neighbours are alike).  Same recurrences and tie rules as dp_stripe_round.
+constexpr int DP_GRP_TMAX = DP_LDS_TB / 64;        // 192 systolic steps, and m + n <= 192 ops, per group
+
+__device__ __forceinline__ int32_t lane_read(int32_t v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+
+template <int G>
+__device__ void dp_groups(int nseq, const int64_t *__restrict__ list, int64_t first, int64_t count, int64_t wave_index, int64_t nwaves,
+                          const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
+                          uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA, uint32_t *__restrict__ cntB,
+                          uint32_t *__restrict__ maskB, uint8_t *s_tb_wave, uint8_t *s_ops_wave, const DpScoring &sc)
+{
+    constexpr int GROUPS = 64 / G;
+    constexpr uint64_t GMASK = G == 32 ? 0xffffffffULL : 0xffffULL;
+    const int lane = threadIdx.x & 63, ql = lane & (G - 1), q = lane / G, gbase = lane & ~(G - 1);
+    const bool leader = ql == 0;
+    const uint32_t below = (1u << ql) - 1u;                       // ql <= 31
+    uint8_t *tbq = s_tb_wave + q * (DP_GRP_TMAX * G);
+    uint8_t *opq = s_ops_wave + q * DP_GRP_TMAX;
+    for (int64_t li0 = wave_index * GROUPS; li0 < count; li0 += nwaves * GROUPS) {
+        const bool have = li0 + q < count;
+        const int64_t iv = have ? list[first + li0 + q] : 0;
+        DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
+        const int64_t base = have ? seq_off[iv * nseq] : 0;
+        for (int g = 0; g < nseq; g++) {
+            int64_t so = 0; int32_t n = 0;
+            if (have) { so = seq_off[iv * nseq + g]; n = (int32_t)(seq_off[iv * nseq + g + 1] - so); }
+            const uint8_t *seq = codes + so;
+            uint32_t *Pc = (mt.cur ? cntB : cntA) + base, *Pm = (mt.cur ? maskB : maskA) + base;
+            uint32_t *Qc = (mt.cur ? cntA : cntB) + base, *Qm = (mt.cur ? maskA : maskB) + base;
+            const bool init = n > 0 && mt.krows == 0, step = n > 0 && mt.krows > 0;
+            if (init) for (int32_t c = ql; c < n; c += G) { Pc[c] = 1u << (8 * seq[c]); Pm[c] = 1u << g; }
+            if (__ballot(step)) {
+                const int32_t m = step ? mt.m : 0, nn = step ? n : 0;
+                const int32_t i = ql + 1;
+                const bool active = i <= m;
+                const uint32_t cn = active ? Pc[i - 1] : 0u;
+                const int32_t c0 = cn & 255, c1 = (cn >> 8) & 255, c2 = (cn >> 16) & 255, c3 = cn >> 24;
+                const int32_t r = c0 + c1 + c2 + c3;
+                const int32_t sub0 = c0 * sc.s[0][0] + c1 * sc.s[1][0] + c2 * sc.s[2][0] + c3 * sc.s[3][0];
+                const int32_t sub1 = c0 * sc.s[0][1] + c1 * sc.s[1][1] + c2 * sc.s[2][1] + c3 * sc.s[3][1];
+                const int32_t sub2 = c0 * sc.s[0][2] + c1 * sc.s[1][2] + c2 * sc.s[2][2] + c3 * sc.s[3][2];
+                const int32_t sub3 = c0 * sc.s[0][3] + c1 * sc.s[1][3] + c2 * sc.s[2][3] + c3 * sc.s[3][3];
+                const int32_t gxo = sc.go * r, gxe = sc.ge * r, gyo = sc.go * mt.krows, gye = sc.ge * mt.krows;
+                const int32_t steps = step ? nn + m : 0;                   // t = 0 .. n + m - 1
+                int32_t tmax = 0;
+#pragma unroll
+                for (int k = 0; k < GROUPS; k++) tmax = max(tmax, __builtin_amdgcn_readlane(steps, k * G));
+                int32_t Mc = DP_NEG_INF, Xc = DP_NEG_INF, Yc = DP_NEG_INF, Md = DP_NEG_INF, Xd = DP_NEG_INF, Yd = DP_NEG_INF;
+                int32_t fM = DP_NEG_INF, fX = DP_NEG_INF, fY = DP_NEG_INF;
+                uint32_t bcur = 0;
+                // chunk k of the group's sequence: lane ql holds base k*G - 1 + ql (column t = k*G + ql reads base t-1)
+                auto chunk = [&](int32_t k) -> uint32_t { return nn > 0 ? (uint32_t)seq[min(max(k * G - 1 + ql, 0), nn - 1)] : 0u; };
+                uint32_t sq_cur = chunk(0), sq_nxt = chunk(1);
+                for (int32_t t = 0; t < tmax; t++) {
+                    if (t > 0 && (t & (G - 1)) == 0) { sq_cur = sq_nxt; sq_nxt = chunk(t / G + 1); }
+                    const int32_t j = t - ql;
+                    int32_t Mu = wave_shr1(Mc), Xu = wave_shr1(Xc), Yu = wave_shr1(Yc);
+                    uint32_t bnext = (uint32_t)wave_shr1((int32_t)bcur);
+                    const uint32_t b0 = (uint32_t)lane_read((int32_t)sq_cur, gbase + (t & (G - 1)));
+                    const int32_t M0 = t == 0 ? 0 : DP_NEG_INF, Y0 = t == 0 ? DP_NEG_INF : gyo + (t - 1) * gye;
+                    Mu = leader ? M0 : Mu; Xu = leader ? DP_NEG_INF : Xu; Yu = leader ? Y0 : Yu; bnext = leader ? b0 : bnext;
+                    bcur = bnext;
+                    const bool on = active && (uint32_t)j <= (uint32_t)nn, j1 = j >= 1;
+                    int32_t best; uint32_t pm, px, py;
+                    max3(Md, Xd, Yd, best, pm);
+                    const int32_t sa = (bnext & 1) ? sub1 : sub0, sb = (bnext & 1) ? sub3 : sub2;
+                    int32_t Mn = max(best + ((bnext & 2) ? sb : sa), DP_NEG_INF);
+                    max3(Mu + gxo, Xu + gxe, Yu + gxo, best, px);
+                    const int32_t Xn = max(best, DP_NEG_INF);
+                    max3(Mc + gyo, Xc + gyo, Yc + gye, best, py);
+                    int32_t Yn = max(best, DP_NEG_INF);
+                    Mn = j1 ? Mn : DP_NEG_INF; Yn = j1 ? Yn : DP_NEG_INF; pm = j1 ? pm : 0u; py = j1 ? py : 0u;
+                    if (on) {
+                        Mc = Mn; Xc = Xn; Yc = Yn;
+                        tbq[t * G + ql] = (uint8_t)(pm | (px << 2) | (py << 4));
+                        if (i == m && j == nn) { fM = Mn; fX = Xn; fY = Yn; }
+                    }
+                    Md = Mu; Xd = Xu; Yd = Yu;
+                }
+                __threadfence_block();                       // traceback bytes: written by the lanes, read by the leader
+                const int owner = gbase + max(m, 1) - 1;
+                fM = lane_read(fM, owner); fX = lane_read(fX, owner); fY = lane_read(fY, owner);
+                int32_t best = fM; int state = 0;
+                if (fX > best) { best = fX; state = 1; }
+                if (fY > best) { best = fY; state = 2; }
+                // ---- traceback: the group leaders walk side by side ----
+                int32_t len = 0;
+                if (leader && step) {
+                    int32_t ti = m, tj = nn;
+                    while (ti > 0 || tj > 0) {
+                        uint32_t op, nstate;
+                        if (ti == 0) { op = 2; nstate = (tj == 1) ? 0 : 2; }
+                        else {
+                            const int32_t l = ti - 1;
+                            const uint8_t bt = tbq[(tj + l) * G + l];
+                            if (state == 0) { op = 3; nstate = bt & 3; }
+                            else if (state == 1) { op = 1; nstate = (bt >> 2) & 3; }
+                            else { op = 2; nstate = (bt >> 4) & 3; }
+                        }
+                        opq[len] = (uint8_t)op;
+                        len++;
+                        if (op & 1) ti--;
+                        if (op & 2) tj--;
+                        state = (int)nstate;
+                    }
+                }
+                __threadfence_block();
+                len = lane_read(len, gbase);
+                int32_t maxlen = 0;
+#pragma unroll
+                for (int k = 0; k < GROUPS; k++) maxlen = max(maxlen, __builtin_amdgcn_readlane(len, k * G));
+                // ---- new profile in forward order, per group ----
+                int32_t carry_p = 0, carry_s = 0;
+                for (int32_t c0i = 0; c0i < maxlen; c0i += G) {
+                    const int32_t c = c0i + ql;
+                    const bool ok = step && c < len;
+                    const uint32_t op = ok ? opq[len - 1 - c] : 0u;
+                    const uint64_t bp = __ballot(ok && (op & 1)), bs = __ballot(ok && (op & 2));
+                    const uint32_t gp = (uint32_t)((bp >> gbase) & GMASK), gs = (uint32_t)((bs >> gbase) & GMASK);
+                    if (ok) {
+                        const int32_t pi = carry_p + (int32_t)__popc(gp & below), sj = carry_s + (int32_t)__popc(gs & below);
+                        uint32_t cv = 0, mv = 0;
+                        if (op & 1) { cv = Pc[pi]; mv = Pm[pi]; }
+                        if (op & 2) { cv += 1u << (8 * seq[sj]); mv |= 1u << g; }
+                        Qc[c] = cv; Qm[c] = mv;
+                    }
+                    carry_p += (int32_t)__popc(gp); carry_s += (int32_t)__popc(gs);
+                }
+                if (step) { mt.cells += (int64_t)m * nn; mt.score += best; mt.m = len; mt.krows += 1; mt.cur ^= 1; }
+            }
+            if (init) { mt.m = n; mt.krows = 1; }
+            __threadfence_block();       // profiles written by some lanes are read by others in the next step
+        }
+        if (have && leader) meta[iv] = mt;
+    }
+}
+
 __global__ void __launch_bounds__(64 * DP_MW_WAVES) dp_step_big(int nseq, const int64_t *__restrict__ list, const uint8_t *__restrict__ codes,
                                                const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
                                                uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
@@ -276,7 +421,9 @@ __global__ void __launch_bounds__(64 * DP_MW_WAVES) dp_step_big(int nseq, const 
     dp_interval_mw(nseq, list[blockIdx.x], codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, sc);
 }
 
-__global__ void __launch_bounds__(256) dp_step(int nseq, const int64_t *__restrict__ list, int64_t n_iv, int n_big, const uint8_t *__restrict__ codes,
+struct DpClasses { int64_t first_med, n_med, first_s32, n_s32, first_s16, n_s16; uint32_t blocks_med, blocks_s32; };
+
+__global__ void __launch_bounds__(256) dp_step(int nseq, const int64_t *__restrict__ list, DpClasses cl, const uint8_t *__restrict__ codes,
                                                const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
                                                uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
                                                uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
@@ -288,13 +435,23 @@ __global__ void __launch_bounds__(256) dp_step(int nseq, const int64_t *__restri
     // walk is a chain of dependent 1-byte loads, ~100 cycles each from LDS against >1000 from L2/HBM.
     __shared__ uint8_t s_tb[4][DP_LDS_TB];
     __shared__ uint8_t s_ops[4][DP_LDS_OPS];
-    // the first n_big entries of the list belong to dp_step_big
+    // The list is [dp_step_big's entries | one-wave | two per wave (m <= 32) | four per wave (m <= 16)], each class
+    // largest first; the block ranges follow the same order so the long ones start first.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (blockIdx.x >= cl.blocks_med) {
+        const bool s32 = blockIdx.x < cl.blocks_med + cl.blocks_s32;
+        const uint32_t b0 = s32 ? cl.blocks_med : cl.blocks_med + cl.blocks_s32;
+        const uint32_t nb = s32 ? cl.blocks_s32 : gridDim.x - cl.blocks_med - cl.blocks_s32;
+        const int64_t widx = (int64_t)(blockIdx.x - b0) * 4 + wv, nw = (int64_t)nb * 4;
+        if (s32) dp_groups<32>(nseq, list, cl.first_s32, cl.n_s32, widx, nw, codes, seq_off, meta, cntA, maskA, cntB, maskB, s_tb[wv], s_ops[wv], sc);
+        else dp_groups<16>(nseq, list, cl.first_s16, cl.n_s16, widx, nw, codes, seq_off, meta, cntA, maskA, cntB, maskB, s_tb[wv], s_ops[wv], sc);
+        return;
+    }
     const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t nwaves = ((int64_t)cl.blocks_med * blockDim.x) >> 6;
     const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
 
-    for (int64_t li = n_big + wave_global; li < n_iv; li += nwaves) {
+    for (int64_t li = cl.first_med + wave_global; li < cl.first_med + cl.n_med; li += nwaves) {
       const int64_t iv = list[li];
       // all progressive steps of one interval run back to back in this wave (they only depend on each other)
       DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
@@ -436,13 +593,15 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     is_big.assign((size_t)n_iv, 0); est.assign((size_t)n_iv, 0);
     int64_t est_total = 0;
     static const bool no_mw = getenv("MAUVE_DP_ONE_WAVE") != nullptr;     // A/B switch for the workgroup path
+    static const bool no_groups = getenv("MAUVE_DP_NO_GROUPS") != nullptr; // A/B switch for the sub-wave path
+    std::vector<uint8_t> &cls = H.cls; cls.assign((size_t)n_iv, 1);
     int64_t tbt = 0, rwt = 0;
     // per-interval figures on the host helpers, then one sequential prefix
     std::vector<int64_t> &need_v = H.need, &nmax_v = H.nmax;
     need_v.resize((size_t)n_iv); nmax_v.resize((size_t)n_iv);
     ctx->pool->parallel_for(n_iv, 2048, [&](int64_t b, int64_t e) {
         for (int64_t iv = b; iv < e; iv++) {
-            int64_t mmax = 0, need = 0, nmax = 0, es = 0; bool first = true; uint8_t big = 0;
+            int64_t mmax = 0, need = 0, nmax = 0, es = 0, mbound = 0, steps_max = 0; bool first = true; uint8_t big = 0;
             for (int g = 0; g < nseq; g++) {
                 const int64_t n = seq_off[iv * nseq + g + 1] - seq_off[iv * nseq + g];
                 if (n == 0) continue;
@@ -452,9 +611,14 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
                 // a step with >= 3 stripes against >= 256 columns pipelines over several waves
                 if (mmax > 128 && n >= 256 && !no_mw) big = 1;
                 es += ((mmax + 63) / 64) * (n + 64);                   // systolic steps of a single wave
+                mbound = std::max(mbound, mmax); steps_max = std::max(steps_max, mmax + n);
                 mmax += n;
             }
             need_v[(size_t)iv] = need; nmax_v[(size_t)iv] = nmax; est[(size_t)iv] = es; is_big[(size_t)iv] = big;
+            // sub-wave classes: every profile the interval will see fits G rows, every step fits the LDS slice
+            uint8_t k = 1;
+            if (!no_groups && steps_max <= DP_GRP_TMAX) k = mbound <= 16 ? 3 : (mbound <= 32 ? 2 : 1);
+            cls[(size_t)iv] = k;
         }
     });
     for (int64_t iv = 0; iv < n_iv; iv++) {
@@ -517,9 +681,22 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
             n_big += b;
         }
     }
-    if (n_big) std::stable_partition(lst.begin(), lst.end(), [&](int64_t iv) { return is_big[(size_t)iv] != 0; });
-    const int64_t n_small = n_iv - n_big;
-    const uint32_t blocks = (uint32_t)std::min<int64_t>((n_small + 3) / 4, 256 * 8);
+    // list = [workgroup path | one wave | two per wave | four per wave], each class still largest first
+    DpClasses cl; memset(&cl, 0, sizeof cl);
+    {
+        std::vector<int64_t> &tmp = H.lst2; tmp.resize((size_t)n_iv);
+        int64_t cnt4[4] = {0, 0, 0, 0};
+        auto klass = [&](int64_t iv) { return is_big[(size_t)iv] ? 0 : (int)cls[(size_t)iv]; };
+        for (int64_t k = 0; k < n_iv; k++) cnt4[klass(lst[(size_t)k])]++;
+        int64_t pos[4] = {0, cnt4[0], cnt4[0] + cnt4[1], cnt4[0] + cnt4[1] + cnt4[2]};
+        cl.first_med = pos[1]; cl.n_med = cnt4[1]; cl.first_s32 = pos[2]; cl.n_s32 = cnt4[2]; cl.first_s16 = pos[3]; cl.n_s16 = cnt4[3];
+        for (int64_t k = 0; k < n_iv; k++) { const int64_t iv = lst[(size_t)k]; tmp[(size_t)pos[klass(iv)]++] = iv; }
+        lst.swap(tmp);
+    }
+    cl.blocks_med = (uint32_t)std::min<int64_t>((cl.n_med + 3) / 4, 256 * 8);
+    cl.blocks_s32 = (uint32_t)std::min<int64_t>((cl.n_s32 + 7) / 8, 256 * 8);
+    const uint32_t blocks_s16 = (uint32_t)std::min<int64_t>((cl.n_s16 + 15) / 16, 256 * 8);
+    const uint32_t blocks = cl.blocks_med + cl.blocks_s32 + blocks_s16;
     HIPCHK(ctx, ctx->dp_list.ensure((size_t)n_iv * 8));
     HIPCHK(ctx, hipMemcpyAsync(ctx->dp_list.p, lst.data(), (size_t)n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
     {
@@ -534,8 +711,8 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
                                d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
             HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
         }
-        if (n_small)
-            hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, nseq, ctx->dp_list.as<int64_t>(), n_iv, (int)n_big,
+        if (blocks)
+            hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, nseq, ctx->dp_list.as<int64_t>(), cl,
                                ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
                                ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
                                ctx->dp_prof2_mask.as<uint32_t>(), ctx->dp_tb.as<uint8_t>(), d_tb_off, ctx->dp_rows.as<int32_t>(),
@@ -549,13 +726,13 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     HIPCHK(ctx, hipMemcpyAsync(hm, ctx->dp_meta.p, (size_t)n_iv * sizeof(DpMeta), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const double td3 = now_ms();
-    int64_t tc = 0, cl = 0;
+    int64_t tc = 0, ncell = 0;
     for (int64_t iv = 0; iv < n_iv; iv++) {
-        col_off[iv] = tc; tc += hm[iv].m; cl += hm[iv].cells;
+        col_off[iv] = tc; tc += hm[iv].m; ncell += hm[iv].cells;
         if (score) score[iv] = hm[iv].score;
     }
     col_off[n_iv] = tc;
-    if (cells) *cells = cl;
+    if (cells) *cells = ncell;
     if (tc) {
         HIPCHK(ctx, hipMemcpyAsync(d_col_off, col_off, (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
         const uint32_t gblocks = (uint32_t)std::min<int64_t>((n_iv + 3) / 4, 256 * 8);
@@ -568,8 +745,8 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     }
     if (trace) {
         std::vector<int64_t> e2(est); std::sort(e2.begin(), e2.end(), std::greater<int64_t>());
-        fprintf(stderr, "[trace] dp_core: %lld intervals, %lld on the workgroup path, single-wave steps: total %lld (balanced %lld), top", (long long)n_iv,
-                (long long)n_big, (long long)est_total, (long long)(est_total / 3072));
+        fprintf(stderr, "[trace] dp_core: %lld intervals: %lld workgroup, %lld one-wave, %lld two/wave, %lld four/wave; single-wave steps: total %lld (balanced %lld), top", (long long)n_iv,
+                (long long)n_big, (long long)cl.n_med, (long long)cl.n_s32, (long long)cl.n_s16, (long long)est_total, (long long)(est_total / 3072));
         for (size_t i = 0; i < e2.size() && i < 8; i++) fprintf(stderr, " %lld", (long long)e2[i]);
         fprintf(stderr, "\n");
     }

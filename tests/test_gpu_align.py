@@ -111,6 +111,32 @@ def test_dp_workgroup_pipeline(ctx):
     _check_dp(ctx, [_rand_interval(rng, 3, 1200, 0.2, 0.0)] + [_rand_interval(rng, 3, 30, 0.1, 0.0) for _ in range(50)])
 
 
+def test_dp_subwave_groups(ctx):
+    """Small intervals share a wave (four per wave when every profile fits 16 rows, two when it fits 32): boundary
+    sizes of the classes, unequal neighbours in one wave, empty members (a different first sequence per group), a
+    count that does not fill the last wave, and long second sequences up to the LDS slice."""
+    rng = np.random.default_rng(11)
+    def iv(lens, div=0.2):
+        base = rng.integers(0, 4, max(max(lens), 1), dtype=np.uint8)
+        out = []
+        for L in lens:
+            if L == 0:
+                out.append(np.zeros(0, np.uint8)); continue
+            x = synth.mutate(base, div, rng, indel_frac=0.3)[:L]
+            if len(x) < L:
+                x = np.concatenate([x, rng.integers(0, 4, L - len(x), dtype=np.uint8)])
+            out.append(x)
+        return out
+    two = [iv(l) for l in ([16, 16], [17, 3], [16, 176], [15, 177], [32, 160], [33, 100], [1, 1], [2, 190], [190, 2],
+                           [31, 161], [8, 8], [16, 1], [1, 16], [5, 0], [0, 7], [12, 13], [3, 150], [9, 9], [4, 4])]
+    _check_dp(ctx, two)
+    three = [iv(l) for l in ([5, 6, 4], [8, 8, 8], [9, 8, 30], [0, 7, 9], [7, 0, 9], [7, 9, 0], [0, 0, 5], [16, 0, 100],
+                             [10, 7, 170], [16, 16, 16], [2, 2, 2], [1, 40, 1], [20, 12, 150], [6, 6, 180])]
+    _check_dp(ctx, three)
+    many = [iv([int(rng.integers(0, 12)) for _ in range(5)], div=0.1) for _ in range(403)]
+    _check_dp(ctx, many)
+
+
 def _same_align(ctx, gs, **kw):
     from mauvealigner_amd import _lib
     ctx.set_genomes(gs)
