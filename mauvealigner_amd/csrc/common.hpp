@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <string>
 #include <vector>
+#include <functional>
 #include "workers.hpp"
 #include <chrono>
 #include <algorithm>
@@ -113,6 +114,7 @@ struct AlignState {
     struct GapRef { int64_t lcb, idx; bool dp; int64_t dp_slot; int64_t tot; };
     struct Item { int64_t lcb; uint32_t idx; int64_t col0; int64_t gap; };
     bool open = false;
+    bool anchor_table_done = false;     // anchor_length/start/lcb already filled (in the DP kernel's shadow)
     mauve_params p{};
     int N = 0; uint32_t full = 0;
     int64_t sum = 0, nm = 0, nl = 0, n_dp = 0, code_total = 0, n_anchor = 0, anchor_cols = 0;
@@ -129,7 +131,7 @@ struct AlignState {
     // start a new alignment: scalars to zero, vectors emptied but not released
     void reset()
     {
-        open = false; p = mauve_params(); N = 0; full = 0;
+        open = false; anchor_table_done = false; p = mauve_params(); N = 0; full = 0;
         sum = nm = nl = n_dp = code_total = n_anchor = anchor_cols = 0; t0 = t_dp0 = 0;
         gaps.clear(); desc.clear(); dcols.clear(); dcol_off.clear(); dscore.clear();
         match_lcb.clear(); items.clear();
@@ -181,6 +183,10 @@ struct mauve_ctx {
         std::vector<uint32_t> order, tmp;
         std::vector<uint64_t> k1;
     } sdh;
+
+    // host work that does not depend on the seed pass, run by the seed pass right before its first wait on the
+    // stream (extract, sort, join and run detection are in flight by then); one shot
+    std::function<void()> shadow;
 
     SpinPool *pool = nullptr;            // host helpers, armed for the duration of an align call (workers.hpp)
 

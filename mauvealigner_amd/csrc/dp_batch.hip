@@ -720,6 +720,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
         if (n_big) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     HIPCHK(ctx, hipGetLastError());
+    if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // host work while the DP kernels run
     H.meta.resize((size_t)n_iv * sizeof(DpMeta));
     DpMeta *hm = reinterpret_cast<DpMeta *>(H.meta.data());
     const double td2 = now_ms();

@@ -58,8 +58,18 @@ static int align_begin(mauve_ctx *c, const mauve_params *p)
     S.full = full;
 
     // ---- seed pass: N-way multi-MUMs (the multiplicity filter is pushed into the join) ----
+    // In its shadow (the host would otherwise wait for the kernels): bring the column buffer back to the
+    // "all anchors" state, i.e. undo the gap ranges the previous call wrote (see align_finish).
+    static const bool no_shadow = getenv("MAUVE_NO_SHADOW") != nullptr;        // A/B switch
+    if (R.cols_fill == full && !R.cols_dirty.empty() && !no_shadow)
+        c->shadow = [c, full]() {
+            AlignResult &Rr = c->res;
+            for (const auto &d : Rr.cols_dirty) std::fill(Rr.cols.begin() + d.first, Rr.cols.begin() + d.first + d.second, full);
+            Rr.cols_dirty.clear();
+        };
     int64_t nm = 0;
     int rc = seedpass_run(c, main_genome_set(c), pat, p->mode, full, 1, nullptr, 0, &nm);
+    c->shadow = nullptr;
     if (rc) return rc;
     S.nm = nm;
     R.mum_length = c->match_len; R.mum_start = c->match_start;
@@ -148,6 +158,23 @@ static int align_dp(mauve_ctx *c, const int64_t *idx, int64_t n, uint32_t *cols,
     return dp_batch_run_desc(c, N, n, sub.data(), &S.p.scoring, cols, col_off, score, cells);
 }
 
+// anchor_length / anchor_start / anchor_lcb of the result: depends on the chains only
+static void fill_anchor_table(mauve_ctx *c)
+{
+    AlignState &S = c->ast; AlignResult &R = c->res;
+    const int N = S.N;
+    R.anchor_length.resize((size_t)S.n_anchor); R.anchor_start.resize((size_t)S.n_anchor * N); R.anchor_lcb.resize((size_t)S.n_anchor);
+    size_t a = 0;
+    for (int64_t l = 0; l < S.nl; l++) {
+        const MatchVec &ch = S.chains[(size_t)l];
+        for (size_t i = 0; i < ch.size(); i++, a++) {
+            R.anchor_length[a] = ch.len(i); R.anchor_lcb[a] = l;
+            std::copy(ch.st(i), ch.st(i) + N, &R.anchor_start[a * N]);
+        }
+    }
+    S.anchor_table_done = true;
+}
+
 static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol_off, const int64_t *dscore, int64_t cells,
                         mauve_align_sizes *sizes)
 {
@@ -218,7 +245,7 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
         R.cols_dirty.clear();
     }
     const double ta2 = now_ms();
-    R.anchor_length.resize((size_t)S.n_anchor); R.anchor_start.resize((size_t)S.n_anchor * N); R.anchor_lcb.resize((size_t)S.n_anchor);
+    if (!S.anchor_table_done) fill_anchor_table(c);
     // pass 2: every anchor writes its record and the stretch that follows it (independent writes, run on the host
     // helpers).  Dirty ranges: one slot per anchor, length 0 where no gap follows.
     {
@@ -228,9 +255,7 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
             for (int64_t a = ab; a < ae; a++) {
                 const Item &it = items[(size_t)a];
                 const MatchVec &ch = chains[(size_t)it.lcb];
-                const int64_t alen = ch.len(it.idx); const int64_t *ast = ch.st(it.idx);
-                R.anchor_length[(size_t)a] = alen; R.anchor_lcb[(size_t)a] = it.lcb;
-                std::copy(ast, ast + N, &R.anchor_start[(size_t)a * N]);
+                const int64_t alen = ch.len(it.idx);
                 uint32_t *o = out + it.col0 + alen;            // the anchor's own columns already hold `full`
                 if (it.gap >= 0) {
                     const AlignState::GapRef &gr = S.gaps[(size_t)it.gap];
@@ -302,7 +327,10 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     S.dcols.resize((size_t)S.code_total + 1);
     S.dcol_off.assign((size_t)S.n_dp + 1, 0); S.dscore.assign((size_t)S.n_dp + 1, 0);
     int64_t cells = 0;
+    static const bool no_shadow = getenv("MAUVE_NO_SHADOW") != nullptr;
+    if (!no_shadow && S.n_dp) c->shadow = [c]() { fill_anchor_table(c); };       // runs while the DP kernels do
     rc = align_dp(c, nullptr, S.n_dp, S.dcols.data(), S.dcol_off.data(), S.dscore.data(), &cells);
+    c->shadow = nullptr;
     if (rc) return rc;
     return align_finish(c, S.dcols.data(), S.dcol_off.data(), S.dscore.data(), cells, sizes);
 }

@@ -823,6 +823,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
                              nseg); }
         HIPCHK(ctx, hipGetLastError());
         uint32_t hc[4] = {0, 0, 0, 0};
+        if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // the kernels above are still running
         HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t nc = hc[1];
