@@ -114,13 +114,17 @@ void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders)
     if (S.cf.size() < n) { S.cf.assign(n, 0); S.cl.assign(n, 0); }     // all-zero between passes
     S.ordg.resize((size_t)N);
     std::vector<Ent> &ents = S.ents;
+    double t_build = 0, t_ord = 0;
+    if (trace) fprintf(stderr, "[trace] eliminate setup %.3f ms\n", now_ms() - te0);
     for (int g = 0; g < N; g++) {
+        const double tb0 = trace ? now_ms() : 0;
         ents.clear();
         for (size_t i = 0; i < n; i++) {
             if (!S.alive[i]) continue;
             const int64_t s = m.st(i)[g];
             ents.push_back({(uint32_t)std::llabs(s), (uint32_t)m.len(i), (uint32_t)i, s > 0 ? 1u : 0u});
         }
+        if (trace) t_build += now_ms() - tb0;
         for (int pass = 0;; pass++) {
             const double tp0 = trace ? now_ms() : 0;
             sort_ents(ents, S.tmp, pass > 0);
@@ -165,10 +169,13 @@ void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders)
                 ents.resize(w);
             }
         }
+        const double to0 = trace ? now_ms() : 0;
         std::vector<uint32_t> &og = S.ordg[(size_t)g];
         og.resize(ents.size());
         for (size_t r = 0; r < ents.size(); r++) og[r] = ents[r].idx;
+        if (trace) t_ord += now_ms() - to0;
     }
+    if (trace) fprintf(stderr, "[trace] eliminate: entry build %.3f ms, order copies %.3f\n", t_build, t_ord);
     const double te1 = trace ? now_ms() : 0;
     S.newidx.resize(n);
     size_t k = 0;

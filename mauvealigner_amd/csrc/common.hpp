@@ -39,6 +39,24 @@ struct DevBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Page-locked host buffer: the destination of the larger device-to-host copies (a pageable destination goes
+// through the runtime's staging buffers at a fraction of the link rate).  Grows, never shrinks; owned by the ctx.
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipHostFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 // Seed pattern decomposed into runs of contiguous care positions (kernel argument, by value).
 // K' ("digit-reversed forward mer"): care offset t_j contributes code << 2j, so that
 //   reverse-complement mer = ~K' (masked) and forward mer = digit_reverse(K').
@@ -122,7 +140,7 @@ struct AlignState {
     std::vector<MatchVec> chains;
     std::vector<GapRef> gaps;
     std::vector<DpSeqDesc> desc;
-    std::vector<uint32_t> dcols; std::vector<int64_t> dcol_off, dscore;
+    std::vector<int64_t> dcol_off, dscore;       // DP columns of mauve_align land in ctx->pin_dcols
     // scratch of the host stages; like everything above it keeps its capacity from call to call -- a fresh
     // megabyte-sized vector per stage and call costs more in page faults than the stage itself
     MatchVec m;
@@ -133,7 +151,7 @@ struct AlignState {
     {
         open = false; anchor_table_done = false; p = mauve_params(); N = 0; full = 0;
         sum = nm = nl = n_dp = code_total = n_anchor = anchor_cols = 0; t0 = t_dp0 = 0;
-        gaps.clear(); desc.clear(); dcols.clear(); dcol_off.clear(); dscore.clear();
+        gaps.clear(); desc.clear(); dcol_off.clear(); dscore.clear();
         match_lcb.clear(); items.clear();
     }
 };
@@ -172,10 +190,12 @@ struct mauve_ctx {
     int64_t k_launch[MAUVE_K_COUNT] = {0};
     int64_t k_units[MAUVE_K_COUNT] = {0};
 
+    PinnedBuf pin_dcols;                 // DP columns of the whole-call path (mauve_align, mauve_progressive_align)
+    PinnedBuf pin_meta;                  // per-interval DP results (length, score, cells)
     // host scratch of dp_core, kept across calls (see AlignState)
     struct DpHost {
         std::vector<int64_t> tb_off, rows_off, est, need, nmax, lst, lst2, seq_off;
-        std::vector<uint8_t> is_big, cls, meta;
+        std::vector<uint8_t> is_big, cls;
     } dph;
     // host scratch of the seed pass (match records before the canonical sort)
     struct SeedHost {

@@ -721,8 +721,8 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // host work while the DP kernels run
-    H.meta.resize((size_t)n_iv * sizeof(DpMeta));
-    DpMeta *hm = reinterpret_cast<DpMeta *>(H.meta.data());
+    HIPCHK(ctx, ctx->pin_meta.ensure((size_t)n_iv * sizeof(DpMeta)));
+    DpMeta *hm = ctx->pin_meta.as<DpMeta>();
     const double td2 = now_ms();
     HIPCHK(ctx, hipMemcpyAsync(hm, ctx->dp_meta.p, (size_t)n_iv * sizeof(DpMeta), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -324,15 +324,16 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     int rc = align_begin(c, p);
     if (rc) return rc;
     AlignState &S = c->ast;
-    S.dcols.resize((size_t)S.code_total + 1);
+    HIPCHK(c, c->pin_dcols.ensure(((size_t)S.code_total + 1) * sizeof(uint32_t)));
+    uint32_t *dcols = c->pin_dcols.as<uint32_t>();
     S.dcol_off.assign((size_t)S.n_dp + 1, 0); S.dscore.assign((size_t)S.n_dp + 1, 0);
     int64_t cells = 0;
     static const bool no_shadow = getenv("MAUVE_NO_SHADOW") != nullptr;
     if (!no_shadow && S.n_dp) c->shadow = [c]() { fill_anchor_table(c); };       // runs while the DP kernels do
-    rc = align_dp(c, nullptr, S.n_dp, S.dcols.data(), S.dcol_off.data(), S.dscore.data(), &cells);
+    rc = align_dp(c, nullptr, S.n_dp, dcols, S.dcol_off.data(), S.dscore.data(), &cells);
     c->shadow = nullptr;
     if (rc) return rc;
-    return align_finish(c, S.dcols.data(), S.dcol_off.data(), S.dscore.data(), cells, sizes);
+    return align_finish(c, dcols, S.dcol_off.data(), S.dscore.data(), cells, sizes);
 }
 
 // ---- sharded form of mauve_align: see the phase comment above -------------------------------------------------

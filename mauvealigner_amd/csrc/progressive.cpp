@@ -192,9 +192,11 @@ int prog_node(Prog &P, int node)
             gaps.push_back(gr);
         }
     }
-    std::vector<uint32_t> dcols((size_t)code_total + 1); std::vector<int64_t> dcol_off((size_t)n_dp + 1, 0), dscore((size_t)n_dp + 1, 0);
+    HIPCHK(c, c->pin_dcols.ensure(((size_t)code_total + 1) * sizeof(uint32_t)));
+    uint32_t *dcols = c->pin_dcols.as<uint32_t>();
+    std::vector<int64_t> dcol_off((size_t)n_dp + 1, 0), dscore((size_t)n_dp + 1, 0);
     int64_t cells = 0;
-    rc = dp_batch_run_desc(c, n, n_dp, desc.data(), &p->scoring, dcols.data(), dcol_off.data(), dscore.data(), &cells);
+    rc = dp_batch_run_desc(c, n, n_dp, desc.data(), &p->scoring, dcols, dcol_off.data(), dscore.data(), &cells);
     if (rc) return rc;
     P.n_gap_dp += n_dp; P.n_cells += cells;
     if (trace) {
