@@ -161,9 +161,11 @@ def main():
 
     # ---- accuracy of the bench workload's alignment against the generator's truth (not timed) ----
     acc = None
+    gpu_result = None
     if rank == 0 and world == 1:
         from mauvealigner_amd import accuracy
-        acc = accuracy.score_alignment(ctx.align(params), origins)
+        gpu_result = ctx.align(params)
+        acc = accuracy.score_alignment(gpu_result, origins)
         acc = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in acc.items()}
 
     # ---- CPU baseline: the oracle on the same workload, host cores of this box ----
@@ -173,11 +175,15 @@ def main():
         sample_scale = 1.0
         gs_cpu = genomes
         tc0 = time.perf_counter()
-        O.align(gs_cpu, O.default_params(seed_weight=weight))
+        ref = O.align(gs_cpu, O.default_params(seed_weight=weight))
         tc = time.perf_counter() - tc0
+        # the same pass doubles as the full-size parity check of the GPU result (the oracle as the checker)
+        import numpy as np
+        parity = all(np.array_equal(gpu_result[k], ref["aln"][k]) for k in
+                     ("anchor_start", "anchor_length", "left", "right", "reverse", "col_off", "cols", "dp_score"))
         cpu = {"value": round(sum(len(g) for g in gs_cpu) / 1e6 / tc, 3), "unit": "Mbp/s", "cores": 1, "kind": "port",
                "sample": "full workload (3 x %d bp, scale %.2f), single thread, one pass, %.1f s" % (L, sample_scale, tc),
-               "host_cpus": os.cpu_count()}
+               "host_cpus": os.cpu_count(), "gpu_result_identical": bool(parity)}
 
     if rank == 0:
         out = {
