@@ -166,3 +166,32 @@ def test_pairwise_match_finder(ctx):
         ln, st = _same(ctx, gs, pat, mode=_lib.MODE_PAIRWISE)
         assert np.all(np.count_nonzero(st, axis=1) == 2)
         _same(ctx, gs, pat, mode=_lib.MODE_PAIRWISE, extend=False)
+
+
+def test_error_behaviour(ctx):
+    """Status codes and messages at the boundary (libMems: boolean / gnException; here MAUVE_ERR_* + last error):
+    the context stays usable after every refused call."""
+    from mauvealigner_amd import _lib
+    rng = np.random.default_rng(3)
+    g = rng.integers(0, 4, 2000, dtype=np.uint8)
+    fresh = _lib.Context(0)
+    try:
+        with pytest.raises(RuntimeError, match=r"\(-5\)"):            # MAUVE_ERR_STATE: no genomes yet
+            fresh.seed_mums(O.get_seed(11, 0))
+        fresh.set_genomes([g])
+        with pytest.raises(RuntimeError, match=r"\(-5\).*two genomes"):
+            fresh.align(_lib.default_params())
+    finally:
+        fresh.close()
+    ctx.set_genomes([g, synth.mutate(g, 0.02, rng)])
+    with pytest.raises(RuntimeError, match=r"\(-1\).*palindromic"):    # MAUVE_ERR_ARG
+        ctx.seed_mums(0b1101)
+    with pytest.raises((RuntimeError, IndexError)):
+        ctx.sorted_mer_list(5, O.get_seed(11, 0))                       # no such sequence
+    with pytest.raises(RuntimeError, match=r"\(-1\)"):
+        ctx.set_genomes([g] * 33)                                        # MAUVE_MAX_SEQ = 32
+    with pytest.raises(ValueError):
+        ctx.dp_batch([[g[:5], g[:5]], [g[:5]]])
+    # still alive, and the refused set_genomes did not replace the genomes
+    ln, st = ctx.seed_mums(O.get_seed(11, 0))
+    assert len(ln) > 0 and st.shape[1] == 2
