@@ -38,6 +38,25 @@ def one(name, gs, weight, mode):
     print(name, "mums", len(ln), "lcbs", r["lcbs"]["n_lcb"], "anchors", len(a["anchor_length"]), "cols", len(a["cols"]))
 
 
+def progressive(name, gs, weight):
+    """progressiveMauve-shaped fixture: pairwise matches, guide tree, progressive alignment."""
+    pat = O.get_seed(weight, 0)
+    pln, pst = O.find_matches(gs, pat, mode=O.MODE_PAIRWISE)
+    names = ["g%d" % g for g in range(len(gs))]
+    r = O.progressive_align(gs, O.default_params(seed_pattern=pat), names=names, want_xmfa=True)
+    a = r["aln"]
+    d = {"nseq": len(gs), "pattern": np.uint64(pat), "pair_length": pln, "pair_start": pst,
+         "tree_left": r["tree"][0], "tree_right": r["tree"][1], "dist": r["dist"],
+         "left": a["left"], "right": a["right"], "reverse": a["reverse"], "col_off": a["col_off"],
+         "cols": a["cols"], "dp_score": a["dp_score"]}
+    for g, x in enumerate(gs):
+        d["genome%d" % g] = x
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    with open(os.path.join(OUT, name + ".xmfa"), "w") as f:
+        f.write(r["xmfa"])
+    print(name, "pairwise matches", len(pln), "blocks", a["n_iv"], "cols", len(a["cols"]))
+
+
 def main():
     rng = np.random.default_rng(20261003)
     anc = rng.integers(0, 4, 2000, dtype=np.uint8)
@@ -51,6 +70,8 @@ def main():
     gs = [synth.mutate(anc, 0.02, rng) for _ in range(5)]
     gs[3] = np.concatenate([gs[3], gs[3][500:900]])     # a duplicated segment: UNIQUE vs MEM differ
     one("g5x3k_unique", gs, 7, O.MODE_UNIQUE)
+    # four leaves of a two-level tree with clade-specific inserts and inversions (config C4 in miniature)
+    progressive("g4x3k_tree", synth.tree_genomes(4, 3000, 0.02, 77, inv_per_branch=1, insert_per_branch=1, insert_len=(60, 300)), 9)
 
 
 if __name__ == "__main__":

@@ -143,7 +143,7 @@ def test_mirror_compiles_and_host_classes_work():
         subprocess.check_call([exe])
 
 
-@pytest.mark.parametrize("name", ["g2x2k", "g3x5k_inv", "g5x3k_unique"])
+@pytest.mark.parametrize("name", ["g2x2k", "g3x5k_inv", "g5x3k_unique", "g4x3k_tree"])
 def test_stage_seam_formats_round_trip(name):
     """the text formats at the stage seams, host only.  A committed golden XMFA goes through
     ReadStandardAlignment -> WriteStandardAlignment and through WriteList(.mln) -> ReadList -> WriteStandardAlignment

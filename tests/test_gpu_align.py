@@ -137,6 +137,23 @@ def test_dp_subwave_groups(ctx):
     _check_dp(ctx, many)
 
 
+def test_golden_progressive(ctx):
+    from mauvealigner_amd import _lib
+    z = np.load(os.path.join(GOLDEN, "g4x3k_tree.npz"))
+    N = int(z["nseq"])
+    gs = [z["genome%d" % g] for g in range(N)]
+    pat = int(z["pattern"])
+    ctx.set_genomes(gs)
+    ln, st = ctx.seed_mums(pat, mode=_lib.MODE_PAIRWISE)
+    assert np.array_equal(ln, z["pair_length"]) and np.array_equal(st, z["pair_start"])
+    r = ctx.progressive_align(_lib.default_params(seed_pattern=pat), names=["g%d" % g for g in range(N)], want_xmfa=True)
+    assert np.array_equal(r["tree"][0], z["tree_left"]) and np.array_equal(r["tree"][1], z["tree_right"])
+    for k in ("left", "right", "reverse", "col_off", "cols", "dp_score"):
+        assert np.array_equal(r[k], z[k]), k
+    with open(os.path.join(GOLDEN, "g4x3k_tree.xmfa")) as f:
+        assert f.read() == r["xmfa"]
+
+
 def _same_align(ctx, gs, **kw):
     from mauvealigner_amd import _lib
     ctx.set_genomes(gs)

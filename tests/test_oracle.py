@@ -470,3 +470,19 @@ def test_golden_fixtures_reproduce(name):
     assert np.array_equal(r["aln"]["anchor_start"], z["anchor_start"])
     with open(os.path.join(GOLDEN, name + ".xmfa")) as f:
         assert f.read() == r["xmfa"]
+
+
+def test_golden_progressive_fixture_reproduces():
+    z = np.load(os.path.join(GOLDEN, "g4x3k_tree.npz"))
+    N = int(z["nseq"])
+    gs = [z["genome%d" % g] for g in range(N)]
+    pat = int(z["pattern"])
+    ln, st = O.find_matches(gs, pat, mode=O.MODE_PAIRWISE)
+    assert np.array_equal(ln, z["pair_length"]) and np.array_equal(st, z["pair_start"])
+    r = O.progressive_align(gs, O.default_params(seed_pattern=pat), names=["g%d" % g for g in range(N)], want_xmfa=True)
+    assert np.array_equal(r["tree"][0], z["tree_left"]) and np.array_equal(r["tree"][1], z["tree_right"])
+    assert np.array_equal(r["dist"], z["dist"])
+    for k in ("left", "right", "reverse", "col_off", "cols", "dp_score"):
+        assert np.array_equal(r["aln"][k], z[k]), k
+    with open(os.path.join(GOLDEN, "g4x3k_tree.xmfa")) as f:
+        assert f.read() == r["xmfa"]
