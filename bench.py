@@ -184,6 +184,28 @@ def main():
         cpu = {"value": round(sum(len(g) for g in gs_cpu) / 1e6 / tc, 3), "unit": "Mbp/s", "cores": 1, "kind": "port",
                "sample": "full workload (3 x %d bp, scale %.2f), single thread, one pass, %.1f s" % (L, sample_scale, tc),
                "host_cpus": os.cpu_count(), "gpu_result_identical": bool(parity)}
+        # the same baseline on all the cores this process may use: independent copies of the workload, one per
+        # worker, started together (the path has no intra-job CPU parallelism to offer; throughput adds up)
+        try:
+            import subprocess
+            ncore = max(1, min(16, len(os.sched_getaffinity(0))))
+            ws = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", "C2", "1.0", str(weight)], cwd=ROOT,
+                                   stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for _ in range(ncore)]
+            for w in ws:
+                assert w.stdout.readline().strip() == "ready"
+            tw0 = time.perf_counter()
+            for w in ws:
+                w.stdin.write("go\n"); w.stdin.flush()
+            bases = 0
+            for w in ws:
+                bases += int(w.stdout.readline().split()[1])
+            tw = time.perf_counter() - tw0
+            for w in ws:
+                w.wait(timeout=30)
+            cpu["all_cores"] = {"value": round(bases / 1e6 / tw, 2), "unit": "Mbp/s", "cores": ncore,
+                                "sample": "%d concurrent copies of the workload, %.1f s" % (ncore, tw)}
+        except Exception as ex:                      # the single-core figure above stands on its own
+            cpu["all_cores"] = {"error": repr(ex)}
 
     if rank == 0:
         out = {
