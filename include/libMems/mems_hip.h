@@ -723,7 +723,7 @@ public:
     void SetMinRecursionGapLength(gnSeqI n) { p_.min_recursive_gap = (int64_t)n; }     // :670-672
     void SetGappedAligner(GappedAligner &) {}                                           // :674 (the HIP DP is built in)
     void SetMaxGappedAlignmentLength(gnSeqI n) { p_.max_gapped_len = (int64_t)n; }     // :675-676
-    void SetMaxExtensionIterations(uint) {}                                             // :687-690 (LCB extension: not implemented)
+    void SetMaxExtensionIterations(uint n) { p_.max_extension_iters = (int32_t)n; }      // :687-690 (LCB extension)
     void SetSeedPattern(int64 seed) { p_.seed_pattern = (uint64_t)seed; }
     void SetScoring(const PairwiseScoringScheme &pss)
     {
@@ -733,7 +733,7 @@ public:
     // align(match_list, interval_list, 0, LCB_size, recursive, extend_lcbs, gapped, tree_filename)  (:698)
     // LCB_size < 0 = collinear hack (:665-666).  The multi-MUM search is redone on the device from the seed
     // pattern of match_list (it is the same search FindMatches performed), so the anchors never leave HBM.
-    void align(MatchList &ml, IntervalList &il, double, int64 LCB_size, boolean recursive, boolean /*extend_lcbs*/, boolean gapped, std::string = "")
+    void align(MatchList &ml, IntervalList &il, double, int64 LCB_size, boolean recursive, boolean extend_lcbs, boolean gapped, std::string = "")
     {
         HipContext &hc = HipContext::global();
         if (ml.seq_table.size() != seq_count_) throw genome::gnException("Aligner::align: sequence count mismatch");
@@ -741,7 +741,7 @@ public:
         mauve_params p = p_;
         if (!p.seed_pattern) p.seed_pattern = (uint64_t)ml.seed_pattern;
         p.collinear = LCB_size < 0; p.lcb_weight = LCB_size < 0 ? -1 : LCB_size;
-        p.recursive = recursive; p.gapped = gapped;
+        p.recursive = recursive; p.gapped = gapped; p.extend_lcbs = extend_lcbs;
         hc.check(mauve_align(hc.get(), &p, &il.sizes), "mauve_align");
         il.seq_table = ml.seq_table; il.seq_filename = ml.seq_filename;
         il.fetch(hc, seq_count_);

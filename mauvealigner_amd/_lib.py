@@ -37,6 +37,7 @@ class Params(C.Structure):
     _fields_ = [("seed_pattern", C.c_uint64), ("seed_weight", C.c_int32), ("seed_rank", C.c_int32),
                 ("mode", C.c_int32), ("lcb_weight", C.c_int64), ("collinear", C.c_int32),
                 ("recursive", C.c_int32), ("gapped", C.c_int32), ("add_unaligned", C.c_int32),
+                ("extend_lcbs", C.c_int32), ("max_extension_iters", C.c_int32),
                 ("min_recursive_gap", C.c_int64), ("max_gapped_len", C.c_int64), ("scoring", Scoring)]
 
 

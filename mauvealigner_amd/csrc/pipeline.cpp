@@ -29,6 +29,104 @@ inline void gap_of(const int64_t *a, const int64_t *b, int g, int64_t &lo, int64
 
 int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector<MatchVec> &chains, int N, const int *gmap);
 
+// LCB extension (lcb_extension, mauveAligner.cpp:95; SetMaxExtensionIterations :687-690), frozen replacement
+// up to max_extension_iters rounds, each with a seed two weights lighter than the last.  A round
+// searches N-way MEMs only where no LCB lies -- one masked seed pass over the resident genomes, the mask being the
+// union of the LCB extents -- adds what it finds to the surviving anchors, eliminates overlaps and recomputes the
+// LCBs with the same minimum weight; it is kept only if it raises the number of anchored columns.
+static int extend_lcbs(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw, MatchVec &m, std::vector<int64_t> &match_lcb,
+                       int64_t &nl)
+{
+    const int N = m.N;
+    const uint32_t full = N >= 32 ? 0xffffffffu : ((1u << N) - 1);
+    int w_e = w;
+    for (int iter = 0; iter < p->max_extension_iters; iter++) {
+        w_e -= 2;
+        if (w_e < 5) break;
+        const uint64_t pe = mauve_get_seed(w_e, 0);
+        if (!pe) break;
+        const int64_t span_e = mauve_seed_length(pe);
+        // LCB extents
+        std::vector<int64_t> lo((size_t)nl * N, 0), hi((size_t)nl * N, 0);
+        int64_t cols_before = 0;
+        for (size_t i = 0; i < m.size(); i++) {
+            const int64_t l = match_lcb[i]; if (l < 0) continue;
+            cols_before += m.len(i);
+            for (int g = 0; g < N; g++) {
+                const int64_t a = std::llabs(m.st(i)[g]), b = a + m.len(i) - 1;
+                int64_t &L = lo[(size_t)l * N + g], &H = hi[(size_t)l * N + g];
+                if (L == 0 || a < L) L = a;
+                if (b > H) H = b;
+            }
+        }
+        // mask bitmap: every base masked, then the valid pieces (gaps between extents, at least one seed long) cleared
+        GenomeSet gs = main_genome_set(c);
+        gs.mask_off.assign((size_t)N, 0);
+        size_t words = 0;
+        for (int g = 0; g < N; g++) { gs.mask_off[(size_t)g] = words; words += (size_t)((c->lens[g] + 63) / 64) + 2; }
+        std::vector<uint64_t> bits(words, ~0ULL);
+        bool starved = false;
+        std::vector<std::pair<int64_t, int64_t>> sp((size_t)nl);
+        for (int g = 0; g < N && !starved; g++) {
+            for (int64_t l = 0; l < nl; l++) sp[(size_t)l] = {lo[(size_t)l * N + g], hi[(size_t)l * N + g]};
+            std::sort(sp.begin(), sp.end());
+            uint64_t *M = bits.data() + gs.mask_off[(size_t)g];
+            int64_t cur = 1; bool any = false;
+            for (int64_t l = 0; l <= nl; l++) {
+                const int64_t vlo = cur, vhi = l < nl ? sp[(size_t)l].first - 1 : c->lens[g];
+                if (vhi - vlo + 1 >= span_e) {
+                    any = true;
+                    for (int64_t b = vlo - 1; b < vhi;) {               // clear [vlo-1, vhi) word-wise
+                        const int64_t wd = b >> 6, e = std::min<int64_t>(vhi, (wd + 1) << 6);
+                        const int n = (int)(e - b), sh = (int)(b & 63);
+                        M[wd] &= ~((n == 64 ? ~0ULL : ((1ULL << n) - 1ULL)) << sh);
+                        b = e;
+                    }
+                }
+                if (l < nl && sp[(size_t)l].second + 1 > cur) cur = sp[(size_t)l].second + 1;
+            }
+            if (!any) starved = true;
+        }
+        if (starved) break;
+        HIPCHK(c, c->placed_mask.ensure(words * 8));
+        HIPCHK(c, hipMemcpyAsync(c->placed_mask.p, bits.data(), words * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        gs.vmask = &c->placed_mask;
+        int64_t nx = 0;
+        int rc = seedpass_run(c, gs, pe, MAUVE_MODE_MEM, full, 1, nullptr, 0, &nx);
+        if (rc) return rc;
+        if (nx == 0) continue;
+        // survivors + new matches, canonical order (both lists already are: merge)
+        auto less = [N](const int64_t *a, const int64_t *b) {                // N-way records: |start0|, starts, length
+            const int64_t sa = std::llabs(a[1]), sb = std::llabs(b[1]);
+            if (sa != sb) return sa < sb;
+            for (int g = 0; g < N; g++) if (a[1 + g] != b[1 + g]) return a[1 + g] < b[1 + g];
+            return a[0] < b[0];
+        };
+        MatchVec ext(N); ext.resize((size_t)nx);
+        for (int64_t i = 0; i < nx; i++) {
+            ext.len((size_t)i) = c->match_len[(size_t)i];
+            std::copy(&c->match_start[(size_t)i * N], &c->match_start[(size_t)i * N] + N, ext.st((size_t)i));
+        }
+        MatchVec comb(N); comb.reserve(m.size() + ext.size());
+        size_t a = 0, b = 0;
+        while (a < m.size() && match_lcb[a] < 0) a++;
+        while (a < m.size() || b < ext.size()) {
+            const bool take_a = b >= ext.size() || (a < m.size() && !less(ext.rec(b), m.rec(a)));
+            if (take_a) { comb.push(m.rec(a)); a++; while (a < m.size() && match_lcb[a] < 0) a++; }
+            else { comb.push(ext.rec(b)); b++; }
+        }
+        ChainOrders orders;
+        host_eliminate_overlaps(comb, &orders);
+        std::vector<int64_t> ml2; int64_t nl2 = 0;
+        host_lcb_chain(comb, lcbw, p->collinear != 0, ml2, nl2, &orders);
+        int64_t cols_after = 0;
+        for (size_t i = 0; i < comb.size(); i++) if (ml2[i] >= 0) cols_after += comb.len(i);
+        if (cols_after > cols_before) { m.d.swap(comb.d); match_lcb.swap(ml2); nl = nl2; }
+    }
+    return MAUVE_OK;
+}
+
 // ---- the whole path in three phases, so that the DP intervals of one alignment can be sharded over ranks ----
 // begin : seed pass, chaining, recursive anchoring, interval descriptors        (every rank, deterministic)
 // dp    : gapped alignment of a subset of the intervals                         (each rank its share)
@@ -88,6 +186,10 @@ static int align_begin(mauve_ctx *c, const mauve_params *p)
     const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight : (int64_t)3 * w * N;
     std::vector<int64_t> &match_lcb = S.match_lcb; int64_t nl = 0;
     host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl, &orders);
+    if (p->extend_lcbs) {
+        rc = extend_lcbs(c, p, w, lcbw, m, match_lcb, nl);
+        if (rc) return rc;
+    }
     S.nl = nl;
     std::vector<MatchVec> &chains = S.chains;
     chains.resize((size_t)nl);                        // element buffers keep their capacity

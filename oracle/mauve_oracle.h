@@ -79,6 +79,8 @@ typedef struct {
     int32_t recursive;        /* mauveAligner.cpp:94 */
     int32_t gapped;           /* mauveAligner.cpp:96 */
     int32_t add_unaligned;    /* mauveAligner.cpp:748 addUnalignedIntervals */
+    int32_t extend_lcbs;      /* lcb_extension (mauveAligner.cpp:95); frozen replacement: DESIGN.md S10 */
+    int32_t max_extension_iters; /* default 4 (mauveAligner.cpp:687-690) */
     int64_t min_recursive_gap;/* default 200 (mauveAligner.cpp:899) */
     int64_t max_gapped_len;   /* default 10000 */
     orc_scoring scoring;

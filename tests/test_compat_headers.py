@@ -205,7 +205,7 @@ def test_example_matches_c_abi(flag):
             if flag == "-p":
                 r = ctx.progressive_align(_lib.default_params(), names=paths, want_xmfa=True)
             else:
-                r = ctx.align(_lib.default_params(), names=paths, want_xmfa=True)
+                r = ctx.align(_lib.default_params(extend_lcbs=1), names=paths, want_xmfa=True)    # the call site passes lcb_extension = true
         finally:
             ctx.close()
         assert out == r["xmfa"]

@@ -137,6 +137,25 @@ def test_dp_subwave_groups(ctx):
     _check_dp(ctx, many)
 
 
+def test_lcb_extension(ctx):
+    """S10 (lcb_extension): masked re-search of the regions outside every LCB with lighter seeds; bit-exact against
+    the oracle, and it only ever adds anchored columns."""
+    from mauvealigner_amd import _lib
+    for cfg, scale, kw in (("C3", 0.02, {}), ("C4", 0.05, {}), ("C3", 0.03, {"seed_weight": 13, "max_extension_iters": 2}),
+                           ("C1", 0.3, {}), ("C3", 0.02, {"mode": 1})):
+        gs = synth.make_config(cfg, scale=scale)
+        r1 = _same_align(ctx, gs, extend_lcbs=1, **kw)
+        r0 = ctx.align(_lib.default_params(**kw))
+        assert int(r1["anchor_length"].sum()) >= int(r0["anchor_length"].sum())
+    # genomes that are one LCB end to end: nothing outside, nothing changes
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 4, 20000, dtype=np.uint8)
+    gs = [g, synth.mutate(g, 0.02, rng)]
+    ctx.set_genomes(gs)
+    a = ctx.align(_lib.default_params(extend_lcbs=1)); b = ctx.align(_lib.default_params())
+    assert np.array_equal(a["cols"], b["cols"]) and np.array_equal(a["anchor_start"], b["anchor_start"])
+
+
 def test_golden_progressive(ctx):
     from mauvealigner_amd import _lib
     z = np.load(os.path.join(GOLDEN, "g4x3k_tree.npz"))

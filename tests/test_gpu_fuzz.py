@@ -59,7 +59,7 @@ def test_random_parity(seed, count, lmax):
             if min(len(g) for g in gs) < 40:
                 continue
             kw = dict(seed_weight=int(rng.choice([0, 7, 9, 11])), mode=int(rng.integers(0, 2)), recursive=int(rng.integers(0, 2)),
-                      collinear=int(rng.random() < 0.2), add_unaligned=int(rng.integers(0, 2)))
+                      collinear=int(rng.random() < 0.2), add_unaligned=int(rng.integers(0, 2)), extend_lcbs=int(rng.random() < 0.4))
             r = ctx.align(_lib.default_params(**kw))
             e = O.align(gs, O.default_params(**kw))["aln"]
             assert all(np.array_equal(r[k], e[k]) for k in KEYS), (seed, it, kw)
