@@ -822,11 +822,11 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
                              sh.span, tmask, tpos, P, extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg,
                              nseg); }
         HIPCHK(ctx, hipGetLastError());
-        uint32_t hc[4] = {0, 0, 0, 0};
         if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // the kernels above are still running
-        HIPCHK(ctx, hipMemcpyAsync(hc, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, ctx->pin_seed.ensure(64));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        const uint32_t nc = hc[1];
+        const uint32_t nc = ctx->pin_seed.as<uint32_t>()[1];
         TRACE(ctx, "runs");
         if (g_trace) fprintf(stderr, "[trace]   %u candidates of %u windows\n", nc, P);
         if (nc == 0) continue;
@@ -843,9 +843,15 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         }
         const size_t old = hl.size();
         hl.resize(old + nc); hs.resize((old + nc) * N);
-        HIPCHK(ctx, hipMemcpyAsync(hl.data() + old, ctx->mlen.p, (size_t)nc * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(hs.data() + old * N, ctx->mstart.p, (size_t)nc * 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+        // records land in page-locked memory (one async copy each at link rate), then move into the host vectors
+        const size_t lbytes = ((size_t)nc * 4 + 63) & ~(size_t)63, sbytes = (size_t)nc * 4 * N;
+        HIPCHK(ctx, ctx->pin_seed.ensure(64 + lbytes + sbytes));
+        char *pin = ctx->pin_seed.as<char>() + 64;
+        HIPCHK(ctx, hipMemcpyAsync(pin, ctx->mlen.p, (size_t)nc * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(pin + lbytes, ctx->mstart.p, sbytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(hl.data() + old, pin, (size_t)nc * 4);
+        memcpy(hs.data() + old * N, pin + lbytes, sbytes);
         TRACE(ctx, "extend+copy");
     }
     const uint32_t ncand = (uint32_t)hl.size();
