@@ -35,6 +35,20 @@ struct DevBuf {
         if (e == hipSuccess) cap = want;
         return e;
     }
+    // grow keeping the first `used` bytes (the stream is drained first: work queued on it may still read the old block)
+    hipError_t ensure_keep(size_t bytes, size_t used, hipStream_t stream)
+    {
+        if (bytes <= cap) return hipSuccess;
+        void *np = nullptr;
+        const size_t want = bytes + bytes / 2 + 4096;
+        hipError_t e = hipMalloc(&np, want);
+        if (e != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) { (void)hipFree(np); return e; }
+        if (p && used && (e = hipMemcpy(np, p, used, hipMemcpyDeviceToDevice)) != hipSuccess) { (void)hipFree(np); return e; }
+        if (p) (void)hipFree(p);
+        p = np; cap = want;
+        return hipSuccess;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
@@ -173,6 +187,9 @@ struct mauve_ctx {
 
     // seed-pass workspace
     DevBuf keysA, keysB, valsA, valsB, hist, totals, posmask, hit_mask, hit_pos, hit_seg, cand, mlen, mstart, counters;
+    DevBuf sorted_rec;                   // canonical order on the device: gathered (length, starts) records as int64
+    DevBuf canon_k1, canon_k2, canon_v1, canon_v2;   // ... and its (key, candidate index) sort buffers
+    DevBuf run_sum;                      // pairwise finder: run list (start, length, exactly-once genome set)
     DevBuf rec_genomes, rec_seg;         // recursive anchoring: gap sub-sequences + segment table
     DevBuf placed_mask;                  // guide-tree recursive anchoring: placed-base bitmap
     // last match list (canonical order, host) + nseq it refers to

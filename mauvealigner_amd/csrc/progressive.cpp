@@ -205,6 +205,7 @@ int prog_node(Prog &P, int node)
                 node, n, (long long)rest_len, tn1 - tn0, (long long)nm, tn2 - tn1, tn3 - tn2, now_ms() - tn3, (long long)n_dp, (long long)cells, (long long)big);
     }
     // ---- blocks ----
+    const double tb0 = now_ms();
     uint32_t gfull = 0; for (int j = 0; j < n; j++) gfull |= 1u << gm[j];
     std::vector<std::vector<std::pair<int64_t, int64_t>>> placed((size_t)n);
     size_t gi = 0;
@@ -242,6 +243,7 @@ int prog_node(Prog &P, int node)
         }
     }
     for (int j = 0; j < n; j++) P.rest[gm[j]].subtract(placed[(size_t)j]);
+    if (trace) fprintf(stderr, "[trace] node %d: blocks %.1f ms\n", node, now_ms() - tb0);
     rc = prog_node(P, P.left[node]);
     if (rc) return rc;
     return prog_node(P, P.right[node]);
@@ -304,6 +306,9 @@ int mauve_progressive_align(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     P.left.assign((size_t)(2 * N - 1), -1); P.right.assign((size_t)(2 * N - 1), -1);
     int rc = mauve_guide_tree(c, pat, dist, P.left.data(), P.right.data());
     if (rc) return rc;
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    const double tg1 = now_ms();
+    if (trace) fprintf(stderr, "[trace] progressive: guide tree %.1f ms\n", tg1 - t0);
     if (tree_left) std::copy(P.left.begin(), P.left.end(), tree_left);
     if (tree_right) std::copy(P.right.begin(), P.right.end(), tree_right);
     AlignResult &R = c->res;
@@ -317,6 +322,8 @@ int mauve_progressive_align(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     for (int g = 0; g < N; g++) P.rest[(size_t)g].push(1, c->lens[g]);
     rc = prog_node(P, 2 * N - 2);
     if (rc) return rc;
+    const double tg2 = now_ms();
+    if (trace) fprintf(stderr, "[trace] progressive: nodes %.1f ms\n", tg2 - tg1);
     const int64_t n_multi = P.n_multi;
     if (p->add_unaligned)
         for (int g = 0; g < N; g++)

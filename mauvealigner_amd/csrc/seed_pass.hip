@@ -423,6 +423,71 @@ __global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// PairwiseMatchFinder: N(N-1)/2 finder passes over ONE sorted mer list.  Instead of re-reading all P sorted entries
+// per pair, one pass (run_summary) lists the runs of identical mers that could matter to any pair -- where the run
+// starts, how long it is, which genomes occur in it exactly once -- and each pair's join (join_pair) walks that
+// list: a run is a hit of pair (i, j) iff both genomes are in its exactly-once set (MemHash restricted to the two
+// genomes: entries of the others are invisible to it).  The order of the list does not matter: hits go to the
+// dense table by anchor position.
+// ------------------------------------------------------------------------------------------------
+template <typename KeyT>
+__global__ void __launch_bounds__(256) run_summary(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t n,
+                                                   GenomeTab tab, int has_invalid, uint32_t *__restrict__ rstart,
+                                                   uint32_t *__restrict__ rlen, uint32_t *__restrict__ runiq,
+                                                   uint32_t *__restrict__ counter)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t uniq = 0, len = 0;
+    if (i < n) {
+        const KeyT k = keys[i];
+        const bool valid = !(has_invalid && k == (KeyT)~0ULL);
+        if (valid && (i == 0 || keys[i - 1] != k) && i + 1 < n && keys[i + 1] == k) {
+            uint32_t once = 0, multi = 0, j = i;
+            while (j < n && keys[j] == k) {
+                const uint32_t bit = 1u << genome_of(vals[j] & 0x7fffffffu, tab);
+                multi |= once & bit; once |= bit; j++;
+            }
+            uniq = once & ~multi; len = j - i;
+        }
+    }
+    const bool emit = __popc(uniq) >= 2;
+    const uint64_t b = __ballot(emit);
+    if (!b) return;
+    uint32_t base = 0;
+    const int leader = __ffsll((unsigned long long)b) - 1;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(b));
+    base = __shfl(base, leader);
+    if (emit) {
+        const uint32_t r = base + (uint32_t)__popcll(b & ((1ULL << lane) - 1ULL));
+        rstart[r] = i; rlen[r] = len; runiq[r] = uniq;
+    }
+}
+
+__global__ void __launch_bounds__(256) join_pair(const uint32_t *__restrict__ vals, GenomeTab tab, const uint32_t *__restrict__ rstart,
+                                                 const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ runiq,
+                                                 uint32_t nruns, int gi, int gj, uint32_t *__restrict__ tmask,
+                                                 uint32_t *__restrict__ tpos)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nruns) return;
+    const uint32_t u = runiq[r];
+    if (!((u >> gi) & (u >> gj) & 1u)) return;
+    const uint32_t s = rstart[r], L = rlen[r];
+    uint32_t vi = 0, vj = 0;
+    for (uint32_t t = s; t < s + L; t++) {
+        const uint32_t v = vals[t];
+        const int g = genome_of(v & 0x7fffffffu, tab);
+        if (g == gi) vi = v;
+        if (g == gj) vj = v;
+    }
+    const uint32_t ap = vi & 0x7fffffffu;               // gi < gj: the anchor is genome gi's window
+    tmask[ap] = (1u << gi) | (1u << gj);
+    tpos[(size_t)ap * tab.nseq + gi] = vi;
+    tpos[(size_t)ap * tab.nseq + gj] = vj;
+}
+
+// ------------------------------------------------------------------------------------------------
 // extension.  A hit fixes a generalized diagonal: component c moves +k (same strand as the
 // anchor) or -k (opposite strand) when the anchor moves +k.  Offset k "agrees" when the masked windows of
 // all components are equal there.  Agreeing offsets at most `span` apart chain into a cluster; the match
@@ -658,6 +723,43 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
 }
 
 // ------------------------------------------------------------------------------------------------
+// canonical order on the device (large candidate sets): key = first component << 32 | |its start| per candidate
+// (dropped candidates get first component = nseq and sort behind everything), the radix sort above on
+// (key, candidate index), then a gather of the surviving records as int64 in sorted order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) canon_keys(const int32_t *__restrict__ mlen, const int32_t *__restrict__ mstart, uint32_t ncand,
+                                                  int nseq, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                  uint32_t *__restrict__ n_valid)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = false;
+    if (i < ncand) {
+        uint64_t key = (uint64_t)nseq << 32;
+        if (mlen[i] != 0) {
+            const int32_t *s = mstart + (size_t)i * nseq;
+            int f = 0; while (f < nseq && s[f] == 0) f++;
+            const uint32_t a = f < nseq ? (uint32_t)(s[f] < 0 ? -s[f] : s[f]) : 0u;
+            key = ((uint64_t)f << 32) | a;
+            valid = true;
+        }
+        keys[i] = key; vals[i] = i;
+    }
+    const uint64_t b = __ballot(valid);
+    if (b && (threadIdx.x & 63) == (uint32_t)(__ffsll((unsigned long long)b) - 1)) atomicAdd(n_valid, (uint32_t)__popcll(b));
+}
+
+__global__ void __launch_bounds__(256) canon_gather(const int32_t *__restrict__ mlen, const int32_t *__restrict__ mstart,
+                                                    const uint32_t *__restrict__ vals, uint32_t nm, int nseq,
+                                                    int64_t *__restrict__ out_len, int64_t *__restrict__ out_start)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nm) return;
+    const uint32_t src = vals[r];
+    out_len[r] = mlen[src];
+    for (int g = 0; g < nseq; g++) out_start[(size_t)r * nseq + g] = mstart[(size_t)src * nseq + g];
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 bool make_seed_shape(uint64_t pattern, SeedShape *sh)
@@ -808,9 +910,35 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     if (n_matches) *n_matches = 0;
     // one record slot per candidate of every pass; length 0 = not a leftmost hit (host scratch kept across calls)
     std::vector<int32_t> &hl = ctx->sdh.hl, &hs = ctx->sdh.hs; hl.clear(); hs.clear();
+    uint32_t cand_total = 0;
+    // pairwise mode: the runs that can matter to any pair, listed once (see run_summary)
+    uint32_t nruns = 0;
+    const bool use_summary = mode == MAUVE_MODE_PAIRWISE && !SEG && passes.size() > 1;
+    uint32_t *rstart = nullptr, *rlen = nullptr, *runiq = nullptr;
+    if (use_summary) {
+        const size_t cap = (size_t)n / 2 + 1;
+        HIPCHK(ctx, ctx->run_sum.ensure(3 * cap * 4));
+        rstart = ctx->run_sum.as<uint32_t>(); rlen = rstart + cap; runiq = rlen + cap;
+        HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+        { KernelTimer t(ctx, MAUVE_K_JOIN, n);
+          hipLaunchKernelGGL((run_summary<KeyT>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, n, tab,
+                             vmask != nullptr, rstart, rlen, runiq, ctx->counters.as<uint32_t>() + 2); }
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, ctx->pin_seed.ensure(64));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        nruns = ctx->pin_seed.as<uint32_t>()[2];
+        TRACE(ctx, "run summary");
+    }
     for (const FinderPass &fp : passes) {
         HIPCHK(ctx, hipMemsetAsync(ctx->posmask.p, 0, (size_t)P * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+        if (use_summary) {
+            KernelTimer t(ctx, MAUVE_K_JOIN, nruns);
+            if (nruns)
+                hipLaunchKernelGGL(join_pair, dim3((nruns + 255) / 256), dim3(256), 0, ctx->stream, vals, tab, rstart, rlen, runiq, nruns,
+                                   __builtin_ctz(fp.consider), 31 - __builtin_clz(fp.consider), tmask, tpos);
+        } else
         { KernelTimer t(ctx, MAUVE_K_JOIN, n);
           hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, n, tab, fp.rule,
                              fp.want, fp.consider, tmask, tpos, P, vmask != nullptr); }
@@ -830,33 +958,108 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         TRACE(ctx, "runs");
         if (g_trace) fprintf(stderr, "[trace]   %u candidates of %u windows\n", nc, P);
         if (nc == 0) continue;
-        // extension phase B
-        HIPCHK(ctx, ctx->mlen.ensure((size_t)nc * 4 + 4));
-        HIPCHK(ctx, ctx->mstart.ensure((size_t)nc * 4 * N + 4));
+        // extension phase B: the records of all passes accumulate on the device
+        HIPCHK(ctx, ctx->mlen.ensure_keep((size_t)(cand_total + nc) * 4 + 4, (size_t)cand_total * 4, ctx->stream));
+        HIPCHK(ctx, ctx->mstart.ensure_keep((size_t)(cand_total + nc) * 4 * N + 4, (size_t)cand_total * 4 * N, ctx->stream));
         {
             uint32_t blocks = std::min<uint32_t>((nc + 3) / 4, 256 * 8);
             KernelTimer t(ctx, MAUVE_K_EXTEND, nc);
             hipLaunchKernelGGL((mum_extend<SEG>), dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh, tmask, tpos, P,
-                               ctx->cand.as<uint32_t>(), nc, extend, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(), seg,
-                               nseg, vmask);
+                               ctx->cand.as<uint32_t>(), nc, extend, ctx->mlen.as<int32_t>() + cand_total,
+                               ctx->mstart.as<int32_t>() + (size_t)cand_total * N, seg, nseg, vmask);
             HIPCHK(ctx, hipGetLastError());
         }
-        const size_t old = hl.size();
-        hl.resize(old + nc); hs.resize((old + nc) * N);
-        // records land in page-locked memory (one async copy each at link rate), then move into the host vectors
-        const size_t lbytes = ((size_t)nc * 4 + 63) & ~(size_t)63, sbytes = (size_t)nc * 4 * N;
-        HIPCHK(ctx, ctx->pin_seed.ensure(64 + lbytes + sbytes));
-        char *pin = ctx->pin_seed.as<char>() + 64;
-        HIPCHK(ctx, hipMemcpyAsync(pin, ctx->mlen.p, (size_t)nc * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(pin + lbytes, ctx->mstart.p, sbytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        memcpy(hl.data() + old, pin, (size_t)nc * 4);
-        memcpy(hs.data() + old * N, pin + lbytes, sbytes);
-        TRACE(ctx, "extend+copy");
+        cand_total += nc;
+        TRACE(ctx, "extend");
     }
-    const uint32_t ncand = (uint32_t)hl.size();
+    const uint32_t ncand = cand_total;
     if (ncand == 0) return MAUVE_OK;
     // ---- canonical order (first component, |start|, mask, starts, length) ----
+    static const uint32_t dev_sort_min = getenv("MAUVE_CANON_DEVICE_MIN") ? (uint32_t)atol(getenv("MAUVE_CANON_DEVICE_MIN")) : 65536u;
+    if (ncand >= dev_sort_min) {
+        // large sets: sort on the device, gather, copy out in order.  (Own buffers: over several finder passes the
+        // candidates can outnumber the windows, so the sorted-mer buffers are not guaranteed to be big enough.)
+        HIPCHK(ctx, ctx->canon_k1.ensure((size_t)ncand * 8 + 64)); HIPCHK(ctx, ctx->canon_k2.ensure((size_t)ncand * 8 + 64));
+        HIPCHK(ctx, ctx->canon_v1.ensure((size_t)ncand * 4 + 64)); HIPCHK(ctx, ctx->canon_v2.ensure((size_t)ncand * 4 + 64));
+        uint64_t *ck = ctx->canon_k1.as<uint64_t>(), *ck2 = ctx->canon_k2.as<uint64_t>();
+        uint32_t *cv = ctx->canon_v1.as<uint32_t>(), *cv2 = ctx->canon_v2.as<uint32_t>();
+        HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+        hipLaunchKernelGGL(canon_keys, dim3((ncand + 255) / 256), dim3(256), 0, ctx->stream, ctx->mlen.as<int32_t>(),
+                           ctx->mstart.as<int32_t>(), ncand, N, ck, cv, ctx->counters.as<uint32_t>() + 3);
+        HIPCHK(ctx, hipGetLastError());
+        int fbits = 1; while ((1 << fbits) <= N) fbits++;
+        int rc2 = sort_pairs<uint64_t>(ctx, ncand, 32 + fbits, &ck, &cv, ck2, cv2, false);
+        if (rc2) return rc2;
+        HIPCHK(ctx, ctx->pin_seed.ensure(64));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        const uint32_t nm = ctx->pin_seed.as<uint32_t>()[3];
+        ctx->match_len.resize(nm); ctx->match_start.resize((size_t)nm * N);
+        if (nm) {
+            HIPCHK(ctx, ctx->sorted_rec.ensure((size_t)nm * (1 + N) * 8));
+            int64_t *ol = ctx->sorted_rec.as<int64_t>(), *os = ol + nm;
+            hipLaunchKernelGGL(canon_gather, dim3((nm + 255) / 256), dim3(256), 0, ctx->stream, ctx->mlen.as<int32_t>(),
+                               ctx->mstart.as<int32_t>(), cv, nm, N, ol, os);
+            HIPCHK(ctx, hipGetLastError());
+            // through page-locked staging: a pageable destination of tens of MB copies at a fraction of the link rate
+            const size_t rbytes = (size_t)nm * (1 + N) * 8;
+            HIPCHK(ctx, ctx->pin_seed.ensure(64 + rbytes));
+            char *pin = ctx->pin_seed.as<char>() + 64;
+            HIPCHK(ctx, hipMemcpyAsync(pin, ol, rbytes, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            memcpy(ctx->match_len.data(), pin, (size_t)nm * 8);
+            memcpy(ctx->match_start.data(), pin + (size_t)nm * 8, (size_t)nm * N * 8);
+            // equal (first component, start) groups: order by the rest of the comparator (rare)
+            auto k1of = [&](uint32_t r) {
+                const int64_t *st = &ctx->match_start[(size_t)r * N];
+                int f = 0; while (f < N && st[f] == 0) f++;
+                return ((uint64_t)f << 32) | (uint64_t)(f < N ? std::llabs(st[f]) : 0);
+            };
+            auto rec_less = [&](const std::vector<int64_t> &x, const std::vector<int64_t> &y) {     // [len, starts...]
+                uint32_t ma = 0, mb = 0;
+                for (int g = 0; g < N; g++) { if (x[1 + g]) ma |= 1u << g; if (y[1 + g]) mb |= 1u << g; }
+                if (ma != mb) return ma < mb;
+                for (int g = 0; g < N; g++) if (x[1 + g] != y[1 + g]) return x[1 + g] < y[1 + g];
+                return x[0] < y[0];
+            };
+            uint64_t prev = k1of(0);
+            for (uint32_t i = 0; i < nm;) {
+                uint32_t j = i + 1; uint64_t kj = 0;
+                while (j < nm && (kj = k1of(j)) == prev) j++;
+                if (j - i > 1) {
+                    std::vector<std::vector<int64_t>> grp;
+                    for (uint32_t r = i; r < j; r++) {
+                        std::vector<int64_t> rec(1 + N); rec[0] = ctx->match_len[r];
+                        std::copy(&ctx->match_start[(size_t)r * N], &ctx->match_start[(size_t)r * N] + N, rec.begin() + 1);
+                        grp.push_back(rec);
+                    }
+                    std::sort(grp.begin(), grp.end(), rec_less);
+                    for (uint32_t r = i; r < j; r++) {
+                        ctx->match_len[r] = grp[r - i][0];
+                        std::copy(grp[r - i].begin() + 1, grp[r - i].end(), &ctx->match_start[(size_t)r * N]);
+                    }
+                }
+                prev = kj; i = j;
+            }
+        }
+        ctx->n_matches = nm;
+        if (n_matches) *n_matches = nm;
+        TRACE(ctx, "canonical sort (device)");
+        return MAUVE_OK;
+    }
+    // small sets: records to the host (page-locked staging), host sort
+    {
+        hl.resize(ncand); hs.resize((size_t)ncand * N);
+        const size_t lbytes = ((size_t)ncand * 4 + 63) & ~(size_t)63, sbytes = (size_t)ncand * 4 * N;
+        HIPCHK(ctx, ctx->pin_seed.ensure(64 + lbytes + sbytes));
+        char *pin = ctx->pin_seed.as<char>() + 64;
+        HIPCHK(ctx, hipMemcpyAsync(pin, ctx->mlen.p, (size_t)ncand * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(pin + lbytes, ctx->mstart.p, sbytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(hl.data(), pin, (size_t)ncand * 4);
+        memcpy(hs.data(), pin + lbytes, sbytes);
+        TRACE(ctx, "records copy");
+    }
     std::vector<uint32_t> &order = ctx->sdh.order; order.clear(); order.reserve(ncand);
     std::vector<uint64_t> &k1 = ctx->sdh.k1; k1.resize(ncand);   // (first component, |start|) packed for a fast first-level compare
     for (uint32_t i = 0; i < ncand; i++) {

@@ -69,3 +69,20 @@ def test_random_parity(seed, count, lmax):
                 assert all(np.array_equal(r[k], e[k]) for k in ("left", "right", "reverse", "col_off", "cols", "dp_score")), (seed, it, "progressive")
     finally:
         ctx.close()
+
+
+def test_device_canonical_sort_path():
+    """Large candidate sets are put in canonical order on the device (canon_keys -> radix sort -> canon_gather).  The
+    switch is a size threshold read once per process, so a child process with the threshold forced to 1 runs part of
+    the sweep above through that path."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_fuzz as t\n"
+            "t.test_random_parity(3, 40, 6000)\n"
+            "print('CHILD OK')\n") % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, MAUVE_CANON_DEVICE_MIN="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CHILD OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
