@@ -52,6 +52,7 @@ void mauve_ctx_destroy(mauve_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     delete c->pool; c->pool = nullptr;
     DevBuf *bufs[] = {&c->genomes, &c->keysA, &c->keysB, &c->valsA, &c->valsB, &c->hist, &c->totals, &c->posmask,
