@@ -105,7 +105,7 @@ void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders)
     const bool trace = trace_on && n >= 1000;          // per-gap calls of the recursion stay quiet
     const double te0 = trace ? now_ms() : 0;
     static thread_local ElimScratch S;
-    if (orders) orders->ord.assign((size_t)N, std::vector<uint32_t>());
+    if (orders) { orders->ord.resize((size_t)N); for (auto &o : orders->ord) o.clear(); }     // capacity is kept: called per gap
     if (n < 2) {
         if (orders) for (int g = 0; g < N; g++) orders->ord[(size_t)g].assign(n, 0u);
         return;
@@ -225,8 +225,9 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
     // initial nodes: maximal collinear runs in genome-0 order
     static thread_local std::vector<int32_t> node_of;
     node_of.resize(n);
-    std::vector<int64_t> weight;
-    std::vector<uint32_t> node_first;     // first match (genome-0 order) of each node
+    static thread_local std::vector<int64_t> weight;
+    static thread_local std::vector<uint32_t> node_first;     // first match (genome-0 order) of each node
+    weight.clear(); node_first.clear();
     for (uint32_t k = 0; k < n; k++) {
         const uint32_t i = order[k];
         bool join = k > 0;
@@ -246,8 +247,10 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
     }
     const int32_t K = (int32_t)weight.size();
     // per-genome doubly linked lists of nodes, flat [K][N]
-    std::vector<int32_t> prevv((size_t)K * N, -1), nextv((size_t)K * N, -1), merged_into((size_t)K, -1);
-    std::vector<uint8_t> alive((size_t)K, 1);
+    static thread_local std::vector<int32_t> prevv, nextv, merged_into;
+    static thread_local std::vector<uint8_t> alive;
+    prevv.assign((size_t)K * N, -1); nextv.assign((size_t)K * N, -1); merged_into.assign((size_t)K, -1);
+    alive.assign((size_t)K, 1);
     auto PREV = [&](int32_t x, int g) -> int32_t & { return prevv[(size_t)x * N + g]; };
     auto NEXT = [&](int32_t x, int g) -> int32_t & { return nextv[(size_t)x * N + g]; };
     for (int g = 0; g < N; g++) {
@@ -287,7 +290,7 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
     auto cmp = [](const HeapEnt &a, const HeapEnt &b) { return a > b; };          // min-heap
     std::make_heap(heap.begin(), heap.end(), cmp);
     int32_t alive_cnt = K;
-    std::vector<std::pair<int32_t, int32_t>> cand;
+    static thread_local std::vector<std::pair<int32_t, int32_t>> cand;
     while (!heap.empty()) {
         const HeapEnt top = heap.front();
         if (!alive[(size_t)top.second] || weight[(size_t)top.second] != top.first) {     // stale entry
@@ -318,7 +321,8 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
     }
     const double tl3 = trace ? now_ms() : 0;
     // final ids in genome-0 order
-    std::vector<int64_t> final_id((size_t)K, -1);
+    static thread_local std::vector<int64_t> final_id;
+    final_id.assign((size_t)K, -1);
     int64_t id = 0;
     for (int32_t i = 0; i < K; i++) {
         if (alive[(size_t)i]) final_id[(size_t)i] = id++;

@@ -175,10 +175,13 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
             double t_elim = 0, t_lcb = 0;
             const uint32_t *seg0 = seg.data();
             int64_t i = 0;
+            MatchVec loc(N), glob(N);            // reused from gap to gap (thousands of gaps per batch)
+            ChainOrders orders;
+            std::vector<int64_t> ml;
             while (i < nm) {
                 const int64_t s0 = c->match_start[(size_t)i * N];      // genome 0 is always forward
                 const uint32_t k = (uint32_t)(std::upper_bound(seg0, seg0 + K + 1, (uint32_t)(s0 - 1)) - seg0) - 1;
-                MatchVec loc(N);
+                loc.d.clear();
                 while (i < nm && (uint32_t)(c->match_start[(size_t)i * N] - 1) < seg0[k + 1]) {
                     bool fwd = true;
                     int64_t rec[1 + MAUVE_MAX_SEQ]; rec[0] = c->match_len[(size_t)i];
@@ -192,15 +195,14 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                 }
                 if (loc.empty()) continue;
                 const double te0 = trace ? now_ms() : 0;
-                ChainOrders orders;
                 host_eliminate_overlaps(loc, &orders);
                 const double te1 = trace ? now_ms() : 0;
-                std::vector<int64_t> ml; int64_t nl = 0;
+                int64_t nl = 0;
                 host_lcb_chain(loc, 0, true, ml, nl, &orders);
                 if (trace) { t_elim += te1 - te0; t_lcb += now_ms() - te1; }
                 const size_t wi = ids[k];
                 const int64_t *A = work.a(wi);
-                MatchVec glob(N);
+                glob.d.clear();
                 for (size_t q = 0; q < loc.size(); q++) {
                     if (ml[q] < 0) continue;
                     int64_t rec[1 + MAUVE_MAX_SEQ]; rec[0] = loc.len(q);
