@@ -21,8 +21,9 @@
 #include <cstdlib>
 
 #define DP_NEG_INF (-(1 << 29))
-constexpr int DP_LDS_TB = 12288;
-constexpr int DP_LDS_OPS = 768;            // 4 groups x 192 reversed ops (dp_groups); >= 256 for the one-wave path
+constexpr int DP_LDS_TB = 8192;             // per wave: 128 systolic steps x 64 lanes.  With 12288 the LDS held dp_step to 3
+                                            // workgroups per CU; 8192 (and <= 128 VGPRs) gives 4 -- C3's DP stage 3.9 -> 2.4 ms
+constexpr int DP_LDS_OPS = 512;            // 4 groups x 128 reversed ops (dp_groups); >= 128 for the one-wave path
 
 struct DpMeta {
     int32_t m;        // current profile length
@@ -274,7 +275,7 @@ __device__ void dp_interval_mw(int nseq, int64_t iv, const uint8_t *__restrict__
 // chunk by ds_bpermute; traceback bytes and reversed ops live in the wave's LDS slice, cut per group; the
 // traceback walks are run by the group leaders side by side.  The step loop runs to the longest group of the wave
 // (the list is sorted by size, so neighbours are alike).  Same recurrences and tie rules as dp_stripe_round.
-constexpr int DP_GRP_TMAX = DP_LDS_TB / 64;        // 192 systolic steps, and m + n <= 192 ops, per group
+constexpr int DP_GRP_TMAX = DP_LDS_TB / 64;        // 128 systolic steps, and m + n <= 128 ops, per group
 
 __device__ __forceinline__ int32_t lane_read(int32_t v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 
@@ -423,7 +424,7 @@ __global__ void __launch_bounds__(64 * DP_MW_WAVES) dp_step_big(int nseq, const 
 
 struct DpClasses { int64_t first_med, n_med, first_s32, n_s32, first_s16, n_s16; uint32_t blocks_med, blocks_s32; };
 
-__global__ void __launch_bounds__(256) dp_step(int nseq, const int64_t *__restrict__ list, DpClasses cl, const uint8_t *__restrict__ codes,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) dp_step(int nseq, const int64_t *__restrict__ list, DpClasses cl, const uint8_t *__restrict__ codes,
                                                const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
                                                uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
                                                uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
@@ -431,7 +432,7 @@ __global__ void __launch_bounds__(256) dp_step(int nseq, const int64_t *__restri
                                                int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
                                                uint8_t *__restrict__ ops, DpScoring sc)
 {
-    // Small steps (one stripe, m + n <= 192) keep their traceback bytes and reversed ops in LDS: the traceback
+    // Small steps (one stripe, m + n <= 128) keep their traceback bytes and reversed ops in LDS: the traceback
     // walk is a chain of dependent 1-byte loads, ~100 cycles each from LDS against >1000 from L2/HBM.
     __shared__ uint8_t s_tb[4][DP_LDS_TB];
     __shared__ uint8_t s_ops[4][DP_LDS_OPS];
