@@ -52,35 +52,45 @@ namespace {
 // one alive match as genome g sees it; kept sorted by left end, so the overlap scan is a sequential sweep
 struct Ent { uint32_t left, len, idx, flag; };     // flag: 1 = forward in g, 0 = reverse, 2 = died this pass
 
-// stable LSD radix sort by left end (3 x 11 bits); returns at once when the order already holds
+// order of the entries inside a genome: left end, ties by match index (every pass sorts by
+// (left end, index) from scratch; equal left ends do occur after crops, mostly among very short matches)
+inline bool ent_after(const Ent &a, const Ent &b) { return a.left != b.left ? a.left > b.left : a.idx > b.idx; }
+
+// sort by (left end, index); returns at once when the order already holds
 void sort_ents(std::vector<Ent> &e, std::vector<Ent> &tmp, bool nearly_sorted)
 {
     const size_t n = e.size();
     if (n < 2) return;
-    // Nearly sorted input (a pass of crops moves a few entries a few places) is repaired by a stable insertion
-    // sort on a shift budget; whatever is left when the budget runs out goes through the radix passes, which are
-    // stable on top of the partly repaired order.
+    // Nearly sorted input (a pass of crops moves a few entries a few places) is repaired by an insertion sort on a
+    // shift budget; whatever is left when the budget runs out goes through the radix passes.
     size_t budget = nearly_sorted ? 4 * n : 0, i = 1;
     for (; i < n; i++) {
-        if (e[i - 1].left <= e[i].left) continue;
+        if (!ent_after(e[i - 1], e[i])) continue;
         const Ent x = e[i];
         size_t j = i;
-        while (j > 0 && e[j - 1].left > x.left && budget) { e[j] = e[j - 1]; j--; budget--; }
+        while (j > 0 && ent_after(e[j - 1], x) && budget) { e[j] = e[j - 1]; j--; budget--; }
         e[j] = x;
-        if (!budget && j > 0 && e[j - 1].left > x.left) break;
+        if (!budget && j > 0 && ent_after(e[j - 1], x)) break;
     }
     if (i >= n) return;
+    // stable LSD radix by left end (3 x 11 bits), then the (rare) groups of equal left ends by index
     tmp.resize(n);
     Ent *src = e.data(), *dst = tmp.data();
     for (int pass = 0; pass < 3; pass++) {
         const int sh = 11 * pass;
         uint32_t cnt[2049] = {0};
-        for (size_t i = 0; i < n; i++) cnt[((src[i].left >> sh) & 2047) + 1]++;
-        for (int b = 0; b < 2048; b++) cnt[b + 1] += cnt[b];
-        for (size_t i = 0; i < n; i++) dst[cnt[(src[i].left >> sh) & 2047]++] = src[i];
+        for (size_t q = 0; q < n; q++) cnt[((src[q].left >> sh) & 2047) + 1]++;
+        for (int b2 = 0; b2 < 2048; b2++) cnt[b2 + 1] += cnt[b2];
+        for (size_t q = 0; q < n; q++) dst[cnt[(src[q].left >> sh) & 2047]++] = src[q];
         std::swap(src, dst);
     }
     if (src != e.data()) std::copy(src, src + n, e.data());
+    for (size_t q = 0; q + 1 < n;) {
+        size_t r = q + 1;
+        while (r < n && e[r].left == e[q].left) r++;
+        if (r - q > 1) std::sort(e.begin() + q, e.begin() + r, [](const Ent &x, const Ent &y) { return x.idx < y.idx; });
+        q = r;
+    }
 }
 
 // buffers kept per thread across calls: fresh multi-hundred-KB vectors cost page faults on every call
@@ -167,6 +177,14 @@ void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders)
                 size_t w = 0;
                 for (size_t r = 0; r < k; r++) if (ents[r].flag != 2) ents[w++] = ents[r];
                 ents.resize(w);
+            } else {
+                // Nothing died: if no cropped entry moved past its right neighbour either, the genome is overlap free
+                // (crops only shrink intervals and every overlapping adjacent pair was just resolved; an overlap
+                // between non-neighbours would have pushed the entry between them out of order) -- the pass that
+                // would merely confirm it is skipped.
+                bool in_order = true;
+                for (uint32_t r : S.touched) if (r + 1 < k && ent_after(ents[r], ents[r + 1])) { in_order = false; break; }
+                if (in_order) break;
             }
         }
         const double to0 = trace ? now_ms() : 0;

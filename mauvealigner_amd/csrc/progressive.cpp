@@ -139,6 +139,13 @@ int prog_node(Prog &P, int node)
     const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight * n / P.N : (int64_t)3 * w * n;
     std::vector<int64_t> match_lcb; int64_t nl = 0;
     host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl, &orders);
+    if (trace) {
+        int64_t surv = 0; for (size_t i = 0; i < m.size(); i++) if (match_lcb[i] >= 0) surv++;
+        fprintf(stderr, "[trace] node %d (n=%d, w=%d): %lld n-way matches, %zu after overlap elimination, %lld lcbs, %lld anchors\n", node, n, w,
+                (long long)nm, m.size(), (long long)nl, (long long)surv);
+        if (getenv("MAUVE_TRACE_MATCHES"))
+            for (size_t i = 0; i < m.size(); i++) { fprintf(stderr, "[trace]   m %zu len %lld lcb %lld:", i, (long long)m.len(i), (long long)match_lcb[i]); for (int j = 0; j < n; j++) fprintf(stderr, " %lld", (long long)m.st(i)[j]); fprintf(stderr, "\n"); }
+    }
     // chains, cut wherever the stretch between two consecutive anchors touches an already placed base
     std::vector<MatchVec> pieces; int64_t cur_lcb = -1;
     for (size_t i = 0; i < m.size(); i++) {

@@ -72,6 +72,35 @@ def test_host_chaining_equals_oracle(cfg, scale, w):
             assert np.array_equal(d1[k], d2[k]), (mw, col, k)
 
 
+def test_host_chaining_random_dense_matches():
+    """Host overlap elimination and LCB chaining against the oracle on random match lists that are short, dense and
+    heavily overlapping -- the regime (light seeds in small pools) where crops leave matches with equal left ends, so
+    the (left end, index) order of S5 matters.  Found by the GPU fuzz sweep; this is its CPU-only form."""
+    rng = np.random.default_rng(2026)
+    for case in range(400):
+        N = int(rng.integers(2, 5))
+        n = int(rng.integers(2, 140))
+        span = int(rng.integers(30, 1500))
+        length = rng.integers(1, int(rng.choice([4, 10, 40])), size=n).astype(np.int64)
+        start = np.zeros((n, N), np.int64)
+        start[:, 0] = rng.integers(1, span, size=n)
+        for g in range(1, N):
+            near = rng.random(n) < 0.6                                  # mostly collinear, the rest anywhere
+            pos = np.where(near, start[:, 0] + rng.integers(-6, 7, size=n), rng.integers(1, span, size=n))
+            pos = np.maximum(pos, 1)
+            start[:, g] = np.where(rng.random(n) < 0.15, -pos, pos)
+        order = np.lexsort((length, *[start[:, g] for g in range(N - 1, 0, -1)], start[:, 0]))   # canonical-ish input order
+        length, start = length[order], start[order]
+        a = O.eliminate_overlaps(length, start)
+        b = _lib.eliminate_overlaps(length, start)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), case
+        for mw, col in ((0, False), (3 * 7 * N, False), (0, True)):
+            d1 = O.compute_lcbs(a[0], a[1], mw, col)
+            d2 = _lib.lcb_chain(a[0], a[1], mw, col)
+            for k in ("n_lcb", "match_lcb", "left_end", "right_end", "weight"):
+                assert np.array_equal(d1[k], d2[k]), (case, mw, col, k)
+
+
 def test_host_chaining_handmade_cases():
     length = np.array([100, 100, 10, 100, 100], dtype=np.int64)
     start = np.array([[1, 1], [201, 201], [401, -5000], [601, 601], [801, 801]], dtype=np.int64)
