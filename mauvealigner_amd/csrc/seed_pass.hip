@@ -213,6 +213,76 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total,
     return wbase + inc - v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Masked seed passes (guide-tree nodes below the root, LCB extension): most windows touch a masked base and
+// would only be carried through the sort as dead all-ones keys.  Instead the valid windows are compacted, in
+// position order (so equal mers still arrive in ascending position, as the join expects): count per tile,
+// one-block scan over the tiles, then an extract that writes each tile's valid (key, val) pairs at the tile's
+// offset.  A thread owns 16 consecutive windows, so one block scan of per-thread counts gives the order.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool window_valid(uint32_t gp, uint32_t P, const GenomeTab &tab, int span, const uint64_t *__restrict__ vmask)
+{
+    if (gp >= P) return false;
+    const int g = genome_of(gp, tab);
+    return !window_masked(vmask + tab.mask_off[g], gp - tab.gpos_off[g], span);
+}
+
+__global__ void __launch_bounds__(256) valid_count(GenomeTab tab, int span, uint32_t P, const uint64_t *__restrict__ vmask,
+                                                   uint32_t *__restrict__ tile_cnt)
+{
+    __shared__ uint32_t lds[8];
+    const uint32_t first = blockIdx.x * 4096u + threadIdx.x * 16u;
+    uint32_t c = 0;
+    for (int i = 0; i < 16; i++) c += window_valid(first + i, P, tab, span, vmask) ? 1u : 0u;
+    uint32_t total;
+    (void)block_excl_scan(c, &total, lds);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+}
+
+// exclusive scan of tile_cnt[0..nblk) in place, total -> *total_out (one workgroup)
+__global__ void __launch_bounds__(256) tile_scan(uint32_t *__restrict__ tile_cnt, uint32_t nblk, uint32_t *__restrict__ total_out)
+{
+    __shared__ uint32_t lds[8];
+    const uint32_t chunk = (nblk + 255) / 256, lo = threadIdx.x * chunk, hi = min(lo + chunk, nblk);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += tile_cnt[i];
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, &total, lds);
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t v = tile_cnt[i]; tile_cnt[i] = run; run += v; }
+    if (threadIdx.x == 0) *total_out = total;
+}
+
+template <typename KeyT, bool NARROW>
+__global__ void __launch_bounds__(256) seed_extract_compact(const uint64_t *__restrict__ packed, GenomeTab tab, SeedShape sh,
+                                                            KeyT *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t P,
+                                                            const uint64_t *__restrict__ vmask, const uint32_t *__restrict__ tile_off)
+{
+    __shared__ uint32_t lds[8];
+    const uint32_t first = blockIdx.x * 4096u + threadIdx.x * 16u;
+    uint32_t ok = 0;
+    for (int i = 0; i < 16; i++) ok |= (window_valid(first + i, P, tab, sh.span, vmask) ? 1u : 0u) << i;
+    uint32_t total;
+    uint32_t o = tile_off[blockIdx.x] + block_excl_scan((uint32_t)__popc(ok), &total, lds);
+    for (int i = 0; i < 16; i++) {
+        if (!(ok >> i & 1)) continue;
+        const uint32_t gp = first + i;
+        const int g = genome_of(gp, tab);
+        const uint32_t p = gp - tab.gpos_off[g];
+        uint64_t key; uint32_t s;
+        if (NARROW) {
+            const uint32_t kp = kprime_narrow(packed + tab.word_off[g], p, sh);
+            const uint32_t f = digit_reverse32(kp, sh.weight), r = (~kp) & (uint32_t)sh.keymask;
+            s = r < f; key = s ? r : f;
+        } else {
+            const uint64_t kp = kprime_at(packed + tab.word_off[g], p, sh);
+            const uint64_t f = digit_reverse(kp, sh.weight), r = (~kp) & sh.keymask;
+            s = r < f; key = s ? r : f;
+        }
+        keys[o] = (KeyT)key; vals[o] = gp | (s << 31);
+        o++;
+    }
+}
+
 constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;   // 4096 keys per workgroup
@@ -852,7 +922,30 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
 
     uint32_t sorted_n = 0;
     bool have_hist0 = false;
-    if (only_seq < 0) {
+    bool compacted = false;
+    if (only_seq < 0 && vmask && !SEG) {
+        // masked pass: only the valid windows go into the sort (see valid_count / seed_extract_compact)
+        const uint32_t nblk = (n + 4095) / 4096;
+        HIPCHK(ctx, ctx->hist.ensure((size_t)nblk * 256 * sizeof(uint32_t)));     // the tile counts live in the histogram buffer
+        uint32_t *tile_cnt = ctx->hist.as<uint32_t>();
+        {
+            KernelTimer t(ctx, MAUVE_K_EXTRACT, n);
+            hipLaunchKernelGGL(valid_count, dim3(nblk), dim3(256), 0, ctx->stream, tab, sh.span, n, vmask, tile_cnt);
+            hipLaunchKernelGGL(tile_scan, dim3(1), dim3(256), 0, ctx->stream, tile_cnt, nblk, ctx->counters.as<uint32_t>());
+            if (sh.span <= 32 && sh.weight <= 15)
+                hipLaunchKernelGGL((seed_extract_compact<KeyT, true>), dim3(nblk), dim3(256), 0, ctx->stream, packed, tab, sh, keys, vals, n,
+                                   vmask, tile_cnt);
+            else
+                hipLaunchKernelGGL((seed_extract_compact<KeyT, false>), dim3(nblk), dim3(256), 0, ctx->stream, packed, tab, sh, keys, vals, n,
+                                   vmask, tile_cnt);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, ctx->pin_seed.ensure(64));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        sorted_n = ctx->pin_seed.as<uint32_t>()[0];
+        compacted = true;
+    } else if (only_seq < 0) {
         const uint32_t nblk = (n + RS_TILE - 1) / RS_TILE;
         HIPCHK(ctx, ctx->hist.ensure((size_t)nblk * 256 * sizeof(uint32_t)));
         KernelTimer t(ctx, MAUVE_K_EXTRACT, n);
@@ -878,7 +971,9 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     TRACE(ctx, "extract");
     if (sorted_n == 0) { if (n_matches) *n_matches = 0; return MAUVE_OK; }
     // segmented keys: segment id above the mer; the all-ones invalid key needs every bit, so sort all 64
-    const int key_bits = SEG ? 64 : (vmask ? (int)sizeof(KeyT) * 8 : 2 * sh.weight);
+    const int key_bits = SEG ? 64 : (vmask && !compacted ? (int)sizeof(KeyT) * 8 : 2 * sh.weight);
+    const int has_invalid = vmask != nullptr && !compacted;
+    const uint32_t ns = sorted_n;                   // entries of the sorted list (all windows, or the valid ones)
     int rc = sort_pairs<KeyT>(ctx, sorted_n, key_bits, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>(), have_hist0);
     if (rc) return rc;
     TRACE(ctx, "sort");
@@ -916,13 +1011,13 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     const bool use_summary = mode == MAUVE_MODE_PAIRWISE && !SEG && passes.size() > 1;
     uint32_t *rstart = nullptr, *rlen = nullptr, *runiq = nullptr;
     if (use_summary) {
-        const size_t cap = (size_t)n / 2 + 1;
+        const size_t cap = (size_t)ns / 2 + 1;
         HIPCHK(ctx, ctx->run_sum.ensure(3 * cap * 4));
         rstart = ctx->run_sum.as<uint32_t>(); rlen = rstart + cap; runiq = rlen + cap;
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
-        { KernelTimer t(ctx, MAUVE_K_JOIN, n);
-          hipLaunchKernelGGL((run_summary<KeyT>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, n, tab,
-                             vmask != nullptr, rstart, rlen, runiq, ctx->counters.as<uint32_t>() + 2); }
+        { KernelTimer t(ctx, MAUVE_K_JOIN, ns);
+          hipLaunchKernelGGL((run_summary<KeyT>), dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, ns, tab,
+                             has_invalid, rstart, rlen, runiq, ctx->counters.as<uint32_t>() + 2); }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, ctx->pin_seed.ensure(64));
         HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -939,9 +1034,9 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
                 hipLaunchKernelGGL(join_pair, dim3((nruns + 255) / 256), dim3(256), 0, ctx->stream, vals, tab, rstart, rlen, runiq, nruns,
                                    __builtin_ctz(fp.consider), 31 - __builtin_clz(fp.consider), tmask, tpos);
         } else
-        { KernelTimer t(ctx, MAUVE_K_JOIN, n);
-          hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, n, tab, fp.rule,
-                             fp.want, fp.consider, tmask, tpos, P, vmask != nullptr); }
+        { KernelTimer t(ctx, MAUVE_K_JOIN, ns);
+          hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, ns, tab, fp.rule,
+                             fp.want, fp.consider, tmask, tpos, P, has_invalid); }
         HIPCHK(ctx, hipGetLastError());
         TRACE(ctx, "join");
         // extension phase A: run starts from the table
