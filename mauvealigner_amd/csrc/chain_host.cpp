@@ -107,7 +107,7 @@ struct ElimScratch {
 // applied together, and the sweep repeats until the genome is overlap free.  `orders` (optional) receives
 // the per-genome order of the survivors -- the (left end, index) order host_lcb_chain needs: once a genome
 // is overlap free, later crops and deaths cannot reorder it.
-void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders)
+void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders, bool compact)
 {
     const int N = m.N;
     const size_t n = m.size();
@@ -115,7 +115,7 @@ void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders)
     const bool trace = trace_on && n >= 1000;          // per-gap calls of the recursion stay quiet
     const double te0 = trace ? now_ms() : 0;
     static thread_local ElimScratch S;
-    if (orders) { orders->ord.resize((size_t)N); for (auto &o : orders->ord) o.clear(); }     // capacity is kept: called per gap
+    if (orders) { orders->ord.resize((size_t)N); for (auto &o : orders->ord) o.clear(); orders->sparse = false; }     // capacity is kept: called per gap
     if (n < 2) {
         if (orders) for (int g = 0; g < N; g++) orders->ord[(size_t)g].assign(n, 0u);
         return;
@@ -195,6 +195,19 @@ void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders)
     }
     if (trace) fprintf(stderr, "[trace] eliminate: entry build %.3f ms, order copies %.3f\n", t_build, t_ord);
     const double te1 = trace ? now_ms() : 0;
+    if (!compact && orders) {
+        // the list keeps its dead records; the survivors are exactly the entries of the order lists (old indices),
+        // which is all host_lcb_chain needs -- saves moving every record and renumbering three index lists
+        for (int g = 0; g < N; g++) {
+            std::vector<uint32_t> &o = orders->ord[(size_t)g];
+            o.clear();
+            for (uint32_t i : S.ordg[(size_t)g]) if (S.alive[i]) o.push_back(i);
+        }
+        orders->sparse = true;
+        if (trace) fprintf(stderr, "[trace] eliminate (no compaction) order lists %.3f ms, total %.3f\n", now_ms() - te1, now_ms() - te0);
+        return;
+    }
+    if (orders) orders->sparse = false;
     S.newidx.resize(n);
     size_t k = 0;
     for (size_t i = 0; i < n; i++) if (S.alive[i]) { S.newidx[i] = (uint32_t)k; m.move(k++, i); }
@@ -227,7 +240,11 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
     static thread_local std::vector<uint64_t> key, tmp;
     order_s.resize((size_t)N * n); rank_s.resize((size_t)N * n);
     uint32_t *order = order_s.data(), *rank = rank_s.data();
-    const bool given = orders && (int)orders->ord.size() == N && orders->ord[0].size() == n;
+    // `sparse` orders (host_eliminate_overlaps without compaction): m still holds dead records, the order lists name
+    // the na survivors by their indices in m; everything below is indexed by those, dead records keep lcb -1
+    const bool given = orders && (int)orders->ord.size() == N && (orders->sparse ? orders->ord[0].size() <= n : orders->ord[0].size() == n);
+    const size_t na = given ? orders->ord[0].size() : n;
+    if (na == 0) return;
     for (int g = 0; g < N; g++) {
         uint32_t *og = order + (size_t)g * n, *rg = rank + (size_t)g * n;
         if (given) std::copy(orders->ord[(size_t)g].begin(), orders->ord[(size_t)g].end(), og);
@@ -237,7 +254,7 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
             sort_by_left(key, tmp);
             for (size_t r = 0; r < n; r++) og[r] = (uint32_t)key[r];
         }
-        for (uint32_t r = 0; r < n; r++) rg[og[r]] = r;
+        for (uint32_t r = 0; r < na; r++) rg[og[r]] = r;
     }
     const double tl1 = trace ? now_ms() : 0;
     // initial nodes: maximal collinear runs in genome-0 order
@@ -246,7 +263,7 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
     static thread_local std::vector<int64_t> weight;
     static thread_local std::vector<uint32_t> node_first;     // first match (genome-0 order) of each node
     weight.clear(); node_first.clear();
-    for (uint32_t k = 0; k < n; k++) {
+    for (uint32_t k = 0; k < na; k++) {
         const uint32_t i = order[k];
         bool join = k > 0;
         if (join) {
@@ -274,7 +291,7 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
     for (int g = 0; g < N; g++) {
         const uint32_t *og = order + (size_t)g * n;
         int32_t last = -1;
-        for (uint32_t r = 0; r < n; r++) {
+        for (uint32_t r = 0; r < na; r++) {
             const int32_t nd = node_of[og[r]];
             if (nd == last) continue;
             // a node's matches are contiguous in every genome, so each node shows up exactly once here
@@ -353,7 +370,7 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
         while (!alive[(size_t)v] && merged_into[(size_t)v] >= 0) v = merged_into[(size_t)v];
         final_id[(size_t)i] = alive[(size_t)v] ? final_id[(size_t)v] : -1;
     }
-    for (size_t i = 0; i < n; i++) match_lcb[i] = final_id[(size_t)node_of[i]];
+    for (uint32_t k = 0; k < na; k++) { const uint32_t i = order[k]; match_lcb[i] = final_id[(size_t)node_of[i]]; }
     if (trace) fprintf(stderr, "[trace] lcb: orders %.3f ms, nodes+lists %.3f (K=%d), greedy %.3f, labels %.3f\n", tl1 - tl0, tl2 - tl1, K, tl3 - tl2, now_ms() - tl3);
 }
 

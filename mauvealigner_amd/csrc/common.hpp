@@ -266,8 +266,9 @@ int seedpass_sorted_list(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t 
                          std::vector<uint32_t> *vals, int *weight);
 
 // host chaining (chain_host.cpp)
-struct ChainOrders { std::vector<std::vector<uint32_t>> ord; };   // per genome: match indices in left-end order
-void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders = nullptr);
+struct ChainOrders { std::vector<std::vector<uint32_t>> ord; bool sparse = false; };   // per genome: match indices in left-end order;
+                                                                                        // sparse: the list still holds dead records (not named here)
+void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders = nullptr, bool compact = true);
 void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb,
                     const ChainOrders *orders = nullptr);
 

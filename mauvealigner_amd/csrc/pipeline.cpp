@@ -181,7 +181,8 @@ static int align_begin(mauve_ctx *c, const mauve_params *p)
         std::copy(&c->match_start[(size_t)i * N], &c->match_start[(size_t)i * N] + N, m.st((size_t)i));
     }
     ChainOrders orders;
-    host_eliminate_overlaps(m, &orders);
+    static const bool elim_compact = getenv("MAUVE_ELIM_COMPACT") != nullptr;       // A/B switch
+    host_eliminate_overlaps(m, &orders, elim_compact);           // default: dead records stay in m, with lcb -1 below
     const double t1b = now_ms();
     const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight : (int64_t)3 * w * N;
     std::vector<int64_t> &match_lcb = S.match_lcb; int64_t nl = 0;
