@@ -3,13 +3,12 @@
 // projectAndStrip.cpp:110-112, toGrimmFormat.cpp:51-79, sortContigs.cpp:55-84).
 //
 // The elimination loop is sequential by nature and runs over the compact LCB
-// graph: per-genome doubly linked lists of LCB nodes, an ordered set keyed by (weight, genome-0
-// order) for the minimum, and local re-merging around each removed node.  Spec: DESIGN.md S5.
+// graph: flat per-genome doubly linked lists of LCB nodes, a lazy-deletion min-heap keyed by (weight,
+// genome-0 order), and local re-merging around each removed node.  Spec: DESIGN.md S5.
 #include "common.hpp"
 #include <algorithm>
 #include <cstdlib>
 #include <numeric>
-#include <set>
 
 namespace {
 // stable LSD radix sort of packed (left end << 32 | index) keys by the left end: 3 passes of 11 bits.

@@ -6,7 +6,8 @@
 // every step is a 3-state affine-gap (Gotoh) DP of the current profile against the next sequence,
 // sum-of-pairs scores from per-column base counts, predecessor preference M > X > Y on ties.
 //
-// Mapping: one wave64 per interval.  The profile columns are the DP rows; the 64 lanes hold 64
+// Mapping: the basic unit is one wave64 per interval (small intervals share a wave, dp_groups; the longest get a
+// 16-wave workgroup, dp_step_big -- same recurrence, different schedules).  The profile columns are the DP rows; the 64 lanes hold 64
 // consecutive rows and sweep the sequence as a systolic anti-diagonal wavefront: lane l works on
 // column j = t - l at step t, takes (i-1, j) from lane l-1 by a wave shuffle, (i-1, j-1) from what it
 // took one step earlier and (i, j-1) from its own registers.  Profiles longer than 64 columns run in

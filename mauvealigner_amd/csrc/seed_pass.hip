@@ -993,7 +993,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     const int N = tab.nseq;
     const uint32_t P = n;
     HIPCHK(ctx, ctx->posmask.ensure((size_t)P * 4));             // tmask
-    HIPCHK(ctx, ctx->hit_pos.ensure((size_t)P * 4 * N));         // tpos [N][P]
+    HIPCHK(ctx, ctx->hit_pos.ensure((size_t)P * 4 * N));         // tpos [P][N]
     HIPCHK(ctx, ctx->cand.ensure((size_t)(P / 2 + 1) * 4));      // a hit needs >= 2 entries
     uint32_t *tmask = ctx->posmask.as<uint32_t>(), *tpos = ctx->hit_pos.as<uint32_t>();
     struct FinderPass { uint32_t consider, want; int rule; };
