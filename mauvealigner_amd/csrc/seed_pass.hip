@@ -1070,7 +1070,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     const uint32_t ncand = cand_total;
     if (ncand == 0) return MAUVE_OK;
     // ---- canonical order (first component, |start|, mask, starts, length) ----
-    static const uint32_t dev_sort_min = getenv("MAUVE_CANON_DEVICE_MIN") ? (uint32_t)atol(getenv("MAUVE_CANON_DEVICE_MIN")) : 65536u;
+    static const uint32_t dev_sort_min = getenv("MAUVE_CANON_DEVICE_MIN") ? (uint32_t)atol(getenv("MAUVE_CANON_DEVICE_MIN")) : 16384u;
     if (ncand >= dev_sort_min) {
         // large sets: sort on the device, gather, copy out in order.  (Own buffers: over several finder passes the
         // candidates can outnumber the windows, so the sorted-mer buffers are not guaranteed to be big enough.)
