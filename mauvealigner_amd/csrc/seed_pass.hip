@@ -879,20 +879,24 @@ static int build_tab(mauve_ctx *ctx, const GenomeSet &gs, int span, GenomeTab *t
 
 template <typename KeyT>
 static int sort_pairs(mauve_ctx *ctx, uint32_t n, int key_bits, KeyT **keys_io, uint32_t **vals_io, KeyT *keys_alt,
-                      uint32_t *vals_alt, bool have_hist0)
+                      uint32_t *vals_alt, bool have_hist0, int timer_id = -1)
 {
+    // timer_id >= 0: all launches are booked under that id (the small canonical-order sort must not dilute the
+    // per-kernel figures of the main sort)
+    const int k_hist = timer_id >= 0 ? timer_id : MAUVE_K_SORT_HIST, k_scan = timer_id >= 0 ? timer_id : MAUVE_K_SORT_SCAN,
+              k_scat = timer_id >= 0 ? timer_id : MAUVE_K_SORT_SCATTER;
     uint32_t nblk = (n + RS_TILE - 1) / RS_TILE;
     HIPCHK(ctx, ctx->hist.ensure((size_t)nblk * 256 * sizeof(uint32_t)));
     HIPCHK(ctx, ctx->totals.ensure(256 * sizeof(uint32_t)));
     KeyT *kin = *keys_io, *kout = keys_alt; uint32_t *vin = *vals_io, *vout = vals_alt;
     for (int shift = 0; shift < key_bits; shift += 8) {
-        if (!(shift == 0 && have_hist0)) { KernelTimer t(ctx, MAUVE_K_SORT_HIST, n);
+        if (!(shift == 0 && have_hist0)) { KernelTimer t(ctx, k_hist, n);
           hipLaunchKernelGGL(rs_hist<KeyT>, dim3(nblk), dim3(RS_THREADS), 0, ctx->stream, kin, n, shift,
                              ctx->hist.as<uint32_t>(), nblk); }
-        { KernelTimer t(ctx, MAUVE_K_SORT_SCAN, n);
+        { KernelTimer t(ctx, k_scan, n);
           hipLaunchKernelGGL(rs_rowscan, dim3(256), dim3(256), 0, ctx->stream, ctx->hist.as<uint32_t>(), nblk,
                              ctx->totals.as<uint32_t>()); }
-        { KernelTimer t(ctx, MAUVE_K_SORT_SCATTER, n);
+        { KernelTimer t(ctx, k_scat, n);
           hipLaunchKernelGGL(rs_scatter<KeyT>, dim3(nblk), dim3(RS_THREADS), 0, ctx->stream, kin, vin, kout, vout, n,
                              shift, ctx->hist.as<uint32_t>(), ctx->totals.as<uint32_t>(), nblk); }
         std::swap(kin, kout); std::swap(vin, vout);
@@ -1083,7 +1087,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
                            ctx->mstart.as<int32_t>(), ncand, N, ck, cv, ctx->counters.as<uint32_t>() + 3);
         HIPCHK(ctx, hipGetLastError());
         int fbits = 1; while ((1 << fbits) <= N) fbits++;
-        int rc2 = sort_pairs<uint64_t>(ctx, ncand, 32 + fbits, &ck, &cv, ck2, cv2, false);
+        int rc2 = sort_pairs<uint64_t>(ctx, ncand, 32 + fbits, &ck, &cv, ck2, cv2, false, MAUVE_K_CANON);
         if (rc2) return rc2;
         HIPCHK(ctx, ctx->pin_seed.ensure(64));
         HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));

@@ -22,8 +22,16 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def short(name):
-    m = re.match(r"(?:void )?([A-Za-z_0-9]+)", name)
-    return m.group(1) if m else name
+    """Kernel name without arguments.  The radix-sort kernels keep their key type: the main sort of C2 runs on 32-bit
+    keys (rs_scatter), the small canonical-order sort on 64-bit keys (rs_scatter<u64>) -- one figure for both would
+    describe neither."""
+    m = re.match(r"(?:void )?([A-Za-z_0-9]+)(<[^(]*>)?", name)
+    if not m:
+        return name
+    base, targs = m.group(1), m.group(2) or ""
+    if base.startswith("rs_") and "unsigned long" in targs:
+        return base + "<u64>"
+    return base
 
 
 def read_pmc(dirname, counter):
@@ -52,7 +60,7 @@ def main():
     P = bench["roofline"]["seed_pass"]["positions"]
     fetch, write = read_pmc("pmc_fetch", "FETCH_SIZE"), read_pmc("pmc_write", "WRITE_SIZE")
     cal = 1.0
-    if "rs_hist" in fetch and P:
+    if "rs_hist" in fetch and P:          # the 32-bit-key instance: the main sort's histogram reads exactly 4 P bytes
         cal = (4.0 * P) / (avg(fetch["rs_hist"]) * 1024.0)
     traffic = {}
     lines = ["# rocprofv3 summary, round %s" % tag, "",
