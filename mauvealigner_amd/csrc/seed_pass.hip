@@ -793,23 +793,24 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
 }
 
 // ------------------------------------------------------------------------------------------------
-// canonical order on the device (large candidate sets): key = first component << 32 | |its start| per candidate
+// canonical order on the device (large candidate sets): key = first component << pos_bits | |its start| per candidate
+// (pos_bits = bits of the longest genome: fewer radix passes than a fixed 32)
 // (dropped candidates get first component = nseq and sort behind everything), the radix sort above on
 // (key, candidate index), then a gather of the surviving records as int64 in sorted order.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) canon_keys(const int32_t *__restrict__ mlen, const int32_t *__restrict__ mstart, uint32_t ncand,
-                                                  int nseq, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                  int nseq, int pos_bits, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                   uint32_t *__restrict__ n_valid)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = false;
     if (i < ncand) {
-        uint64_t key = (uint64_t)nseq << 32;
+        uint64_t key = (uint64_t)nseq << pos_bits;
         if (mlen[i] != 0) {
             const int32_t *s = mstart + (size_t)i * nseq;
             int f = 0; while (f < nseq && s[f] == 0) f++;
             const uint32_t a = f < nseq ? (uint32_t)(s[f] < 0 ? -s[f] : s[f]) : 0u;
-            key = ((uint64_t)f << 32) | a;
+            key = ((uint64_t)f << pos_bits) | a;
             valid = true;
         }
         keys[i] = key; vals[i] = i;
@@ -1083,11 +1084,14 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         uint64_t *ck = ctx->canon_k1.as<uint64_t>(), *ck2 = ctx->canon_k2.as<uint64_t>();
         uint32_t *cv = ctx->canon_v1.as<uint32_t>(), *cv2 = ctx->canon_v2.as<uint32_t>();
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
-        hipLaunchKernelGGL(canon_keys, dim3((ncand + 255) / 256), dim3(256), 0, ctx->stream, ctx->mlen.as<int32_t>(),
-                           ctx->mstart.as<int32_t>(), ncand, N, ck, cv, ctx->counters.as<uint32_t>() + 3);
-        HIPCHK(ctx, hipGetLastError());
+        int64_t maxlen = 1; for (int g = 0; g < N; g++) maxlen = std::max<int64_t>(maxlen, gs.lens[(size_t)g]);
+        int pos_bits = 1; while (pos_bits < 32 && (1LL << pos_bits) <= maxlen) pos_bits++;
         int fbits = 1; while ((1 << fbits) <= N) fbits++;
-        int rc2 = sort_pairs<uint64_t>(ctx, ncand, 32 + fbits, &ck, &cv, ck2, cv2, false, MAUVE_K_CANON);
+        { KernelTimer t(ctx, MAUVE_K_CANON, ncand);
+          hipLaunchKernelGGL(canon_keys, dim3((ncand + 255) / 256), dim3(256), 0, ctx->stream, ctx->mlen.as<int32_t>(),
+                             ctx->mstart.as<int32_t>(), ncand, N, pos_bits, ck, cv, ctx->counters.as<uint32_t>() + 3); }
+        HIPCHK(ctx, hipGetLastError());
+        int rc2 = sort_pairs<uint64_t>(ctx, ncand, pos_bits + fbits, &ck, &cv, ck2, cv2, false, MAUVE_K_CANON);
         if (rc2) return rc2;
         HIPCHK(ctx, ctx->pin_seed.ensure(64));
         HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
