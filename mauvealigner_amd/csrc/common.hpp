@@ -209,6 +209,7 @@ struct mauve_ctx {
 
     PinnedBuf pin_dcols;                 // DP columns of the whole-call path (mauve_align, mauve_progressive_align)
     PinnedBuf pin_meta;                  // per-interval DP results (length, score, cells)
+    PinnedBuf pin_dp_in;                 // DP inputs on their way to the device: offset tables, interval list, descriptors
     PinnedBuf pin_seed;                  // seed pass: counter readback (first 64 B) and the candidates' match records
     // host scratch of dp_core, kept across calls (see AlignState)
     struct DpHost {

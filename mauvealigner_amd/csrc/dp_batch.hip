@@ -645,13 +645,22 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     int64_t *d_tb_off = d_seq_off + (n_iv * nseq + 1);
     int64_t *d_rows_off = d_tb_off + (n_iv + 1);
     int64_t *d_col_off = d_rows_off + (n_iv + 1);
-    HIPCHK(ctx, hipMemcpyAsync(d_seq_off, seq_off, (size_t)(n_iv * nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(d_tb_off, tb_off.data(), (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(d_rows_off, rows_off.data(), (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    // the three offset tables are adjacent on the device: one copy, from page-locked staging (a pageable source is
+    // first copied by the runtime, synchronously)
+    const size_t n_so = (size_t)(n_iv * nseq + 1), n_o = (size_t)n_iv + 1;
+    const size_t desc_bytes = desc ? (size_t)n_iv * nseq * sizeof(DpSeqDesc) : 0;
+    HIPCHK(ctx, ctx->pin_dp_in.ensure((n_so + 3 * n_o) * 8 + desc_bytes + 64));
+    int64_t *pin_off = ctx->pin_dp_in.as<int64_t>();
+    memcpy(pin_off, seq_off, n_so * 8);
+    memcpy(pin_off + n_so, tb_off.data(), n_o * 8);
+    memcpy(pin_off + n_so + n_o, rows_off.data(), n_o * 8);
+    HIPCHK(ctx, hipMemcpyAsync(d_seq_off, pin_off, (n_so + 2 * n_o) * 8, hipMemcpyHostToDevice, ctx->stream));
     if (desc) {
         const int64_t nd = n_iv * nseq;
         HIPCHK(ctx, ctx->dp_desc.ensure((size_t)nd * sizeof(DpSeqDesc)));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->dp_desc.p, desc, (size_t)nd * sizeof(DpSeqDesc), hipMemcpyHostToDevice, ctx->stream));
+        char *pin_desc = reinterpret_cast<char *>(pin_off + n_so + 3 * n_o);
+        memcpy(pin_desc, desc, desc_bytes);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->dp_desc.p, pin_desc, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
         DpGenomeWords gw; memset(&gw, 0, sizeof gw);
         for (int g = 0; g < ctx->nseq; g++) gw.word_off[g] = ctx->word_off[g];
         const uint32_t gb = (uint32_t)std::min<int64_t>((nd + 3) / 4, 256 * 8);
@@ -700,7 +709,9 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     const uint32_t blocks_s16 = (uint32_t)std::min<int64_t>((cl.n_s16 + 15) / 16, 256 * 8);
     const uint32_t blocks = cl.blocks_med + cl.blocks_s32 + blocks_s16;
     HIPCHK(ctx, ctx->dp_list.ensure((size_t)n_iv * 8));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->dp_list.p, lst.data(), (size_t)n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
+    int64_t *pin_list = pin_off + n_so + 2 * n_o;               // the fourth slot of the offsets block
+    memcpy(pin_list, lst.data(), (size_t)n_iv * 8);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->dp_list.p, pin_list, (size_t)n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
     {
         KernelTimer t(ctx, MAUVE_K_DP, n_iv);
         if (n_big) {   // the workgroup-per-interval launch runs beside the one-wave launch on a second stream
