@@ -86,3 +86,66 @@ def test_device_canonical_sort_path():
     env = dict(os.environ, MAUVE_CANON_DEVICE_MIN="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "CHILD OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_random_small_entries():
+    """Randomised checks of the smaller C-ABI entries: multiplicity masks over arbitrary genome subsets, sorted mer lists
+    (incl. 64-bit keys and genomes shorter than the seed), SeedMatchEnumerator on repetitive genomes, dp_batch with
+    sizes around the kernel's class boundaries.  (scratch-scale run of the same generator: > 50 000 cases.)"""
+    from mauvealigner_amd import _lib
+    ctx = _lib.Context(0)
+    try:
+        for it in range(240):
+            rng = np.random.default_rng(7000003 + it)
+            kind = it % 4
+            if kind == 0:
+                N = int(rng.integers(2, 7)); L = int(rng.integers(100, 3000))
+                anc = rng.integers(0, 4, L, dtype=np.uint8)
+                gs = [synth.mutate(anc, float(rng.choice([0.0, 0.02, 0.1])), rng) if rng.random() < 0.8 else rng.integers(0, 4, L, dtype=np.uint8)
+                      for _ in range(N)]
+                ctx.set_genomes(gs)
+                pat = O.get_seed(int(rng.choice([5, 7, 9, 11, 15, 21])), int(rng.integers(0, 3)))
+                for _ in range(3):
+                    mask = int(rng.integers(0, 1 << N)); mode = int(rng.integers(0, 2)); ext = bool(rng.integers(0, 2))
+                    a = ctx.seed_mums(pat, mode=mode, mask=mask, extend=ext); b = O.find_matches(gs, pat, mode=mode, mask=mask, extend=ext)
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (it, mask, mode, ext)
+            elif kind == 1:
+                N = int(rng.integers(1, 4))
+                gs = [rng.integers(0, 4, int(rng.integers(1, 5000)), dtype=np.uint8) if rng.random() < 0.8
+                      else np.tile(rng.integers(0, 4, 7, dtype=np.uint8), 300) for _ in range(N)]
+                ctx.set_genomes(gs)
+                pat = O.get_seed(int(rng.choice([5, 9, 13, 16, 17, 23, 31])), int(rng.integers(0, 3)))
+                s = int(rng.integers(0, N))
+                a = ctx.sorted_mer_list(s, pat); b = O.sorted_mer_list(gs[s], pat)
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (it, s)
+            elif kind == 2:
+                unit = rng.integers(0, 4, int(rng.integers(20, 300)), dtype=np.uint8)
+                parts = [rng.integers(0, 4, int(rng.integers(10, 500)), dtype=np.uint8)]
+                for _ in range(int(rng.integers(1, 6))):
+                    parts.append(unit if rng.random() < 0.6 else synth.revcomp(unit))
+                    parts.append(rng.integers(0, 4, int(rng.integers(1, 300)), dtype=np.uint8))
+                g = np.concatenate(parts); ctx.set_genomes([g])
+                args = (int(rng.integers(2, 4)), int(rng.choice([3, 10, 1000])), bool(rng.integers(0, 2)))
+                pat = O.get_seed(int(rng.choice([7, 9, 11])), 0)
+                a = ctx.seed_match_enumerate(0, pat, *args); b = O.seed_match_enumerate(g, pat, *args)
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (it, args)
+            else:
+                nseq = int(rng.integers(2, 9)); ivs = []
+                for _ in range(int(rng.integers(1, 40))):
+                    base = rng.integers(0, 4, int(rng.choice([3, 15, 16, 17, 31, 33, 64, 65, 127, 129, 200, 700])), dtype=np.uint8)
+                    iv = []
+                    for _ in range(nseq):
+                        r = rng.random()
+                        if r < 0.15:
+                            iv.append(np.zeros(0, np.uint8))
+                        elif r < 0.25:
+                            iv.append(rng.integers(0, 4, int(rng.integers(1, 300)), dtype=np.uint8))
+                        else:
+                            iv.append(synth.mutate(base, float(rng.choice([0.0, 0.05, 0.3])), rng, indel_frac=0.3)[: int(rng.integers(1, len(base) + 1))])
+                    ivs.append(iv)
+                cols, score = ctx.dp_batch(ivs)
+                for iv, c, s in zip(ivs, cols, score):
+                    ec, es = O.align_interval(iv)
+                    assert np.array_equal(c, ec) and int(s) == es, it
+    finally:
+        ctx.close()
