@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) seed_extract_all(const uint64_t *__restri
                                                         KeyT *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t P,
                                                         const uint32_t *__restrict__ seg, uint32_t nseg,
                                                         uint32_t *__restrict__ hist, uint32_t nblk,
-                                                        const uint64_t *__restrict__ vmask)
+                                                        const uint64_t *__restrict__ vmask, int hist_shift)
 {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) seed_extract_all(const uint64_t *__restri
         if (vmask && window_masked(vmask + tab.mask_off[g], p, sh.span)) key = ~0ULL;
         keys[gp] = (KeyT)key;
         vals[gp] = gp | (s << 31);
-        atomicAdd(&h[(uint32_t)key & 255u], 1u);
+        atomicAdd(&h[(uint32_t)(key >> hist_shift) & 255u], 1u);
     }
     __syncthreads();
     hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
@@ -489,6 +489,137 @@ __global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, c
         if (!(m >> g & 1)) continue;
         if (ap == 0xFFFFFFFFu) { ap = gp; tmask[ap] = m; }
         tpos[(size_t)ap * tab.nseq + g] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// join_hash: the finder rule without a full sort.  The (mer, position) pairs are radix-sorted on their HIGH bits
+// only (bits [L, key_bits): as many 8-bit passes as bring the average bucket -- entries sharing those bits -- down to
+// a few hundred); every occurrence of a mer then lies in one bucket, and a workgroup groups the mers of a range of
+// whole buckets in an LDS hash table instead of ordering them: the finder rules only ask, per distinct mer, which
+// genomes hold it once and which more than once -- the order of the mers is irrelevant, and the anchor (lowest genome
+// of the component set) is found by genome id, not by position.  Two 8-bit passes and the join's read replace four
+// passes, three histogram sweeps and a join that walked every run serially (C2: 30-bit mers, 15 M windows).
+//
+// join_bounds: bound[c] = first bucket boundary at or after c*HJ_T (bound[0] = 0, bound[nchunk] = n); one wave per
+// chunk edge, 64 entries per probe, a binary search (the list is ordered by the high bits) when a bucket is long.
+// join_hash: workgroup c owns [bound[c], bound[c+1]) -- the buckets that start in its chunk.  A range longer than the
+// HJ_CAP entries its table takes (a bucket blown up by a repeat family or low-complexity sequence) is not processed:
+// it goes to the overflow list and the host gives that slice to the full sort and the serial join below
+// (rs_* + mum_join), which have no size limit.
+// Slot = {mer, once | multi << 16 genome sets, anchor's value}; 4096 slots, at most 3072 entries (load <= 0.75).
+// ------------------------------------------------------------------------------------------------
+constexpr int HJ_T = 2048;                   // nominal entries per workgroup
+constexpr int HJ_ROWS = 12;                  // rows of 256 entries a workgroup can take
+constexpr int HJ_CAP = HJ_ROWS * 256;        // 3072
+constexpr int HJ_SLOTS = 4096;
+static_assert(HJ_CAP * 4 <= 3 * HJ_SLOTS, "join_hash: table load factor above 0.75");
+constexpr uint32_t HJ_NONE = 0xffffffffu;
+constexpr int HJ_OVF_CAP = 4096;            // ranges the overflow list holds; beyond that the whole list goes the old way
+
+template <typename KeyT>
+__global__ void __launch_bounds__(256) join_bounds(const KeyT *__restrict__ keys, uint32_t n, int L, uint32_t nchunk,
+                                                   uint32_t *__restrict__ bound)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t c = (blockIdx.x * 256u + threadIdx.x) >> 6;           // one wave per chunk edge 0 .. nchunk
+    if (c > nchunk) return;
+    const uint32_t start = c * (uint32_t)HJ_T;
+    uint32_t res = HJ_NONE;
+    if (c == 0) res = 0;
+    else if (start >= n) res = n;
+    else {
+        const uint64_t h0 = (uint64_t)keys[start - 1] >> L;              // the bucket the edge falls into (or just behind)
+        for (int step = 0; step < 4 && res == HJ_NONE; step++) {          // 256 entries, 64 per probe
+            const uint32_t idx = start + (uint32_t)step * 64u + (uint32_t)lane;
+            const bool bnd = idx >= n || ((uint64_t)keys[idx] >> L) != h0;
+            const uint64_t b = __ballot(bnd);
+            if (b) res = start + (uint32_t)step * 64u + (uint32_t)(__ffsll((unsigned long long)b) - 1);
+        }
+        if (res == HJ_NONE) {
+            // long bucket: first index in (lo, hi] whose high bits differ (keys[lo] still belongs to the bucket, index n counts as different)
+            uint32_t lo = start + 255u, hi = n;
+            while (hi - lo > 1) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                if (((uint64_t)keys[mid] >> L) != h0) hi = mid; else lo = mid;
+            }
+            res = hi;
+        }
+        res = min(res, n);
+    }
+    if (lane == 0) bound[c] = res;
+}
+
+template <typename KeyT, bool WIDE>
+__global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t n,
+                                                 const uint32_t *__restrict__ bound, GenomeTab tab, int mode, uint32_t want_mask,
+                                                 uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos,
+                                                 uint32_t *__restrict__ ovf, uint32_t P)
+{
+    __shared__ KeyT skey[HJ_SLOTS];
+    __shared__ uint32_t som[HJ_SLOTS];                       // once (low half) | multi (high half); WIDE: once only
+    __shared__ uint32_t som2[WIDE ? HJ_SLOTS : 1];           // WIDE (> 16 genomes): multi
+    __shared__ uint32_t sanch[HJ_SLOTS];
+    constexpr KeyT EMPTY = (KeyT)~0ULL;                       // never a canonical mer; also the invalid-window key
+    const int tid = threadIdx.x;
+    const uint32_t lo = bound[blockIdx.x], hi = min(bound[blockIdx.x + 1], n);
+    if (lo >= hi) return;                                     // no bucket starts in this chunk
+    if (hi - lo > (uint32_t)HJ_CAP) {                         // oversize: hand the range to the host
+        if (tid == 0) {
+            const uint32_t o = atomicAdd(&ovf[0], 1u);
+            if (o < (uint32_t)HJ_OVF_CAP) { ovf[2 + 2 * o] = lo; ovf[3 + 2 * o] = hi; }
+        }
+        return;
+    }
+    for (int i = tid; i < HJ_SLOTS; i += 256) { skey[i] = EMPTY; som[i] = 0; if (WIDE) som2[i] = 0; }
+    KeyT k[HJ_ROWS]; uint32_t v[HJ_ROWS];
+#pragma unroll
+    for (int r = 0; r < HJ_ROWS; r++) {
+        const uint32_t idx = lo + (uint32_t)r * 256u + (uint32_t)tid;
+        const bool in = idx < hi;
+        k[r] = in ? keys[idx] : EMPTY; v[r] = in ? vals[idx] : 0u;
+    }
+    __syncthreads();
+    // ---- pass 1: group by mer ----
+    uint32_t slot[HJ_ROWS]; uint32_t gbit[HJ_ROWS];
+#pragma unroll
+    for (int r = 0; r < HJ_ROWS; r++) {
+        slot[r] = HJ_NONE; gbit[r] = 0;
+        if (k[r] == EMPTY) continue;                          // beyond the range, or an invalid window
+        uint32_t s = ((uint32_t)k[r] ^ (uint32_t)((uint64_t)k[r] >> 32)) * 0x9E3779B1u >> 20;       // 12 bits
+        for (;;) {
+            const KeyT old = atomicCAS(&skey[s], EMPTY, k[r]);
+            if (old == EMPTY || old == k[r]) break;
+            s = (s + 1) & (HJ_SLOTS - 1);
+        }
+        const uint32_t bit = 1u << genome_of(v[r] & 0x7fffffffu, tab);
+        const uint32_t old = atomicOr(&som[s], bit);
+        if (old & bit) { if (WIDE) atomicOr(&som2[s], bit); else atomicOr(&som[s], bit << 16); }
+        slot[r] = s; gbit[r] = bit;
+    }
+    __syncthreads();
+    // ---- pass 2: the finder rule per mer; the entry of the lowest component genome is the anchor ----
+    uint32_t mm[HJ_ROWS];
+#pragma unroll
+    for (int r = 0; r < HJ_ROWS; r++) {
+        mm[r] = 0;
+        if (slot[r] == HJ_NONE) continue;
+        const uint32_t om = som[slot[r]];
+        const uint32_t once = WIDE ? om : (om & 0xffffu), multi = WIDE ? som2[slot[r]] : (om >> 16);
+        const uint32_t m = once & ~multi;
+        if (mode == MAUVE_MODE_MEM && multi) continue;
+        if (__popc(m) < 2 || (want_mask && m != want_mask) || !(m & gbit[r])) continue;
+        mm[r] = m;
+        if ((m & (0u - m)) == gbit[r]) sanch[slot[r]] = v[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < HJ_ROWS; r++) {
+        if (!mm[r]) continue;
+        const uint32_t ap = sanch[slot[r]] & 0x7fffffffu;
+        if (ap >= P) { atomicAdd(&ovf[1], 1u); continue; }   // cannot happen; a wild store could take the device down
+        tpos[(size_t)ap * tab.nseq + (__ffs(gbit[r]) - 1)] = v[r];
+        if ((mm[r] & (0u - mm[r])) == gbit[r]) tmask[ap] = mm[r];
     }
 }
 
@@ -880,8 +1011,9 @@ static int build_tab(mauve_ctx *ctx, const GenomeSet &gs, int span, GenomeTab *t
 
 template <typename KeyT>
 static int sort_pairs(mauve_ctx *ctx, uint32_t n, int key_bits, KeyT **keys_io, uint32_t **vals_io, KeyT *keys_alt,
-                      uint32_t *vals_alt, bool have_hist0, int timer_id = -1)
+                      uint32_t *vals_alt, bool have_hist0, int timer_id = -1, int shift_lo = 0)
 {
+    // LSD passes over bits [shift_lo, key_bits); have_hist0: the tile histograms of the first pass are already in ctx->hist
     // timer_id >= 0: all launches are booked under that id (the small canonical-order sort must not dilute the
     // per-kernel figures of the main sort)
     const int k_hist = timer_id >= 0 ? timer_id : MAUVE_K_SORT_HIST, k_scan = timer_id >= 0 ? timer_id : MAUVE_K_SORT_SCAN,
@@ -890,8 +1022,8 @@ static int sort_pairs(mauve_ctx *ctx, uint32_t n, int key_bits, KeyT **keys_io, 
     HIPCHK(ctx, ctx->hist.ensure((size_t)nblk * 256 * sizeof(uint32_t)));
     HIPCHK(ctx, ctx->totals.ensure(256 * sizeof(uint32_t)));
     KeyT *kin = *keys_io, *kout = keys_alt; uint32_t *vin = *vals_io, *vout = vals_alt;
-    for (int shift = 0; shift < key_bits; shift += 8) {
-        if (!(shift == 0 && have_hist0)) { KernelTimer t(ctx, k_hist, n);
+    for (int shift = shift_lo; shift < key_bits; shift += 8) {
+        if (!(shift == shift_lo && have_hist0)) { KernelTimer t(ctx, k_hist, n);
           hipLaunchKernelGGL(rs_hist<KeyT>, dim3(nblk), dim3(RS_THREADS), 0, ctx->stream, kin, n, shift,
                              ctx->hist.as<uint32_t>(), nblk); }
         { KernelTimer t(ctx, k_scan, n);
@@ -928,6 +1060,25 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     uint32_t sorted_n = 0;
     bool have_hist0 = false;
     bool compacted = false;
+    // Which join: the LDS hash join over a partial sort (join_hash) for the one-pass finders; the full sort and the
+    // serial join for PairwiseMatchFinder (its run list needs sorted order), for the sorted-mer-list export and for
+    // slices join_hash hands back.  MAUVE_OLD_JOIN forces the second (A/B switch).
+    static const bool force_old_join = getenv("MAUVE_OLD_JOIN") != nullptr;
+    const bool hash_path = mode != MAUVE_MODE_PAIRWISE && !out_keys && only_seq < 0 && !force_old_join && !(vmask && SEG);
+    // segmented keys: segment id above the mer; ids 0 .. nseg-1, the all-ones id is left to the invalid (all-ones) key
+    int segbits = 0;
+    if (SEG) while (segbits < 32 && (1ull << segbits) <= (uint64_t)nseg) segbits++;
+    if (SEG && 2 * sh.weight + segbits > 64) { ctx->err = "recursive anchoring: segment id and mer do not fit 64 bits"; return MAUVE_ERR_LIMIT; }
+    const int full_bits = SEG ? 2 * sh.weight + segbits : ((vmask && (SEG || only_seq >= 0)) ? (int)sizeof(KeyT) * 8 : 2 * sh.weight);
+    // globally sorted bits: 8-bit passes until a bucket averages <= 512 entries; a segmented list sorts at least the
+    // segment id, so that the invalid windows form the last bucket on their own
+    auto low_bits = [&](uint32_t entries) {
+        if (!hash_path) return 0;
+        int G = 0;
+        while (G < full_bits && ((uint64_t)entries >> G) > 512) G += 8;
+        if (SEG) G = std::max(G, (segbits + 7) / 8 * 8);
+        return full_bits - std::min(G, full_bits);
+    };
     if (only_seq < 0 && vmask && !SEG) {
         // masked pass: only the valid windows go into the sort (see valid_count / seed_extract_compact)
         const uint32_t nblk = (n + 4095) / 4096;
@@ -954,12 +1105,13 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         const uint32_t nblk = (n + RS_TILE - 1) / RS_TILE;
         HIPCHK(ctx, ctx->hist.ensure((size_t)nblk * 256 * sizeof(uint32_t)));
         KernelTimer t(ctx, MAUVE_K_EXTRACT, n);
+        const int hshift = low_bits(n);
         if (sh.span <= 32 && sh.weight <= 15)
             hipLaunchKernelGGL((seed_extract_all<KeyT, SEG, true>), dim3(nblk), dim3(256), 0, ctx->stream, packed, tab, sh, keys,
-                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk, vmask);
+                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk, vmask, hshift);
         else
             hipLaunchKernelGGL((seed_extract_all<KeyT, SEG, false>), dim3(nblk), dim3(256), 0, ctx->stream, packed, tab, sh, keys,
-                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk, vmask);
+                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk, vmask, hshift);
         sorted_n = n; have_hist0 = true;
     } else {
         const int g = only_seq;
@@ -975,11 +1127,11 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     HIPCHK(ctx, hipGetLastError());
     TRACE(ctx, "extract");
     if (sorted_n == 0) { if (n_matches) *n_matches = 0; return MAUVE_OK; }
-    // segmented keys: segment id above the mer; the all-ones invalid key needs every bit, so sort all 64
-    const int key_bits = SEG ? 64 : (vmask && !compacted ? (int)sizeof(KeyT) * 8 : 2 * sh.weight);
+    const int key_bits = full_bits;
     const int has_invalid = vmask != nullptr && !compacted;
     const uint32_t ns = sorted_n;                   // entries of the sorted list (all windows, or the valid ones)
-    int rc = sort_pairs<KeyT>(ctx, sorted_n, key_bits, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>(), have_hist0);
+    const int L = low_bits(ns);                     // the passes order bits [L, key_bits); 0 = full sort
+    int rc = sort_pairs<KeyT>(ctx, sorted_n, key_bits, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>(), have_hist0, -1, L);
     if (rc) return rc;
     TRACE(ctx, "sort");
 
@@ -1038,6 +1190,20 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             if (nruns)
                 hipLaunchKernelGGL(join_pair, dim3((nruns + 255) / 256), dim3(256), 0, ctx->stream, vals, tab, rstart, rlen, runiq, nruns,
                                    __builtin_ctz(fp.consider), 31 - __builtin_clz(fp.consider), tmask, tpos);
+        } else if (hash_path) {
+            const uint32_t nchunk = (ns + HJ_T - 1) / HJ_T;
+            HIPCHK(ctx, ctx->join_ovf.ensure((2 + 2 * (size_t)HJ_OVF_CAP) * 4));
+            HIPCHK(ctx, ctx->join_bound.ensure(((size_t)nchunk + 2) * 4));
+            HIPCHK(ctx, hipMemsetAsync(ctx->join_ovf.p, 0, 8, ctx->stream));
+            KernelTimer t(ctx, MAUVE_K_JOIN, ns);
+            hipLaunchKernelGGL((join_bounds<KeyT>), dim3((nchunk + 1 + 3) / 4), dim3(256), 0, ctx->stream, keys, ns, L, nchunk,
+                               ctx->join_bound.as<uint32_t>());
+            if (N > 16)
+                hipLaunchKernelGGL((join_hash<KeyT, true>), dim3(nchunk), dim3(256), 0, ctx->stream, keys, vals, ns,
+                                   ctx->join_bound.as<uint32_t>(), tab, fp.rule, fp.want, tmask, tpos, ctx->join_ovf.as<uint32_t>(), P);
+            else
+                hipLaunchKernelGGL((join_hash<KeyT, false>), dim3(nchunk), dim3(256), 0, ctx->stream, keys, vals, ns,
+                                   ctx->join_bound.as<uint32_t>(), tab, fp.rule, fp.want, tmask, tpos, ctx->join_ovf.as<uint32_t>(), P);
         } else
         { KernelTimer t(ctx, MAUVE_K_JOIN, ns);
           hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, ns, tab, fp.rule,
@@ -1053,8 +1219,43 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // the kernels above are still running
         HIPCHK(ctx, ctx->pin_seed.ensure(64));
         HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (hash_path) HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.as<char>() + 32, ctx->join_ovf.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        const uint32_t nc = ctx->pin_seed.as<uint32_t>()[1];
+        uint32_t nc = ctx->pin_seed.as<uint32_t>()[1];
+        const uint32_t novf = hash_path ? ctx->pin_seed.as<uint32_t>()[8] : 0u;
+        if (hash_path && ctx->pin_seed.as<uint32_t>()[9]) { ctx->err = "join_hash: anchor out of range (internal error)"; return MAUVE_ERR_HIP; }
+        if (novf) {
+            // ranges join_hash declined (a bucket beyond its LDS table): full sort + serial join of each slice, or of
+            // the whole list when there are more of them than the list holds; then the run detection again
+            std::vector<uint32_t> rng;
+            if (novf > (uint32_t)HJ_OVF_CAP) rng = {0u, ns};
+            else {
+                rng.resize(2 * (size_t)novf);
+                HIPCHK(ctx, hipMemcpy(rng.data(), ctx->join_ovf.as<uint32_t>() + 2, rng.size() * 4, hipMemcpyDeviceToHost));
+            }
+            KeyT *alt_k = keys == ctx->keysA.as<KeyT>() ? ctx->keysB.as<KeyT>() : ctx->keysA.as<KeyT>();
+            uint32_t *alt_v = vals == ctx->valsA.as<uint32_t>() ? ctx->valsB.as<uint32_t>() : ctx->valsA.as<uint32_t>();
+            for (size_t q = 0; q + 1 < rng.size(); q += 2) {
+                const uint32_t s0 = rng[q], cnt = rng[q + 1] - rng[q];
+                KeyT *kp = keys + s0; uint32_t *vp = vals + s0;
+                int rc3 = sort_pairs<KeyT>(ctx, cnt, key_bits, &kp, &vp, alt_k + s0, alt_v + s0, false, MAUVE_K_JOIN);
+                if (rc3) return rc3;
+                KernelTimer t(ctx, MAUVE_K_JOIN, cnt);
+                hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, kp, vp, cnt, tab, fp.rule,
+                                   fp.want, fp.consider, tmask, tpos, P, has_invalid);
+            }
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+            { KernelTimer t(ctx, MAUVE_K_RUNS, P);
+              hipLaunchKernelGGL((mum_runs<SEG>), dim3((P + 256 * RUNS_ITEMS - 1) / (256 * RUNS_ITEMS)), dim3(256), 0, ctx->stream, tab,
+                                 sh.span, tmask, tpos, P, extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg,
+                                 nseg); }
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            nc = ctx->pin_seed.as<uint32_t>()[1];
+            if (g_trace) fprintf(stderr, "[trace]   join_hash handed back %u range(s)\n", novf);
+        }
         TRACE(ctx, "runs");
         if (g_trace) fprintf(stderr, "[trace]   %u candidates of %u windows\n", nc, P);
         if (nc == 0) continue;
