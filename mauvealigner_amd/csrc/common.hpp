@@ -189,7 +189,6 @@ struct mauve_ctx {
     DevBuf keysA, keysB, valsA, valsB, hist, totals, posmask, hit_mask, hit_pos, hit_seg, cand, mlen, mstart, counters;
     DevBuf sorted_rec;                   // canonical order on the device: gathered (length, starts) records as int64
     DevBuf canon_k1, canon_k2, canon_v1, canon_v2;   // ... and its (key, candidate index) sort buffers
-    DevBuf join_bound;                   // join_hash: first bucket boundary at or after every chunk edge
     DevBuf join_ovf;                     // join_hash: [count, pad, (lo, hi) ...] ranges handed back to the full sort + serial join
     DevBuf run_sum;                      // pairwise finder: run list (start, length, exactly-once genome set)
     DevBuf rec_genomes, rec_seg;         // recursive anchoring: gap sub-sequences + segment table

@@ -501,9 +501,8 @@ __global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, c
 // of the component set) is found by genome id, not by position.  Two 8-bit passes and the join's read replace four
 // passes, three histogram sweeps and a join that walked every run serially (C2: 30-bit mers, 15 M windows).
 //
-// join_bounds: bound[c] = first bucket boundary at or after c*HJ_T (bound[0] = 0, bound[nchunk] = n); one wave per
-// chunk edge, 64 entries per probe, a binary search (the list is ordered by the high bits) when a bucket is long.
-// join_hash: workgroup c owns [bound[c], bound[c+1]) -- the buckets that start in its chunk.  A range longer than the
+// Workgroup c owns [bound(c), bound(c+1)) -- the buckets that start in its chunk; bound(c) = first bucket boundary at
+// or after c*HJ_T (chunk_bound; two waves look the two edges up side by side).  A range longer than the
 // HJ_CAP entries its table takes (a bucket blown up by a repeat family or low-complexity sequence) is not processed:
 // it goes to the overflow list and the host gives that slice to the full sort and the serial join below
 // (rs_* + mum_join), which have no size limit.
@@ -517,42 +516,37 @@ static_assert(HJ_CAP * 4 <= 3 * HJ_SLOTS, "join_hash: table load factor above 0.
 constexpr uint32_t HJ_NONE = 0xffffffffu;
 constexpr int HJ_OVF_CAP = 4096;            // ranges the overflow list holds; beyond that the whole list goes the old way
 
+// first bucket boundary at or after chunk edge c (wave-uniform result): 64 entries per probe, a binary search (the
+// list is ordered by the high bits) when a bucket is long
 template <typename KeyT>
-__global__ void __launch_bounds__(256) join_bounds(const KeyT *__restrict__ keys, uint32_t n, int L, uint32_t nchunk,
-                                                   uint32_t *__restrict__ bound)
+__device__ __forceinline__ uint32_t chunk_bound(const KeyT *__restrict__ keys, uint32_t n, int L, uint32_t c, int lane)
 {
-    const int lane = threadIdx.x & 63;
-    const uint32_t c = (blockIdx.x * 256u + threadIdx.x) >> 6;           // one wave per chunk edge 0 .. nchunk
-    if (c > nchunk) return;
     const uint32_t start = c * (uint32_t)HJ_T;
+    if (c == 0) return 0u;
+    if (start >= n) return n;
+    const uint64_t h0 = (uint64_t)keys[start - 1] >> L;                  // the bucket the edge falls into (or just behind)
     uint32_t res = HJ_NONE;
-    if (c == 0) res = 0;
-    else if (start >= n) res = n;
-    else {
-        const uint64_t h0 = (uint64_t)keys[start - 1] >> L;              // the bucket the edge falls into (or just behind)
-        for (int step = 0; step < 4 && res == HJ_NONE; step++) {          // 256 entries, 64 per probe
-            const uint32_t idx = start + (uint32_t)step * 64u + (uint32_t)lane;
-            const bool bnd = idx >= n || ((uint64_t)keys[idx] >> L) != h0;
-            const uint64_t b = __ballot(bnd);
-            if (b) res = start + (uint32_t)step * 64u + (uint32_t)(__ffsll((unsigned long long)b) - 1);
-        }
-        if (res == HJ_NONE) {
-            // long bucket: first index in (lo, hi] whose high bits differ (keys[lo] still belongs to the bucket, index n counts as different)
-            uint32_t lo = start + 255u, hi = n;
-            while (hi - lo > 1) {
-                const uint32_t mid = lo + (hi - lo) / 2;
-                if (((uint64_t)keys[mid] >> L) != h0) hi = mid; else lo = mid;
-            }
-            res = hi;
-        }
-        res = min(res, n);
+    for (int step = 0; step < 4 && res == HJ_NONE; step++) {              // 256 entries, 64 per probe
+        const uint32_t idx = start + (uint32_t)step * 64u + (uint32_t)lane;
+        const bool bnd = idx >= n || ((uint64_t)keys[idx] >> L) != h0;
+        const uint64_t b = __ballot(bnd);
+        if (b) res = start + (uint32_t)step * 64u + (uint32_t)(__ffsll((unsigned long long)b) - 1);
     }
-    if (lane == 0) bound[c] = res;
+    if (res == HJ_NONE) {
+        // long bucket: first index in (lo, hi] whose high bits differ (keys[lo] still belongs to the bucket, index n counts)
+        uint32_t lo = start + 255u, hi = n;
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (((uint64_t)keys[mid] >> L) != h0) hi = mid; else lo = mid;
+        }
+        res = hi;
+    }
+    return min(res, n);
 }
 
 template <typename KeyT, bool WIDE>
 __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t n,
-                                                 const uint32_t *__restrict__ bound, GenomeTab tab, int mode, uint32_t want_mask,
+                                                 int L, GenomeTab tab, int mode, uint32_t want_mask,
                                                  uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos,
                                                  uint32_t *__restrict__ ovf, uint32_t P)
 {
@@ -561,8 +555,14 @@ __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, 
     __shared__ uint32_t som2[WIDE ? HJ_SLOTS : 1];           // WIDE (> 16 genomes): multi
     __shared__ uint32_t sanch[HJ_SLOTS];
     constexpr KeyT EMPTY = (KeyT)~0ULL;                       // never a canonical mer; also the invalid-window key
+    __shared__ uint32_t s_bound[2];
     const int tid = threadIdx.x;
-    const uint32_t lo = bound[blockIdx.x], hi = min(bound[blockIdx.x + 1], n);
+    if (tid < 128) {                                          // wave 0: where this chunk's buckets start; wave 1: where the next chunk's do
+        const uint32_t bnd = chunk_bound(keys, n, L, blockIdx.x + (uint32_t)(tid >> 6), tid & 63);
+        if ((tid & 63) == 0) s_bound[tid >> 6] = bnd;
+    }
+    __syncthreads();
+    const uint32_t lo = s_bound[0], hi = s_bound[1];
     if (lo >= hi) return;                                     // no bucket starts in this chunk
     if (hi - lo > (uint32_t)HJ_CAP) {                         // oversize: hand the range to the host
         if (tid == 0) {
@@ -580,23 +580,32 @@ __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, 
         k[r] = in ? keys[idx] : EMPTY; v[r] = in ? vals[idx] : 0u;
     }
     __syncthreads();
-    // ---- pass 1: group by mer ----
-    uint32_t slot[HJ_ROWS]; uint32_t gbit[HJ_ROWS];
+    // ---- pass 1: group by mer.  The LDS operations of all rows are issued phase by phase (first probes, collision
+    // walks, genome-set updates), so that their latencies overlap instead of adding up row by row ----
+    uint32_t slot[HJ_ROWS]; uint32_t gbit[HJ_ROWS]; KeyT seen[HJ_ROWS];
 #pragma unroll
     for (int r = 0; r < HJ_ROWS; r++) {
-        slot[r] = HJ_NONE; gbit[r] = 0;
-        if (k[r] == EMPTY) continue;                          // beyond the range, or an invalid window
-        uint32_t s = ((uint32_t)k[r] ^ (uint32_t)((uint64_t)k[r] >> 32)) * 0x9E3779B1u >> 20;       // 12 bits
-        for (;;) {
-            const KeyT old = atomicCAS(&skey[s], EMPTY, k[r]);
-            if (old == EMPTY || old == k[r]) break;
-            s = (s + 1) & (HJ_SLOTS - 1);
-        }
-        const uint32_t bit = 1u << genome_of(v[r] & 0x7fffffffu, tab);
-        const uint32_t old = atomicOr(&som[s], bit);
-        if (old & bit) { if (WIDE) atomicOr(&som2[s], bit); else atomicOr(&som[s], bit << 16); }
-        slot[r] = s; gbit[r] = bit;
+        slot[r] = ((uint32_t)k[r] ^ (uint32_t)((uint64_t)k[r] >> 32)) * 0x9E3779B1u >> 20;         // 12 bits
+        gbit[r] = 1u << genome_of(v[r] & 0x7fffffffu, tab);
+        seen[r] = k[r];
+        if (k[r] != EMPTY) seen[r] = atomicCAS(&skey[slot[r]], EMPTY, k[r]);                       // EMPTY: beyond the range, or an invalid window
     }
+#pragma unroll
+    for (int r = 0; r < HJ_ROWS; r++) {
+        if (k[r] == EMPTY) { slot[r] = HJ_NONE; gbit[r] = 0; continue; }
+        uint32_t s = slot[r]; KeyT old = seen[r];
+        while (!(old == EMPTY || old == k[r])) {
+            s = (s + 1) & (HJ_SLOTS - 1);
+            old = atomicCAS(&skey[s], EMPTY, k[r]);
+        }
+        slot[r] = s;
+    }
+    uint32_t prev[HJ_ROWS];
+#pragma unroll
+    for (int r = 0; r < HJ_ROWS; r++) prev[r] = slot[r] != HJ_NONE ? atomicOr(&som[slot[r]], gbit[r]) : 0u;
+#pragma unroll
+    for (int r = 0; r < HJ_ROWS; r++)
+        if (prev[r] & gbit[r]) { if (WIDE) atomicOr(&som2[slot[r]], gbit[r]); else atomicOr(&som[slot[r]], gbit[r] << 16); }
     __syncthreads();
     // ---- pass 2: the finder rule per mer; the entry of the lowest component genome is the anchor ----
     uint32_t mm[HJ_ROWS];
@@ -1193,17 +1202,14 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         } else if (hash_path) {
             const uint32_t nchunk = (ns + HJ_T - 1) / HJ_T;
             HIPCHK(ctx, ctx->join_ovf.ensure((2 + 2 * (size_t)HJ_OVF_CAP) * 4));
-            HIPCHK(ctx, ctx->join_bound.ensure(((size_t)nchunk + 2) * 4));
             HIPCHK(ctx, hipMemsetAsync(ctx->join_ovf.p, 0, 8, ctx->stream));
             KernelTimer t(ctx, MAUVE_K_JOIN, ns);
-            hipLaunchKernelGGL((join_bounds<KeyT>), dim3((nchunk + 1 + 3) / 4), dim3(256), 0, ctx->stream, keys, ns, L, nchunk,
-                               ctx->join_bound.as<uint32_t>());
             if (N > 16)
                 hipLaunchKernelGGL((join_hash<KeyT, true>), dim3(nchunk), dim3(256), 0, ctx->stream, keys, vals, ns,
-                                   ctx->join_bound.as<uint32_t>(), tab, fp.rule, fp.want, tmask, tpos, ctx->join_ovf.as<uint32_t>(), P);
+                                   L, tab, fp.rule, fp.want, tmask, tpos, ctx->join_ovf.as<uint32_t>(), P);
             else
                 hipLaunchKernelGGL((join_hash<KeyT, false>), dim3(nchunk), dim3(256), 0, ctx->stream, keys, vals, ns,
-                                   ctx->join_bound.as<uint32_t>(), tab, fp.rule, fp.want, tmask, tpos, ctx->join_ovf.as<uint32_t>(), P);
+                                   L, tab, fp.rule, fp.want, tmask, tpos, ctx->join_ovf.as<uint32_t>(), P);
         } else
         { KernelTimer t(ctx, MAUVE_K_JOIN, ns);
           hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, ns, tab, fp.rule,

@@ -102,6 +102,31 @@ def test_edge_cases(ctx):
         _same(ctx, [x, synth.mutate(x, 0.02, rng)], pat)
 
 
+def test_oversize_buckets_fall_back(ctx):
+    """Genome sets large enough for the partial sort + LDS hash join (join_hash), with repeat families and
+    low-complexity blocks that blow single buckets far beyond the hash table: those slices must come back through
+    the full sort + serial join with the same result (MEM and UNIQUE rules, with and without the N-way mask)."""
+    rng = np.random.default_rng(77)
+    anc = rng.integers(0, 4, 60000, dtype=np.uint8)
+    unit = rng.integers(0, 4, 37, dtype=np.uint8)
+    gs = []
+    for g in range(3):
+        x = synth.mutate(anc, 0.02, rng)
+        x = np.concatenate([x[:20000], np.zeros(9000, np.uint8), x[20000:40000], np.tile(unit, 250),
+                            x[40000:], np.tile(np.array([0, 1], np.uint8), 3000 + 500 * g)])
+        gs.append(x)
+    for w in (11, 15):
+        pat = O.get_seed(w, 0)
+        _same(ctx, gs, pat, mode=0)
+        _same(ctx, gs, pat, mode=1)
+        _same(ctx, gs, pat, mode=0, mask=7)
+        _same(ctx, gs, pat, mode=1, mask=3)
+    # 64-bit keys, and one bucket holding nearly everything (every range oversize: the whole list goes back)
+    _same(ctx, gs, O.get_seed(19, 0), mode=1)
+    poly = [np.zeros(40000, np.uint8), np.zeros(30000, np.uint8)]
+    _same(ctx, poly, O.get_seed(11, 0), mode=1)
+
+
 def test_many_genomes(ctx):
     rng = np.random.default_rng(4)
     anc = rng.integers(0, 4, 3000, dtype=np.uint8)
