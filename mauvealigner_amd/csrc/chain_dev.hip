@@ -1,0 +1,473 @@
+// chain_dev.hip -- the chaining stage on the device: EliminateOverlaps and the LCB graph of Aligner::align [EXT]
+// (call sites mauveAligner.cpp:596,600,698; helper usage toGrimmFormat.cpp:51-79, projectAndStrip.cpp:110-112),
+// frozen spec DESIGN.md S5, for the N-way match list the seed pass leaves in HBM in canonical order.
+//
+// Shape: the list is a few 10^4 .. 10^5 records and the elimination is a chain of dependent passes (genome after
+// genome, pass after pass).  The passes of one genome decompose into independent overlap clusters (see
+// ch_cluster_pass), so a genome costs a fixed, short sequence of launches -- its order by the radix sort of
+// seed_pass.hip, a prefix maximum of the right ends, the cluster starts, one thread per cluster for ALL its passes,
+// the survivors' order -- with no launch per pass and no host round trip.  The LCB graph (collinear runs in genome-0
+// order, their weights, the per-genome neighbour lists) is built by flag compactions; the greedy breakpoint
+// elimination over that compact graph (10^2 .. 10^4 nodes, inherently sequential) stays on the host (lcb_greedy,
+// chain_host.cpp).  Every kernel is tiled (1024 entries per workgroup, four consecutive entries per thread); the
+// per-tile aggregates of a compaction are summed by each workgroup for itself, which saves the scan launches.
+// The host code of chain_host.cpp remains the path for lists the seed pass sorted on the host (small ones, or with
+// ties in the canonical order) and for the per-gap chains of the recursion.
+#include "common.hpp"
+#include <cstring>
+#include <cstdlib>
+
+namespace {
+
+constexpr int CH_TILE = 1024;               // entries per workgroup: 256 threads x 4 consecutive entries
+
+// exclusive scans over the 256 threads of a workgroup (sum, maximum with identity 0); *total = all-thread aggregate
+__device__ __forceinline__ uint32_t bscan_add(uint32_t v, uint32_t *total, uint32_t *lds /*[4]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    __syncthreads();                         // lds may still be read from an earlier call
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const uint32_t c = lds[w]; if (w < wave) wbase += c; tot += c; }
+    *total = tot;
+    return wbase + inc - v;
+}
+__device__ __forceinline__ uint32_t bscan_max(uint32_t v, uint32_t *total, uint32_t *lds /*[4]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= o) inc = max(inc, t); }
+    __syncthreads();
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const uint32_t c = lds[w]; if (w < wave) wbase = max(wbase, c); tot = max(tot, c); }
+    *total = tot;
+    const uint32_t up = __shfl_up(inc, 1);
+    return max(wbase, lane ? up : 0u);
+}
+// aggregate of the per-tile values before tile b (sum / maximum), and of all nb tiles
+__device__ __forceinline__ void tiles_before_add(const uint32_t *__restrict__ v, uint32_t b, uint32_t nb, uint32_t *before, uint32_t *all, uint32_t *lds)
+{
+    uint32_t sb = 0, sa = 0;
+    for (uint32_t t = threadIdx.x; t < nb; t += 256) { const uint32_t x = v[t]; sa += x; if (t < b) sb += x; }
+    uint32_t tb, ta;
+    (void)bscan_add(sb, &tb, lds); (void)bscan_add(sa, &ta, lds);
+    *before = tb; *all = ta;
+}
+
+// records as the seed pass left them (int64 length[n], start[n*N]) -> working arrays (int32)
+__global__ void __launch_bounds__(256) ch_init(const int64_t *__restrict__ rlen, const int64_t *__restrict__ rst, uint32_t n, int N,
+                                               int32_t *__restrict__ len, int32_t *__restrict__ st, uint32_t *__restrict__ crop)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    len[i] = (int32_t)rlen[i];
+    for (int g = 0; g < N; g++) st[(size_t)i * N + g] = (int32_t)rst[(size_t)i * N + g];
+    crop[2 * (size_t)i] = 0; crop[2 * (size_t)i + 1] = 0;
+}
+
+// sort keys of genome g: left end of every alive match (dead ones sort behind everything), value = match index
+__global__ void __launch_bounds__(256) ch_keys(const int32_t *__restrict__ len, const int32_t *__restrict__ st, uint32_t n, int N, int g,
+                                               uint32_t dead_key, uint32_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const int32_t s = st[(size_t)i * N + g];
+    key[i] = len[i] > 0 ? (uint32_t)(s < 0 ? -s : s) : dead_key;
+    val[i] = i;
+}
+
+// ---- EliminateOverlaps of one genome, decomposed into overlap clusters ----------------------------
+// The passes of genome g only ever shrink intervals in g, so two matches interact only if their intervals are linked
+// through a chain of overlaps when g's turn starts: cut the (left end, index) order wherever the running maximum of
+// the right ends stays below the next left end, and the pieces -- clusters -- never see each other again: the global
+// order is the concatenation of the clusters' orders and no pair across a cut ever overlaps.  Every cluster
+// therefore runs ALL its passes on its own (sort, sweep of adjacent pairs, crops applied together, the dead leave,
+// repeat until overlap free), exactly as the whole list would, and the clusters run side by side, one thread each:
+// no pass-by-pass launches, no host round trip.  Nearly all clusters are pairs; one beyond CH_CL_MAX entries (a
+// repeat family) raises *fail and the host chains this list with chain_host.cpp instead.
+constexpr int CH_CL_MAX = 48;
+
+// right end of entry r (0 for the dead entries behind the alive ones and beyond the list)
+__device__ __forceinline__ uint32_t ch_right(const int32_t *__restrict__ len, uint32_t n, uint32_t dead_key,
+                                             const uint32_t *__restrict__ eleft, const uint32_t *__restrict__ eidx, uint32_t r)
+{
+    if (r >= n) return 0u;
+    const uint32_t l = eleft[r];
+    return l == dead_key ? 0u : l + (uint32_t)len[eidx[r]] - 1u;
+}
+
+// per tile: the largest right end and the number of alive entries
+__global__ void __launch_bounds__(256) cl_partial(const int32_t *__restrict__ len, uint32_t n, uint32_t dead_key, const uint32_t *__restrict__ eleft,
+                                                  const uint32_t *__restrict__ eidx, uint32_t *__restrict__ bmax, uint32_t *__restrict__ balive)
+{
+    __shared__ uint32_t lds[4];
+    const uint32_t r0 = blockIdx.x * (uint32_t)CH_TILE + threadIdx.x * 4u;
+    uint32_t mx = 0, c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t rt = ch_right(len, n, dead_key, eleft, eidx, r0 + i);
+        mx = max(mx, rt); c += rt != 0;
+    }
+    uint32_t tm, tc;
+    (void)bscan_max(mx, &tm, lds); (void)bscan_add(c, &tc, lds);
+    if (threadIdx.x == 0) { bmax[blockIdx.x] = tm; balive[blockIdx.x] = tc; }
+}
+
+// cluster starts: entry r starts a cluster iff every right end before it lies left of its left end
+__global__ void __launch_bounds__(256) cl_flags(const int32_t *__restrict__ len, uint32_t n, uint32_t dead_key, const uint32_t *__restrict__ eleft,
+                                                const uint32_t *__restrict__ eidx, const uint32_t *__restrict__ bmax,
+                                                const uint32_t *__restrict__ balive, uint32_t nb, uint8_t *__restrict__ cflag,
+                                                uint32_t *__restrict__ cnt)
+{
+    __shared__ uint32_t lds[4];
+    const uint32_t b = blockIdx.x, r0 = b * (uint32_t)CH_TILE + threadIdx.x * 4u;
+    uint32_t mb = 0;
+    for (uint32_t t = threadIdx.x; t < b; t += 256) mb = max(mb, bmax[t]);
+    uint32_t before;
+    (void)bscan_max(mb, &before, lds);
+    uint32_t rt[4], mx = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { rt[i] = ch_right(len, n, dead_key, eleft, eidx, r0 + i); mx = max(mx, rt[i]); }
+    uint32_t dummy;
+    uint32_t run = max(before, bscan_max(mx, &dummy, lds));
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t r = r0 + i;
+        if (r < n) cflag[r] = (rt[i] != 0 && (r == 0 || run < eleft[r])) ? 1 : 0;
+        run = max(run, rt[i]);
+    }
+    if (b == 0) {                                        // alive entries of the genome in turn -> cnt[5]
+        uint32_t sa = 0, k;
+        for (uint32_t t = threadIdx.x; t < nb; t += 256) sa += balive[t];
+        (void)bscan_add(sa, &k, lds);
+        if (threadIdx.x == 0) cnt[5] = k;
+    }
+}
+
+// ---- flag compaction over the tiles: cmp_count (flags per tile) + cmp_write (every workgroup sums the tiles before it) ----
+// F: domain(y) entries; flag(r, y); each(r, exclusive count, flag, y) for every entry; emit(r, slot, y) for the flagged;
+// total(count, y) once.
+template <class F>
+__global__ void __launch_bounds__(256) cmp_count(F f, uint32_t *__restrict__ bcnt)
+{
+    __shared__ uint32_t lds[4];
+    const int y = blockIdx.y;
+    const uint32_t dom = f.domain(y), r0 = blockIdx.x * (uint32_t)CH_TILE + threadIdx.x * 4u;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (r0 + i < dom) c += f.flag(r0 + i, y) ? 1u : 0u;
+    uint32_t tc;
+    (void)bscan_add(c, &tc, lds);
+    if (threadIdx.x == 0) bcnt[(size_t)y * gridDim.x + blockIdx.x] = tc;
+}
+template <class F>
+__global__ void __launch_bounds__(256) cmp_write(F f, const uint32_t *__restrict__ bcnt)
+{
+    __shared__ uint32_t lds[4];
+    const int y = blockIdx.y;
+    const uint32_t dom = f.domain(y), r0 = blockIdx.x * (uint32_t)CH_TILE + threadIdx.x * 4u;
+    uint32_t before, all;
+    tiles_before_add(bcnt + (size_t)y * gridDim.x, blockIdx.x, gridDim.x, &before, &all, lds);
+    bool fl[4]; uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { fl[i] = r0 + i < dom && f.flag(r0 + i, y); c += fl[i] ? 1u : 0u; }
+    uint32_t dummy;
+    uint32_t o = before + bscan_add(c, &dummy, lds);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (r0 + i >= dom) break;
+        f.each(r0 + i, o, fl[i], y);
+        if (fl[i]) { f.emit(r0 + i, o, y); o++; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) f.total(all, y);
+}
+
+struct ClusterStarts {                      // flagged entries -> cstart[]; cstart[J] = k
+    const uint8_t *cflag; uint32_t n; uint32_t *cstart; uint32_t *cnt;
+    __device__ uint32_t domain(int) const { return n; }
+    __device__ bool flag(uint32_t r, int) const { return cflag[r] != 0; }
+    __device__ void each(uint32_t, uint32_t, bool, int) const {}
+    __device__ void emit(uint32_t r, uint32_t o, int) const { cstart[o] = r; }
+    __device__ void total(uint32_t J, int) const { cnt[4] = J; cstart[J] = cnt[5]; }
+};
+struct GenomeOrder {                        // the survivors of the genome in turn, in order -> ord[], their number -> *k_out
+    uint32_t dead_key; const uint32_t *eleft, *eidx; const uint32_t *cnt; uint32_t *ord; uint32_t *k_out;
+    __device__ uint32_t domain(int) const { return cnt[5]; }
+    __device__ bool flag(uint32_t r, int) const { return eleft[r] != dead_key; }
+    __device__ void each(uint32_t, uint32_t, bool, int) const {}
+    __device__ void emit(uint32_t r, uint32_t o, int) const { ord[o] = eidx[r]; }
+    __device__ void total(uint32_t k, int) const { *k_out = k; }
+};
+struct FinalRanks {                         // y = genome: its order without the matches that died later; rank of every survivor
+    const int32_t *len; uint32_t n; const uint32_t *ord; uint32_t *ordc, *rank; uint32_t *cnt;
+    __device__ uint32_t domain(int y) const { return cnt[8 + y]; }
+    __device__ bool flag(uint32_t r, int y) const { return len[ord[(size_t)y * n + r]] > 0; }
+    __device__ void each(uint32_t, uint32_t, bool, int) const {}
+    __device__ void emit(uint32_t r, uint32_t o, int y) const { const uint32_t i = ord[(size_t)y * n + r]; ordc[(size_t)y * n + o] = i; rank[(size_t)y * n + i] = o; }
+    __device__ void total(uint32_t na, int y) const { if (y == 0) cnt[0] = na; }
+};
+// LCB nodes = maximal collinear runs in genome-0 order: two neighbours belong together iff in every other genome
+// they have the same orientation and are neighbours there too (next if forward, previous if reverse)
+struct LcbNodes {
+    const int32_t *len, *st; uint32_t n; int N; const uint32_t *ordc, *rank; uint32_t *cnt; int32_t *node_of;
+    unsigned long long *weight; uint32_t *orient;
+    __device__ uint32_t domain(int) const { return cnt[0]; }
+    __device__ bool flag(uint32_t k, int) const
+    {
+        if (k == 0) return true;
+        const uint32_t i = ordc[k], p = ordc[k - 1];
+        for (int g = 1; g < N; g++) {
+            const bool oi = st[(size_t)i * N + g] < 0, op = st[(size_t)p * N + g] < 0;
+            if (oi != op) return true;
+            const uint32_t ri = rank[(size_t)g * n + i], rp = rank[(size_t)g * n + p];
+            if (!oi ? ri != rp + 1 : ri + 1 != rp) return true;
+        }
+        return false;
+    }
+    __device__ void each(uint32_t k, uint32_t o, bool fl, int) const
+    {
+        const uint32_t i = ordc[k], nd = o + (fl ? 1u : 0u) - 1u;
+        node_of[i] = (int32_t)nd;
+        atomicAdd(&weight[nd], (unsigned long long)len[i] * (unsigned long long)N);
+    }
+    __device__ void emit(uint32_t k, uint32_t o, int) const
+    {
+        const uint32_t i = ordc[k];
+        uint32_t ob = 0;
+        for (int g = 0; g < N; g++) if (st[(size_t)i * N + g] < 0) ob |= 1u << g;
+        orient[o] = ob;
+    }
+    __device__ void total(uint32_t K, int) const { cnt[1] = K; }
+};
+struct NodeSeq {                            // y = genome: the nodes in genome-y order (a node's matches are contiguous in every genome)
+    uint32_t n; const uint32_t *ordc; uint32_t *cnt; const int32_t *node_of; int32_t *seq;
+    __device__ uint32_t domain(int) const { return cnt[0]; }
+    __device__ bool flag(uint32_t r, int y) const { return r == 0 || node_of[ordc[(size_t)y * n + r]] != node_of[ordc[(size_t)y * n + r - 1]]; }
+    __device__ void each(uint32_t, uint32_t, bool, int) const {}
+    __device__ void emit(uint32_t r, uint32_t o, int y) const { if (o < cnt[1]) seq[(size_t)y * cnt[1] + o] = node_of[ordc[(size_t)y * n + r]]; }
+    __device__ void total(uint32_t t, int) const { if (t != cnt[1]) atomicAdd(&cnt[2], 1u); }    // cannot happen (contiguity); the host checks
+};
+__global__ void __launch_bounds__(256) ch_links(int N, const uint32_t *__restrict__ cnt, const int32_t *__restrict__ seq,
+                                                int32_t *__restrict__ prevv, int32_t *__restrict__ nextv)
+{
+    const uint32_t K = cnt[1], j = blockIdx.x * 256u + threadIdx.x;
+    const int g = blockIdx.y;
+    if (j >= K) return;
+    const int32_t *sq = seq + (size_t)g * K;
+    const int32_t nd = sq[j];
+    prevv[(size_t)nd * N + g] = j > 0 ? sq[j - 1] : -1;
+    nextv[(size_t)nd * N + g] = j + 1 < K ? sq[j + 1] : -1;
+}
+
+// ch_cluster_pass: thread j runs every pass of cluster j.  Entries come back in (left end, index) order, the dead
+// behind them as dead_key; the survivors' crops are applied to the match records (all genomes) at the end.
+__global__ void __launch_bounds__(256) ch_cluster_pass(int32_t *__restrict__ len, int32_t *__restrict__ st, int N, int g, uint32_t dead_key,
+                                                       uint32_t *__restrict__ eleft, uint32_t *__restrict__ eidx,
+                                                       const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ cnt_in,
+                                                       uint32_t *__restrict__ fail)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= cnt_in[0]) return;
+    const uint32_t a = cstart[j];
+    int s = (int)(cstart[j + 1] - a);
+    if (s < 2) return;
+    if (s > CH_CL_MAX) { *fail = 1; return; }
+    // entry state: left end in g, length, index, forward in g, crops so far at the match's first / last column side
+    uint32_t L[CH_CL_MAX], Ln[CH_CL_MAX], I[CH_CL_MAX], CF[CH_CL_MAX], CL[CH_CL_MAX], pf[CH_CL_MAX], pl[CH_CL_MAX];
+    uint8_t F[CH_CL_MAX];
+    for (int q = 0; q < s; q++) {
+        L[q] = eleft[a + q]; I[q] = eidx[a + q]; Ln[q] = (uint32_t)len[I[q]]; F[q] = st[(size_t)I[q] * N + g] > 0;
+        CF[q] = 0; CL[q] = 0;
+    }
+    const int s0 = s;
+    for (;;) {
+        // (left end, index) order; the entries arrive sorted and a pass of crops moves them little: insertion sort
+        for (int q = 1; q < s; q++) {
+            const uint32_t l = L[q], n2 = Ln[q], i2 = I[q], cf = CF[q], cl = CL[q]; const uint8_t f = F[q];
+            int t = q;
+            while (t > 0 && (L[t - 1] > l || (L[t - 1] == l && I[t - 1] > i2))) {
+                L[t] = L[t - 1]; Ln[t] = Ln[t - 1]; I[t] = I[t - 1]; CF[t] = CF[t - 1]; CL[t] = CL[t - 1]; F[t] = F[t - 1]; t--;
+            }
+            L[t] = l; Ln[t] = n2; I[t] = i2; CF[t] = cf; CL[t] = cl; F[t] = f;
+        }
+        // sweep: of two overlapping neighbours the shorter (the right one on ties) gives up the overlap on the side
+        // facing the other; lengths as of the pass start; every side gets at most one request
+        bool any = false;
+        for (int q = 0; q < s; q++) { pf[q] = 0; pl[q] = 0; }
+        for (int q = 0; q + 1 < s; q++) {
+            const int64_t ov = (int64_t)L[q] + Ln[q] - (int64_t)L[q + 1];
+            if (ov <= 0) continue;
+            any = true;
+            if (Ln[q] < Ln[q + 1]) { if (F[q]) pl[q] = (uint32_t)ov; else pf[q] = (uint32_t)ov; }              // its right side in g
+            else { if (F[q + 1]) pf[q + 1] = (uint32_t)ov; else pl[q + 1] = (uint32_t)ov; }                    // its left side in g
+        }
+        if (!any) break;
+        // the crops of the pass together; a match whose requests reach its length dies
+        int w = 0;
+        for (int q = 0; q < s; q++) {
+            const int64_t nl = (int64_t)Ln[q] - pf[q] - pl[q];
+            if (nl <= 0) { len[I[q]] = 0; continue; }
+            L[w] = L[q] + (F[q] ? pf[q] : pl[q]); Ln[w] = (uint32_t)nl; I[w] = I[q]; F[w] = F[q];
+            CF[w] = CF[q] + pf[q]; CL[w] = CL[q] + pl[q];
+            w++;
+        }
+        s = w;
+    }
+    for (int q = 0; q < s; q++) {
+        eleft[a + q] = L[q]; eidx[a + q] = I[q];
+        if (CF[q] | CL[q]) {
+            const uint32_t i = I[q];
+            for (int c = 0; c < N; c++) {
+                const int32_t v = st[(size_t)i * N + c];
+                st[(size_t)i * N + c] = v > 0 ? v + (int32_t)CF[q] : v - (int32_t)CL[q];
+            }
+            len[i] = (int32_t)Ln[q];
+        }
+    }
+    for (int q = s; q < s0; q++) eleft[a + q] = dead_key;
+}
+
+// final LCB id of every match (-1: dead, or its LCB was eliminated)
+__global__ void __launch_bounds__(256) ch_label(const int32_t *__restrict__ len, uint32_t n, const int32_t *__restrict__ node_of,
+                                                const int32_t *__restrict__ final_id, int32_t *__restrict__ lcb)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    lcb[i] = len[i] > 0 ? final_id[node_of[i]] : -1;
+}
+
+}  // namespace
+
+int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchVec &m, std::vector<int64_t> &match_lcb, int64_t &n_lcb)
+{
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    const double t0 = now_ms();
+    const int64_t nm = c->dev_rec_n;
+    if (nm <= 0 || nm >= (1LL << 31)) { c->err = "chain_device: no device-resident match list"; return MAUVE_ERR_STATE; }
+    const uint32_t n = (uint32_t)nm;
+    int64_t maxlen = 1; for (int g = 0; g < N; g++) maxlen = std::max<int64_t>(maxlen, c->lens[(size_t)g]);
+    int pos_bits = 1; while (pos_bits < 31 && (1LL << pos_bits) <= maxlen) pos_bits++;
+    const uint32_t dead_key = 1u << pos_bits;                      // one above every left end
+    HIPCHK(c, c->ch_len.ensure((size_t)n * 4 * 3));               // len, node_of, lcb
+    HIPCHK(c, c->ch_st.ensure((size_t)n * N * 4));
+    HIPCHK(c, c->ch_crop.ensure((size_t)n * 8));
+    const uint32_t nb = (n + CH_TILE - 1) / CH_TILE;
+    HIPCHK(c, c->ch_ent.ensure((size_t)n * 4 * 6 + 64 + (size_t)n + 64 + (size_t)nb * 4 * (2 + (size_t)N)));   // 2 x (key, val) for the sort, the cluster starts, flags, tile aggregates
+    HIPCHK(c, c->ch_ord.ensure((size_t)n * N * 4 * 2));           // ord[N][n], ordc[N][n]
+    HIPCHK(c, c->ch_rank.ensure((size_t)n * N * 4));
+    HIPCHK(c, c->ch_cnt.ensure(256));
+    int32_t *len = c->ch_len.as<int32_t>(), *node_of = len + n, *lcb = node_of + n;
+    int32_t *st = c->ch_st.as<int32_t>();
+    uint32_t *crop = c->ch_crop.as<uint32_t>();
+    uint32_t *k1 = c->ch_ent.as<uint32_t>(), *v1 = k1 + n, *k2 = v1 + n, *v2 = k2 + n, *sl = v2 + n;     // sl: cluster starts (up to n + 1)
+    uint8_t *cflag = reinterpret_cast<uint8_t *>(sl + 2 * (size_t)n + 16);
+    uint32_t *bmax = reinterpret_cast<uint32_t *>(cflag + (((size_t)n + 63) & ~(size_t)63)), *balive = bmax + nb, *bcnt = balive + nb;
+    uint32_t *ord = c->ch_ord.as<uint32_t>(), *ordc = ord + (size_t)n * N;
+    uint32_t *rank = c->ch_rank.as<uint32_t>();
+    uint32_t *cnt = c->ch_cnt.as<uint32_t>();                     // [0] na, [1] K, [2] link check, [3] fail, [4] clusters, [5] alive entries of the genome in turn,
+                                                                  // [8+g] survivors of genome g
+    const int64_t *rlen = c->sorted_rec.as<int64_t>(), *rst = rlen + n;
+    const uint32_t blocks = (n + 255) / 256;
+    HIPCHK(c, hipMemsetAsync(cnt, 0, 256, c->stream));
+    hipLaunchKernelGGL(ch_init, dim3(blocks), dim3(256), 0, c->stream, rlen, rst, n, N, len, st, crop);
+    for (int g = 0; g < N; g++) {
+        hipLaunchKernelGGL(ch_keys, dim3(blocks), dim3(256), 0, c->stream, len, st, n, N, g, dead_key, k1, v1);
+        uint32_t *kk = k1, *vv = v1;
+        int rc = sort_pairs_u32(c, n, pos_bits + 1, &kk, &vv, k2, v2, MAUVE_K_CANON);
+        if (rc) return rc;
+        hipLaunchKernelGGL(cl_partial, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive);
+        hipLaunchKernelGGL(cl_flags, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive, nb, cflag, cnt);
+        const ClusterStarts cs{cflag, n, sl, cnt};
+        hipLaunchKernelGGL((cmp_count<ClusterStarts>), dim3(nb), dim3(256), 0, c->stream, cs, bcnt);
+        hipLaunchKernelGGL((cmp_write<ClusterStarts>), dim3(nb), dim3(256), 0, c->stream, cs, bcnt);
+        hipLaunchKernelGGL(ch_cluster_pass, dim3(blocks), dim3(256), 0, c->stream, len, st, N, g, dead_key, kk, vv, sl, cnt + 4, cnt + 3);
+        const GenomeOrder go{dead_key, kk, vv, cnt, ord + (size_t)g * n, cnt + 8 + g};
+        hipLaunchKernelGGL((cmp_count<GenomeOrder>), dim3(nb), dim3(256), 0, c->stream, go, bcnt);
+        hipLaunchKernelGGL((cmp_write<GenomeOrder>), dim3(nb), dim3(256), 0, c->stream, go, bcnt);
+    }
+    const FinalRanks fr{len, n, ord, ordc, rank, cnt};
+    hipLaunchKernelGGL((cmp_count<FinalRanks>), dim3(nb, N), dim3(256), 0, c->stream, fr, bcnt);
+    hipLaunchKernelGGL((cmp_write<FinalRanks>), dim3(nb, N), dim3(256), 0, c->stream, fr, bcnt);
+    // the graph arrays are sized for the worst case K = n
+    HIPCHK(c, c->ch_graph.ensure((size_t)n * (8 + 4 + (size_t)N * 4 * 3 + 4)));
+    unsigned long long *weight = c->ch_graph.as<unsigned long long>();
+    uint32_t *orient = reinterpret_cast<uint32_t *>(weight + n);
+    int32_t *prevv = reinterpret_cast<int32_t *>(orient + n), *nextv = prevv + (size_t)n * N, *seq = nextv + (size_t)n * N;
+    int32_t *final_dev = seq + (size_t)n * N;
+    HIPCHK(c, hipMemsetAsync(weight, 0, (size_t)n * 8, c->stream));
+    const LcbNodes ln{len, st, n, N, ordc, rank, cnt, node_of, weight, orient};
+    hipLaunchKernelGGL((cmp_count<LcbNodes>), dim3(nb), dim3(256), 0, c->stream, ln, bcnt);
+    hipLaunchKernelGGL((cmp_write<LcbNodes>), dim3(nb), dim3(256), 0, c->stream, ln, bcnt);
+    const NodeSeq ns{n, ordc, cnt, node_of, seq};
+    hipLaunchKernelGGL((cmp_count<NodeSeq>), dim3(nb, N), dim3(256), 0, c->stream, ns, bcnt);
+    hipLaunchKernelGGL((cmp_write<NodeSeq>), dim3(nb, N), dim3(256), 0, c->stream, ns, bcnt);
+    hipLaunchKernelGGL(ch_links, dim3(blocks, N), dim3(256), 0, c->stream, N, cnt, seq, prevv, nextv);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, c->pin_chain.ensure(256));
+    HIPCHK(c, hipMemcpyAsync(c->pin_chain.p, cnt, 256, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint32_t *hc = c->pin_chain.as<uint32_t>();
+    if (hc[3]) { c->err = "chain_device: overlap cluster beyond the per-thread limit"; return MAUVE_ERR_LIMIT; }      // caller falls back to the host chain
+    const uint32_t na = hc[0], K = hc[1];
+    const double t1 = now_ms();
+    match_lcb.assign((size_t)n, -1);
+    n_lcb = 0;
+    std::vector<int64_t> final_id;
+    if (K) {
+        // graph to the host: weight[K], orient[K], prev[K*N], next[K*N]
+        const size_t gbytes = (size_t)K * (8 + 4 + (size_t)N * 8) + 64;
+        HIPCHK(c, c->pin_chain.ensure(256 + gbytes + (size_t)K * 4));
+        char *pg = c->pin_chain.as<char>() + 256;
+        int64_t *hw = reinterpret_cast<int64_t *>(pg);
+        uint32_t *ho = reinterpret_cast<uint32_t *>(hw + K);
+        int32_t *hp = reinterpret_cast<int32_t *>(ho + K), *hn = hp + (size_t)K * N;
+        HIPCHK(c, hipMemcpyAsync(hw, weight, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(ho, orient, (size_t)K * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hp, prevv, (size_t)K * N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hn, nextv, (size_t)K * N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->pin_chain.p, cnt, 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->pin_chain.as<uint32_t>()[2]) { c->err = "chain_device: node lists inconsistent"; return MAUVE_ERR_LIMIT; }
+        lcb_greedy(N, (int32_t)K, hw, ho, hp, hn, min_weight, collinear, final_id, n_lcb);
+        int32_t *hf = reinterpret_cast<int32_t *>(pg + gbytes);
+        for (uint32_t i = 0; i < K; i++) hf[i] = (int32_t)final_id[i];
+        HIPCHK(c, hipMemcpyAsync(final_dev, hf, (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(ch_label, dim3(blocks), dim3(256), 0, c->stream, len, n, node_of, final_dev, lcb);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipMemsetAsync(lcb, 0xff, (size_t)n * 4, c->stream));
+    }
+    const double t2 = now_ms();
+    // the cropped list and its labels back to the host (dead records stay in the list with length 0 / LCB -1)
+    const size_t rb = (size_t)n * 4 * (2 + (size_t)N);
+    HIPCHK(c, c->pin_chain.ensure(256 + rb));
+    int32_t *hl = reinterpret_cast<int32_t *>(c->pin_chain.as<char>() + 256), *hs = hl + n, *hb = hs + (size_t)n * N;
+    HIPCHK(c, hipMemcpyAsync(hl, len, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs, st, (size_t)n * N * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hb, lcb, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    m.N = N; m.resize((size_t)n);
+    for (uint32_t i = 0; i < n; i++) {
+        int64_t *r = &m.d[(size_t)i * (1 + N)];
+        if (hl[i] > 0) {                                           // a dead record keeps what it was when it died on the host path too;
+            r[0] = hl[i];                                          // nothing downstream reads it (LCB -1)
+            for (int g = 0; g < N; g++) r[1 + g] = hs[(size_t)i * N + g];
+        } else {
+            r[0] = c->match_len[(size_t)i];
+            for (int g = 0; g < N; g++) r[1 + g] = c->match_start[(size_t)i * N + g];
+        }
+        match_lcb[i] = hb[i];
+    }
+    if (trace) fprintf(stderr, "[trace] chain (device): eliminate+nodes %.3f ms (na=%u K=%u), links+greedy+labels %.3f, copy back %.3f\n",
+                       t1 - t0, na, K, t2 - t1, now_ms() - t2);
+    return MAUVE_OK;
+}

@@ -221,6 +221,90 @@ void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders, bool compact)
     if (trace) fprintf(stderr, "[trace] eliminate compaction %.3f ms, total %.3f\n", now_ms() - te1, now_ms() - te0);
 }
 
+// Greedy breakpoint elimination over the compact LCB graph: K nodes in genome-0 order with weights,
+// per-genome doubly linked lists prevv/nextv [K][N] (-1 = none; modified), orient[nd] bit g = reverse in genome g.
+// While the minimum weight is below min_weight (collinear: until one node is left) the minimum-weight node (first in
+// genome-0 order on ties) is deleted and its neighbours re-merged.  final_id[nd] = id of the surviving LCB holding
+// node nd, in genome-0 order, or -1.  Used by the host chain (below) and by the device chain (chain_dev.hip), which
+// builds the same graph with kernels.
+void lcb_greedy(int N, int32_t K, int64_t *weight, const uint32_t *orient_bits, int32_t *prevv, int32_t *nextv, int64_t min_weight,
+                bool collinear, std::vector<int64_t> &final_id, int64_t &n_lcb)
+{
+    static thread_local std::vector<int32_t> merged_into;
+    static thread_local std::vector<uint8_t> alive;
+    merged_into.assign((size_t)K, -1);
+    alive.assign((size_t)K, 1);
+    auto PREV = [&](int32_t x, int g) -> int32_t & { return prevv[(size_t)x * N + g]; };
+    auto NEXT = [&](int32_t x, int g) -> int32_t & { return nextv[(size_t)x * N + g]; };
+    auto orient = [&](int32_t nd, int g) { return (orient_bits[(size_t)nd] >> g & 1u) != 0; };
+    auto mergeable = [&](int32_t a, int32_t b) {   // b == next_0(a)
+        for (int g = 1; g < N; g++) {
+            const bool oa = orient(a, g);
+            if (oa != orient(b, g)) return false;
+            if (!oa ? NEXT(a, g) != b : PREV(a, g) != b) return false;
+        }
+        return true;
+    };
+    auto unlink = [&](int32_t x, int g) {
+        const int32_t p = PREV(x, g), q = NEXT(x, g);
+        if (p >= 0) NEXT(p, g) = q;
+        if (q >= 0) PREV(q, g) = p;
+    };
+    // min-heap of (weight, node id) -- node ids are in genome-0 order, so ties resolve as the spec says -- with lazy
+    // deletion: an entry counts only while its node is alive and still has the weight recorded in the entry
+    // (weights only grow, by merges).  No per-node allocation: recursive anchoring calls this once per gap.
+    typedef std::pair<int64_t, int32_t> HeapEnt;
+    static thread_local std::vector<HeapEnt> heap;
+    heap.clear();
+    for (int32_t i = 0; i < K; i++) heap.push_back({weight[(size_t)i], i});
+    auto cmp = [](const HeapEnt &a, const HeapEnt &b) { return a > b; };          // min-heap
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    int32_t alive_cnt = K;
+    static thread_local std::vector<std::pair<int32_t, int32_t>> cand;
+    while (!heap.empty()) {
+        const HeapEnt top = heap.front();
+        if (!alive[(size_t)top.second] || weight[(size_t)top.second] != top.first) {     // stale entry
+            std::pop_heap(heap.begin(), heap.end(), cmp); heap.pop_back();
+            continue;
+        }
+        if (collinear ? alive_cnt <= 1 : top.first >= min_weight) break;
+        const int32_t x = top.second;
+        std::pop_heap(heap.begin(), heap.end(), cmp); heap.pop_back();
+        // neighbours that may become mergeable once x is gone
+        cand.clear();
+        for (int g = 0; g < N; g++) cand.push_back({PREV(x, g), NEXT(x, g)});
+        for (int g = 0; g < N; g++) unlink(x, g);
+        alive[(size_t)x] = 0; alive_cnt--;
+        for (auto pr : cand) {
+            int32_t a = pr.first, b = pr.second;
+            auto resolve = [&](int32_t v) { while (v >= 0 && !alive[(size_t)v] && merged_into[(size_t)v] >= 0) v = merged_into[(size_t)v]; return v; };
+            a = resolve(a); b = resolve(b);
+            if (a < 0 || b < 0 || a == b || !alive[(size_t)a] || !alive[(size_t)b]) continue;
+            if (NEXT(b, 0) == a) std::swap(a, b);
+            if (NEXT(a, 0) != b) continue;
+            if (!mergeable(a, b)) continue;
+            weight[(size_t)a] += weight[(size_t)b];              // the old entries of a and b are stale from here on
+            for (int g = 0; g < N; g++) unlink(b, g);
+            alive[(size_t)b] = 0; merged_into[(size_t)b] = a; alive_cnt--;
+            heap.push_back({weight[(size_t)a], a}); std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+    }
+    // final ids in genome-0 order
+    final_id.assign((size_t)K, -1);
+    int64_t id = 0;
+    for (int32_t i = 0; i < K; i++) {
+        if (alive[(size_t)i]) final_id[(size_t)i] = id++;
+    }
+    n_lcb = id;
+    // a dead node resolves through its merge chain; memoised per node, matches just look their node up
+    for (int32_t i = 0; i < K; i++) {
+        if (alive[(size_t)i]) continue;
+        int32_t v = i;
+        while (!alive[(size_t)v] && merged_into[(size_t)v] >= 0) v = merged_into[(size_t)v];
+        final_id[(size_t)i] = alive[(size_t)v] ? final_id[(size_t)v] : -1;
+    }
+}
+
 // Greedy breakpoint elimination over the compact LCB graph.  `orders` (optional): the
 // per-genome (left end, index) order of m as produced by host_eliminate_overlaps; sorted here otherwise.
 void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb,
@@ -281,12 +365,11 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
     }
     const int32_t K = (int32_t)weight.size();
     // per-genome doubly linked lists of nodes, flat [K][N]
-    static thread_local std::vector<int32_t> prevv, nextv, merged_into;
-    static thread_local std::vector<uint8_t> alive;
-    prevv.assign((size_t)K * N, -1); nextv.assign((size_t)K * N, -1); merged_into.assign((size_t)K, -1);
-    alive.assign((size_t)K, 1);
-    auto PREV = [&](int32_t x, int g) -> int32_t & { return prevv[(size_t)x * N + g]; };
-    auto NEXT = [&](int32_t x, int g) -> int32_t & { return nextv[(size_t)x * N + g]; };
+    static thread_local std::vector<int32_t> prevv, nextv;
+    static thread_local std::vector<uint32_t> orient;              // bit g: the node is reverse in genome g
+    prevv.assign((size_t)K * N, -1); nextv.assign((size_t)K * N, -1); orient.assign((size_t)K, 0u);
+    for (int32_t nd = 0; nd < K; nd++)
+        for (int g = 0; g < N; g++) if (m.st(node_first[(size_t)nd])[g] < 0) orient[(size_t)nd] |= 1u << g;
     for (int g = 0; g < N; g++) {
         const uint32_t *og = order + (size_t)g * n;
         int32_t last = -1;
@@ -294,81 +377,15 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
             const int32_t nd = node_of[og[r]];
             if (nd == last) continue;
             // a node's matches are contiguous in every genome, so each node shows up exactly once here
-            PREV(nd, g) = last;
-            if (last >= 0) NEXT(last, g) = nd;
+            prevv[(size_t)nd * N + g] = last;
+            if (last >= 0) nextv[(size_t)last * N + g] = nd;
             last = nd;
         }
     }
-    auto orient = [&](int32_t nd, int g) { return m.st(node_first[(size_t)nd])[g] < 0; };
-    auto mergeable = [&](int32_t a, int32_t b) {   // b == next_0(a)
-        for (int g = 1; g < N; g++) {
-            const bool oa = orient(a, g);
-            if (oa != orient(b, g)) return false;
-            if (!oa ? NEXT(a, g) != b : PREV(a, g) != b) return false;
-        }
-        return true;
-    };
-    auto unlink = [&](int32_t x, int g) {
-        const int32_t p = PREV(x, g), q = NEXT(x, g);
-        if (p >= 0) NEXT(p, g) = q;
-        if (q >= 0) PREV(q, g) = p;
-    };
     const double tl2 = trace ? now_ms() : 0;
-    // min-heap of (weight, node id) -- node ids are in genome-0 order, so ties resolve as the spec says -- with lazy
-    // deletion: an entry counts only while its node is alive and still has the weight recorded in the entry
-    // (weights only grow, by merges).  No per-node allocation: recursive anchoring calls this once per gap.
-    typedef std::pair<int64_t, int32_t> HeapEnt;
-    static thread_local std::vector<HeapEnt> heap;
-    heap.clear();
-    for (int32_t i = 0; i < K; i++) heap.push_back({weight[(size_t)i], i});
-    auto cmp = [](const HeapEnt &a, const HeapEnt &b) { return a > b; };          // min-heap
-    std::make_heap(heap.begin(), heap.end(), cmp);
-    int32_t alive_cnt = K;
-    static thread_local std::vector<std::pair<int32_t, int32_t>> cand;
-    while (!heap.empty()) {
-        const HeapEnt top = heap.front();
-        if (!alive[(size_t)top.second] || weight[(size_t)top.second] != top.first) {     // stale entry
-            std::pop_heap(heap.begin(), heap.end(), cmp); heap.pop_back();
-            continue;
-        }
-        if (collinear ? alive_cnt <= 1 : top.first >= min_weight) break;
-        const int32_t x = top.second;
-        std::pop_heap(heap.begin(), heap.end(), cmp); heap.pop_back();
-        // neighbours that may become mergeable once x is gone
-        cand.clear();
-        for (int g = 0; g < N; g++) cand.push_back({PREV(x, g), NEXT(x, g)});
-        for (int g = 0; g < N; g++) unlink(x, g);
-        alive[(size_t)x] = 0; alive_cnt--;
-        for (auto pr : cand) {
-            int32_t a = pr.first, b = pr.second;
-            auto resolve = [&](int32_t v) { while (v >= 0 && !alive[(size_t)v] && merged_into[(size_t)v] >= 0) v = merged_into[(size_t)v]; return v; };
-            a = resolve(a); b = resolve(b);
-            if (a < 0 || b < 0 || a == b || !alive[(size_t)a] || !alive[(size_t)b]) continue;
-            if (NEXT(b, 0) == a) std::swap(a, b);
-            if (NEXT(a, 0) != b) continue;
-            if (!mergeable(a, b)) continue;
-            weight[(size_t)a] += weight[(size_t)b];              // the old entries of a and b are stale from here on
-            for (int g = 0; g < N; g++) unlink(b, g);
-            alive[(size_t)b] = 0; merged_into[(size_t)b] = a; alive_cnt--;
-            heap.push_back({weight[(size_t)a], a}); std::push_heap(heap.begin(), heap.end(), cmp);
-        }
-    }
-    const double tl3 = trace ? now_ms() : 0;
-    // final ids in genome-0 order
     static thread_local std::vector<int64_t> final_id;
-    final_id.assign((size_t)K, -1);
-    int64_t id = 0;
-    for (int32_t i = 0; i < K; i++) {
-        if (alive[(size_t)i]) final_id[(size_t)i] = id++;
-    }
-    n_lcb = id;
-    // a dead node resolves through its merge chain; memoised per node, matches just look their node up
-    for (int32_t i = 0; i < K; i++) {
-        if (alive[(size_t)i]) continue;
-        int32_t v = i;
-        while (!alive[(size_t)v] && merged_into[(size_t)v] >= 0) v = merged_into[(size_t)v];
-        final_id[(size_t)i] = alive[(size_t)v] ? final_id[(size_t)v] : -1;
-    }
+    lcb_greedy(N, K, weight.data(), orient.data(), prevv.data(), nextv.data(), min_weight, collinear, final_id, n_lcb);
+    const double tl3 = trace ? now_ms() : 0;
     for (uint32_t k = 0; k < na; k++) { const uint32_t i = order[k]; match_lcb[i] = final_id[(size_t)node_of[i]]; }
     if (trace) fprintf(stderr, "[trace] lcb: orders %.3f ms, nodes+lists %.3f (K=%d), greedy %.3f, labels %.3f\n", tl1 - tl0, tl2 - tl1, K, tl3 - tl2, now_ms() - tl3);
 }

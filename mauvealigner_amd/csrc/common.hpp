@@ -189,13 +189,17 @@ struct mauve_ctx {
     DevBuf keysA, keysB, valsA, valsB, hist, totals, posmask, hit_mask, hit_pos, hit_seg, cand, mlen, mstart, counters;
     DevBuf sorted_rec;                   // canonical order on the device: gathered (length, starts) records as int64
     DevBuf canon_k1, canon_k2, canon_v1, canon_v2;   // ... and its (key, candidate index) sort buffers
+    DevBuf join_bound;                   // join_hash: first bucket boundary at or after every chunk edge
     DevBuf join_ovf;                     // join_hash: [count, pad, (lo, hi) ...] ranges handed back to the full sort + serial join
+    DevBuf ch_len, ch_st, ch_crop, ch_ent, ch_ord, ch_rank, ch_node, ch_graph, ch_cnt;   // device chain (chain_dev.hip)
+    PinnedBuf pin_chain;
     DevBuf run_sum;                      // pairwise finder: run list (start, length, exactly-once genome set)
     DevBuf rec_genomes, rec_seg;         // recursive anchoring: gap sub-sequences + segment table
     DevBuf placed_mask;                  // guide-tree recursive anchoring: placed-base bitmap
     // last match list (canonical order, host) + nseq it refers to
     std::vector<int64_t> match_len, match_start;
     int64_t n_matches = 0;
+    int64_t dev_rec_n = -1;              // >= 0: sorted_rec holds that many records (int64 length[n], start[n*nseq]) in canonical order
 
     // DP workspace
     DevBuf dp_desc, dp_list, dp_codes, dp_off, dp_prof_cnt, dp_prof_mask, dp_prof2_cnt, dp_prof2_mask, dp_tb, dp_meta, dp_score,
@@ -267,12 +271,20 @@ int seedpass_run(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, int mode
 int seedpass_sorted_list(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t pattern, std::vector<uint64_t> *keys,
                          std::vector<uint32_t> *vals, int *weight);
 
+int sort_pairs_u32(mauve_ctx *ctx, uint32_t n, int key_bits, uint32_t **keys_io, uint32_t **vals_io, uint32_t *keys_alt, uint32_t *vals_alt,
+                   int timer_id);
+// device chain (chain_dev.hip): EliminateOverlaps + LCBs of the N-way list the seed pass left in ctx->sorted_rec
+int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchVec &m, std::vector<int64_t> &match_lcb, int64_t &n_lcb);
+
 // host chaining (chain_host.cpp)
 struct ChainOrders { std::vector<std::vector<uint32_t>> ord; bool sparse = false; };   // per genome: match indices in left-end order;
                                                                                         // sparse: the list still holds dead records (not named here)
 void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders = nullptr, bool compact = true);
 void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb,
                     const ChainOrders *orders = nullptr);
+
+void lcb_greedy(int N, int32_t K, int64_t *weight, const uint32_t *orient_bits, int32_t *prevv, int32_t *nextv, int64_t min_weight,
+                bool collinear, std::vector<int64_t> &final_id, int64_t &n_lcb);
 
 // DP (dp_batch.hip)
 int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *sc,

@@ -175,18 +175,32 @@ static int align_begin(mauve_ctx *c, const mauve_params *p)
     c->stage.seed_ms = t1 - S.t0;
 
     // ---- chaining ----
-    MatchVec &m = S.m; m.N = N; m.resize((size_t)nm);
-    for (int64_t i = 0; i < nm; i++) {
-        m.len((size_t)i) = c->match_len[(size_t)i];
-        std::copy(&c->match_start[(size_t)i * N], &c->match_start[(size_t)i * N] + N, m.st((size_t)i));
-    }
-    ChainOrders orders;
-    static const bool elim_compact = getenv("MAUVE_ELIM_COMPACT") != nullptr;       // A/B switch
-    host_eliminate_overlaps(m, &orders, elim_compact);           // default: dead records stay in m, with lcb -1 below
-    const double t1b = now_ms();
+    // On the device when the seed pass left the list there in canonical order (chain_dev.hip); on the host otherwise
+    // (small lists, ties in the canonical order) or when the device repair gives up.  MAUVE_HOST_CHAIN: A/B switch.
+    MatchVec &m = S.m; m.N = N;
     const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight : (int64_t)3 * w * N;
     std::vector<int64_t> &match_lcb = S.match_lcb; int64_t nl = 0;
-    host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl, &orders);
+    static const bool host_chain = getenv("MAUVE_HOST_CHAIN") != nullptr;
+    bool on_device = !host_chain && nm > 0 && c->dev_rec_n == nm;
+    double t1b = t1;
+    if (on_device) {
+        rc = chain_device(c, N, lcbw, p->collinear != 0, m, match_lcb, nl);
+        if (rc == MAUVE_ERR_LIMIT) on_device = false;
+        else if (rc) return rc;
+        t1b = now_ms();
+    }
+    if (!on_device) {
+        m.resize((size_t)nm);
+        for (int64_t i = 0; i < nm; i++) {
+            m.len((size_t)i) = c->match_len[(size_t)i];
+            std::copy(&c->match_start[(size_t)i * N], &c->match_start[(size_t)i * N] + N, m.st((size_t)i));
+        }
+        ChainOrders orders;
+        static const bool elim_compact = getenv("MAUVE_ELIM_COMPACT") != nullptr;       // A/B switch
+        host_eliminate_overlaps(m, &orders, elim_compact);           // default: dead records stay in m, with lcb -1 below
+        t1b = now_ms();
+        host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl, &orders);
+    }
     if (p->extend_lcbs) {
         rc = extend_lcbs(c, p, w, lcbw, m, match_lcb, nl);
         if (rc) return rc;

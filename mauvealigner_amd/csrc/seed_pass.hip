@@ -102,10 +102,16 @@ __device__ __forceinline__ uint64_t digit_reverse(uint64_t k, int weight)
     return ((x & 0xAAAAAAAAAAAAAAAAULL) >> 1) | ((x & 0x5555555555555555ULL) << 1);
 }
 
+// genome of a global window index.  gpos_off[i] for i > nseq is all ones (build_tab), so up to eight genomes need no
+// loop: seven compares against values the scalar unit loads once per kernel.
 __device__ __forceinline__ int genome_of(uint32_t gpos, const GenomeTab &t)
 {
     int g = 0;
-    for (int i = 1; i < t.nseq; i++) g += (gpos >= t.gpos_off[i]) ? 1 : 0;
+    if (t.nseq <= 8) {
+#pragma unroll
+        for (int i = 1; i < 8; i++) g += (gpos >= t.gpos_off[i]) ? 1 : 0;
+    } else
+        for (int i = 1; i < t.nseq; i++) g += (gpos >= t.gpos_off[i]) ? 1 : 0;
     return g;
 }
 
@@ -506,7 +512,7 @@ __global__ void __launch_bounds__(256) mum_join(const KeyT *__restrict__ keys, c
 // HJ_CAP entries its table takes (a bucket blown up by a repeat family or low-complexity sequence) is not processed:
 // it goes to the overflow list and the host gives that slice to the full sort and the serial join below
 // (rs_* + mum_join), which have no size limit.
-// Slot = {mer, once | multi << 16 genome sets, anchor's value}; 4096 slots, at most 3072 entries (load <= 0.75).
+// Slot = {mer (later the anchor's value), once | multi << 16 genome sets}; 4096 slots, at most 3072 entries (load <= 0.75).
 // ------------------------------------------------------------------------------------------------
 constexpr int HJ_T = 2048;                   // nominal entries per workgroup
 constexpr int HJ_ROWS = 12;                  // rows of 256 entries a workgroup can take
@@ -544,45 +550,62 @@ __device__ __forceinline__ uint32_t chunk_bound(const KeyT *__restrict__ keys, u
     return min(res, n);
 }
 
-template <typename KeyT, bool WIDE>
+template <typename KeyT>
+__global__ void __launch_bounds__(256) join_bounds(const KeyT *__restrict__ keys, uint32_t n, int L, uint32_t nchunk,
+                                                   uint32_t *__restrict__ bound)
+{
+    const uint32_t c = (blockIdx.x * 256u + threadIdx.x) >> 6;           // one wave per chunk edge 0 .. nchunk
+    if (c > nchunk) return;
+    const uint32_t res = chunk_bound(keys, n, L, c, threadIdx.x & 63);
+    if ((threadIdx.x & 63) == 0) bound[c] = res;
+}
+
+template <typename KeyT, bool WIDE, int VARIANT>
 __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t n,
-                                                 int L, GenomeTab tab, int mode, uint32_t want_mask,
+                                                 const uint32_t *__restrict__ bound, GenomeTab tab, int mode, uint32_t want_mask,
                                                  uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos,
                                                  uint32_t *__restrict__ ovf, uint32_t P)
 {
     __shared__ KeyT skey[HJ_SLOTS];
     __shared__ uint32_t som[HJ_SLOTS];                       // once (low half) | multi (high half); WIDE: once only
     __shared__ uint32_t som2[WIDE ? HJ_SLOTS : 1];           // WIDE (> 16 genomes): multi
-    __shared__ uint32_t sanch[HJ_SLOTS];
     constexpr KeyT EMPTY = (KeyT)~0ULL;                       // never a canonical mer; also the invalid-window key
-    __shared__ uint32_t s_bound[2];
     const int tid = threadIdx.x;
-    if (tid < 128) {                                          // wave 0: where this chunk's buckets start; wave 1: where the next chunk's do
-        const uint32_t bnd = chunk_bound(keys, n, L, blockIdx.x + (uint32_t)(tid >> 6), tid & 63);
-        if ((tid & 63) == 0) s_bound[tid >> 6] = bnd;
+    const uint32_t cs = blockIdx.x * (uint32_t)HJ_T;
+    // the rows sit at fixed places (cs + r*256 + tid), so their loads do not wait for the range: the first nine go out
+    // at once; the range only decides which entries take part
+    KeyT k[HJ_ROWS]; uint32_t v[HJ_ROWS];
+#pragma unroll
+    for (int r = 0; r <= HJ_T / 256; r++) {
+        const uint32_t idx = cs + (uint32_t)r * 256u + (uint32_t)tid;
+        k[r] = idx < n ? keys[idx] : EMPTY; v[r] = idx < n ? vals[idx] : 0u;
     }
+    for (int i = tid; i < HJ_SLOTS; i += 256) { skey[i] = EMPTY; som[i] = 0; if (WIDE) som2[i] = 0; }
     __syncthreads();
-    const uint32_t lo = s_bound[0], hi = s_bound[1];
+    const uint32_t lo = bound[blockIdx.x], hi = bound[blockIdx.x + 1];
     if (lo >= hi) return;                                     // no bucket starts in this chunk
-    if (hi - lo > (uint32_t)HJ_CAP) {                         // oversize: hand the range to the host
+    if (hi > cs + (uint32_t)HJ_CAP) {                         // oversize: hand the range to the host
         if (tid == 0) {
             const uint32_t o = atomicAdd(&ovf[0], 1u);
             if (o < (uint32_t)HJ_OVF_CAP) { ovf[2 + 2 * o] = lo; ovf[3 + 2 * o] = hi; }
         }
         return;
     }
-    for (int i = tid; i < HJ_SLOTS; i += 256) { skey[i] = EMPTY; som[i] = 0; if (WIDE) som2[i] = 0; }
-    KeyT k[HJ_ROWS]; uint32_t v[HJ_ROWS];
 #pragma unroll
     for (int r = 0; r < HJ_ROWS; r++) {
-        const uint32_t idx = lo + (uint32_t)r * 256u + (uint32_t)tid;
-        const bool in = idx < hi;
-        k[r] = in ? keys[idx] : EMPTY; v[r] = in ? vals[idx] : 0u;
+        const uint32_t idx = cs + (uint32_t)r * 256u + (uint32_t)tid;
+        if (r > HJ_T / 256) {                                 // rows the range rarely reaches
+            k[r] = EMPTY; v[r] = 0u;
+            if (cs + (uint32_t)r * 256u < hi && idx < hi) { k[r] = keys[idx]; v[r] = vals[idx]; }
+        }
+        if (idx < lo || idx >= hi) k[r] = EMPTY;
     }
-    __syncthreads();
     // ---- pass 1: group by mer.  The LDS operations of all rows are issued phase by phase (first probes, collision
     // walks, genome-set updates), so that their latencies overlap instead of adding up row by row ----
-    uint32_t slot[HJ_ROWS]; uint32_t gbit[HJ_ROWS]; KeyT seen[HJ_ROWS];
+    if (VARIANT == 2) return;
+    uint32_t slot[HJ_ROWS]; uint32_t gbit[HJ_ROWS];
+    if (false) {
+    KeyT seen[HJ_ROWS];
 #pragma unroll
     for (int r = 0; r < HJ_ROWS; r++) {
         slot[r] = ((uint32_t)k[r] ^ (uint32_t)((uint64_t)k[r] >> 32)) * 0x9E3779B1u >> 20;         // 12 bits
@@ -606,6 +629,23 @@ __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, 
 #pragma unroll
     for (int r = 0; r < HJ_ROWS; r++)
         if (prev[r] & gbit[r]) { if (WIDE) atomicOr(&som2[slot[r]], gbit[r]); else atomicOr(&som[slot[r]], gbit[r] << 16); }
+    } else {
+#pragma unroll
+    for (int r = 0; r < HJ_ROWS; r++) {
+        slot[r] = HJ_NONE; gbit[r] = 0;
+        if (k[r] == EMPTY) continue;                          // beyond the range, or an invalid window
+        uint32_t s = ((uint32_t)k[r] ^ (uint32_t)((uint64_t)k[r] >> 32)) * 0x9E3779B1u >> 20;       // 12 bits
+        for (;;) {
+            const KeyT old = atomicCAS(&skey[s], EMPTY, k[r]);
+            if (old == EMPTY || old == k[r]) break;
+            s = (s + 1) & (HJ_SLOTS - 1);
+        }
+        const uint32_t bit = 1u << genome_of(v[r] & 0x7fffffffu, tab);
+        const uint32_t old = atomicOr(&som[s], bit);
+        if (old & bit) { if (WIDE) atomicOr(&som2[s], bit); else atomicOr(&som[s], bit << 16); }
+        slot[r] = s; gbit[r] = bit;
+    }
+    }
     __syncthreads();
     // ---- pass 2: the finder rule per mer; the entry of the lowest component genome is the anchor ----
     uint32_t mm[HJ_ROWS];
@@ -619,14 +659,15 @@ __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, 
         if (mode == MAUVE_MODE_MEM && multi) continue;
         if (__popc(m) < 2 || (want_mask && m != want_mask) || !(m & gbit[r])) continue;
         mm[r] = m;
-        if ((m & (0u - m)) == gbit[r]) sanch[slot[r]] = v[r];
+        if ((m & (0u - m)) == gbit[r]) skey[slot[r]] = (KeyT)v[r];          // grouping is over: the slot's mer makes room for the anchor
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < HJ_ROWS; r++) {
         if (!mm[r]) continue;
-        const uint32_t ap = sanch[slot[r]] & 0x7fffffffu;
+        const uint32_t ap = (uint32_t)skey[slot[r]] & 0x7fffffffu;
         if (ap >= P) { atomicAdd(&ovf[1], 1u); continue; }   // cannot happen; a wild store could take the device down
+        if (VARIANT == 1) continue;
         tpos[(size_t)ap * tab.nseq + (__ffs(gbit[r]) - 1)] = v[r];
         if ((mm[r] & (0u - mm[r])) == gbit[r]) tmask[ap] = mm[r];
     }
@@ -1014,6 +1055,7 @@ static int build_tab(mauve_ctx *ctx, const GenomeSet &gs, int span, GenomeTab *t
         if (tot >= (1LL << 31)) { ctx->err = "total genome length exceeds 2^31 windows"; return MAUVE_ERR_LIMIT; }
     }
     tab->gpos_off[gs.nseq] = (uint32_t)tot;
+    for (int g = gs.nseq + 1; g <= MAUVE_MAX_SEQ; g++) tab->gpos_off[g] = 0xffffffffu;      // see genome_of
     *total_windows = tot;
     return MAUVE_OK;
 }
@@ -1204,12 +1246,17 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             HIPCHK(ctx, ctx->join_ovf.ensure((2 + 2 * (size_t)HJ_OVF_CAP) * 4));
             HIPCHK(ctx, hipMemsetAsync(ctx->join_ovf.p, 0, 8, ctx->stream));
             KernelTimer t(ctx, MAUVE_K_JOIN, ns);
-            if (N > 16)
-                hipLaunchKernelGGL((join_hash<KeyT, true>), dim3(nchunk), dim3(256), 0, ctx->stream, keys, vals, ns,
-                                   L, tab, fp.rule, fp.want, tmask, tpos, ctx->join_ovf.as<uint32_t>(), P);
-            else
-                hipLaunchKernelGGL((join_hash<KeyT, false>), dim3(nchunk), dim3(256), 0, ctx->stream, keys, vals, ns,
-                                   L, tab, fp.rule, fp.want, tmask, tpos, ctx->join_ovf.as<uint32_t>(), P);
+            static const int jv = getenv("MAUVE_JH_VARIANT") ? atoi(getenv("MAUVE_JH_VARIANT")) : 0;
+            HIPCHK(ctx, ctx->join_bound.ensure(((size_t)nchunk + 2) * 4));
+            hipLaunchKernelGGL((join_bounds<KeyT>), dim3((nchunk + 1 + 3) / 4), dim3(256), 0, ctx->stream, keys, ns, L, nchunk,
+                               ctx->join_bound.as<uint32_t>());
+#define JH_LAUNCH(W, V) hipLaunchKernelGGL((join_hash<KeyT, W, V>), dim3(nchunk), dim3(256), 0, ctx->stream, keys, vals, ns, \
+                                           ctx->join_bound.as<uint32_t>(), tab, fp.rule, fp.want, tmask, tpos, ctx->join_ovf.as<uint32_t>(), P)
+            if (N > 16) JH_LAUNCH(true, 0);
+            else if (jv == 1) JH_LAUNCH(false, 1);
+            else if (jv == 2) JH_LAUNCH(false, 2);
+            else JH_LAUNCH(false, 0);
+#undef JH_LAUNCH
         } else
         { KernelTimer t(ctx, MAUVE_K_JOIN, ns);
           hipLaunchKernelGGL((mum_join<KeyT, SEG>), dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, ns, tab, fp.rule,
@@ -1305,6 +1352,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t nm = ctx->pin_seed.as<uint32_t>()[3];
         ctx->match_len.resize(nm); ctx->match_start.resize((size_t)nm * N);
+        bool canon_ties = false;
         if (nm) {
             HIPCHK(ctx, ctx->sorted_rec.ensure((size_t)nm * (1 + N) * 8));
             int64_t *ol = ctx->sorted_rec.as<int64_t>(), *os = ol + nm;
@@ -1337,6 +1385,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
                 uint32_t j = i + 1; uint64_t kj = 0;
                 while (j < nm && (kj = k1of(j)) == prev) j++;
                 if (j - i > 1) {
+                    canon_ties = true;
                     std::vector<std::vector<int64_t>> grp;
                     for (uint32_t r = i; r < j; r++) {
                         std::vector<int64_t> rec(1 + N); rec[0] = ctx->match_len[r];
@@ -1353,6 +1402,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             }
         }
         ctx->n_matches = nm;
+        ctx->dev_rec_n = canon_ties ? -1 : (int64_t)nm;      // sorted_rec holds the list in canonical order (no host fix-up was needed)
         if (n_matches) *n_matches = nm;
         TRACE(ctx, "canonical sort (device)");
         return MAUVE_OK;
@@ -1421,6 +1471,13 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     return MAUVE_OK;
 }
 
+// stable LSD radix sort of (32-bit key, 32-bit value) pairs for the other translation units (chain_dev.hip)
+int sort_pairs_u32(mauve_ctx *ctx, uint32_t n, int key_bits, uint32_t **keys_io, uint32_t **vals_io, uint32_t *keys_alt, uint32_t *vals_alt,
+                   int timer_id)
+{
+    return sort_pairs<uint32_t>(ctx, n, key_bits, keys_io, vals_io, keys_alt, vals_alt, false, timer_id);
+}
+
 int seedpass_run(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, int mode, uint64_t mask, int extend,
                  const uint32_t *seg_dev, uint32_t nseg, int64_t *n_matches)
 {
@@ -1431,6 +1488,7 @@ int seedpass_run(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, int mode
     int rc = build_tab(ctx, gs, sh.span, &tab, &total);
     if (rc) return rc;
     ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear();
+    ctx->dev_rec_n = -1;
     if (n_matches) *n_matches = 0;
     if (total == 0) return MAUVE_OK;
     if (seg_dev) return seedpass_impl<uint64_t, true>(ctx, gs, sh, tab, total, mode, mask, extend, -1, seg_dev, nseg, n_matches, nullptr, nullptr);
