@@ -196,7 +196,8 @@ int mauve_write_xmfa(mauve_ctx *ctx, const char *const *names, char *buf, int64_
 #define MAUVE_K_DP 6
 #define MAUVE_K_RUNS 7
 #define MAUVE_K_CANON 8           /* canonical order on the device: key build, its (small) radix sort, gather */
-#define MAUVE_K_COUNT 9
+#define MAUVE_K_MISC 9            /* the small sorts of the device chain and of the DP front end */
+#define MAUVE_K_COUNT 10
 int mauve_profile_enable(mauve_ctx *ctx, int on);
 int mauve_profile_reset(mauve_ctx *ctx);
 int mauve_profile_get(mauve_ctx *ctx, int kernel, double *total_ms, int64_t *launches, int64_t *units);

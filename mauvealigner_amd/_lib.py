@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libmauve_hip.so")
 MODE_MEM, MODE_UNIQUE, MODE_PAIRWISE = 0, 1, 2
 CODING_SEED, SOLID_SEED = 3, 0x7FFFFFFF
 K_EXTRACT, K_SORT_HIST, K_SORT_SCAN, K_SORT_SCATTER, K_JOIN, K_EXTEND, K_DP, K_RUNS = range(8)
-KERNEL_NAMES = ["seed_extract", "rs_hist", "rs_rowscan", "rs_scatter", "mum_join", "mum_extend", "dp_step", "mum_runs", "canon_sort"]
+KERNEL_NAMES = ["seed_extract", "rs_hist", "rs_rowscan", "rs_scatter", "mum_join", "mum_extend", "dp_step", "mum_runs", "canon_sort", "misc_sort"]
 
 # every symbol include/mauve_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = [

@@ -14,54 +14,14 @@
 // The host code of chain_host.cpp remains the path for lists the seed pass sorted on the host (small ones, or with
 // ties in the canonical order) and for the per-gap chains of the recursion.
 #include "common.hpp"
+#include "dev_scan.hpp"
 #include <cstring>
 #include <cstdlib>
 
 namespace {
 
-constexpr int CH_TILE = 1024;               // entries per workgroup: 256 threads x 4 consecutive entries
-
-// exclusive scans over the 256 threads of a workgroup (sum, maximum with identity 0); *total = all-thread aggregate
-__device__ __forceinline__ uint32_t bscan_add(uint32_t v, uint32_t *total, uint32_t *lds /*[4]*/)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    __syncthreads();                         // lds may still be read from an earlier call
-    if (lane == 63) lds[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) { const uint32_t c = lds[w]; if (w < wave) wbase += c; tot += c; }
-    *total = tot;
-    return wbase + inc - v;
-}
-__device__ __forceinline__ uint32_t bscan_max(uint32_t v, uint32_t *total, uint32_t *lds /*[4]*/)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= o) inc = max(inc, t); }
-    __syncthreads();
-    if (lane == 63) lds[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) { const uint32_t c = lds[w]; if (w < wave) wbase = max(wbase, c); tot = max(tot, c); }
-    *total = tot;
-    const uint32_t up = __shfl_up(inc, 1);
-    return max(wbase, lane ? up : 0u);
-}
-// aggregate of the per-tile values before tile b (sum / maximum), and of all nb tiles
-__device__ __forceinline__ void tiles_before_add(const uint32_t *__restrict__ v, uint32_t b, uint32_t nb, uint32_t *before, uint32_t *all, uint32_t *lds)
-{
-    uint32_t sb = 0, sa = 0;
-    for (uint32_t t = threadIdx.x; t < nb; t += 256) { const uint32_t x = v[t]; sa += x; if (t < b) sb += x; }
-    uint32_t tb, ta;
-    (void)bscan_add(sb, &tb, lds); (void)bscan_add(sa, &ta, lds);
-    *before = tb; *all = ta;
-}
+using namespace devscan;
+constexpr int CH_TILE = devscan::TILE;
 
 // records as the seed pass left them (int64 length[n], start[n*N]) -> working arrays (int32)
 __global__ void __launch_bounds__(256) ch_init(const int64_t *__restrict__ rlen, const int64_t *__restrict__ rst, uint32_t n, int N,
@@ -151,44 +111,6 @@ __global__ void __launch_bounds__(256) cl_flags(const int32_t *__restrict__ len,
         (void)bscan_add(sa, &k, lds);
         if (threadIdx.x == 0) cnt[5] = k;
     }
-}
-
-// ---- flag compaction over the tiles: cmp_count (flags per tile) + cmp_write (every workgroup sums the tiles before it) ----
-// F: domain(y) entries; flag(r, y); each(r, exclusive count, flag, y) for every entry; emit(r, slot, y) for the flagged;
-// total(count, y) once.
-template <class F>
-__global__ void __launch_bounds__(256) cmp_count(F f, uint32_t *__restrict__ bcnt)
-{
-    __shared__ uint32_t lds[4];
-    const int y = blockIdx.y;
-    const uint32_t dom = f.domain(y), r0 = blockIdx.x * (uint32_t)CH_TILE + threadIdx.x * 4u;
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) if (r0 + i < dom) c += f.flag(r0 + i, y) ? 1u : 0u;
-    uint32_t tc;
-    (void)bscan_add(c, &tc, lds);
-    if (threadIdx.x == 0) bcnt[(size_t)y * gridDim.x + blockIdx.x] = tc;
-}
-template <class F>
-__global__ void __launch_bounds__(256) cmp_write(F f, const uint32_t *__restrict__ bcnt)
-{
-    __shared__ uint32_t lds[4];
-    const int y = blockIdx.y;
-    const uint32_t dom = f.domain(y), r0 = blockIdx.x * (uint32_t)CH_TILE + threadIdx.x * 4u;
-    uint32_t before, all;
-    tiles_before_add(bcnt + (size_t)y * gridDim.x, blockIdx.x, gridDim.x, &before, &all, lds);
-    bool fl[4]; uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { fl[i] = r0 + i < dom && f.flag(r0 + i, y); c += fl[i] ? 1u : 0u; }
-    uint32_t dummy;
-    uint32_t o = before + bscan_add(c, &dummy, lds);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (r0 + i >= dom) break;
-        f.each(r0 + i, o, fl[i], y);
-        if (fl[i]) { f.emit(r0 + i, o, y); o++; }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) f.total(all, y);
 }
 
 struct ClusterStarts {                      // flagged entries -> cstart[]; cstart[J] = k
@@ -382,7 +304,7 @@ int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchV
     for (int g = 0; g < N; g++) {
         hipLaunchKernelGGL(ch_keys, dim3(blocks), dim3(256), 0, c->stream, len, st, n, N, g, dead_key, k1, v1);
         uint32_t *kk = k1, *vv = v1;
-        int rc = sort_pairs_u32(c, n, pos_bits + 1, &kk, &vv, k2, v2, MAUVE_K_CANON);
+        int rc = sort_pairs_u32(c, n, pos_bits + 1, &kk, &vv, k2, v2, MAUVE_K_MISC);
         if (rc) return rc;
         hipLaunchKernelGGL(cl_partial, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive);
         hipLaunchKernelGGL(cl_flags, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive, nb, cflag, cnt);

@@ -205,6 +205,8 @@ struct mauve_ctx {
     DevBuf dp_desc, dp_list, dp_codes, dp_off, dp_prof_cnt, dp_prof_mask, dp_prof2_cnt, dp_prof2_mask, dp_tb, dp_meta, dp_score,
         dp_cols, dp_rows;
 
+    DevBuf dpf_anch, dpf_work, dpf_tot;   // device front end of the DP stage (dp_run_from_anchors)
+
     // profiling
     bool prof = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -212,6 +214,7 @@ struct mauve_ctx {
     int64_t k_launch[MAUVE_K_COUNT] = {0};
     int64_t k_units[MAUVE_K_COUNT] = {0};
 
+    PinnedBuf pin_anch;                  // anchors in chain order on their way to the device, and the gap codes coming back
     PinnedBuf pin_dcols;                 // DP columns of the whole-call path (mauve_align, mauve_progressive_align)
     PinnedBuf pin_meta;                  // per-interval DP results (length, score, cells)
     PinnedBuf pin_dp_in;                 // DP inputs on their way to the device: offset tables, interval list, descriptors
@@ -289,5 +292,8 @@ void lcb_greedy(int N, int32_t K, int64_t *weight, const uint32_t *orient_bits, 
 // DP (dp_batch.hip)
 int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *sc,
                       uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells);
+int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na, const int32_t *h_len, const int32_t *h_st, const int32_t *h_lcb, int gapped,
+                        int64_t max_gapped_len, const mauve_scoring *scoring, int32_t *gapcode, int64_t *n_dp_out, int64_t *code_total_out,
+                        PinnedBuf *dcols, std::vector<int64_t> &dcol_off, std::vector<int64_t> &dscore, int64_t *cells);
 int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,
                  const mauve_scoring *sc, uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells);

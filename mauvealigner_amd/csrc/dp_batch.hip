@@ -16,6 +16,7 @@
 // the new profile is rebuilt in forward order with ballot prefix counts.  Integer VALU + shuffle
 // bound, not HBM and not MFMA.
 #include "common.hpp"
+#include "dev_scan.hpp"
 #include <algorithm>
 #include <functional>
 #include <cstring>
@@ -576,6 +577,31 @@ __global__ void __launch_bounds__(256) dp_gather_codes(const uint64_t *__restric
     }
 }
 
+// the two DP launches: dp_step_big (workgroup per interval, second stream) beside dp_step (wave / sub-wave per interval)
+static int dp_launch_steps(mauve_ctx *ctx, int nseq, int64_t n_iv, int64_t n_big, const DpClasses &cl, uint32_t blocks,
+                           const int64_t *d_seq_off, const int64_t *d_tb_off, const int64_t *d_rows_off, const DpScoring &sc)
+{
+    KernelTimer t(ctx, MAUVE_K_DP, n_iv);
+    if (n_big) {   // the workgroup-per-interval launch runs beside the one-wave launch on a second stream
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        hipLaunchKernelGGL(dp_step_big, dim3((uint32_t)n_big), dim3(64 * DP_MW_WAVES), 0, ctx->stream2, nseq,
+                           ctx->dp_list.as<int64_t>(), ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(),
+                           ctx->dp_prof_cnt.as<uint32_t>(), ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
+                           ctx->dp_prof2_mask.as<uint32_t>(), ctx->dp_tb.as<uint8_t>(), d_tb_off, ctx->dp_rows.as<int32_t>(),
+                           d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+    }
+    if (blocks)
+        hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, nseq, ctx->dp_list.as<int64_t>(), cl,
+                           ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
+                           ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
+                           ctx->dp_prof2_mask.as<uint32_t>(), ctx->dp_tb.as<uint8_t>(), d_tb_off, ctx->dp_rows.as<int32_t>(),
+                           d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
+    if (n_big) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return MAUVE_OK;
+}
+
 // shared core: seq_off is a host array; the codes are either uploaded from `codes` or gathered from `desc`
 static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const DpSeqDesc *desc,
                    const int64_t *seq_off, const mauve_scoring *scoring, uint32_t *cols, int64_t *col_off,
@@ -712,26 +738,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     int64_t *pin_list = pin_off + n_so + 2 * n_o;               // the fourth slot of the offsets block
     memcpy(pin_list, lst.data(), (size_t)n_iv * 8);
     HIPCHK(ctx, hipMemcpyAsync(ctx->dp_list.p, pin_list, (size_t)n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
-    {
-        KernelTimer t(ctx, MAUVE_K_DP, n_iv);
-        if (n_big) {   // the workgroup-per-interval launch runs beside the one-wave launch on a second stream
-            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            hipLaunchKernelGGL(dp_step_big, dim3((uint32_t)n_big), dim3(64 * DP_MW_WAVES), 0, ctx->stream2, nseq,
-                               ctx->dp_list.as<int64_t>(), ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(),
-                               ctx->dp_prof_cnt.as<uint32_t>(), ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
-                               ctx->dp_prof2_mask.as<uint32_t>(), ctx->dp_tb.as<uint8_t>(), d_tb_off, ctx->dp_rows.as<int32_t>(),
-                               d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
-            HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-        }
-        if (blocks)
-            hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, nseq, ctx->dp_list.as<int64_t>(), cl,
-                               ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
-                               ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
-                               ctx->dp_prof2_mask.as<uint32_t>(), ctx->dp_tb.as<uint8_t>(), d_tb_off, ctx->dp_rows.as<int32_t>(),
-                               d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
-        if (n_big) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-    }
+    { int rcl = dp_launch_steps(ctx, nseq, n_iv, n_big, cl, blocks, d_seq_off, d_tb_off, d_rows_off, sc); if (rcl) return rcl; }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // host work while the DP kernels run
     HIPCHK(ctx, ctx->pin_meta.ensure((size_t)n_iv * sizeof(DpMeta)));
@@ -766,6 +773,287 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     }
     if (trace) fprintf(stderr, "[trace] dp_core: sizing+H2D %.3f ms, order+launch %.3f, kernel+meta D2H %.3f, gather+cols D2H %.3f\n",
                        td1 - td0, td2 - td1, td3 - td2, now_ms() - td3);
+    return MAUVE_OK;
+}
+
+
+// ================================================================================================================
+// Device front end of the whole-call path (mauve_align): from the anchor table straight to the DP launches.
+// The host used to walk every inter-anchor gap three times (interval table, per-interval sizing, size-class order:
+// ~1 us of pointer chasing per gap and genome, 2 ms at C3 for 0.6 ms of DP kernel).  Here the anchors go up once
+// (flat int32 records in chain order) and kernels do the rest: gap of every anchor pair -> which gaps are aligned ->
+// their descriptors, traceback / parked-row needs and step estimates -> offsets by tiled scans -> the launch order by
+// two stable radix passes of seed_pass.hip (size class, then kernel class).  One small read-back (totals, and the gap
+// code of every anchor for the assembly) sizes the buffers; the DP kernels and their result layout are unchanged.
+// ================================================================================================================
+namespace {
+using namespace devscan;
+
+struct DpFrontTotals {                       // device block read back once
+    int64_t codes, tb, rows, est, n_dp, first_med, first_s32, first_s16, cols, cells;
+};
+
+__device__ __forceinline__ void dpf_gap(const int32_t *__restrict__ alen, const int32_t *__restrict__ ast, int N, uint32_t k, int g,
+                                        int64_t &lo, int64_t &ln, bool &rev)
+{
+    const int64_t sa = ast[(size_t)k * N + g], sb = ast[(size_t)(k + 1) * N + g];
+    int64_t hi;
+    if (sa > 0) { lo = sa + alen[k]; hi = sb - 1; rev = false; }
+    else { lo = -sb + alen[k + 1]; hi = -sa - 1; rev = true; }
+    ln = hi - lo + 1; if (ln < 0) ln = 0;
+}
+
+// gap code of anchor k: -1 no gap behind it, -2 a gap that is emitted unaligned, 0 a gap for the DP (slot follows)
+__global__ void __launch_bounds__(256) dpf_gap_flags(const int32_t *__restrict__ alen, const int32_t *__restrict__ ast,
+                                                     const int32_t *__restrict__ alcb, uint32_t na, int N, int gapped, int64_t max_gapped,
+                                                     int32_t *__restrict__ gapcode)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= na) return;
+    int32_t code = -1;
+    if (k + 1 < na && alcb[k] == alcb[k + 1]) {
+        int64_t tot = 0, mx = 0; int nonempty = 0;
+        for (int g = 0; g < N; g++) {
+            int64_t lo, ln; bool rv;
+            dpf_gap(alen, ast, N, k, g, lo, ln, rv);
+            tot += ln; mx = max(mx, ln); nonempty += ln > 0;
+        }
+        if (tot > 0) code = (gapped && nonempty >= 2 && mx <= max_gapped) ? 0 : -2;
+    }
+    gapcode[k] = code;
+}
+struct DpSlots {                             // DP gaps in chain order -> slots
+    int32_t *gapcode; uint32_t na; uint32_t *anchor_of; DpFrontTotals *tot;
+    __device__ uint32_t domain(int) const { return na; }
+    __device__ bool flag(uint32_t k, int) const { return gapcode[k] == 0; }
+    __device__ void each(uint32_t, uint32_t, bool, int) const {}
+    __device__ void emit(uint32_t k, uint32_t o, int) const { gapcode[k] = (int32_t)o; anchor_of[o] = k; }
+    __device__ void total(uint32_t n, int) const { tot->n_dp = n; }
+};
+
+// per DP interval: descriptors of its sequences, traceback bytes (worst profile length before each step), parked
+// rows, single-wave step estimate, whether a step is long enough for the workgroup pipeline, sub-wave class
+__global__ void __launch_bounds__(256) dpf_desc(const int32_t *__restrict__ alen, const int32_t *__restrict__ ast, int N,
+                                                const uint32_t *__restrict__ anchor_of, const DpFrontTotals *__restrict__ tot,
+                                                DpSeqDesc *__restrict__ desc, int64_t *__restrict__ need, int64_t *__restrict__ rowsn,
+                                                int64_t *__restrict__ est, uint8_t *__restrict__ cand, uint8_t *__restrict__ cls,
+                                                uint32_t *__restrict__ sizekey, uint32_t *__restrict__ slotval, int no_mw, int no_groups)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= (uint32_t)tot->n_dp) return;
+    const uint32_t k = anchor_of[s];
+    int64_t mmax = 0, nd = 0, nmax = 0, es = 0, mbound = 0, steps_max = 0; bool first = true; uint8_t big = 0;
+    for (int g = 0; g < N; g++) {
+        int64_t lo, n; bool rv;
+        dpf_gap(alen, ast, N, k, g, lo, n, rv);
+        DpSeqDesc d; d.genome = g; d.rev = rv; d.lo0 = lo - 1; d.len = n;
+        desc[(size_t)s * N + g] = d;
+        if (n == 0) continue;
+        if (first) { first = false; mmax = n; continue; }
+        nd = max(nd, ((mmax + 63) / 64) * (n + 64) * 64);
+        nmax = max(nmax, n);
+        if (mmax > 128 && n >= 256 && !no_mw) big = 1;       // a step with >= 3 stripes against >= 256 columns pipelines over several waves
+        es += ((mmax + 63) / 64) * (n + 64);
+        mbound = max(mbound, mmax); steps_max = max(steps_max, mmax + n);
+        mmax += n;
+    }
+    need[s] = nd; rowsn[s] = 6 * (nmax + 1); est[s] = es; cand[s] = big;
+    uint8_t kc = 1;
+    if (!no_groups && steps_max <= DP_GRP_TMAX) kc = mbound <= 16 ? 3 : (mbound <= 32 ? 2 : 1);
+    cls[s] = kc;
+    int c = 0; for (int64_t f = nd; f > 1; f >>= 1) c++;
+    sizekey[s] = (uint32_t)(63 - c);                         // largest traceback footprint first
+    slotval[s] = s;
+}
+struct DescLen { const DpSeqDesc *d; __device__ int64_t value(uint32_t i) const { return d[i].len; } };
+struct ArrVal { const int64_t *a; __device__ int64_t value(uint32_t i) const { return a[i]; } };
+
+// workgroup-pipeline entries: candidates well above a balanced one-wave share, the first 128 of them in size order
+struct DpBigPick {
+    const uint32_t *order; const uint8_t *cand, *cls; const int64_t *est; const DpFrontTotals *tot; uint32_t *key2;
+    __device__ uint32_t domain(int) const { return (uint32_t)tot->n_dp; }
+    __device__ bool flag(uint32_t j, int) const { const uint32_t s = order[j]; return cand[s] && est[s] > 4 * (tot->est / 3072); }
+    __device__ void each(uint32_t j, uint32_t before, bool fl, int) const { key2[j] = (fl && before < 128) ? 0u : (uint32_t)cls[order[j]]; }
+    __device__ void emit(uint32_t, uint32_t, int) const {}
+    __device__ void total(uint32_t, int) const {}
+};
+// list for the kernels (int64 slots) and the class boundaries of the class-sorted keys
+__global__ void __launch_bounds__(256) dpf_list(const uint32_t *__restrict__ key2, const uint32_t *__restrict__ order, DpFrontTotals *__restrict__ tot,
+                                                int64_t *__restrict__ list)
+{
+    const uint32_t n = (uint32_t)tot->n_dp, j = blockIdx.x * 256u + threadIdx.x;
+    if (j < n) list[j] = order[j];
+    if (j < 3) {                                              // first index with key >= j + 1
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (key2[mid] >= j + 1) hi = mid; else lo = mid + 1; }
+        if (j == 0) tot->first_med = lo; else if (j == 1) tot->first_s32 = lo; else tot->first_s16 = lo;
+    }
+}
+struct MetaCols { const DpMeta *m; __device__ int64_t value(uint32_t i) const { return m[i].m; } };
+struct MetaCells { const DpMeta *m; __device__ int64_t value(uint32_t i) const { return m[i].cells; } };
+__global__ void __launch_bounds__(256) dpf_scores(const DpMeta *__restrict__ meta, uint32_t n, int64_t *__restrict__ score)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) score[i] = meta[i].score;
+}
+
+}  // namespace
+
+// anchors: na records in chain order (LCB by LCB, genome-0 order inside), host arrays (page-locked).  Out: gapcode[na]
+// (-1 / -2 / DP slot), n_dp, the DP columns in *dcols (page-locked, grown here), dcol_off[n_dp + 1], dscore[n_dp].
+int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_len, const int32_t *h_st, const int32_t *h_lcb, int gapped,
+                        int64_t max_gapped_len, const mauve_scoring *scoring, int32_t *gapcode, int64_t *n_dp_out, int64_t *code_total_out,
+                        PinnedBuf *dcols, std::vector<int64_t> &dcol_off, std::vector<int64_t> &dscore, int64_t *cells)
+{
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    static const bool no_mw = getenv("MAUVE_DP_ONE_WAVE") != nullptr, no_groups = getenv("MAUVE_DP_NO_GROUPS") != nullptr;
+    const double t0 = now_ms();
+    *n_dp_out = 0; *code_total_out = 0; if (cells) *cells = 0;
+    dcol_off.assign(1, 0); dscore.clear();
+    if (na64 < 2) { for (int64_t k = 0; k < na64; k++) gapcode[k] = -1; return MAUVE_OK; }
+    if (na64 >= (1LL << 31)) { ctx->err = "dp: too many anchors"; return MAUVE_ERR_LIMIT; }
+    const uint32_t na = (uint32_t)na64, nb = (na + TILE - 1) / TILE, blocks = (na + 255) / 256;
+    // device arrays sized by na (an upper bound of n_dp)
+    const size_t w_anch = (size_t)na * (2 + (size_t)N) * 4;
+    HIPCHK(ctx, ctx->dpf_anch.ensure(w_anch + (size_t)na * 4 * 2 + 64));                       // anchors, gapcode, anchor_of
+    HIPCHK(ctx, ctx->dp_desc.ensure((size_t)na * N * sizeof(DpSeqDesc)));
+    // work area: need / rows / est (int64), cand / cls (bytes), 5 x uint32 sort arrays, tile counts, tile sums (int64)
+    auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    const size_t o_cand = (size_t)na * 24, o_k = up8(o_cand + 2 * (size_t)na), o_bcnt = o_k + (size_t)na * 20, o_bsum = up8(o_bcnt + (size_t)nb * 4),
+                 o_bsum2 = o_bsum + ((size_t)nb * N + 8) * 8, w_total = o_bsum2 + ((size_t)nb + 8) * 8;
+    HIPCHK(ctx, ctx->dpf_work.ensure(w_total));
+    HIPCHK(ctx, ctx->dp_off.ensure(((size_t)na * N + 1 + 3 * ((size_t)na + 1)) * sizeof(int64_t)));
+    HIPCHK(ctx, ctx->dp_list.ensure((size_t)na * 8));
+    HIPCHK(ctx, ctx->dp_meta.ensure((size_t)na * sizeof(DpMeta)));
+    HIPCHK(ctx, ctx->dpf_tot.ensure(256));
+    int32_t *alen = ctx->dpf_anch.as<int32_t>(), *ast = alen + na, *alcb = ast + (size_t)na * N, *d_gapcode = alcb + na;
+    uint32_t *anchor_of = reinterpret_cast<uint32_t *>(d_gapcode + na);
+    DpSeqDesc *desc = ctx->dp_desc.as<DpSeqDesc>();
+    char *wk = ctx->dpf_work.as<char>();
+    int64_t *need = reinterpret_cast<int64_t *>(wk), *rowsn = need + na, *est = rowsn + na;
+    uint8_t *cand = reinterpret_cast<uint8_t *>(wk + o_cand), *cls = cand + na;
+    uint32_t *k1 = reinterpret_cast<uint32_t *>(wk + o_k), *v1 = k1 + na, *k2 = v1 + na, *v2 = k2 + na, *k3 = v2 + na;
+    uint32_t *bcnt = reinterpret_cast<uint32_t *>(wk + o_bcnt);
+    int64_t *bsum = reinterpret_cast<int64_t *>(wk + o_bsum), *bsum2 = reinterpret_cast<int64_t *>(wk + o_bsum2);
+    DpFrontTotals *tot = ctx->dpf_tot.as<DpFrontTotals>();
+    int64_t *d_seq_off = ctx->dp_off.as<int64_t>();
+    int64_t *d_tb_off = d_seq_off + ((size_t)na * N + 1), *d_rows_off = d_tb_off + (na + 1), *d_col_off = d_rows_off + (na + 1);
+    HIPCHK(ctx, hipMemsetAsync(tot, 0, 256, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(alen, h_len, (size_t)na * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ast, h_st, (size_t)na * N * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(alcb, h_lcb, (size_t)na * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(dpf_gap_flags, dim3(blocks), dim3(256), 0, ctx->stream, alen, ast, alcb, na, N, gapped, max_gapped_len, d_gapcode);
+    const DpSlots sl{d_gapcode, na, anchor_of, tot};
+    hipLaunchKernelGGL((cmp_count<DpSlots>), dim3(nb), dim3(256), 0, ctx->stream, sl, bcnt);
+    hipLaunchKernelGGL((cmp_write<DpSlots>), dim3(nb), dim3(256), 0, ctx->stream, sl, bcnt);
+    hipLaunchKernelGGL(dpf_desc, dim3(blocks), dim3(256), 0, ctx->stream, alen, ast, N, anchor_of, tot, desc, need, rowsn, est, cand, cls, k1, v1,
+                       (int)no_mw, (int)no_groups);
+    // the counts below are device values; the launches cover na (>= n_dp) entries and the kernels stop at n_dp.
+    // Offsets: the value functors return 0 beyond n_dp because the arrays there are never read -- so clear them first.
+    // (need / rows / est / desc of slots >= n_dp are not written: scan over exactly n_dp needs the count -> two-phase:
+    //  read the small totals block back first.)
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, ctx->pin_dp_in.ensure(256 + (size_t)na * 4));
+    DpFrontTotals *ht = ctx->pin_dp_in.as<DpFrontTotals>();
+    int32_t *h_gapcode = reinterpret_cast<int32_t *>(ctx->pin_dp_in.as<char>() + 256);
+    HIPCHK(ctx, hipMemcpyAsync(ht, tot, sizeof(DpFrontTotals), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_gapcode, d_gapcode, (size_t)na * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t n_dp = (uint32_t)ht->n_dp;
+    memcpy(gapcode, h_gapcode, (size_t)na * 4);
+    *n_dp_out = n_dp;
+    const double t1 = now_ms();
+    if (n_dp == 0) return MAUVE_OK;
+    const uint32_t nbd = (n_dp + TILE - 1) / TILE, nbs = (n_dp * (uint32_t)N + TILE - 1) / TILE, blk_d = (n_dp + 255) / 256;
+    hipLaunchKernelGGL((vscan_partial<int64_t, DescLen>), dim3(nbs), dim3(256), 0, ctx->stream, DescLen{desc}, n_dp * (uint32_t)N, bsum);
+    hipLaunchKernelGGL((vscan_write<int64_t, DescLen>), dim3(nbs), dim3(256), 0, ctx->stream, DescLen{desc}, n_dp * (uint32_t)N, bsum, d_seq_off, &tot->codes);
+    hipLaunchKernelGGL((vscan_partial<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{need}, n_dp, bsum2);
+    hipLaunchKernelGGL((vscan_write<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{need}, n_dp, bsum2, d_tb_off, &tot->tb);
+    hipLaunchKernelGGL((vscan_partial<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{rowsn}, n_dp, bsum);
+    hipLaunchKernelGGL((vscan_write<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{rowsn}, n_dp, bsum, d_rows_off, &tot->rows);
+    hipLaunchKernelGGL((vscan_partial<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{est}, n_dp, bsum2);
+    hipLaunchKernelGGL((vscan_write<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{est}, n_dp, bsum2, d_col_off /*scratch*/, &tot->est);
+    // launch order: size class (stable), the workgroup-pipeline pick in that order, then kernel class (stable)
+    uint32_t *ok = k1, *ov = v1;
+    int rc = sort_pairs_u32(ctx, n_dp, 6, &ok, &ov, k2, v2, MAUVE_K_MISC);
+    if (rc) return rc;
+    uint32_t *fk = ok == k1 ? k2 : k1, *fv = ov == v1 ? v2 : v1;        // free pair
+    const DpBigPick bp{ov, cand, cls, est, tot, fk};
+    hipLaunchKernelGGL((cmp_count<DpBigPick>), dim3(nbd), dim3(256), 0, ctx->stream, bp, bcnt);
+    hipLaunchKernelGGL((cmp_write<DpBigPick>), dim3(nbd), dim3(256), 0, ctx->stream, bp, bcnt);
+    uint32_t *ck = fk, *cv = ov;
+    rc = sort_pairs_u32(ctx, n_dp, 2, &ck, &cv, k3, fv, MAUVE_K_MISC);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dpf_list, dim3(blk_d), dim3(256), 0, ctx->stream, ck, cv, tot, ctx->dp_list.as<int64_t>());
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ht, tot, sizeof(DpFrontTotals), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t total = ht->codes, tbt = ht->tb, rwt = ht->rows;
+    *code_total_out = total;
+    DpClasses cl; memset(&cl, 0, sizeof cl);
+    const int64_t n_big = ht->first_med;
+    cl.first_med = ht->first_med; cl.n_med = ht->first_s32 - ht->first_med;
+    cl.first_s32 = ht->first_s32; cl.n_s32 = ht->first_s16 - ht->first_s32;
+    cl.first_s16 = ht->first_s16; cl.n_s16 = (int64_t)n_dp - ht->first_s16;
+    cl.blocks_med = (uint32_t)std::min<int64_t>((cl.n_med + 3) / 4, 256 * 8);
+    cl.blocks_s32 = (uint32_t)std::min<int64_t>((cl.n_s32 + 7) / 8, 256 * 8);
+    const uint32_t blocks_s16 = (uint32_t)std::min<int64_t>((cl.n_s16 + 15) / 16, 256 * 8);
+    const uint32_t dpblocks = cl.blocks_med + cl.blocks_s32 + blocks_s16;
+    const double t2 = now_ms();
+    HIPCHK(ctx, ctx->dp_codes.ensure((size_t)total + 16));
+    HIPCHK(ctx, ctx->dp_prof_cnt.ensure((size_t)(total + 1) * 4));
+    HIPCHK(ctx, ctx->dp_prof_mask.ensure((size_t)(total + 1) * 4));
+    HIPCHK(ctx, ctx->dp_prof2_cnt.ensure((size_t)(total + 1) * 4));
+    HIPCHK(ctx, ctx->dp_prof2_mask.ensure((size_t)(total + 1) * 4));
+    HIPCHK(ctx, ctx->dp_tb.ensure((size_t)tbt + 64));
+    HIPCHK(ctx, ctx->dp_rows.ensure((size_t)(rwt + 1) * 4));
+    HIPCHK(ctx, ctx->dp_score.ensure((size_t)total + 16));           // reversed-ops scratch
+    HIPCHK(ctx, ctx->dp_cols.ensure((size_t)(total + 1) * 4));
+    {
+        DpGenomeWords gw; memset(&gw, 0, sizeof gw);
+        for (int g = 0; g < ctx->nseq; g++) gw.word_off[g] = ctx->word_off[g];
+        const int64_t nd = (int64_t)n_dp * N;
+        const uint32_t gb = (uint32_t)std::min<int64_t>((nd + 3) / 4, 256 * 8);
+        hipLaunchKernelGGL(dp_gather_codes, dim3(gb), dim3(256), 0, ctx->stream, ctx->genomes.as<uint64_t>(), gw, desc, d_seq_off, nd,
+                           ctx->dp_codes.as<uint8_t>());
+    }
+    DpScoring sc; sc.go = scoring->gap_open; sc.ge = scoring->gap_extend; memcpy(sc.s, scoring->matrix, sizeof sc.s);
+    rc = dp_launch_steps(ctx, N, n_dp, n_big, cl, dpblocks, d_seq_off, d_tb_off, d_rows_off, sc);
+    if (rc) return rc;
+    // results: column offsets, scores and the cell count by scans over the per-interval records; the columns compacted
+    const DpMeta *meta = ctx->dp_meta.as<DpMeta>();
+    int64_t *d_score = need;                                            // the sizing arrays are free again
+    hipLaunchKernelGGL((vscan_partial<int64_t, MetaCols>), dim3(nbd), dim3(256), 0, ctx->stream, MetaCols{meta}, n_dp, bsum);
+    hipLaunchKernelGGL((vscan_write<int64_t, MetaCols>), dim3(nbd), dim3(256), 0, ctx->stream, MetaCols{meta}, n_dp, bsum, d_col_off, &tot->cols);
+    hipLaunchKernelGGL((vscan_partial<int64_t, MetaCells>), dim3(nbd), dim3(256), 0, ctx->stream, MetaCells{meta}, n_dp, bsum2);
+    hipLaunchKernelGGL((vscan_write<int64_t, MetaCells>), dim3(nbd), dim3(256), 0, ctx->stream, MetaCells{meta}, n_dp, bsum2, rowsn /*scratch*/, &tot->cells);
+    hipLaunchKernelGGL(dpf_scores, dim3(blk_d), dim3(256), 0, ctx->stream, meta, n_dp, d_score);
+    {
+        const uint32_t gblocks = (uint32_t)std::min<int64_t>(((int64_t)n_dp + 3) / 4, 256 * 8);
+        hipLaunchKernelGGL(dp_gather, dim3(gblocks), dim3(256), 0, ctx->stream, N, (int64_t)n_dp, d_seq_off, meta, ctx->dp_prof_mask.as<uint32_t>(),
+                           ctx->dp_prof2_mask.as<uint32_t>(), d_col_off, ctx->dp_cols.as<uint32_t>());
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // host work while the DP kernels run
+    dcol_off.resize((size_t)n_dp + 1); dscore.resize((size_t)n_dp);
+    HIPCHK(ctx, ctx->pin_meta.ensure(((size_t)n_dp * 2 + 2) * 8));
+    int64_t *p_off = ctx->pin_meta.as<int64_t>(), *p_score = p_off + n_dp + 1;
+    HIPCHK(ctx, hipMemcpyAsync(ht, tot, sizeof(DpFrontTotals), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(p_off, d_col_off, ((size_t)n_dp + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(p_score, d_score, (size_t)n_dp * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const double t3 = now_ms();
+    const int64_t tc = ht->cols;
+    if (cells) *cells = ht->cells;
+    memcpy(dcol_off.data(), p_off, ((size_t)n_dp + 1) * 8);
+    memcpy(dscore.data(), p_score, (size_t)n_dp * 8);
+    HIPCHK(ctx, dcols->ensure(((size_t)tc + 1) * 4));
+    if (tc) {
+        HIPCHK(ctx, hipMemcpyAsync(dcols->p, ctx->dp_cols.p, (size_t)tc * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (trace) fprintf(stderr, "[trace] dp (device front): %u intervals (%lld workgroup, %lld one-wave, %lld two/wave, %lld four/wave); gaps+slots %.3f ms, sizing+order %.3f, kernels+offsets %.3f, columns %.3f\n",
+                       n_dp, (long long)n_big, (long long)cl.n_med, (long long)cl.n_s32, (long long)cl.n_s16, t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
     return MAUVE_OK;
 }
 

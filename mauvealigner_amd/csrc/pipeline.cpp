@@ -131,7 +131,7 @@ static int extend_lcbs(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
 // begin : seed pass, chaining, recursive anchoring, interval descriptors        (every rank, deterministic)
 // dp    : gapped alignment of a subset of the intervals                         (each rank its share)
 // finish: assembly of the interval table from the columns of ALL intervals      (every rank)
-static int align_begin(mauve_ctx *c, const mauve_params *p)
+static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = false)
 {
     const int N = c->nseq;
     AlignState &S = c->ast;
@@ -230,6 +230,13 @@ static int align_begin(mauve_ctx *c, const mauve_params *p)
     // ---- inter-anchor intervals.  Descriptors only: the bases are gathered from the resident packed genomes on
     // the device. ----
     S.gaps.reserve((size_t)R.mum_length.size() + 16);
+    if (device_front) {              // mauve_align: the interval table is made on the device (dp_run_from_anchors)
+        for (int64_t l = 0; l < nl; l++) {
+            const MatchVec &ch = chains[(size_t)l];
+            S.n_anchor += (int64_t)ch.size();
+            for (size_t i = 0; i < ch.size(); i++) S.anchor_cols += ch.len(i);
+        }
+    } else
     for (int64_t l = 0; l < nl; l++) {
         const MatchVec &ch = chains[(size_t)l];
         S.n_anchor += (int64_t)ch.size();
@@ -438,19 +445,58 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     if (!c || !p || !sizes) return MAUVE_ERR_ARG;
     if (c->nseq < 2) { c->err = "align: at least two genomes required"; return MAUVE_ERR_STATE; }
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = align_begin(c, p);
+    static const bool host_front = getenv("MAUVE_HOST_DP_FRONT") != nullptr;      // A/B switch
+    static const bool no_shadow = getenv("MAUVE_NO_SHADOW") != nullptr;
+    int rc = align_begin(c, p, !host_front);
     if (rc) return rc;
     AlignState &S = c->ast;
-    HIPCHK(c, c->pin_dcols.ensure(((size_t)S.code_total + 1) * sizeof(uint32_t)));
-    uint32_t *dcols = c->pin_dcols.as<uint32_t>();
-    S.dcol_off.assign((size_t)S.n_dp + 1, 0); S.dscore.assign((size_t)S.n_dp + 1, 0);
     int64_t cells = 0;
-    static const bool no_shadow = getenv("MAUVE_NO_SHADOW") != nullptr;
-    if (!no_shadow && S.n_dp) c->shadow = [c]() { fill_anchor_table(c); };       // runs while the DP kernels do
-    rc = align_dp(c, nullptr, S.n_dp, dcols, S.dcol_off.data(), S.dscore.data(), &cells);
+    if (host_front) {
+        HIPCHK(c, c->pin_dcols.ensure(((size_t)S.code_total + 1) * sizeof(uint32_t)));
+        uint32_t *dcols = c->pin_dcols.as<uint32_t>();
+        S.dcol_off.assign((size_t)S.n_dp + 1, 0); S.dscore.assign((size_t)S.n_dp + 1, 0);
+        if (!no_shadow && S.n_dp) c->shadow = [c]() { fill_anchor_table(c); };       // runs while the DP kernels do
+        rc = align_dp(c, nullptr, S.n_dp, dcols, S.dcol_off.data(), S.dscore.data(), &cells);
+        c->shadow = nullptr;
+        if (rc) return rc;
+        return align_finish(c, dcols, S.dcol_off.data(), S.dscore.data(), cells, sizes);
+    }
+    // the anchors in chain order as flat int32 records (page-locked), then everything up to the DP columns on the device
+    const int N = S.N; const int64_t na = S.n_anchor;
+    HIPCHK(c, c->pin_anch.ensure((size_t)na * (3 + (size_t)N) * 4 + 64));
+    int32_t *h_len = c->pin_anch.as<int32_t>(), *h_st = h_len + na, *h_lcb = h_st + (size_t)na * N, *gapcode = h_lcb + na;
+    {
+        size_t a = 0;
+        for (int64_t l = 0; l < S.nl; l++) {
+            const MatchVec &ch = S.chains[(size_t)l];
+            for (size_t i = 0; i < ch.size(); i++, a++) {
+                const int64_t *r = ch.rec(i);
+                h_len[a] = (int32_t)r[0]; h_lcb[a] = (int32_t)l;
+                for (int g = 0; g < N; g++) h_st[a * N + g] = (int32_t)r[1 + g];
+            }
+        }
+    }
+    if (!no_shadow && na) c->shadow = [c]() { fill_anchor_table(c); };               // runs while the DP kernels do
+    rc = dp_run_from_anchors(c, N, na, h_len, h_st, h_lcb, S.p.gapped, S.p.max_gapped_len, &S.p.scoring, gapcode, &S.n_dp, &S.code_total,
+                             &c->pin_dcols, S.dcol_off, S.dscore, &cells);
     c->shadow = nullptr;
     if (rc) return rc;
-    return align_finish(c, dcols, S.dcol_off.data(), S.dscore.data(), cells, sizes);
+    {   // the gap list of the assembly, from the gap codes
+        size_t a = 0;
+        for (int64_t l = 0; l < S.nl; l++) {
+            const MatchVec &ch = S.chains[(size_t)l];
+            for (size_t i = 0; i < ch.size(); i++, a++) {
+                const int32_t code = gapcode[a];
+                if (code == -1) continue;
+                AlignState::GapRef gr; gr.lcb = l; gr.idx = (int64_t)i; gr.dp = code >= 0; gr.dp_slot = code >= 0 ? code : -1; gr.tot = 0;
+                if (!gr.dp)
+                    for (int g = 0; g < N; g++) { int64_t lo, ln; bool rv; gap_of(ch.rec(i), ch.rec(i + 1), g, lo, ln, rv); gr.tot += ln; }
+                S.gaps.push_back(gr);
+            }
+        }
+    }
+    S.dscore.push_back(0);
+    return align_finish(c, c->pin_dcols.as<uint32_t>(), S.dcol_off.data(), S.dscore.data(), cells, sizes);
 }
 
 // ---- sharded form of mauve_align: see the phase comment above -------------------------------------------------
