@@ -117,6 +117,14 @@ int mauve_sorted_mer_list(mauve_ctx *ctx, int seq, uint64_t pattern, uint64_t *m
 int mauve_seed_mums(mauve_ctx *ctx, uint64_t pattern, int mode, uint64_t mask, int extend,
                     int64_t *n_matches);
 int mauve_get_matches(mauve_ctx *ctx, int64_t *length, int64_t *start);
+/* ---- MemHash::HashMatch for seed hits a host-side finder enumerated itself: the host callback path of a MatchFinder
+        subclass that overrides EnumerateMatches(IdmerList&) and calls HashMatch per hit (UniqueMatchFinder.cpp:36-60;
+        the virtuals UniqueMatchFinder.h:31, SeedMatchEnumerator.h:38-39).  Hit h has the genomes of mask[h]; genome g's
+        window starts at 0-based base pos[h*nseq+g] and strand[h*nseq+g] is the strand flag of its stored mer (bit 0 of
+        SortedMerList::GetMer, SeedMatchEnumerator.h:133).  The hits are extended (extend != 0) and put in canonical
+        order exactly like the hits of mauve_seed_mums; fetch with mauve_get_matches. ----------------------------- */
+int mauve_extend_hits(mauve_ctx *ctx, uint64_t pattern, int64_t n_hits, const uint32_t *mask, const int64_t *pos,
+                      const uint8_t *strand, int extend, int64_t *n_matches);
 
 /* ---- SeedMatchEnumerator::FindMatches (SeedMatchEnumerator.h:19-33): single genome `seq`, every
         mer with min_multi..max_multi occurrences becomes one match (CSR output).  Two-phase: call
@@ -150,6 +158,12 @@ int mauve_dp_batch(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
         alignment of every inter-anchor interval -> interval table.  Results are held by the context
         until the next call; fetch them with mauve_align_fetch.  Any fetch pointer may be NULL. ---- */
 int mauve_align(mauve_ctx *ctx, const mauve_params *p, mauve_align_sizes *sizes);
+/* The same with the match list the caller holds (Aligner::align(MatchList&, ...), mauveAligner.cpp:698: the list may come
+   from a file, mauveAligner.cpp:484-503, or from a finder of the caller's own): no seed pass; the N-way matches of the
+   list (all nseq starts non-zero; the others are ignored) are put in canonical order, overlap-eliminated and chained.
+   length[n], start[n*nseq] signed 1-based. */
+int mauve_align_matches(mauve_ctx *ctx, const mauve_params *p, int64_t n, const int64_t *length, const int64_t *start,
+                        mauve_align_sizes *sizes);
 int mauve_align_fetch(mauve_ctx *ctx,
                       int64_t *mum_length, int64_t *mum_start,            /* [n_mums], [n_mums*nseq] */
                       int64_t *lcb_left, int64_t *lcb_right, int64_t *lcb_weight, /* [n_lcb*nseq] x2, [n_lcb] */
@@ -165,7 +179,13 @@ int mauve_align_fetch(mauve_ctx *ctx,
         intervals in table order.  mauve_align_dp_cost gives per-interval DP cells (for LPT packing) and the
         column capacity each interval needs. ------------------------------------------------------------- */
 int mauve_align_begin(mauve_ctx *ctx, const mauve_params *p, int64_t *n_dp, int64_t *n_codes);
+int mauve_align_begin_matches(mauve_ctx *ctx, const mauve_params *p, int64_t n, const int64_t *length, const int64_t *start,
+                              int64_t *n_dp, int64_t *n_codes);            /* mauve_align_begin on the caller's match list */
 int mauve_align_dp_cost(mauve_ctx *ctx, int64_t *cost, int64_t *max_cols);
+/* the two anchors that flank every DP interval, records of (1 + nseq): length, signed starts -- what a GappedAligner
+   other than the built-in one is called with (GappedAligner::Align(cr, left match, right match, seq_table),
+   MatchRecord.h:311): left[n_dp*(1+nseq)], right[n_dp*(1+nseq)] */
+int mauve_align_dp_anchors(mauve_ctx *ctx, int64_t *left, int64_t *right);
 int mauve_align_dp(mauve_ctx *ctx, const int64_t *idx, int64_t n, uint32_t *cols, int64_t *col_off,
                    int64_t *score, int64_t *cells);
 int mauve_align_finish(mauve_ctx *ctx, const uint32_t *cols, const int64_t *col_off, const int64_t *score,

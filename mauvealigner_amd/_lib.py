@@ -21,9 +21,9 @@ EXPORTS = [
     "mauve_ctx_create", "mauve_ctx_destroy", "mauve_last_error", "mauve_device_name", "mauve_synchronize",
     "mauve_get_seed", "mauve_seed_length", "mauve_seed_weight", "mauve_default_seed_weight", "mauve_default_scoring",
     "mauve_default_params", "mauve_packed_words", "mauve_pack_ascii", "mauve_pack_codes", "mauve_set_genomes",
-    "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_seed_match_enumerate",
+    "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_extend_hits", "mauve_seed_match_enumerate",
     "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_align", "mauve_align_fetch",
-    "mauve_align_begin", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
+    "mauve_align_matches", "mauve_align_begin", "mauve_align_begin_matches", "mauve_align_dp_anchors", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
     "mauve_guide_tree", "mauve_progressive_align",
     "mauve_write_xmfa", "mauve_profile_enable", "mauve_profile_reset", "mauve_profile_get", "mauve_last_stage_times",
 ]
@@ -216,6 +216,38 @@ class Context:
         st = np.zeros((n.value, self.nseq), np.int64)
         self._chk(self.L.mauve_get_matches(self.h, _p(ln, C.c_int64), _p(st, C.c_int64)), "mauve_get_matches")
         return ln, st
+
+    def extend_hits(self, pattern, mask, pos, strand, extend=True):
+        """seed hits enumerated on the host (the MatchFinder callback path) -> extended matches in canonical order"""
+        mask = np.ascontiguousarray(mask, dtype=np.uint32)
+        pos = np.ascontiguousarray(pos, dtype=np.int64)
+        strand = np.ascontiguousarray(strand, dtype=np.uint8)
+        n = C.c_int64()
+        self._chk(self.L.mauve_extend_hits(self.h, C.c_uint64(pattern), C.c_int64(len(mask)), _p(mask, C.c_uint32), _p(pos, C.c_int64),
+                                           _p(strand, C.c_uint8), int(bool(extend)), C.byref(n)), "mauve_extend_hits")
+        ln = np.zeros(n.value, np.int64)
+        st = np.zeros((n.value, self.nseq), np.int64)
+        self._chk(self.L.mauve_get_matches(self.h, _p(ln, C.c_int64), _p(st, C.c_int64)), "mauve_get_matches")
+        return ln, st
+
+    def align_matches(self, params, length, start, fetch=True, names=None, want_xmfa=False):
+        """Aligner::align on the caller's match list (no seed pass)"""
+        p = params or default_params()
+        length = np.ascontiguousarray(length, dtype=np.int64)
+        start = np.ascontiguousarray(start, dtype=np.int64)
+        sz = AlignSizes()
+        self._chk(self.L.mauve_align_matches(self.h, C.byref(p), C.c_int64(len(length)), _p(length, C.c_int64), _p(start, C.c_int64),
+                                             C.byref(sz)), "mauve_align_matches")
+        if not fetch:
+            return {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
+        return self._fetch(sz, names, want_xmfa)
+
+    def align_dp_anchors(self, n_dp):
+        N = self.nseq
+        left = np.zeros((max(n_dp, 1), 1 + N), np.int64)
+        right = np.zeros((max(n_dp, 1), 1 + N), np.int64)
+        self._chk(self.L.mauve_align_dp_anchors(self.h, _p(left, C.c_int64), _p(right, C.c_int64)), "mauve_align_dp_anchors")
+        return left[:n_dp], right[:n_dp]
 
     def sorted_mer_list(self, seq, pattern):
         n = max(0, self.lens[seq] - seed_length(pattern) + 1)

@@ -129,6 +129,35 @@ int mauve_seed_mums(mauve_ctx *c, uint64_t pattern, int mode, uint64_t mask, int
     return seedpass_run(c, main_genome_set(c), pattern, mode, mask, extend, nullptr, 0, n_matches);
 }
 
+int mauve_extend_hits(mauve_ctx *c, uint64_t pattern, int64_t n_hits, const uint32_t *mask, const int64_t *pos, const uint8_t *strand,
+                      int extend, int64_t *n_matches)
+{
+    if (!c) return MAUVE_ERR_ARG;
+    if (n_hits < 0 || n_hits >= (1LL << 31) || (n_hits && (!mask || !pos || !strand))) { c->err = "extend_hits: bad argument"; return MAUVE_ERR_ARG; }
+    if (c->nseq < 1) { c->err = "extend_hits: no genomes set"; return MAUVE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int N = c->nseq;
+    const int span = mauve_seed_length(pattern);
+    if (span < 1) { c->err = "extend_hits: bad seed pattern"; return MAUVE_ERR_ARG; }
+    std::vector<uint32_t> off((size_t)N + 1, 0);                  // first global window index of every genome
+    std::vector<int64_t> nwin((size_t)N, 0);
+    for (int g = 0; g < N; g++) { nwin[(size_t)g] = std::max<int64_t>(0, c->lens[(size_t)g] - span + 1); off[(size_t)g + 1] = off[(size_t)g] + (uint32_t)nwin[(size_t)g]; }
+    std::vector<uint32_t> rec((size_t)n_hits * (N + 1), 0);
+    for (int64_t h = 0; h < n_hits; h++) {
+        const uint32_t m = mask[h];
+        if (__builtin_popcount(m) < 2 || (N < 32 && (m >> N))) { c->err = "extend_hits: a hit needs two or more components among the genomes set"; return MAUVE_ERR_ARG; }
+        rec[(size_t)h * (N + 1)] = m;
+        for (int g = 0; g < N; g++) {
+            if (!(m >> g & 1)) continue;
+            const int64_t p = pos[h * N + g];
+            if (p < 0 || p >= nwin[(size_t)g]) { c->err = "extend_hits: window start outside its genome"; return MAUVE_ERR_ARG; }
+            rec[(size_t)h * (N + 1) + 1 + g] = (off[(size_t)g] + (uint32_t)p) | (strand[h * N + g] ? 0x80000000u : 0u);
+        }
+    }
+    HostHits hh; hh.n = (uint32_t)n_hits; hh.rec = rec.data();
+    return seedpass_from_hits(c, main_genome_set(c), pattern, hh, extend, n_matches);
+}
+
 int mauve_get_matches(mauve_ctx *c, int64_t *length, int64_t *start)
 {
     if (!c) return MAUVE_ERR_ARG;

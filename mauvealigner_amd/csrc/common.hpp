@@ -105,6 +105,9 @@ struct GenomeSet {
     std::vector<uint64_t> mask_off;
 };
 
+// seed hits handed in by a host-side finder: n records of (1 + nseq) words {component set, value of every genome}
+struct HostHits { uint32_t n; const uint32_t *rec; };
+
 struct AlignResult {
     mauve_align_sizes sz{};
     std::vector<int64_t> mum_length, mum_start;
@@ -199,6 +202,7 @@ struct mauve_ctx {
     // last match list (canonical order, host) + nseq it refers to
     std::vector<int64_t> match_len, match_start;
     int64_t n_matches = 0;
+    const HostHits *host_hits = nullptr;  // set for the duration of mauve_extend_hits
     int64_t dev_rec_n = -1;              // >= 0: sorted_rec holds that many records (int64 length[n], start[n*nseq]) in canonical order
 
     // DP workspace
@@ -271,6 +275,7 @@ bool make_seed_shape(uint64_t pattern, SeedShape *out);
 GenomeSet main_genome_set(mauve_ctx *ctx);
 int seedpass_run(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, int mode, uint64_t mask, int extend,
                  const uint32_t *seg_dev, uint32_t nseg, int64_t *n_matches);
+int seedpass_from_hits(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, const HostHits &hits, int extend, int64_t *n_matches);
 int seedpass_sorted_list(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t pattern, std::vector<uint64_t> *keys,
                          std::vector<uint32_t> *vals, int *weight);
 

@@ -131,7 +131,7 @@ static int extend_lcbs(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
 // begin : seed pass, chaining, recursive anchoring, interval descriptors        (every rank, deterministic)
 // dp    : gapped alignment of a subset of the intervals                         (each rank its share)
 // finish: assembly of the interval table from the columns of ALL intervals      (every rank)
-static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = false)
+static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = false, const MatchVec *given = nullptr)
 {
     const int N = c->nseq;
     AlignState &S = c->ast;
@@ -166,9 +166,40 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
             Rr.cols_dirty.clear();
         };
     int64_t nm = 0;
-    int rc = seedpass_run(c, main_genome_set(c), pat, p->mode, full, 1, nullptr, 0, &nm);
-    c->shadow = nullptr;
-    if (rc) return rc;
+    int rc = MAUVE_OK;
+    if (given) {
+        // the caller's list: its N-way matches in canonical order (|start 0|, starts, length) stand where the seed pass's stood
+        c->shadow = nullptr;
+        if (R.cols_fill == full && !R.cols_dirty.empty()) {
+            for (const auto &d : R.cols_dirty) std::fill(R.cols.begin() + d.first, R.cols.begin() + d.first + d.second, full);
+            R.cols_dirty.clear();
+        }
+        std::vector<size_t> keep;
+        for (size_t i = 0; i < given->size(); i++) {
+            bool nway = given->len(i) > 0;
+            for (int g = 0; g < N && nway; g++) nway = given->st(i)[g] != 0;
+            if (nway) keep.push_back(i);
+        }
+        std::sort(keep.begin(), keep.end(), [&](size_t a, size_t b) {
+            const int64_t *x = given->rec(a), *y = given->rec(b);
+            const int64_t sa = std::llabs(x[1]), sb = std::llabs(y[1]);
+            if (sa != sb) return sa < sb;
+            for (int g = 0; g < N; g++) if (x[1 + g] != y[1 + g]) return x[1 + g] < y[1 + g];
+            if (x[0] != y[0]) return x[0] < y[0];
+            return a < b;
+        });
+        nm = (int64_t)keep.size();
+        c->match_len.resize((size_t)nm); c->match_start.resize((size_t)nm * N);
+        for (int64_t i = 0; i < nm; i++) {
+            c->match_len[(size_t)i] = given->len(keep[(size_t)i]);
+            std::copy(given->st(keep[(size_t)i]), given->st(keep[(size_t)i]) + N, &c->match_start[(size_t)i * N]);
+        }
+        c->n_matches = nm; c->dev_rec_n = -1;
+    } else {
+        rc = seedpass_run(c, main_genome_set(c), pat, p->mode, full, 1, nullptr, 0, &nm);
+        c->shadow = nullptr;
+        if (rc) return rc;
+    }
     S.nm = nm;
     R.mum_length = c->match_len; R.mum_start = c->match_start;
     const double t1 = now_ms();
@@ -497,6 +528,74 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     }
     S.dscore.push_back(0);
     return align_finish(c, c->pin_dcols.as<uint32_t>(), S.dcol_off.data(), S.dscore.data(), cells, sizes);
+}
+
+// Aligner::align(MatchList&, ...) with the caller's own match list: chaining, recursion and gapped alignment as in
+// mauve_align, no seed pass of its own
+static int given_matches(mauve_ctx *c, int64_t n, const int64_t *length, const int64_t *start, MatchVec &mv)
+{
+    if (n < 0 || (n && (!length || !start))) { c->err = "align_matches: bad match list"; return MAUVE_ERR_ARG; }
+    mv.N = c->nseq; mv.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        if (length[i] <= 0) { c->err = "align_matches: match of length <= 0"; return MAUVE_ERR_ARG; }
+        mv.len((size_t)i) = length[i];
+        for (int g = 0; g < c->nseq; g++) {
+            const int64_t s = start[i * c->nseq + g];
+            if (s && std::llabs(s) + length[i] - 1 > c->lens[(size_t)g]) { c->err = "align_matches: match outside its genome"; return MAUVE_ERR_ARG; }
+            mv.st((size_t)i)[g] = s;
+        }
+    }
+    return MAUVE_OK;
+}
+
+int mauve_align_matches(mauve_ctx *c, const mauve_params *p, int64_t n, const int64_t *length, const int64_t *start, mauve_align_sizes *sizes)
+{
+    if (!c || !p || !sizes) return MAUVE_ERR_ARG;
+    if (c->nseq < 2) { c->err = "align: at least two genomes required"; return MAUVE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    MatchVec mv;
+    int rc = given_matches(c, n, length, start, mv);
+    if (rc) return rc;
+    rc = align_begin(c, p, false, &mv);
+    if (rc) return rc;
+    AlignState &S = c->ast;
+    HIPCHK(c, c->pin_dcols.ensure(((size_t)S.code_total + 1) * sizeof(uint32_t)));
+    uint32_t *dcols = c->pin_dcols.as<uint32_t>();
+    S.dcol_off.assign((size_t)S.n_dp + 1, 0); S.dscore.assign((size_t)S.n_dp + 1, 0);
+    int64_t cells = 0;
+    rc = align_dp(c, nullptr, S.n_dp, dcols, S.dcol_off.data(), S.dscore.data(), &cells);
+    if (rc) return rc;
+    return align_finish(c, dcols, S.dcol_off.data(), S.dscore.data(), cells, sizes);
+}
+
+int mauve_align_begin_matches(mauve_ctx *c, const mauve_params *p, int64_t n, const int64_t *length, const int64_t *start, int64_t *n_dp,
+                              int64_t *n_codes)
+{
+    if (!c || !p || !n_dp) return MAUVE_ERR_ARG;
+    if (c->nseq < 2) { c->err = "align: at least two genomes required"; return MAUVE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    MatchVec mv;
+    int rc = given_matches(c, n, length, start, mv);
+    if (rc) return rc;
+    rc = align_begin(c, p, false, &mv);
+    if (rc) return rc;
+    *n_dp = c->ast.n_dp;
+    if (n_codes) *n_codes = c->ast.code_total;
+    return MAUVE_OK;
+}
+
+int mauve_align_dp_anchors(mauve_ctx *c, int64_t *left, int64_t *right)
+{
+    if (!c || !c->ast.open) { if (c) c->err = "align_dp_anchors: no alignment in progress"; return c ? MAUVE_ERR_STATE : MAUVE_ERR_ARG; }
+    const AlignState &S = c->ast;
+    const int N = S.N;
+    for (const AlignState::GapRef &gr : S.gaps) {
+        if (!gr.dp) continue;
+        const MatchVec &ch = S.chains[(size_t)gr.lcb];
+        if (left) std::copy(ch.rec((size_t)gr.idx), ch.rec((size_t)gr.idx) + 1 + N, left + gr.dp_slot * (1 + N));
+        if (right) std::copy(ch.rec((size_t)gr.idx + 1), ch.rec((size_t)gr.idx + 1) + 1 + N, right + gr.dp_slot * (1 + N));
+    }
+    return MAUVE_OK;
 }
 
 // ---- sharded form of mauve_align: see the phase comment above -------------------------------------------------

@@ -673,6 +673,20 @@ __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, 
     }
 }
 
+// hits found by a host-side finder (mauve_extend_hits): record h = {component set, value of genome 0 .. N-1} -> hit table
+__global__ void __launch_bounds__(256) hits_scatter(const uint32_t *__restrict__ rec, uint32_t nh, int N, uint32_t P,
+                                                    uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos)
+{
+    const uint32_t h = blockIdx.x * 256u + threadIdx.x;
+    if (h >= nh) return;
+    const uint32_t *r = rec + (size_t)h * (N + 1);
+    const uint32_t m = r[0];
+    const uint32_t ap = r[1 + (__ffs(m) - 1)] & 0x7fffffffu;
+    if (ap >= P) return;                                      // validated on the host; never a wild store
+    tmask[ap] = m;
+    for (int g = 0; g < N; g++) if (m >> g & 1) tpos[(size_t)ap * N + g] = r[1 + g];
+}
+
 // ------------------------------------------------------------------------------------------------
 // PairwiseMatchFinder: N(N-1)/2 finder passes over ONE sorted mer list.  Instead of re-reading all P sorted entries
 // per pair, one pass (run_summary) lists the runs of identical mers that could matter to any pair -- where the run
@@ -1115,7 +1129,8 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     // serial join for PairwiseMatchFinder (its run list needs sorted order), for the sorted-mer-list export and for
     // slices join_hash hands back.  MAUVE_OLD_JOIN forces the second (A/B switch).
     static const bool force_old_join = getenv("MAUVE_OLD_JOIN") != nullptr;
-    const bool hash_path = mode != MAUVE_MODE_PAIRWISE && !out_keys && only_seq < 0 && !force_old_join && !(vmask && SEG);
+    const HostHits *hh = ctx->host_hits;                      // mauve_extend_hits: the hits come from the host, no sort, no join
+    const bool hash_path = !hh && mode != MAUVE_MODE_PAIRWISE && !out_keys && only_seq < 0 && !force_old_join && !(vmask && SEG);
     // segmented keys: segment id above the mer; ids 0 .. nseg-1, the all-ones id is left to the invalid (all-ones) key
     int segbits = 0;
     if (SEG) while (segbits < 32 && (1ull << segbits) <= (uint64_t)nseg) segbits++;
@@ -1130,7 +1145,8 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         if (SEG) G = std::max(G, (segbits + 7) / 8 * 8);
         return full_bits - std::min(G, full_bits);
     };
-    if (only_seq < 0 && vmask && !SEG) {
+    if (hh) sorted_n = 1;
+    else if (only_seq < 0 && vmask && !SEG) {
         // masked pass: only the valid windows go into the sort (see valid_count / seed_extract_compact)
         const uint32_t nblk = (n + 4095) / 4096;
         HIPCHK(ctx, ctx->hist.ensure((size_t)nblk * 256 * sizeof(uint32_t)));     // the tile counts live in the histogram buffer
@@ -1182,7 +1198,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     const int has_invalid = vmask != nullptr && !compacted;
     const uint32_t ns = sorted_n;                   // entries of the sorted list (all windows, or the valid ones)
     const int L = low_bits(ns);                     // the passes order bits [L, key_bits); 0 = full sort
-    int rc = sort_pairs<KeyT>(ctx, sorted_n, key_bits, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>(), have_hist0, -1, L);
+    int rc = hh ? MAUVE_OK : sort_pairs<KeyT>(ctx, sorted_n, key_bits, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>(), have_hist0, -1, L);
     if (rc) return rc;
     TRACE(ctx, "sort");
 
@@ -1236,7 +1252,12 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     for (const FinderPass &fp : passes) {
         HIPCHK(ctx, hipMemsetAsync(ctx->posmask.p, 0, (size_t)P * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
-        if (use_summary) {
+        if (hh) {
+            HIPCHK(ctx, ctx->run_sum.ensure((size_t)hh->n * (N + 1) * 4 + 64));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->run_sum.p, hh->rec, (size_t)hh->n * (N + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+            if (hh->n) hipLaunchKernelGGL(hits_scatter, dim3((hh->n + 255) / 256), dim3(256), 0, ctx->stream, ctx->run_sum.as<uint32_t>(), hh->n, N, P, tmask, tpos);
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // the host records must outlive the copy
+        } else if (use_summary) {
             KernelTimer t(ctx, MAUVE_K_JOIN, nruns);
             if (nruns)
                 hipLaunchKernelGGL(join_pair, dim3((nruns + 255) / 256), dim3(256), 0, ctx->stream, vals, tab, rstart, rlen, runiq, nruns,
@@ -1494,6 +1515,25 @@ int seedpass_run(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, int mode
     if (seg_dev) return seedpass_impl<uint64_t, true>(ctx, gs, sh, tab, total, mode, mask, extend, -1, seg_dev, nseg, n_matches, nullptr, nullptr);
     if (2 * sh.weight <= 32) return seedpass_impl<uint32_t, false>(ctx, gs, sh, tab, total, mode, mask, extend, -1, nullptr, 0, n_matches, nullptr, nullptr);
     return seedpass_impl<uint64_t, false>(ctx, gs, sh, tab, total, mode, mask, extend, -1, nullptr, 0, n_matches, nullptr, nullptr);
+}
+
+// extension + canonical order of hits a host-side finder supplies (records of 1 + nseq words: component set, values)
+int seedpass_from_hits(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, const HostHits &hits, int extend, int64_t *n_matches)
+{
+    SeedShape sh;
+    if (!make_seed_shape(pattern, &sh)) { ctx->err = "seed pattern must be palindromic, span <= 49, weight <= 31"; return MAUVE_ERR_ARG; }
+    if (gs.nseq < 1) { ctx->err = "no genomes set"; return MAUVE_ERR_STATE; }
+    GenomeTab tab; int64_t total = 0;
+    int rc = build_tab(ctx, gs, sh.span, &tab, &total);
+    if (rc) return rc;
+    ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear();
+    ctx->dev_rec_n = -1;
+    if (n_matches) *n_matches = 0;
+    if (total == 0 || hits.n == 0) return MAUVE_OK;
+    ctx->host_hits = &hits;
+    rc = seedpass_impl<uint32_t, false>(ctx, gs, sh, tab, total, MAUVE_MODE_MEM, 0, extend, -1, nullptr, 0, n_matches, nullptr, nullptr);
+    ctx->host_hits = nullptr;
+    return rc;
 }
 
 int seedpass_sorted_list(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t pattern, std::vector<uint64_t> *keys,

@@ -252,6 +252,47 @@ def test_align_recursion_hyperdivergent(ctx):
     assert r1["n_anchor"] > r0["n_anchor"]
 
 
+def test_align_matches_given_list(ctx):
+    """Aligner::align(MatchList&, ...) (mauveAligner.cpp:698): the caller's match list is chained, not re-found.
+    The finder's own N-way list reproduces mauve_align; order, subset matches and duplicates-free shuffles do not
+    matter; a list with some matches removed gives an alignment anchored on the rest only."""
+    from mauvealigner_amd import _lib
+    gs = synth.make_config("C3", scale=0.03)
+    ctx.set_genomes(gs)
+    N = len(gs)
+    p = _lib.default_params()
+    whole = ctx.align(p)
+    w = _lib.default_seed_weight(sum(len(g) for g in gs) // N)
+    pat = _lib.get_seed(w, 0)
+    ln, st = ctx.seed_mums(pat, mask=(1 << N) - 1)
+    assert np.array_equal(ln, whole["mum_length"])
+    keys = ("cols", "col_off", "left", "right", "reverse", "dp_score", "anchor_start", "anchor_length", "lcb_weight", "mum_start")
+    same = ctx.align_matches(p, ln, st)
+    for k in keys:
+        assert np.array_equal(whole[k], same[k]), k
+    # shuffled, with subset matches of the UNIQUE finder mixed in (ignored: not N-way)
+    sl, ss = ctx.seed_mums(pat, mode=1)
+    sub = np.count_nonzero(ss, axis=1) < N
+    rng = np.random.default_rng(1)
+    al, as_ = np.concatenate([ln, sl[sub]]), np.concatenate([st, ss[sub]])
+    perm = rng.permutation(len(al))
+    mixed = ctx.align_matches(p, al[perm], as_[perm])
+    for k in keys:
+        assert np.array_equal(whole[k], mixed[k]), k
+    # a thinned list: every anchor of the result comes from a kept match
+    keep = rng.random(len(ln)) < 0.5
+    thin = ctx.align_matches(_lib.default_params(recursive=0), ln[keep], st[keep])
+    kept = {tuple(r) for r in np.abs(st[keep]).tolist()}
+    a0 = thin["anchor_start"][:, 0]
+    assert thin["n_mums"] == int(keep.sum()) and len(a0) > 0
+    lo, hi = np.abs(st[keep][:, 0]), np.abs(st[keep][:, 0]) + ln[keep] - 1
+    order = np.argsort(lo)
+    idx = np.searchsorted(lo[order], a0, side="right") - 1
+    assert np.all(idx >= 0) and np.all(a0 <= hi[order][idx])
+    with pytest.raises(RuntimeError, match=r"\(-1\)"):
+        ctx.align_matches(p, np.array([50], np.int64), np.array([[10 ** 9] * N], np.int64))
+
+
 def test_full_size_c2_properties(ctx):
     """BASELINE config C2 (3 x 5 Mbp, weight 15) through the whole path: size-independent properties --
     every base of every genome appears in exactly one interval, rows reproduce the genomes, determinism."""

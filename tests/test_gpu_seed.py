@@ -160,6 +160,58 @@ def test_seed_match_enumerator(ctx):
         assert np.array_equal(m, em) and np.array_equal(o, eo) and np.array_equal(s, es)
 
 
+def _host_unique_hits(ctx, gs, pat):
+    """The host callback path in miniature: merge the per-genome sorted mer lists, and for every mer apply the rule
+    of UniqueMatchFinder::EnumerateMatches (UniqueMatchFinder.cpp:36-60: ids seen exactly once; >= 2 of them)."""
+    keys, gen, pos, strand = [], [], [], []
+    for g in range(len(gs)):
+        mer, p = ctx.sorted_mer_list(g, pat)
+        keys.append(mer >> np.uint64(1)); gen.append(np.full(len(mer), g)); pos.append(p); strand.append((mer & np.uint64(1)).astype(np.uint8))
+    keys, gen, pos, strand = map(np.concatenate, (keys, gen, pos, strand))
+    order = np.lexsort((gen, keys))
+    keys, gen, pos, strand = keys[order], gen[order], pos[order], strand[order]
+    cut = np.flatnonzero(np.concatenate([[True], keys[1:] != keys[:-1], [True]]))
+    N = len(gs)
+    masks, hp, hs = [], [], []
+    for a, b in zip(cut[:-1], cut[1:]):
+        if b - a < 2:
+            continue
+        ids, cnt = np.unique(gen[a:b], return_counts=True)
+        uniq = ids[cnt == 1]
+        if len(uniq) < 2:
+            continue
+        m = 0
+        prow, srow = np.zeros(N, np.int64), np.zeros(N, np.uint8)
+        for i in range(a, b):
+            if gen[i] in uniq:
+                m |= 1 << int(gen[i]); prow[gen[i]] = pos[i]; srow[gen[i]] = strand[i]
+        masks.append(m); hp.append(prow); hs.append(srow)
+    return np.array(masks, np.uint32), np.array(hp, np.int64).reshape(-1, N), np.array(hs, np.uint8).reshape(-1, N)
+
+
+def test_extend_hits_host_callback_path(ctx):
+    """mauve_extend_hits: hits enumerated on the host by the UniqueMatchFinder rule, extended on the device, equal
+    the in-kernel UNIQUE finder and the oracle; the strand flags and window starts are validated."""
+    rng = np.random.default_rng(5)
+    anc = rng.integers(0, 4, 6000, dtype=np.uint8)
+    gs = [synth.mutate(anc, 0.03, rng) for _ in range(4)]
+    gs[2] = synth.revcomp(gs[2])
+    gs[3] = np.concatenate([gs[3], gs[3][1000:1400]])          # a repeat: genome 3 drops out of those seeds
+    pat = O.get_seed(9, 0)
+    ctx.set_genomes(gs)
+    m, p, s = _host_unique_hits(ctx, gs, pat)
+    assert len(m) > 100
+    for extend in (True, False):
+        ln, st = ctx.extend_hits(pat, m, p, s, extend=extend)
+        eln, est = O.find_matches(gs, pat, mode=1, extend=extend)
+        assert np.array_equal(ln, eln) and np.array_equal(st, est)
+    bad = p.copy(); bad[0, int(np.flatnonzero([m[0] >> g & 1 for g in range(4)])[0])] = 10 ** 7
+    with pytest.raises(RuntimeError, match=r"\(-1\).*outside"):
+        ctx.extend_hits(pat, m, bad, s)
+    with pytest.raises(RuntimeError, match=r"\(-1\)"):
+        ctx.extend_hits(pat, np.array([1], np.uint32), p[:1], s[:1])          # one component is not a match
+
+
 def test_full_size_properties(ctx):
     """BASELINE config C2 at full size (3 x 5 Mbp, weight 15): too big for the oracle in a unit test, so check
     size-independent properties: determinism, canonical order, reverse-complement symmetry of the input."""
