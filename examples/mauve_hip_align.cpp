@@ -12,6 +12,7 @@
 
 #include "libGenome/gnSequence.h"
 #include "libMems/Aligner.h"
+#include "libMems/HipFinders.h"
 #include "libMems/MaskedMemHash.h"
 #include "libMems/MatchList.h"
 #include "libMems/ProgressiveAligner.h"
@@ -51,7 +52,7 @@ int main(int argc, char **argv)
         const uint N = (uint)match_list.seq_table.size();
 
         std::unique_ptr<MatchFinder> finder;
-        if (unique) finder.reset(new UniqueMatchFinder());               // progressiveMauve.cpp:490-495
+        if (unique) finder.reset(new HipUniqueMatchFinder());            // progressiveMauve.cpp:490-495 (UniqueMatchFinder's rule in the join kernel)
         else { finder.reset(new MaskedMemHash()); finder->SetMask((1ull << N) - 1); }   // mauveAligner.cpp:523-531
         finder->LogProgress(&std::cerr);
         finder->FindMatches(match_list);                                 // :585

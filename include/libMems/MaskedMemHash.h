@@ -1,2 +1,14 @@
-// libMems/MaskedMemHash.h -- forwarding header: the hot-path surface lives in mems_hip.h (see its header note).
-#include "mems_hip.h"
+// libMems/MaskedMemHash.h -- MemHash restricted to one component set (mauveAligner.cpp:523-531:
+// `MaskedMemHash match_finder; match_finder.SetMask((1 << seq_count) - 1)`): the mask goes into the join kernel.
+#ifndef MAUVE_HIP_MASKEDMEMHASH_H
+#define MAUVE_HIP_MASKEDMEMHASH_H
+#include "MemHash.h"
+namespace mems {
+class MaskedMemHash : public MemHash {
+public:
+    virtual MaskedMemHash *Clone() const { return new MaskedMemHash(*this); }
+protected:
+    virtual int kernelRule() const { return typeid(*this) == typeid(MaskedMemHash) ? MAUVE_MODE_MEM : -1; }
+};
+}  // namespace mems
+#endif

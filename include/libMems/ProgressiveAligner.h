@@ -1,2 +1,62 @@
-// libMems/ProgressiveAligner.h -- forwarding header: the hot-path surface lives in mems_hip.h (see its header note).
-#include "mems_hip.h"
+// libMems/ProgressiveAligner.h -- the progressiveMauve alignment stage: setters and align() as called at
+// progressiveMauve.cpp:575-710.
+#ifndef MAUVE_HIP_PROGRESSIVEALIGNER_H
+#define MAUVE_HIP_PROGRESSIVEALIGNER_H
+
+#include "Aligner.h"
+
+namespace mems {
+
+// ---- ProgressiveAligner: setters and align() as called at progressiveMauve.cpp:575-710 -------------------
+// The guide tree and the progressive anchoring run on the device (mauve_progressive_align).  The
+// setters that tune libMems' sum-of-pairs LCB scoring have no counterpart in the frozen replacement; they are
+// accepted so that the call site compiles, and documented as inert.
+class ProgressiveAligner {
+public:
+    explicit ProgressiveAligner(uint seq_count) : seq_count_(seq_count), tree_left_(2 * seq_count - 1, -1), tree_right_(2 * seq_count - 1, -1)
+    {
+        mauve_default_params(&p_);
+    }
+    void setBreakpointPenalty(double w) { if (w >= 0) p_.lcb_weight = (int64_t)w * (int64_t)seq_count_; }   // --weight, :584-593
+    void setMinimumBreakpointPenalty(double) {}
+    void setCollinear(boolean c) { p_.collinear = c; }                        // :594-597
+    void setGappedAlignment(boolean g) { p_.gapped = g; }                     // --skip-gapped-alignment
+    void setRefinement(boolean) {}                                            // :578-579 (no refinement stage)
+    void setRecursion(boolean r) { p_.recursive = r; }                        // :661-664
+    void SetMaxGappedAlignmentLength(gnSeqI n) { p_.max_gapped_len = (int64_t)n; }
+    void setPairwiseScoringScheme(const PairwiseScoringScheme &pss)           // :666-687
+    {
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) p_.scoring.matrix[i][j] = pss.matrix[i][j];
+        p_.scoring.gap_open = pss.gap_open; p_.scoring.gap_extend = pss.gap_extend;
+    }
+    void setLcbScoringScheme(int) {}                                          // :611-625 (ExtantSumOfPairs...: inert)
+    void setUseLcbWeightScaling(boolean) {}                                   // :626-642
+    void setBpDistEstimateMinScore(double) {}
+    void setUseSeedFamilies(boolean) {}
+    void SetUseCacheDb(boolean) {}                                            // :643-646
+    // progressiveMauve.cpp:652-655 hands the pairwise matches over; the device path finds them itself
+    // (PairwiseMatchFinder rule on the resident genomes), so only the seed pattern is taken from the list.
+    void setPairwiseMatches(MatchList &pairwise) { if (pairwise.seed_pattern) p_.seed_pattern = (uint64_t)pairwise.seed_pattern; }
+    void setSeedWeight(uint w) { p_.seed_weight = (int32_t)w; }
+    // aligner.align(interval_list.seq_table, interval_list)  (:710)
+    void align(std::vector<genome::gnSequence *> &seq_table, IntervalList &il)
+    {
+        if (seq_table.size() != seq_count_) throw genome::gnException("ProgressiveAligner::align: sequence count mismatch");
+        HipContext &hc = HipContext::global();
+        MatchList tmp; tmp.seq_table = seq_table;
+        tmp.upload(hc);
+        hc.check(mauve_progressive_align(hc.get(), &p_, &il.sizes, tree_left_.data(), tree_right_.data(), nullptr), "mauve_progressive_align");
+        il.seq_table = seq_table;
+        il.fetch(hc, seq_count_);
+    }
+    // guide tree of the last align(): child ids per node (leaves -1), nodes seq_count.. in merge order
+    const std::vector<int32_t> &treeLeft() const { return tree_left_; }
+    const std::vector<int32_t> &treeRight() const { return tree_right_; }
+private:
+    uint seq_count_;
+    mauve_params p_;
+    std::vector<int32_t> tree_left_, tree_right_;
+};
+
+}  // namespace mems
+#endif

@@ -101,6 +101,18 @@ void mauve_pack_codes(const uint8_t *codes, int64_t len, uint64_t *words);
         Uploads the packed genomes; they stay resident in HBM until the next call / destroy. ------- */
 int mauve_set_genomes(mauve_ctx *ctx, int nseq, const uint64_t *const *packed, const int64_t *lens);
 
+/* The same for sequences that are concatenations of contigs and / or hold ambiguous bases (a multi-record FastA
+   loaded as one gnSequence, mauveAligner.cpp:453-465; the contig-start table RepeatHashCat keeps for concatenated
+   input, RepeatHashCat.h:19-20 `concat_contig_start`).  n_contigs[g] 0-based ascending starts per genome (the first
+   is 0), concatenated in contig_starts; invalid[g]: bitmap of the bases that are not A, C, G, T (bit i of word i/64;
+   mauve_ambiguity_bitmap builds it; the array or any entry may be NULL).  No seed window touches an ambiguous base
+   or runs across a contig join: matches never cover an ambiguous base, and a match continues over a join only where
+   windows on its two sides abut on one diagonal in every genome.  The packed genomes carry A at ambiguous bases
+   (the gapped alignment sees A); mauve_write_xmfa prints N there. */
+int mauve_set_genomes_contigs(mauve_ctx *ctx, int nseq, const uint64_t *const *packed, const int64_t *lens,
+                              const int64_t *n_contigs, const int64_t *contig_starts, const uint64_t *const *invalid);
+void mauve_ambiguity_bitmap(const char *ascii, int64_t len, uint64_t *bits);      /* bits: len/64 + 1 words */
+
 /* ---- sorted mer list: MatchList::CreateMemorySMLs / DNAFileSML for one genome
         (mauveAligner.cpp:456,465; SortedMerList::GetMer semantics SeedMatchEnumerator.h:133).
         mer_out: mer left-aligned in 64 bits | strand flag in bit 0; pos_out: 0-based positions;

@@ -20,7 +20,8 @@ KERNEL_NAMES = ["seed_extract", "rs_hist", "rs_rowscan", "rs_scatter", "mum_join
 EXPORTS = [
     "mauve_ctx_create", "mauve_ctx_destroy", "mauve_last_error", "mauve_device_name", "mauve_synchronize",
     "mauve_get_seed", "mauve_seed_length", "mauve_seed_weight", "mauve_default_seed_weight", "mauve_default_scoring",
-    "mauve_default_params", "mauve_packed_words", "mauve_pack_ascii", "mauve_pack_codes", "mauve_set_genomes",
+    "mauve_default_params", "mauve_packed_words", "mauve_pack_ascii", "mauve_pack_codes", "mauve_set_genomes", "mauve_set_genomes_contigs",
+    "mauve_ambiguity_bitmap",
     "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_extend_hits", "mauve_seed_match_enumerate",
     "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_align", "mauve_align_fetch",
     "mauve_align_matches", "mauve_align_begin", "mauve_align_begin_matches", "mauve_align_dp_anchors", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
@@ -196,13 +197,30 @@ class Context:
     def synchronize(self):
         self._chk(self.L.mauve_synchronize(self.h), "mauve_synchronize")
 
-    def set_genomes(self, codes_list):
-        """codes_list: list of uint8 arrays of 0..3 codes (packed here with mauve_pack_codes)."""
+    def set_genomes(self, codes_list, contig_starts=None, invalid=None):
+        """codes_list: list of uint8 arrays of 0..3 codes (packed here with mauve_pack_codes).  contig_starts: per genome
+        the 0-based starts of its contigs (first 0); invalid: per genome a boolean array, True = ambiguous base."""
         packed = [pack_codes(c) for c in codes_list]
         n = len(packed)
         arr = (C.POINTER(C.c_uint64) * n)(*[_p(w, C.c_uint64) for w in packed])
         lens = (C.c_int64 * n)(*[len(c) for c in codes_list])
-        self._chk(self.L.mauve_set_genomes(self.h, n, arr, lens), "mauve_set_genomes")
+        if contig_starts is None and invalid is None:
+            self._chk(self.L.mauve_set_genomes(self.h, n, arr, lens), "mauve_set_genomes")
+        else:
+            cs = contig_starts or [[0]] * n
+            ncont = (C.c_int64 * n)(*[len(x) for x in cs])
+            flat = np.array([int(v) for x in cs for v in x] + [0], dtype=np.int64)
+            bits = []
+            for g in range(n):
+                L = len(codes_list[g])
+                w = np.zeros(L // 64 + 1, np.uint64)
+                if invalid is not None and invalid[g] is not None:
+                    b = np.zeros((L // 64 + 1) * 64, np.uint8)
+                    b[:L] = np.asarray(invalid[g], dtype=np.uint8)
+                    w = np.packbits(b, bitorder="little").view(np.uint64).copy()
+                bits.append(w)
+            inv = (C.POINTER(C.c_uint64) * n)(*[_p(w, C.c_uint64) for w in bits])
+            self._chk(self.L.mauve_set_genomes_contigs(self.h, n, arr, lens, ncont, _p(flat, C.c_int64), inv), "mauve_set_genomes_contigs")
         self.nseq = n
         self.lens = [len(c) for c in codes_list]
 

@@ -9,6 +9,9 @@ GenomeSet main_genome_set(mauve_ctx *c)
 {
     GenomeSet gs;
     gs.buf = &c->genomes; gs.nseq = c->nseq; gs.lens = c->lens; gs.word_off = c->word_off;
+    if (c->has_invalid) gs.vmask = &c->base_invalid;
+    if (c->has_contigs) gs.cmask = &c->contig_mask;
+    if (c->has_invalid || c->has_contigs) gs.mask_off = c->base_mask_off;
     return gs;
 }
 
@@ -56,7 +59,7 @@ void mauve_ctx_destroy(mauve_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     delete c->pool; c->pool = nullptr;
     DevBuf *bufs[] = {&c->genomes, &c->keysA, &c->keysB, &c->valsA, &c->valsB, &c->hist, &c->totals, &c->posmask,
-                      &c->hit_mask, &c->hit_pos, &c->hit_seg, &c->run_sum, &c->join_ovf, &c->join_bound, &c->dpf_anch, &c->dpf_work, &c->dpf_tot, &c->ch_len, &c->ch_st, &c->ch_crop, &c->ch_ent, &c->ch_ord, &c->ch_rank, &c->ch_node, &c->ch_graph, &c->ch_cnt, &c->sorted_rec, &c->canon_k1, &c->canon_k2, &c->canon_v1, &c->canon_v2, &c->rec_genomes, &c->rec_seg, &c->placed_mask, &c->cand, &c->mlen, &c->mstart, &c->counters, &c->dp_desc, &c->dp_list, &c->dp_codes, &c->dp_off,
+                      &c->hit_mask, &c->hit_pos, &c->hit_seg, &c->base_invalid, &c->contig_mask, &c->node_cmask, &c->run_sum, &c->join_ovf, &c->join_bound, &c->dpf_anch, &c->dpf_work, &c->dpf_tot, &c->ch_len, &c->ch_st, &c->ch_crop, &c->ch_ent, &c->ch_ord, &c->ch_rank, &c->ch_node, &c->ch_graph, &c->ch_cnt, &c->sorted_rec, &c->canon_k1, &c->canon_k2, &c->canon_v1, &c->canon_v2, &c->rec_genomes, &c->rec_seg, &c->rec_vinv, &c->rec_vcm, &c->placed_mask, &c->cand, &c->mlen, &c->mstart, &c->counters, &c->dp_desc, &c->dp_list, &c->dp_codes, &c->dp_off,
                       &c->dp_prof_cnt, &c->dp_prof_mask, &c->dp_prof2_cnt, &c->dp_prof2_mask, &c->dp_tb, &c->dp_meta,
                       &c->dp_score, &c->dp_cols, &c->dp_rows};
     for (DevBuf *b : bufs) b->release();
@@ -117,7 +120,67 @@ int mauve_set_genomes(mauve_ctx *c, int nseq, const uint64_t *const *packed, con
     c->nseq = nseq;
     c->lens.assign(lens, lens + nseq);
     c->word_off = off;
+    c->has_invalid = false; c->has_contigs = false; c->h_invalid.clear(); c->h_contig.clear(); c->base_mask_off.clear();
     c->n_matches = 0; c->match_len.clear(); c->match_start.clear();
+    return MAUVE_OK;
+}
+
+void mauve_ambiguity_bitmap(const char *ascii, int64_t len, uint64_t *bits)
+{
+    const size_t words = (size_t)(len / 64 + 1);
+    for (size_t w = 0; w < words; w++) bits[w] = 0;
+    for (int64_t i = 0; i < len; i++) {
+        switch (ascii[i]) {
+        case 'A': case 'C': case 'G': case 'T': case 'a': case 'c': case 'g': case 't': break;
+        default: bits[i >> 6] |= 1ULL << (i & 63);
+        }
+    }
+}
+
+int mauve_set_genomes_contigs(mauve_ctx *c, int nseq, const uint64_t *const *packed, const int64_t *lens, const int64_t *n_contigs,
+                              const int64_t *contig_starts, const uint64_t *const *invalid)
+{
+    int rc = mauve_set_genomes(c, nseq, packed, lens);
+    if (rc) return rc;
+    // word layout of both bitmaps: genome after genome, (len + 63) / 64 + 2 words each (two words of slack: a window read
+    // never leaves its genome's words)
+    std::vector<uint64_t> off((size_t)nseq, 0);
+    size_t words = 0;
+    for (int g = 0; g < nseq; g++) { off[(size_t)g] = words; words += (size_t)((lens[g] + 63) / 64) + 2; }
+    std::vector<uint64_t> inv(words, 0), cm(words, 0);
+    bool any_inv = false, any_contig = false;
+    size_t cs = 0;
+    for (int g = 0; g < nseq; g++) {
+        uint64_t *I = inv.data() + off[(size_t)g], *M = cm.data() + off[(size_t)g];
+        if (invalid && invalid[g]) {
+            const size_t w = (size_t)((lens[g] + 63) / 64);
+            for (size_t k = 0; k < w; k++) { I[k] = invalid[g][k]; }
+            if (lens[g] & 63) I[w - 1] &= (1ULL << (lens[g] & 63)) - 1ULL;
+            for (size_t k = 0; k < w; k++) any_inv |= I[k] != 0;
+        }
+        const int64_t nc = n_contigs ? n_contigs[g] : 0;
+        int64_t prev = -1;
+        for (int64_t k = 0; k < nc; k++) {
+            const int64_t b = contig_starts[cs + (size_t)k];
+            if (b < 0 || b > lens[g] || (k == 0 && b != 0) || (k && b <= prev)) { c->err = "set_genomes_contigs: contig starts must ascend inside the sequence"; return MAUVE_ERR_ARG; }
+            prev = b;
+            if (b > 0 && b < lens[g]) { M[b >> 6] |= 1ULL << (b & 63); any_contig = true; }
+        }
+        cs += (size_t)nc;
+    }
+    if (!any_inv && !any_contig) return MAUVE_OK;
+    if (any_inv) {
+        HIPCHK(c, c->base_invalid.ensure(words * 8));
+        HIPCHK(c, hipMemcpy(c->base_invalid.p, inv.data(), words * 8, hipMemcpyHostToDevice));
+    }
+    if (any_contig) {
+        HIPCHK(c, c->contig_mask.ensure(words * 8));
+        HIPCHK(c, hipMemcpy(c->contig_mask.p, cm.data(), words * 8, hipMemcpyHostToDevice));
+    }
+    c->has_invalid = any_inv; c->has_contigs = any_contig;
+    c->base_mask_off = off;
+    if (any_inv) c->h_invalid.swap(inv);
+    if (any_contig) c->h_contig.swap(cm);
     return MAUVE_OK;
 }
 

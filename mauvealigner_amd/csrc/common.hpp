@@ -102,6 +102,9 @@ struct GenomeSet {
     // guide-tree recursive anchoring: 1 bit per base, set = already placed by an ancestor node;
     // windows touching a set bit are invalid for seeding and extension.  nullptr = no mask.
     DevBuf *vmask = nullptr;
+    // contig starts (mauve_set_genomes_contigs): 1 bit per base, set = a contig begins here; a window may not run
+    // across such a base.  Same word layout as vmask (mask_off).  nullptr = single-contig sequences.
+    DevBuf *cmask = nullptr;
     std::vector<uint64_t> mask_off;
 };
 
@@ -187,6 +190,12 @@ struct mauve_ctx {
     std::vector<uint64_t> word_off;      // per genome, in 64-bit words
     std::vector<std::vector<uint64_t>> host_packed;   // host copy (XMFA text, interval extraction)
     DevBuf genomes;
+    // ambiguous bases and contig starts of the resident genomes (mauve_set_genomes_contigs): device bitmaps in the
+    // layout of GenomeSet::vmask / cmask, their host copies (masks of the guide-tree nodes and of the LCB extension
+    // are built on top of the first; the XMFA writer prints N where it is set)
+    DevBuf base_invalid, contig_mask, node_cmask;
+    bool has_invalid = false, has_contigs = false;
+    std::vector<uint64_t> h_invalid, h_contig, base_mask_off;
 
     // seed-pass workspace
     DevBuf keysA, keysB, valsA, valsB, hist, totals, posmask, hit_mask, hit_pos, hit_seg, cand, mlen, mstart, counters;
@@ -197,6 +206,7 @@ struct mauve_ctx {
     DevBuf ch_len, ch_st, ch_crop, ch_ent, ch_ord, ch_rank, ch_node, ch_graph, ch_cnt;   // device chain (chain_dev.hip)
     PinnedBuf pin_chain;
     DevBuf run_sum;                      // pairwise finder: run list (start, length, exactly-once genome set)
+    DevBuf rec_vinv, rec_vcm;            // ... and their ambiguity / contig bitmaps, when the resident genomes have them
     DevBuf rec_genomes, rec_seg;         // recursive anchoring: gap sub-sequences + segment table
     DevBuf placed_mask;                  // guide-tree recursive anchoring: placed-base bitmap
     // last match list (canonical order, host) + nseq it refers to

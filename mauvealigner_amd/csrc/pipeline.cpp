@@ -88,6 +88,7 @@ static int extend_lcbs(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
             if (!any) starved = true;
         }
         if (starved) break;
+        if (c->has_invalid) for (size_t k = 0; k < words && k < c->h_invalid.size(); k++) bits[k] |= c->h_invalid[k];     // same word layout
         HIPCHK(c, c->placed_mask.ensure(words * 8));
         HIPCHK(c, hipMemcpyAsync(c->placed_mask.p, bits.data(), words * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -695,6 +696,7 @@ int mauve_write_xmfa(mauve_ctx *c, const char *const *names, char *buf, int64_t 
                 if (R.cols[(size_t)(c0 + k)] >> g & 1) {
                     uint8_t b = base_at(w, nxt - 1);
                     row[(size_t)k] = rev ? B[3 - b] : B[b];
+                    if (c->has_invalid && (c->h_invalid[c->base_mask_off[(size_t)g] + (size_t)((nxt - 1) >> 6)] >> ((nxt - 1) & 63) & 1)) row[(size_t)k] = 'N';
                     nxt += rev ? -1 : 1;
                 } else row[(size_t)k] = '-';
             }

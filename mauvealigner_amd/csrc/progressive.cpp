@@ -93,8 +93,24 @@ int upload_mask(Prog &P, const std::vector<int> &gm, GenomeSet &gs)
                 M[w] &= ~m; b = e;
             }
     }
+    // ambiguous bases stay unusable at every node; contig joins likewise (mauve_set_genomes_contigs)
+    if (c->has_invalid)
+        for (size_t j = 0; j < gm.size(); j++) {
+            const size_t w = (size_t)((c->lens[gm[j]] + 63) / 64);
+            for (size_t k = 0; k < w; k++) bits[gs.mask_off[j] + k] |= c->h_invalid[c->base_mask_off[(size_t)gm[j]] + k];
+        }
     HIPCHK(c, c->placed_mask.ensure(words * 8));
     HIPCHK(c, hipMemcpyAsync(c->placed_mask.p, bits.data(), words * 8, hipMemcpyHostToDevice, c->stream));
+    if (c->has_contigs) {
+        std::vector<uint64_t> cm(words, 0);
+        for (size_t j = 0; j < gm.size(); j++) {
+            const size_t w = (size_t)((c->lens[gm[j]] + 63) / 64);
+            for (size_t k = 0; k < w; k++) cm[gs.mask_off[j] + k] = c->h_contig[c->base_mask_off[(size_t)gm[j]] + k];
+        }
+        HIPCHK(c, c->node_cmask.ensure(words * 8));
+        HIPCHK(c, hipMemcpy(c->node_cmask.p, cm.data(), words * 8, hipMemcpyHostToDevice));
+        gs.cmask = &c->node_cmask;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     gs.vmask = &c->placed_mask;
     return MAUVE_OK;

@@ -56,6 +56,44 @@ __global__ void __launch_bounds__(256) rec_gather(const uint64_t *__restrict__ g
     out[ga.dst_word_off[g] + j] = word;
 }
 
+// The unusable-base and contig-start bitmaps of the virtual genomes (only when the resident genomes carry them,
+// mauve_set_genomes_contigs): thread (g, j) builds word j -- 64 virtual bases -- of both.  A contig boundary lies
+// between a base and its predecessor, so on a reverse gap it moves to the other side of the base pair.
+__global__ void __launch_bounds__(256) rec_gather_mask(const uint64_t *__restrict__ inv, const uint64_t *__restrict__ cm, uint64_t *__restrict__ vinv,
+                                                       uint64_t *__restrict__ vcm, RecGatherArgs ga /* src = base mask words, dst = virtual mask words */,
+                                                       const uint32_t *__restrict__ seg, const int64_t *__restrict__ glo0,
+                                                       const uint8_t *__restrict__ grev, uint32_t K)
+{
+    const int g = blockIdx.y;
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ga.dst_words[g]) return;
+    const uint32_t *sg = seg + (size_t)g * (K + 1);
+    const uint32_t tot = sg[K];
+    const uint64_t base0 = j * 64;
+    uint64_t wi = 0, wc = 0;
+    if (base0 < tot) {
+        uint32_t lo = 0, hi = K;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sg[mid] <= base0) lo = mid; else hi = mid; }
+        uint32_t k = lo;
+        const uint64_t *I = inv ? inv + ga.src_word_off[g] : nullptr, *C = cm ? cm + ga.src_word_off[g] : nullptr;
+        for (int b = 0; b < 64; b++) {
+            const uint64_t p = base0 + b;
+            if (p >= tot) break;
+            while (p >= sg[k + 1]) k++;
+            const int64_t off = (int64_t)(p - sg[k]), len = (int64_t)(sg[k + 1] - sg[k]), s0 = glo0[(size_t)g * K + k];
+            const bool rev = grev[(size_t)g * K + k] != 0;
+            const int64_t src = rev ? s0 + len - 1 - off : s0 + off;
+            if (I && (I[src >> 6] >> (src & 63) & 1)) wi |= 1ULL << b;
+            if (C && off > 0) {                                   // a boundary before the gap's first base is the gap's own edge
+                const int64_t cb = rev ? src + 1 : src;           // the source base whose bit says "a contig starts here"
+                if (C[cb >> 6] >> (cb & 63) & 1) wc |= 1ULL << b;
+            }
+        }
+    }
+    if (vinv) vinv[ga.dst_word_off[g] + j] = wi;
+    if (vcm) vcm[ga.dst_word_off[g] + j] = wc;
+}
+
 // A gap waiting for a recursive search: flat record [lcb, prev_w, a(1+N), b(1+N)] in `work`.
 struct WorkList {
     int N; std::vector<int64_t> d;
@@ -163,6 +201,25 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                                c->genomes.as<uint64_t>(), c->rec_genomes.as<uint64_t>(), ga, (const uint32_t *)side,
                                (const int64_t *)(side + seg_bytes), (const uint8_t *)(side + seg_bytes + glo_bytes), K);
             HIPCHK(c, hipGetLastError());
+            if (c->has_invalid || c->has_contigs) {
+                // the gaps inherit the ambiguity / contig bitmaps of the resident genomes
+                RecGatherArgs gm; memset(&gm, 0, sizeof gm);
+                vs.mask_off.assign((size_t)N, 0);
+                size_t mwords = 0; uint64_t max_mw = 0;
+                for (int g = 0; g < N; g++) {
+                    const size_t nw = (size_t)((vs.lens[(size_t)g] + 63) / 64) + 2;
+                    vs.mask_off[(size_t)g] = mwords; gm.src_word_off[g] = c->base_mask_off[(size_t)(gmap ? gmap[g] : g)]; gm.dst_word_off[g] = mwords; gm.dst_words[g] = nw;
+                    max_mw = std::max<uint64_t>(max_mw, nw); mwords += nw;
+                }
+                HIPCHK(c, c->rec_vinv.ensure(mwords * 8)); HIPCHK(c, c->rec_vcm.ensure(mwords * 8));
+                hipLaunchKernelGGL(rec_gather_mask, dim3((uint32_t)((max_mw + 255) / 256), (uint32_t)N), dim3(256), 0, c->stream,
+                                   c->has_invalid ? c->base_invalid.as<uint64_t>() : nullptr, c->has_contigs ? c->contig_mask.as<uint64_t>() : nullptr,
+                                   c->has_invalid ? c->rec_vinv.as<uint64_t>() : nullptr, c->has_contigs ? c->rec_vcm.as<uint64_t>() : nullptr, gm,
+                                   (const uint32_t *)side, (const int64_t *)(side + seg_bytes), (const uint8_t *)(side + seg_bytes + glo_bytes), K);
+                HIPCHK(c, hipGetLastError());
+                if (c->has_invalid) vs.vmask = &c->rec_vinv;
+                if (c->has_contigs) vs.cmask = &c->rec_vcm;
+            }
             HIPCHK(c, hipStreamSynchronize(c->stream));    // the host vectors must outlive the copies
             for (auto &x : glo) x += 1;                    // back to 1-based for the coordinate mapping below
             int64_t nm = 0;

@@ -52,6 +52,17 @@ __device__ __forceinline__ bool window_masked(const uint64_t *__restrict__ M, ui
     return (v & ((span >= 64) ? ~0ULL : ((1ULL << span) - 1ULL))) != 0;
 }
 
+// Is the window starting at base p unusable?  VM: 1 bit per base, set = no window may touch it (an ancestor placed it,
+// DESIGN.md S9; or it is an ambiguous base, mauve_set_genomes_contigs); CM: 1 bit per base, set = a contig starts
+// here -- a window may begin at such a base but not run across it (RepeatHashCat.h:19-20).  Either may be null.
+__device__ __forceinline__ bool window_blocked(const uint64_t *__restrict__ VM, const uint64_t *__restrict__ CM, uint32_t p, int span)
+{
+    bool b = false;
+    if (VM) b = window_masked(VM, p, span);
+    if (CM && span > 1) b |= window_masked(CM, p + 1, span - 1);
+    return b;
+}
+
 // narrow form (span <= 32, weight <= 16): the window is one 64-bit word and K' fits 32 bits
 __device__ __forceinline__ uint32_t kprime_narrow(const uint64_t *__restrict__ G, uint32_t p, const SeedShape &sh)
 {
@@ -161,7 +172,8 @@ __global__ void __launch_bounds__(256) seed_extract_all(const uint64_t *__restri
                                                         KeyT *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t P,
                                                         const uint32_t *__restrict__ seg, uint32_t nseg,
                                                         uint32_t *__restrict__ hist, uint32_t nblk,
-                                                        const uint64_t *__restrict__ vmask, int hist_shift)
+                                                        const uint64_t *__restrict__ vmask, int hist_shift,
+                                                        const uint64_t *__restrict__ cmask)
 {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
@@ -188,7 +200,7 @@ __global__ void __launch_bounds__(256) seed_extract_all(const uint64_t *__restri
             const uint32_t k = seg_of(sg, nseg, p);
             key = (p + sh.span <= sg[k + 1]) ? (((uint64_t)k << (2 * sh.weight)) | key) : ~0ULL;
         }
-        if (vmask && window_masked(vmask + tab.mask_off[g], p, sh.span)) key = ~0ULL;
+        if ((vmask || cmask) && window_blocked(vmask ? vmask + tab.mask_off[g] : nullptr, cmask ? cmask + tab.mask_off[g] : nullptr, p, sh.span)) key = ~0ULL;
         keys[gp] = (KeyT)key;
         vals[gp] = gp | (s << 31);
         atomicAdd(&h[(uint32_t)(key >> hist_shift) & 255u], 1u);
@@ -226,20 +238,21 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total,
 // one-block scan over the tiles, then an extract that writes each tile's valid (key, val) pairs at the tile's
 // offset.  A thread owns 16 consecutive windows, so one block scan of per-thread counts gives the order.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool window_valid(uint32_t gp, uint32_t P, const GenomeTab &tab, int span, const uint64_t *__restrict__ vmask)
+__device__ __forceinline__ bool window_valid(uint32_t gp, uint32_t P, const GenomeTab &tab, int span, const uint64_t *__restrict__ vmask,
+                                             const uint64_t *__restrict__ cmask)
 {
     if (gp >= P) return false;
     const int g = genome_of(gp, tab);
-    return !window_masked(vmask + tab.mask_off[g], gp - tab.gpos_off[g], span);
+    return !window_blocked(vmask ? vmask + tab.mask_off[g] : nullptr, cmask ? cmask + tab.mask_off[g] : nullptr, gp - tab.gpos_off[g], span);
 }
 
 __global__ void __launch_bounds__(256) valid_count(GenomeTab tab, int span, uint32_t P, const uint64_t *__restrict__ vmask,
-                                                   uint32_t *__restrict__ tile_cnt)
+                                                   uint32_t *__restrict__ tile_cnt, const uint64_t *__restrict__ cmask)
 {
     __shared__ uint32_t lds[8];
     const uint32_t first = blockIdx.x * 4096u + threadIdx.x * 16u;
     uint32_t c = 0;
-    for (int i = 0; i < 16; i++) c += window_valid(first + i, P, tab, span, vmask) ? 1u : 0u;
+    for (int i = 0; i < 16; i++) c += window_valid(first + i, P, tab, span, vmask, cmask) ? 1u : 0u;
     uint32_t total;
     (void)block_excl_scan(c, &total, lds);
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
@@ -261,12 +274,13 @@ __global__ void __launch_bounds__(256) tile_scan(uint32_t *__restrict__ tile_cnt
 template <typename KeyT, bool NARROW>
 __global__ void __launch_bounds__(256) seed_extract_compact(const uint64_t *__restrict__ packed, GenomeTab tab, SeedShape sh,
                                                             KeyT *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t P,
-                                                            const uint64_t *__restrict__ vmask, const uint32_t *__restrict__ tile_off)
+                                                            const uint64_t *__restrict__ vmask, const uint32_t *__restrict__ tile_off,
+                                                            const uint64_t *__restrict__ cmask)
 {
     __shared__ uint32_t lds[8];
     const uint32_t first = blockIdx.x * 4096u + threadIdx.x * 16u;
     uint32_t ok = 0;
-    for (int i = 0; i < 16; i++) ok |= (window_valid(first + i, P, tab, sh.span, vmask) ? 1u : 0u) << i;
+    for (int i = 0; i < 16; i++) ok |= (window_valid(first + i, P, tab, sh.span, vmask, cmask) ? 1u : 0u) << i;
     uint32_t total;
     uint32_t o = tile_off[blockIdx.x] + block_excl_scan((uint32_t)__popc(ok), &total, lds);
     for (int i = 0; i < 16; i++) {
@@ -760,7 +774,7 @@ __global__ void __launch_bounds__(256) join_pair(const uint32_t *__restrict__ va
 // ------------------------------------------------------------------------------------------------
 // One component of the hit a wave is extending: where its windows live, the window index at offset 0, its walking
 // direction relative to the anchor and the window range it may use.  Built once per candidate (LDS, per wave).
-struct ExtComp { const uint64_t *G; const uint64_t *VM; int64_t pos, lo, hi; uint32_t rev, pad; };
+struct ExtComp { const uint64_t *G; const uint64_t *VM; const uint64_t *CM; int64_t pos, lo, hi; uint32_t rev, pad; };
 
 // Does offset k agree?  Components are handled four at a time: the window loads of a batch are issued together from
 // clamped (always valid) addresses and compared afterwards, so a call costs one memory round trip per batch rather
@@ -781,7 +795,7 @@ __device__ __forceinline__ bool agree_at(const ExtComp *__restrict__ comp, int n
                 const bool inb = q >= C.lo && q <= C.hi;
                 const uint32_t qq = (uint32_t)(inb ? q : C.lo);
                 ok &= inb;
-                if (C.VM) ok &= !window_masked(C.VM, qq, sh.span);
+                if (C.VM || C.CM) ok &= !window_blocked(C.VM, C.CM, qq, sh.span);
                 window_at(C.G, qq, wl[i], wh[i]);
                 rv[i] = C.rev;
             }
@@ -896,7 +910,7 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
                                                   uint32_t P, const uint32_t *__restrict__ cand, uint32_t ncand,
                                                   int extend, int32_t *__restrict__ mlen, int32_t *__restrict__ mstart,
                                                   const uint32_t *__restrict__ seg, uint32_t nseg,
-                                                  const uint64_t *__restrict__ vmask)
+                                                  const uint64_t *__restrict__ vmask, const uint64_t *__restrict__ cmask)
 {
     __shared__ ExtComp s_comp[4][MAUVE_MAX_SEQ];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -919,6 +933,7 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
             ExtComp C;
             C.G = packed + tab.word_off[g];
             C.VM = vmask ? vmask + tab.mask_off[g] : nullptr;
+            C.CM = cmask ? cmask + tab.mask_off[g] : nullptr;
             C.pos = (int64_t)((vg & 0x7fffffffu) - tab.gpos_off[g]);
             C.rev = (vg >> 31) ^ sa; C.pad = 0;
             C.lo = 0; C.hi = (int64_t)tab.nwin[g] - 1;
@@ -1064,7 +1079,7 @@ static int build_tab(mauve_ctx *ctx, const GenomeSet &gs, int span, GenomeTab *t
     for (int g = 0; g < gs.nseq; g++) {
         int64_t nw = gs.lens[g] - span + 1; if (nw < 0) nw = 0;
         tab->gpos_off[g] = (uint32_t)tot; tab->nwin[g] = (uint32_t)nw; tab->word_off[g] = gs.word_off[g];
-        tab->mask_off[g] = gs.vmask ? gs.mask_off[g] : 0;
+        tab->mask_off[g] = (gs.vmask || gs.cmask) ? gs.mask_off[g] : 0;
         tot += nw;
         if (tot >= (1LL << 31)) { ctx->err = "total genome length exceeds 2^31 windows"; return MAUVE_ERR_LIMIT; }
     }
@@ -1121,6 +1136,8 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     KeyT *keys = ctx->keysA.as<KeyT>(); uint32_t *vals = ctx->valsA.as<uint32_t>();
     const uint64_t *packed = gs.buf->as<uint64_t>();
     const uint64_t *vmask = gs.vmask ? gs.vmask->as<uint64_t>() : nullptr;
+    const uint64_t *cmask = gs.cmask ? gs.cmask->as<uint64_t>() : nullptr;
+    const bool masked = vmask || cmask;              // some windows are unusable: placed or ambiguous bases, contig joins
 
     uint32_t sorted_n = 0;
     bool have_hist0 = false;
@@ -1130,12 +1147,12 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     // slices join_hash hands back.  MAUVE_OLD_JOIN forces the second (A/B switch).
     static const bool force_old_join = getenv("MAUVE_OLD_JOIN") != nullptr;
     const HostHits *hh = ctx->host_hits;                      // mauve_extend_hits: the hits come from the host, no sort, no join
-    const bool hash_path = !hh && mode != MAUVE_MODE_PAIRWISE && !out_keys && only_seq < 0 && !force_old_join && !(vmask && SEG);
+    const bool hash_path = !hh && mode != MAUVE_MODE_PAIRWISE && !out_keys && only_seq < 0 && !force_old_join && !(masked && SEG);
     // segmented keys: segment id above the mer; ids 0 .. nseg-1, the all-ones id is left to the invalid (all-ones) key
     int segbits = 0;
     if (SEG) while (segbits < 32 && (1ull << segbits) <= (uint64_t)nseg) segbits++;
     if (SEG && 2 * sh.weight + segbits > 64) { ctx->err = "recursive anchoring: segment id and mer do not fit 64 bits"; return MAUVE_ERR_LIMIT; }
-    const int full_bits = SEG ? 2 * sh.weight + segbits : ((vmask && (SEG || only_seq >= 0)) ? (int)sizeof(KeyT) * 8 : 2 * sh.weight);
+    const int full_bits = SEG ? 2 * sh.weight + segbits : ((masked && (SEG || only_seq >= 0)) ? (int)sizeof(KeyT) * 8 : 2 * sh.weight);
     // globally sorted bits: 8-bit passes until a bucket averages <= 512 entries; a segmented list sorts at least the
     // segment id, so that the invalid windows form the last bucket on their own
     auto low_bits = [&](uint32_t entries) {
@@ -1146,21 +1163,21 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         return full_bits - std::min(G, full_bits);
     };
     if (hh) sorted_n = 1;
-    else if (only_seq < 0 && vmask && !SEG) {
+    else if (only_seq < 0 && masked && !SEG) {
         // masked pass: only the valid windows go into the sort (see valid_count / seed_extract_compact)
         const uint32_t nblk = (n + 4095) / 4096;
         HIPCHK(ctx, ctx->hist.ensure((size_t)nblk * 256 * sizeof(uint32_t)));     // the tile counts live in the histogram buffer
         uint32_t *tile_cnt = ctx->hist.as<uint32_t>();
         {
             KernelTimer t(ctx, MAUVE_K_EXTRACT, n);
-            hipLaunchKernelGGL(valid_count, dim3(nblk), dim3(256), 0, ctx->stream, tab, sh.span, n, vmask, tile_cnt);
+            hipLaunchKernelGGL(valid_count, dim3(nblk), dim3(256), 0, ctx->stream, tab, sh.span, n, vmask, tile_cnt, cmask);
             hipLaunchKernelGGL(tile_scan, dim3(1), dim3(256), 0, ctx->stream, tile_cnt, nblk, ctx->counters.as<uint32_t>());
             if (sh.span <= 32 && sh.weight <= 15)
                 hipLaunchKernelGGL((seed_extract_compact<KeyT, true>), dim3(nblk), dim3(256), 0, ctx->stream, packed, tab, sh, keys, vals, n,
-                                   vmask, tile_cnt);
+                                   vmask, tile_cnt, cmask);
             else
                 hipLaunchKernelGGL((seed_extract_compact<KeyT, false>), dim3(nblk), dim3(256), 0, ctx->stream, packed, tab, sh, keys, vals, n,
-                                   vmask, tile_cnt);
+                                   vmask, tile_cnt, cmask);
         }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, ctx->pin_seed.ensure(64));
@@ -1175,10 +1192,10 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         const int hshift = low_bits(n);
         if (sh.span <= 32 && sh.weight <= 15)
             hipLaunchKernelGGL((seed_extract_all<KeyT, SEG, true>), dim3(nblk), dim3(256), 0, ctx->stream, packed, tab, sh, keys,
-                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk, vmask, hshift);
+                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk, vmask, hshift, cmask);
         else
             hipLaunchKernelGGL((seed_extract_all<KeyT, SEG, false>), dim3(nblk), dim3(256), 0, ctx->stream, packed, tab, sh, keys,
-                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk, vmask, hshift);
+                               vals, n, seg, nseg, ctx->hist.as<uint32_t>(), nblk, vmask, hshift, cmask);
         sorted_n = n; have_hist0 = true;
     } else {
         const int g = only_seq;
@@ -1195,7 +1212,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     TRACE(ctx, "extract");
     if (sorted_n == 0) { if (n_matches) *n_matches = 0; return MAUVE_OK; }
     const int key_bits = full_bits;
-    const int has_invalid = vmask != nullptr && !compacted;
+    const int has_invalid = masked && !compacted;
     const uint32_t ns = sorted_n;                   // entries of the sorted list (all windows, or the valid ones)
     const int L = low_bits(ns);                     // the passes order bits [L, key_bits); 0 = full sort
     int rc = hh ? MAUVE_OK : sort_pairs<KeyT>(ctx, sorted_n, key_bits, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>(), have_hist0, -1, L);
@@ -1341,7 +1358,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             KernelTimer t(ctx, MAUVE_K_EXTEND, nc);
             hipLaunchKernelGGL((mum_extend<SEG>), dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh, tmask, tpos, P,
                                ctx->cand.as<uint32_t>(), nc, extend, ctx->mlen.as<int32_t>() + cand_total,
-                               ctx->mstart.as<int32_t>() + (size_t)cand_total * N, seg, nseg, vmask);
+                               ctx->mstart.as<int32_t>() + (size_t)cand_total * N, seg, nseg, vmask, cmask);
             HIPCHK(ctx, hipGetLastError());
         }
         cand_total += nc;

@@ -1,0 +1,83 @@
+// Host-side data model of the mirror (include/libMems): the shapes the in-tree tools use, checked on small hand cases.
+#include <cassert>
+#include <iostream>
+#include <sstream>
+#include "libMems/mems_hip.h"
+using namespace mems;
+
+int main()
+{
+    // ---- MatchProjectionAdapter (SeedMatchEnumerator.h:98; MatchRecord.h:242) ----
+    Match m(4); m.SetLength(20); m.SetStart(0, 101); m.SetStart(1, -301); m.SetStart(3, 501);
+    std::vector<size_t> map; map.push_back(3); map.push_back(1);
+    MatchProjectionAdapter mpa(m.Copy(), map);
+    assert(mpa.SeqCount() == 2 && mpa.Multiplicity() == 2 && mpa.Start(0) == 501 && mpa.Start(1) == -301 && mpa.LeftEnd(1) == 301 && mpa.RightEnd(1) == 320);
+    AbstractMatch *cp = mpa.Copy(); cp->CropLeft(5, 0); assert(cp->Start(0) == 506 && cp->Length(0) == 15 && mpa.Start(0) == 501); cp->Free();
+    // ---- GappedAlignment (repeatoire.cpp:1238,1264-1265) ----
+    GappedAlignment ga(3, 0);
+    std::vector<std::string> rows; rows.push_back("ACG-TA"); rows.push_back("A-GGTA"); rows.push_back("------");
+    ga.SetAlignment(rows); ga.SetStart(0, 11); ga.SetStart(1, -21);
+    assert(ga.AlignmentLength() == 6 && ga.Length(0) == 5 && ga.Length(1) == 5 && ga.Length(2) == 0 && ga.Multiplicity() == 2);
+    assert(ga.LeftEnd(0) == 11 && ga.RightEnd(0) == 15 && ga.RightEnd(1) == 25);
+    std::vector<gnSeqI> pos; std::vector<bool> col;
+    ga.GetColumn(4, pos, col); assert(col[0] && col[1] && !col[2] && pos[0] == 14 && pos[1] == 22);   // reverse row counts down from its right end
+    ga.GetColumn(1, pos, col); assert(col[0] && !col[1] && pos[0] == 12);
+    GappedAlignment g2 = ga; g2.CropStart(2); assert(g2.AlignmentLength() == 4 && g2.Start(0) == 13 && g2.Length(0) == 3 && g2.Start(1) == -21 && g2.Length(1) == 4);
+    g2 = ga; g2.CropEnd(2); assert(g2.Start(0) == 11 && g2.Length(0) == 3 && g2.Start(1) == -23 && g2.Length(1) == 3);
+    g2 = ga; g2.Invert(); assert(g2.Start(0) == -11 && g2.Start(1) == 21 && g2.GetAlignment()[0] == "TA-CGT");
+    // ---- CompactGappedAlignment (repeatoire.cpp:1316-1318,1347; bbBreakOnGenes.cpp:154-155) ----
+    CompactGappedAlignment<> cga(ga);
+    assert(cga.AlignmentLength() == 6 && cga.Length(0) == 5 && cga.GetAlignment()[1][1] == false && cga.GetAlignment()[0][3] == false);
+    assert(cga.SeqPosToColumn(0, 11) == 0 && cga.SeqPosToColumn(0, 14) == 4 && cga.SeqPosToColumn(1, 25) == 0 && cga.SeqPosToColumn(1, 21) == 5);
+    CompactGappedAlignment<> part; cga.copyRange(part, 2, 3);
+    assert(part.AlignmentLength() == 3 && part.Start(0) == 13 && part.Length(0) == 2 && part.Length(1) == 3 && part.Start(1) == -22);
+    // ---- Interval over matches: SetMatches steals, GetColumn, StealMatches (MatchRecord.h:338-343) ----
+    std::vector<AbstractMatch *> chain;
+    Match a(2); a.SetLength(10); a.SetStart(0, 1); a.SetStart(1, 101);
+    GappedAlignment mid(2, 0); std::vector<std::string> mr; mr.push_back("AC-"); mr.push_back("A-G"); mid.SetAlignment(mr); mid.SetStart(0, 11); mid.SetStart(1, 111);
+    Match b(2); b.SetLength(5); b.SetStart(0, 13); b.SetStart(1, 113);
+    chain.push_back(a.Copy()); chain.push_back(mid.Copy()); chain.push_back(b.Copy());
+    Interval iv; iv.SetMatches(chain);
+    assert(chain.empty() && iv.GetMatches().size() == 3 && iv.AlignmentLength() == 18 && iv.LeftEnd(0) == 1 && iv.RightEnd(0) == 17 && iv.RightEnd(1) == 117);
+    iv.GetColumn(11, pos, col); assert(col[0] && !col[1] && pos[0] == 12);
+    iv.GetColumn(12, pos, col); assert(!col[0] && col[1] && pos[1] == 112);
+    CompactGappedAlignment<> civ(iv); assert(civ.AlignmentLength() == 18 && civ.SeqPosToColumn(1, 113) == 13);
+    std::vector<AbstractMatch *> back; iv.StealMatches(back); assert(back.size() == 3 && iv.GetMatches().empty());
+    for (AbstractMatch *x : back) x->Free();
+    // ---- LCB helpers (toGrimmFormat.cpp:51-79; projectAndStrip.cpp:110-112; sortContigs.cpp:55-84) ----
+    MatchList ml;
+    const int64 st[5][2] = {{1, 1001}, {101, 1101}, {201, -2201}, {301, -2101}, {401, 1301}};      // 2 forward, 2 in an inversion, 1 forward
+    for (int i = 0; i < 5; i++) { Match x(2); x.SetLength(50); x.SetStart(0, st[i][0]); x.SetStart(1, st[i][1]); ml.push_back(x.Copy()); }
+    std::vector<gnSeqI> bps; IdentifyBreakpoints(ml, bps);
+    assert(bps.size() == 3 && bps[0] == 1 && bps[1] == 3 && bps[2] == 4);
+    std::vector<MatchList> lcbs; std::vector<int64> w; ComputeLCBs_v2(ml, bps, lcbs, w);
+    assert(lcbs.size() == 3 && lcbs[0].size() == 2 && lcbs[1].size() == 2 && w[0] == 200 && w[2] == 100);
+    std::vector<LCB> adj; computeLCBAdjacencies_v2(lcbs, w, adj);
+    assert(adj[1].left_end[1] == -2101 && adj[1].right_end[1] == -2250 && adj[0].right_end[0] == 150 && adj[1].lcb_id == 1);
+    assert(adj[0].left_adjacency[0] == NO_ADJACENCY && adj[0].right_adjacency[0] == 1 && adj[1].right_adjacency[0] == 2);
+    assert(adj[0].right_adjacency[1] == 2 && adj[2].right_adjacency[1] == 1 && adj[1].right_adjacency[1] == NO_ADJACENCY);      // genome 1 order: 0, 2, 1
+    std::vector<int64> tr; transposeMatches(ml, 1, tr); assert(tr.size() == 5 && tr[2] == -2201);
+    // EliminateOverlaps: the shorter of two overlapping matches gives way
+    MatchList ov; { Match x(2); x.SetLength(100); x.SetStart(0, 1); x.SetStart(1, 1); ov.push_back(x.Copy()); Match y(2); y.SetLength(30); y.SetStart(0, 91); y.SetStart(1, 91); ov.push_back(y.Copy()); }
+    EliminateOverlaps(ov); assert(ov.size() == 2 && ov[1]->Start(0) == 101 && ov[1]->Length() == 20 && ov[0]->Length() == 100);
+    ov.Clear(); ml.Clear();
+    // addUnalignedIntervals (mauveAligner.cpp:748)
+    IntervalList il; genome::gnSequence s0(std::string(30, 'A')), s1(std::string(20, 'C'));
+    il.seq_table.push_back(&s0); il.seq_table.push_back(&s1);
+    { std::vector<int64> l(2), r(2); std::vector<char> rv(2, 0); l[0] = 5; r[0] = 14; l[1] = 1; r[1] = 10; il.push_back(Interval(l, r, rv, std::vector<uint32_t>(10, 3u))); }
+    addUnalignedIntervals(il);
+    assert(il.size() == 4 && il[1].LeftEnd(0) == 1 && il[1].RightEnd(0) == 4 && il[2].LeftEnd(0) == 15 && il[2].RightEnd(0) == 30 && il[3].LeftEnd(1) == 11 && il[3].RightEnd(1) == 20);
+    // readSubstitutionMatrix (progressiveMauve.cpp:684)
+    std::istringstream mat("# HOXD70\n  A C G T\nA 91 -114 -31 -123\nC -114 100 -125 -31\nG -31 -125 100 -114\nT -123 -31 -114 91\n");
+    score_t M[4][4]; readSubstitutionMatrix(mat, M);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) assert(M[i][j] == hoxd_matrix[i][j]);
+    // .mln of another library is refused, not misparsed
+    std::istringstream foreign("FormatVersion\t4\nSequenceCount\t2\n");
+    bool threw = false; try { IntervalList x; x.ReadList(foreign); } catch (genome::gnException &) { threw = true; }
+    assert(threw);
+    std::istringstream bigdef("> 40:1-5 + x\nACGTA\n=\n");
+    threw = false; try { IntervalList x; x.ReadStandardAlignment(bigdef); } catch (genome::gnException &) { threw = true; }
+    assert(threw);
+    std::cout << "OK" << std::endl;
+    return 0;
+}

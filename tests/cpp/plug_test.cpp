@@ -1,0 +1,119 @@
+// The plug-in seams of the reference, exercised on the device (usage: plug_test a.fa b.fa c.fa):
+//  1. a MatchFinder subclass with its own EnumerateMatches (the shape of src/UniqueMatchFinder.cpp, written here
+//     independently) -> host callback path -> same matches as the in-kernel rule (HipUniqueMatchFinder);
+//  2. a MatchFinder subclass that builds its matches itself in HashMatch, no extension (the shape of
+//     src/SeedMatchEnumerator.h) -> same matches as the device enumeration (HipSeedMatchEnumerator);
+//  3. a GappedAligner of the caller's own installed with Aligner::SetGappedAligner is called once per interval and,
+//     delegating to the built-in DP, reproduces the batched result;
+//  4. Aligner::align chains the match list it is given: with half the matches removed the anchors change.
+#include <cassert>
+#include <iostream>
+#include <map>
+#include <set>
+#include <sstream>
+#include "libMems/mems_hip.h"
+using namespace mems;
+
+// rule: every sequence that holds the mer exactly once takes part; two or more must remain
+class OnceOnlyFinder : public MemHash {
+public:
+    virtual OnceOnlyFinder *Clone() const { return new OnceOnlyFinder(*this); }
+    size_t calls = 0;
+protected:
+    virtual boolean EnumerateMatches(IdmerList &match_list)
+    {
+        calls++;
+        std::map<uint32, int> seen;
+        for (const idmer &e : match_list) seen[e.id]++;
+        IdmerList keep;
+        for (const idmer &e : match_list) if (seen[e.id] == 1) keep.push_back(e);
+        return keep.size() >= 2 ? HashMatch(keep) : true;
+    }
+};
+
+// every repeated mer of ONE sequence becomes a match of seed length, components in position order, strands relative to the first
+class RepeatLister : public MatchFinder {
+public:
+    virtual RepeatLister *Clone() const { return new RepeatLister(*this); }
+    MatchList found;
+protected:
+    virtual boolean EnumerateMatches(IdmerList &l) { return HashMatch(l); }
+    virtual boolean HashMatch(IdmerList &l)
+    {
+        l.sort(&idmer_position_lessthan);
+        if (l.size() < 2 || l.size() > 1000) return true;
+        Match m((uint)l.size());
+        m.SetLength(GetSar(0)->SeedLength());
+        const uint64 first_strand = l.front().mer & 1;
+        uint k = 0;
+        for (const idmer &e : l) { const int64 p1 = (int64)e.position + 1; m.SetStart(k++, (e.mer & 1) == first_strand ? p1 : -p1); }
+        found.push_back(m.Copy());
+        return true;
+    }
+};
+
+class CountingAligner : public GappedAligner {
+public:
+    size_t aligned = 0, fast = 0;
+    virtual bool CallMuscleFast(std::vector<std::string> &out, const std::vector<std::string> &in, int go, int ge)
+    {
+        fast++;
+        return HipGappedAligner::getInterface().CallMuscleFast(out, in, go, ge);
+    }
+    virtual boolean Align(GappedAlignment &cr, AbstractMatch *l, AbstractMatch *r, std::vector<genome::gnSequence *> &seq_table)
+    {
+        aligned++;
+        return GappedAligner::Align(cr, l, r, seq_table);
+    }
+};
+
+static std::string xmfa(const IntervalList &il) { std::ostringstream os; il.WriteStandardAlignment(os); return os.str(); }
+static std::multiset<std::string> rows(const MatchList &ml) { std::multiset<std::string> s; for (const Match *m : ml) { std::ostringstream os; os << *m; s.insert(os.str()); } return s; }
+
+int main(int argc, char **argv)
+{
+    try {
+        MatchList ml;
+        for (int a = 1; a < argc; a++) { genome::gnSequence *s = new genome::gnSequence(); s->LoadSource(argv[a]); ml.seq_table.push_back(s); ml.seq_filename.push_back(argv[a]); }
+        const uint N = (uint)ml.seq_table.size();
+        ml.CreateMemorySMLs(11, nullptr, 0);
+        // 1. host callback path == in-kernel rule
+        MatchList dev; dev.seq_table = ml.seq_table; dev.sml_table = ml.sml_table; dev.seq_filename = ml.seq_filename;
+        HipUniqueMatchFinder huf; huf.FindMatches(dev);
+        MatchList cb; cb.seq_table = ml.seq_table; cb.sml_table = ml.sml_table; cb.seq_filename = ml.seq_filename;
+        OnceOnlyFinder oof; oof.FindMatches(cb);
+        assert(oof.calls > 100 && dev.size() > 50 && dev.size() == cb.size());
+        for (size_t i = 0; i < dev.size(); i++) { std::ostringstream x, y; x << *dev[i]; y << *cb[i]; assert(x.str() == y.str()); }
+        // ... and with the N-way mask of MaskedMemHash
+        MatchList devm = dev; devm.clear(); MatchList cbm = cb; cbm.clear();
+        { MaskedMemHash mmh; mmh.SetMask((1ull << N) - 1); mmh.FindMatches(devm); OnceOnlyFinder o2; o2.SetMask((1ull << N) - 1); o2.FindMatches(cbm); }
+        assert(devm.size() > 10 && rows(devm) == rows(cbm));
+        // 2. matches built on the host from the enumerated runs == the device enumeration
+        MatchList one; one.seq_table.push_back(ml.seq_table[0]); one.sml_table.push_back(ml.sml_table[0]); one.seq_filename.push_back(ml.seq_filename[0]);
+        MatchList devrep = one; HipSeedMatchEnumerator hse; hse.FindMatches(devrep);
+        RepeatLister rl; rl.AddSequence(one.sml_table[0], one.seq_table[0]); rl.CreateMatches();
+        assert(rows(devrep) == rows(rl.found));
+        RepeatHash rh; MatchList rhl = one; rh.FindMatches(rhl); assert(rows(rhl) == rows(devrep));
+        // 3. a GappedAligner of the caller's own
+        const uint w = MatchList::GetDefaultMerSize(ml.seq_table);
+        MatchList nway = ml; nway.clear(); nway.seed_pattern = getSeed((int)w, 0);
+        { MatchList tmp; tmp.seq_table = ml.seq_table; tmp.seq_filename = ml.seq_filename; tmp.CreateMemorySMLs(w, nullptr, 0);
+          MaskedMemHash f; f.SetMask((1ull << N) - 1); f.FindMatches(tmp); nway.insert(nway.end(), tmp.begin(), tmp.end()); nway.sml_table = tmp.sml_table; nway.seed_pattern = tmp.seed_pattern; }
+        Aligner builtin(N); IntervalList il1; builtin.SetGappedAligner(HipGappedAligner::getInterface());
+        builtin.align(nway, il1, 0, (int64)w * 3 * N, true, false, true, "");
+        CountingAligner ca; Aligner plugged(N); plugged.SetGappedAligner(ca); IntervalList il2;
+        plugged.align(nway, il2, 0, (int64)w * 3 * N, true, false, true, "");
+        assert(il1.sizes.n_gap_dp > 10 && ca.aligned == (size_t)il1.sizes.n_gap_dp && ca.fast == ca.aligned);
+        assert(xmfa(il1) == xmfa(il2));
+        // 4. the list that is handed in is what gets chained
+        MatchList half = nway; half.clear();
+        for (size_t i = 0; i < nway.size(); i += 2) half.push_back(nway[i]);
+        IntervalList il3; builtin.align(half, il3, 0, (int64)w * 3 * N, false, false, true, "");
+        assert(il3.sizes.n_mums == (int64_t)half.size() && il3.sizes.n_anchor <= (int64_t)half.size() && il3.sizes.n_anchor > 0);
+        std::cout << "callbacks " << oof.calls << ", matches " << dev.size() << ", repeats " << devrep.size() << ", plug calls " << ca.aligned << "\nOK" << std::endl;
+        return 0;
+    } catch (std::exception &e) {
+        std::cerr << "exception: " << e.what() << std::endl;
+        return 2;
+    }
+}

@@ -212,6 +212,57 @@ def test_extend_hits_host_callback_path(ctx):
         ctx.extend_hits(pat, np.array([1], np.uint32), p[:1], s[:1])          # one component is not a match
 
 
+def _valid_intervals(L, contig_starts, invalid):
+    """1-based inclusive intervals a seed window must lie in: the contigs, cut at every ambiguous base"""
+    out = []
+    edges = list(contig_starts) + [L]
+    for a, b in zip(edges[:-1], edges[1:]):
+        cur = a
+        bad = np.flatnonzero(invalid[a:b]) + a if invalid is not None else []
+        for x in list(bad) + [b]:
+            if x > cur:
+                out.append((cur + 1, int(x)))
+            cur = x + 1
+    return out
+
+
+def test_contigs_and_ambiguous_bases(ctx):
+    """mauve_set_genomes_contigs (RepeatHashCat.h:19-20 concat_contig_start; multi-record FastA, runs of N): no seed
+    window and no ungapped extension crosses a contig join or touches an ambiguous base -- bit-exact against the
+    oracle's interval-restricted finder -- while matches still pair windows of different contigs."""
+    from mauvealigner_amd import _lib
+    rng = np.random.default_rng(42)
+    anc = rng.integers(0, 4, 20000, dtype=np.uint8)
+    gs = [synth.mutate(anc, 0.02, rng) for _ in range(3)]
+    contigs = [[0, 5000, 5003, 12000], [0], [0, 9000]]
+    invalid = [np.zeros(len(g), bool) for g in gs]
+    invalid[0][7000:7100] = True                      # a run of N (packed as A: would seed poly-A matches)
+    invalid[1][300] = True
+    invalid[2][15000:15040] = True
+    for g in range(3):
+        gs[g] = gs[g].copy(); gs[g][invalid[g]] = 0
+    gs[1][2000:2200] = 0; gs[0][1500:1700] = 0        # real poly-A stays seedable
+    valid = [_valid_intervals(len(gs[g]), contigs[g], invalid[g]) for g in range(3)]
+    ctx.set_genomes(gs, contig_starts=contigs, invalid=invalid)
+    for w, mode, mask in ((11, 0, 0), (11, 1, 0), (9, 0, 7), (15, 1, 0)):
+        pat = O.get_seed(w, 0)
+        ln, st = ctx.seed_mums(pat, mode=mode, mask=mask)
+        eln, est = O.find_matches_masked(gs, pat, valid, mode=mode, mask=mask)
+        assert len(ln) > 20 and np.array_equal(ln, eln) and np.array_equal(st, est), (w, mode, mask)
+        # no match of genome 0 covers an ambiguous base (windows on the two sides of a contig join may still abut
+        # into one match when the join is collinear in the other genomes: no single window crosses it)
+        a = np.abs(st[:, 0]); has = a > 0
+        assert not np.any(has & (a <= 7100) & (a + ln - 1 >= 7001))
+    # the whole path: alignment still partitions the genomes; XMFA prints N at the ambiguous bases
+    ctx.set_genomes(gs, contig_starts=contigs, invalid=invalid)
+    r = ctx.align(_lib.default_params(), names=["a", "b", "c"], want_xmfa=True)
+    assert r["n_anchor"] > 10
+    rows = "".join(l for l in r["xmfa"].splitlines() if l and l[0] not in "#>=")
+    assert rows.count("N") == int(sum(x.sum() for x in invalid))
+    with pytest.raises(RuntimeError, match=r"\(-1\).*ascend"):
+        ctx.set_genomes(gs, contig_starts=[[0, 50, 40], [0], [0]])
+
+
 def test_full_size_properties(ctx):
     """BASELINE config C2 at full size (3 x 5 Mbp, weight 15): too big for the oracle in a unit test, so check
     size-independent properties: determinism, canonical order, reverse-complement symmetry of the input."""
