@@ -43,22 +43,27 @@ def interval_cost(interval):
 
 def all_gather_ragged(arr, dist, group=None):
     """all_gather of one 1-D numpy array per rank with different lengths: one size exchange + one padded
-    all_gather.  Returns the list of arrays by rank."""
+    all_gather.  The payload travels in its own width (uint32 column masks as int32 bit patterns: no widening), and
+    on RCCL through ONE device buffer per rank (H2D of the rank's share, the collective, D2H of everybody's).
+    Returns the list of arrays by rank."""
     import torch
     world = dist.get_world_size(group)
     dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
     arr = np.ascontiguousarray(arr)
-    n = torch.tensor([arr.size], dtype=torch.int64, device=dev)
+    wire = {np.dtype(np.uint32): np.int32, np.dtype(np.uint64): np.int64}.get(arr.dtype)
+    payload = arr.view(wire) if wire is not None else arr
+    n = torch.tensor([payload.size], dtype=torch.int64, device=dev)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
     sizes = [int(s.item()) for s in sizes]
     mx = max(max(sizes), 1)
-    buf = torch.zeros(mx, dtype=torch.from_numpy(arr[:0].copy()).dtype, device=dev)
-    if arr.size:
-        buf[:arr.size] = torch.from_numpy(arr.reshape(-1)).to(dev)
-    outs = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(outs, buf, group=group)
-    return [o[:s].cpu().numpy() for o, s in zip(outs, sizes)]
+    buf = torch.zeros(mx, dtype=torch.from_numpy(payload[:0].copy()).dtype, device=dev)
+    if payload.size:
+        buf[:payload.size] = torch.from_numpy(payload.reshape(-1)).to(dev, non_blocking=True)
+    out = torch.empty(world * mx, dtype=buf.dtype, device=dev)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    host = out.cpu().numpy()
+    return [host[r * mx:r * mx + s].view(arr.dtype).copy() for r, s in enumerate(sizes)]
 
 
 def dp_sharded(dp_fn, intervals, dist=None, group=None):
@@ -72,7 +77,7 @@ def dp_sharded(dp_fn, intervals, dist=None, group=None):
     mine = parts[rank]
     cols, score = dp_fn([intervals[i] for i in mine.tolist()]) if len(mine) else ([], np.zeros(0, np.int64))
     lens = np.array([len(c) for c in cols], dtype=np.int64)
-    flat = np.concatenate(cols).astype(np.int64) if len(cols) and lens.sum() else np.zeros(0, np.int64)
+    flat = np.concatenate(cols).astype(np.uint32) if len(cols) and lens.sum() else np.zeros(0, np.uint32)
     g_lens = all_gather_ragged(lens, dist, group)
     g_flat = all_gather_ragged(flat, dist, group)
     g_score = all_gather_ragged(np.asarray(score, dtype=np.int64), dist, group)
@@ -122,7 +127,7 @@ def align_sharded(ctx, params=None, dist=None, group=None, names=None, want_xmfa
             all_score[i] = score[k]
     else:
         lens = np.array([len(c) for c in cols], dtype=np.int64)
-        flat = np.concatenate(cols).astype(np.int64) if len(cols) and lens.sum() else np.zeros(0, np.int64)
+        flat = np.concatenate(cols).astype(np.uint32) if len(cols) and lens.sum() else np.zeros(0, np.uint32)
         g_lens = all_gather_ragged(lens, dist, group)
         g_flat = all_gather_ragged(flat, dist, group)
         g_score = all_gather_ragged(np.asarray(score, dtype=np.int64), dist, group)

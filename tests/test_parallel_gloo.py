@@ -52,6 +52,62 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+class _StandInContext:
+    """The begin / dp / finish protocol of mauvealigner_amd._lib.Context (mauve_align_begin / _dp / _finish) with the
+    CPU oracle behind it: lets align_sharded itself run under gloo without a GPU."""
+
+    def __init__(self, intervals):
+        self.ivs = intervals
+        self.finished = None
+
+    def align_begin(self, params=None):
+        cost = np.array([parallel.interval_cost(iv) for iv in self.ivs], np.int64)
+        cap = np.array([sum(len(s) for s in iv) for iv in self.ivs], np.int64)
+        return len(self.ivs), cost, cap
+
+    def align_dp(self, idx, cap):
+        cols, score = _oracle_dp([self.ivs[i] for i in np.asarray(idx).tolist()])
+        return [np.asarray(c, np.uint32) for c in cols], score, int(sum(parallel.interval_cost(self.ivs[i]) for i in np.asarray(idx).tolist()))
+
+    def align_finish(self, cols_list, scores, cells, fetch=True, names=None, want_xmfa=False):
+        assert all(c is not None for c in cols_list)
+        self.finished = {"cols": [np.asarray(c).tolist() for c in cols_list], "score": np.asarray(scores).tolist(), "cells": int(cells)}
+        return self.finished
+
+
+def _worker_align(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = parallel.align_sharded(_StandInContext(_intervals(seed=11, n=31)), None, dist)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_align_sharded_world2_gloo():
+    """align_sharded end to end with two ranks (begin, LPT split, one ragged all_gather of uint32 columns, finish):
+    every rank assembles the whole result, equal to the single-rank run."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_align, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ivs = _intervals(seed=11, n=31)
+    want = parallel.align_sharded(_StandInContext(ivs), None, None)
+    assert want["cells"] == sum(parallel.interval_cost(iv) for iv in ivs)
+    for rank, out in res:
+        assert out == want
+
+
 def test_lpt_partition_deterministic_and_balanced():
     costs = [5, 1, 9, 9, 2, 7, 3, 3, 0, 12]
     parts = parallel.lpt_partition(costs, 3)
