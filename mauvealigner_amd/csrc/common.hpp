@@ -235,7 +235,7 @@ struct mauve_ctx {
     PinnedBuf pin_seed;                  // seed pass: counter readback (first 64 B) and the candidates' match records
     // host scratch of dp_core, kept across calls (see AlignState)
     struct DpHost {
-        std::vector<int64_t> tb_off, rows_off, est, need, nmax, lst, lst2, seq_off;
+        std::vector<int64_t> tb_off, rows_off, est, need, nmax, lst, lst2, seq_off, tb_list;
         std::vector<uint8_t> is_big, cls;
     } dph;
     // host scratch of the seed pass (match records before the canonical sort)

@@ -577,18 +577,31 @@ __global__ void __launch_bounds__(256) dp_gather_codes(const uint64_t *__restric
     }
 }
 
-// the two DP launches: dp_step_big (workgroup per interval, second stream) beside dp_step (wave / sub-wave per interval)
-static int dp_launch_steps(mauve_ctx *ctx, int nseq, int64_t n_iv, int64_t n_big, const DpClasses &cl, uint32_t blocks,
-                           const int64_t *d_seq_off, const int64_t *d_tb_off, const int64_t *d_rows_off, const DpScoring &sc)
+// the two DP launches: dp_step_big (workgroup per interval, second stream) beside dp_step (wave / sub-wave per interval),
+// over the positions [a, b) of the launch list [workgroup | one wave | two per wave | four per wave]; tb_base is
+// subtracted from the traceback offsets (rounds, below)
+static int dp_launch_steps(mauve_ctx *ctx, int nseq, int64_t a, int64_t b, int64_t n_big, const DpClasses &full, const int64_t *d_seq_off,
+                           const int64_t *d_tb_off, const int64_t *d_rows_off, const DpScoring &sc, int64_t tb_base)
 {
-    KernelTimer t(ctx, MAUVE_K_DP, n_iv);
-    if (n_big) {   // the workgroup-per-interval launch runs beside the one-wave launch on a second stream
+    auto clip = [&](int64_t first, int64_t n, int64_t &f2, int64_t &n2) { f2 = std::max(first, a); n2 = std::max<int64_t>(0, std::min(first + n, b) - f2); };
+    int64_t bf, bn;
+    clip(0, n_big, bf, bn);
+    DpClasses cl; memset(&cl, 0, sizeof cl);
+    clip(full.first_med, full.n_med, cl.first_med, cl.n_med);
+    clip(full.first_s32, full.n_s32, cl.first_s32, cl.n_s32);
+    clip(full.first_s16, full.n_s16, cl.first_s16, cl.n_s16);
+    cl.blocks_med = (uint32_t)std::min<int64_t>((cl.n_med + 3) / 4, 256 * 8);
+    cl.blocks_s32 = (uint32_t)std::min<int64_t>((cl.n_s32 + 7) / 8, 256 * 8);
+    const uint32_t blocks = cl.blocks_med + cl.blocks_s32 + (uint32_t)std::min<int64_t>((cl.n_s16 + 15) / 16, 256 * 8);
+    uint8_t *tb = ctx->dp_tb.as<uint8_t>() - tb_base;                   // only offsets >= tb_base are used in this round
+    KernelTimer t(ctx, MAUVE_K_DP, b - a);
+    if (bn) {   // the workgroup-per-interval launch runs beside the one-wave launch on a second stream
         HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        hipLaunchKernelGGL(dp_step_big, dim3((uint32_t)n_big), dim3(64 * DP_MW_WAVES), 0, ctx->stream2, nseq,
-                           ctx->dp_list.as<int64_t>(), ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(),
+        hipLaunchKernelGGL(dp_step_big, dim3((uint32_t)bn), dim3(64 * DP_MW_WAVES), 0, ctx->stream2, nseq,
+                           ctx->dp_list.as<int64_t>() + bf, ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(),
                            ctx->dp_prof_cnt.as<uint32_t>(), ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
-                           ctx->dp_prof2_mask.as<uint32_t>(), ctx->dp_tb.as<uint8_t>(), d_tb_off, ctx->dp_rows.as<int32_t>(),
+                           ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(),
                            d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
         HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
     }
@@ -596,9 +609,38 @@ static int dp_launch_steps(mauve_ctx *ctx, int nseq, int64_t n_iv, int64_t n_big
         hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, nseq, ctx->dp_list.as<int64_t>(), cl,
                            ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
                            ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
-                           ctx->dp_prof2_mask.as<uint32_t>(), ctx->dp_tb.as<uint8_t>(), d_tb_off, ctx->dp_rows.as<int32_t>(),
+                           ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(),
                            d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
-    if (n_big) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    if (bn) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return MAUVE_OK;
+}
+
+// Traceback budget: the bytes are m x n per progressive step (1 B per cell), so a batch of long intervals -- a few
+// hundred gaps near max_gapped_len, or profiles of many genomes -- would ask for more than any allocation gives.
+// The launch list is cut into rounds whose traceback fits the budget (MAUVE_DP_TB_BUDGET bytes, default 8 GiB); the
+// rounds run one after the other over the same buffer.  tb_list: cumulative traceback bytes in LIST order (n + 1).
+static int64_t dp_tb_budget()
+{
+    static const int64_t b = getenv("MAUVE_DP_TB_BUDGET") ? atoll(getenv("MAUVE_DP_TB_BUDGET")) : (8LL << 30);
+    return std::max<int64_t>(b, 1 << 16);
+}
+static int dp_launch_rounds(mauve_ctx *ctx, int nseq, int64_t n_iv, int64_t n_big, const DpClasses &cl, const int64_t *d_seq_off,
+                            const int64_t *d_tb_off, const int64_t *d_rows_off, const DpScoring &sc, const int64_t *tb_list, int *rounds_out)
+{
+    const int64_t budget = dp_tb_budget();
+    int rounds = 0;
+    for (int64_t a = 0; a < n_iv;) {
+        int64_t b = a + 1;
+        if (tb_list) {
+            if (tb_list[a + 1] - tb_list[a] > budget) { ctx->err = "dp: one interval needs more traceback than MAUVE_DP_TB_BUDGET allows"; return MAUVE_ERR_LIMIT; }
+            while (b < n_iv && tb_list[b + 1] - tb_list[a] <= budget) b++;
+        } else b = n_iv;
+        int rc = dp_launch_steps(ctx, nseq, a, b, n_big, cl, d_seq_off, d_tb_off, d_rows_off, sc, tb_list ? tb_list[a] : 0);
+        if (rc) return rc;
+        rounds++;
+        a = b;
+    }
+    if (rounds_out) *rounds_out = rounds;
     return MAUVE_OK;
 }
 
@@ -656,13 +698,54 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     }
     tb_off[n_iv] = tbt; rows_off[n_iv] = rwt;
 
+    DpScoring sc; sc.go = scoring->gap_open; sc.ge = scoring->gap_extend; memcpy(sc.s, scoring->matrix, sizeof sc.s);
+    // longest intervals first: one wave per interval, so the tail of the launch is its longest interval
+    std::vector<int64_t> &lst = H.lst; lst.resize((size_t)n_iv);
+    {   // counting sort by size class (log2 of the traceback footprint), largest class first
+        int64_t cnt[66] = {0};
+        auto cls = [&](int64_t iv) { int64_t f = need_v[(size_t)iv]; int c = 0; while (f > 1) { f >>= 1; c++; } return 63 - c; };
+        for (int64_t iv = 0; iv < n_iv; iv++) cnt[cls(iv) + 1]++;
+        for (int c = 0; c < 65; c++) cnt[c + 1] += cnt[c];
+        for (int64_t iv = 0; iv < n_iv; iv++) lst[(size_t)cnt[cls(iv)]++] = iv;
+    }
+    // workgroup-per-interval entries first (still largest first), one-wave entries after them
+    // A 16-wave workgroup fills a CU, so it only pays for the tail: intervals well above what a balanced one-wave
+    // schedule (3072 resident waves) would take, and at most half the CUs' worth of them.
+    int64_t n_big = 0;
+    {
+        const int64_t balanced = est_total / 3072;
+        for (int64_t k = 0; k < n_iv; k++) {          // lst is largest first
+            uint8_t &b = is_big[(size_t)lst[(size_t)k]];
+            if (b && (n_big >= 128 || est[(size_t)lst[(size_t)k]] <= 4 * balanced)) b = 0;
+            n_big += b;
+        }
+    }
+    // list = [workgroup path | one wave | two per wave | four per wave], each class still largest first
+    DpClasses cl; memset(&cl, 0, sizeof cl);
+    {
+        std::vector<int64_t> &tmp = H.lst2; tmp.resize((size_t)n_iv);
+        int64_t cnt4[4] = {0, 0, 0, 0};
+        auto klass = [&](int64_t iv) { return is_big[(size_t)iv] ? 0 : (int)cls[(size_t)iv]; };
+        for (int64_t k = 0; k < n_iv; k++) cnt4[klass(lst[(size_t)k])]++;
+        int64_t pos[4] = {0, cnt4[0], cnt4[0] + cnt4[1], cnt4[0] + cnt4[1] + cnt4[2]};
+        cl.first_med = pos[1]; cl.n_med = cnt4[1]; cl.first_s32 = pos[2]; cl.n_s32 = cnt4[2]; cl.first_s16 = pos[3]; cl.n_s16 = cnt4[3];
+        for (int64_t k = 0; k < n_iv; k++) { const int64_t iv = lst[(size_t)k]; tmp[(size_t)pos[klass(iv)]++] = iv; }
+        lst.swap(tmp);
+    }
+    // traceback offsets follow the launch list, so that a round of the list uses one contiguous piece of the buffer
+    std::vector<int64_t> &tb_list = H.tb_list; tb_list.resize((size_t)n_iv + 1);
+    tbt = 0;
+    for (int64_t k = 0; k < n_iv; k++) { const int64_t iv = lst[(size_t)k]; tb_off[iv] = tbt; tb_list[(size_t)k] = tbt; tbt += need_v[(size_t)iv]; }
+    tb_list[(size_t)n_iv] = tbt; tb_off[n_iv] = tbt;
+    const bool one_round = tbt <= dp_tb_budget();
+
     HIPCHK(ctx, ctx->dp_codes.ensure((size_t)total + 16));
     HIPCHK(ctx, ctx->dp_off.ensure((size_t)(n_iv * nseq + 1 + 3 * (n_iv + 1)) * sizeof(int64_t)));
     HIPCHK(ctx, ctx->dp_prof_cnt.ensure((size_t)(total + 1) * 4));
     HIPCHK(ctx, ctx->dp_prof_mask.ensure((size_t)(total + 1) * 4));
     HIPCHK(ctx, ctx->dp_prof2_cnt.ensure((size_t)(total + 1) * 4));
     HIPCHK(ctx, ctx->dp_prof2_mask.ensure((size_t)(total + 1) * 4));
-    HIPCHK(ctx, ctx->dp_tb.ensure((size_t)tbt + 64));
+    HIPCHK(ctx, ctx->dp_tb.ensure((size_t)std::min<int64_t>(tbt, dp_tb_budget()) + 64));
     HIPCHK(ctx, ctx->dp_rows.ensure((size_t)(rwt + 1) * 4));
     HIPCHK(ctx, ctx->dp_meta.ensure((size_t)n_iv * sizeof(DpMeta)));
     HIPCHK(ctx, ctx->dp_score.ensure((size_t)total + 16));           // reversed-ops scratch
@@ -696,49 +779,12 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
         HIPCHK(ctx, hipMemcpyAsync(ctx->dp_codes.p, codes, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
     }
     const double td1 = now_ms();
-    DpScoring sc; sc.go = scoring->gap_open; sc.ge = scoring->gap_extend; memcpy(sc.s, scoring->matrix, sizeof sc.s);
-    // longest intervals first: one wave per interval, so the tail of the launch is its longest interval
-    std::vector<int64_t> &lst = H.lst; lst.resize((size_t)n_iv);
-    {   // counting sort by size class (log2 of the traceback footprint), largest class first
-        int64_t cnt[66] = {0};
-        auto cls = [&](int64_t iv) { int64_t f = tb_off[iv + 1] - tb_off[iv]; int c = 0; while (f > 1) { f >>= 1; c++; } return 63 - c; };
-        for (int64_t iv = 0; iv < n_iv; iv++) cnt[cls(iv) + 1]++;
-        for (int c = 0; c < 65; c++) cnt[c + 1] += cnt[c];
-        for (int64_t iv = 0; iv < n_iv; iv++) lst[(size_t)cnt[cls(iv)]++] = iv;
-    }
-    // workgroup-per-interval entries first (still largest first), one-wave entries after them
-    // A 16-wave workgroup fills a CU, so it only pays for the tail: intervals well above what a balanced one-wave
-    // schedule (3072 resident waves) would take, and at most half the CUs' worth of them.
-    int64_t n_big = 0;
-    {
-        const int64_t balanced = est_total / 3072;
-        for (int64_t k = 0; k < n_iv; k++) {          // lst is largest first
-            uint8_t &b = is_big[(size_t)lst[(size_t)k]];
-            if (b && (n_big >= 128 || est[(size_t)lst[(size_t)k]] <= 4 * balanced)) b = 0;
-            n_big += b;
-        }
-    }
-    // list = [workgroup path | one wave | two per wave | four per wave], each class still largest first
-    DpClasses cl; memset(&cl, 0, sizeof cl);
-    {
-        std::vector<int64_t> &tmp = H.lst2; tmp.resize((size_t)n_iv);
-        int64_t cnt4[4] = {0, 0, 0, 0};
-        auto klass = [&](int64_t iv) { return is_big[(size_t)iv] ? 0 : (int)cls[(size_t)iv]; };
-        for (int64_t k = 0; k < n_iv; k++) cnt4[klass(lst[(size_t)k])]++;
-        int64_t pos[4] = {0, cnt4[0], cnt4[0] + cnt4[1], cnt4[0] + cnt4[1] + cnt4[2]};
-        cl.first_med = pos[1]; cl.n_med = cnt4[1]; cl.first_s32 = pos[2]; cl.n_s32 = cnt4[2]; cl.first_s16 = pos[3]; cl.n_s16 = cnt4[3];
-        for (int64_t k = 0; k < n_iv; k++) { const int64_t iv = lst[(size_t)k]; tmp[(size_t)pos[klass(iv)]++] = iv; }
-        lst.swap(tmp);
-    }
-    cl.blocks_med = (uint32_t)std::min<int64_t>((cl.n_med + 3) / 4, 256 * 8);
-    cl.blocks_s32 = (uint32_t)std::min<int64_t>((cl.n_s32 + 7) / 8, 256 * 8);
-    const uint32_t blocks_s16 = (uint32_t)std::min<int64_t>((cl.n_s16 + 15) / 16, 256 * 8);
-    const uint32_t blocks = cl.blocks_med + cl.blocks_s32 + blocks_s16;
     HIPCHK(ctx, ctx->dp_list.ensure((size_t)n_iv * 8));
     int64_t *pin_list = pin_off + n_so + 2 * n_o;               // the fourth slot of the offsets block
     memcpy(pin_list, lst.data(), (size_t)n_iv * 8);
     HIPCHK(ctx, hipMemcpyAsync(ctx->dp_list.p, pin_list, (size_t)n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
-    { int rcl = dp_launch_steps(ctx, nseq, n_iv, n_big, cl, blocks, d_seq_off, d_tb_off, d_rows_off, sc); if (rcl) return rcl; }
+    int rounds = 1;
+    { int rcl = dp_launch_rounds(ctx, nseq, n_iv, n_big, cl, d_seq_off, d_tb_off, d_rows_off, sc, one_round ? nullptr : tb_list.data(), &rounds); if (rcl) return rcl; }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // host work while the DP kernels run
     HIPCHK(ctx, ctx->pin_meta.ensure((size_t)n_iv * sizeof(DpMeta)));
@@ -766,7 +812,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     }
     if (trace) {
         std::vector<int64_t> e2(est); std::sort(e2.begin(), e2.end(), std::greater<int64_t>());
-        fprintf(stderr, "[trace] dp_core: %lld intervals: %lld workgroup, %lld one-wave, %lld two/wave, %lld four/wave; single-wave steps: total %lld (balanced %lld), top", (long long)n_iv,
+        fprintf(stderr, "[trace] dp_core: %d round(s); %lld intervals: %lld workgroup, %lld one-wave, %lld two/wave, %lld four/wave; single-wave steps: total %lld (balanced %lld), top", rounds, (long long)n_iv,
                 (long long)n_big, (long long)cl.n_med, (long long)cl.n_s32, (long long)cl.n_s16, (long long)est_total, (long long)(est_total / 3072));
         for (size_t i = 0; i < e2.size() && i < 8; i++) fprintf(stderr, " %lld", (long long)e2[i]);
         fprintf(stderr, "\n");
@@ -867,6 +913,13 @@ __global__ void __launch_bounds__(256) dpf_desc(const int32_t *__restrict__ alen
 }
 struct DescLen { const DpSeqDesc *d; __device__ int64_t value(uint32_t i) const { return d[i].len; } };
 struct ArrVal { const int64_t *a; __device__ int64_t value(uint32_t i) const { return a[i]; } };
+struct ListVal { const int64_t *a; const uint32_t *order; __device__ int64_t value(uint32_t j) const { return a[order[j]]; } };
+// traceback offsets follow the launch list: tb_off[slot at list position j] = cumulative bytes before j
+__global__ void __launch_bounds__(256) dpf_tb_scatter(const int64_t *__restrict__ tb_list, const uint32_t *__restrict__ order, uint32_t n, int64_t *__restrict__ tb_off)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j < n) tb_off[order[j]] = tb_list[j];
+}
 
 // workgroup-pipeline entries: candidates well above a balanced one-wave share, the first 128 of them in size order
 struct DpBigPick {
@@ -967,8 +1020,6 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     const uint32_t nbd = (n_dp + TILE - 1) / TILE, nbs = (n_dp * (uint32_t)N + TILE - 1) / TILE, blk_d = (n_dp + 255) / 256;
     hipLaunchKernelGGL((vscan_partial<int64_t, DescLen>), dim3(nbs), dim3(256), 0, ctx->stream, DescLen{desc}, n_dp * (uint32_t)N, bsum);
     hipLaunchKernelGGL((vscan_write<int64_t, DescLen>), dim3(nbs), dim3(256), 0, ctx->stream, DescLen{desc}, n_dp * (uint32_t)N, bsum, d_seq_off, &tot->codes);
-    hipLaunchKernelGGL((vscan_partial<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{need}, n_dp, bsum2);
-    hipLaunchKernelGGL((vscan_write<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{need}, n_dp, bsum2, d_tb_off, &tot->tb);
     hipLaunchKernelGGL((vscan_partial<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{rowsn}, n_dp, bsum);
     hipLaunchKernelGGL((vscan_write<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{rowsn}, n_dp, bsum, d_rows_off, &tot->rows);
     hipLaunchKernelGGL((vscan_partial<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{est}, n_dp, bsum2);
@@ -985,6 +1036,11 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     rc = sort_pairs_u32(ctx, n_dp, 2, &ck, &cv, k3, fv, MAUVE_K_MISC);
     if (rc) return rc;
     hipLaunchKernelGGL(dpf_list, dim3(blk_d), dim3(256), 0, ctx->stream, ck, cv, tot, ctx->dp_list.as<int64_t>());
+    // traceback offsets in list order (a round of the list then uses one contiguous piece of the buffer)
+    int64_t *tb_list_dev = d_col_off;                                   // scratch until the results need it
+    hipLaunchKernelGGL((vscan_partial<int64_t, ListVal>), dim3(nbd), dim3(256), 0, ctx->stream, ListVal{need, cv}, n_dp, bsum2);
+    hipLaunchKernelGGL((vscan_write<int64_t, ListVal>), dim3(nbd), dim3(256), 0, ctx->stream, ListVal{need, cv}, n_dp, bsum2, tb_list_dev, &tot->tb);
+    hipLaunchKernelGGL(dpf_tb_scatter, dim3(blk_d), dim3(256), 0, ctx->stream, tb_list_dev, cv, n_dp, d_tb_off);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(ht, tot, sizeof(DpFrontTotals), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -997,18 +1053,21 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     cl.first_s16 = ht->first_s16; cl.n_s16 = (int64_t)n_dp - ht->first_s16;
     cl.blocks_med = (uint32_t)std::min<int64_t>((cl.n_med + 3) / 4, 256 * 8);
     cl.blocks_s32 = (uint32_t)std::min<int64_t>((cl.n_s32 + 7) / 8, 256 * 8);
-    const uint32_t blocks_s16 = (uint32_t)std::min<int64_t>((cl.n_s16 + 15) / 16, 256 * 8);
-    const uint32_t dpblocks = cl.blocks_med + cl.blocks_s32 + blocks_s16;
     const double t2 = now_ms();
     HIPCHK(ctx, ctx->dp_codes.ensure((size_t)total + 16));
     HIPCHK(ctx, ctx->dp_prof_cnt.ensure((size_t)(total + 1) * 4));
     HIPCHK(ctx, ctx->dp_prof_mask.ensure((size_t)(total + 1) * 4));
     HIPCHK(ctx, ctx->dp_prof2_cnt.ensure((size_t)(total + 1) * 4));
     HIPCHK(ctx, ctx->dp_prof2_mask.ensure((size_t)(total + 1) * 4));
-    HIPCHK(ctx, ctx->dp_tb.ensure((size_t)tbt + 64));
+    HIPCHK(ctx, ctx->dp_tb.ensure((size_t)std::min<int64_t>(tbt, dp_tb_budget()) + 64));
     HIPCHK(ctx, ctx->dp_rows.ensure((size_t)(rwt + 1) * 4));
     HIPCHK(ctx, ctx->dp_score.ensure((size_t)total + 16));           // reversed-ops scratch
     HIPCHK(ctx, ctx->dp_cols.ensure((size_t)(total + 1) * 4));
+    std::vector<int64_t> &tb_list = ctx->dph.tb_list; tb_list.clear();
+    if (tbt > dp_tb_budget()) {                                         // several rounds: the host needs the cumulative bytes to cut them
+        tb_list.resize((size_t)n_dp + 1);
+        HIPCHK(ctx, hipMemcpy(tb_list.data(), tb_list_dev, ((size_t)n_dp + 1) * 8, hipMemcpyDeviceToHost));
+    }
     {
         DpGenomeWords gw; memset(&gw, 0, sizeof gw);
         for (int g = 0; g < ctx->nseq; g++) gw.word_off[g] = ctx->word_off[g];
@@ -1018,7 +1077,8 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
                            ctx->dp_codes.as<uint8_t>());
     }
     DpScoring sc; sc.go = scoring->gap_open; sc.ge = scoring->gap_extend; memcpy(sc.s, scoring->matrix, sizeof sc.s);
-    rc = dp_launch_steps(ctx, N, n_dp, n_big, cl, dpblocks, d_seq_off, d_tb_off, d_rows_off, sc);
+    int rounds = 1;
+    rc = dp_launch_rounds(ctx, N, n_dp, n_big, cl, d_seq_off, d_tb_off, d_rows_off, sc, tb_list.empty() ? nullptr : tb_list.data(), &rounds);
     if (rc) return rc;
     // results: column offsets, scores and the cell count by scans over the per-interval records; the columns compacted
     const DpMeta *meta = ctx->dp_meta.as<DpMeta>();
@@ -1052,8 +1112,8 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
         HIPCHK(ctx, hipMemcpyAsync(dcols->p, ctx->dp_cols.p, (size_t)tc * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    if (trace) fprintf(stderr, "[trace] dp (device front): %u intervals (%lld workgroup, %lld one-wave, %lld two/wave, %lld four/wave); gaps+slots %.3f ms, sizing+order %.3f, kernels+offsets %.3f, columns %.3f\n",
-                       n_dp, (long long)n_big, (long long)cl.n_med, (long long)cl.n_s32, (long long)cl.n_s16, t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
+    if (trace) fprintf(stderr, "[trace] dp (device front): %u intervals (%lld workgroup, %lld one-wave, %lld two/wave, %lld four/wave), %d round(s); gaps+slots %.3f ms, sizing+order %.3f, kernels+offsets %.3f, columns %.3f\n",
+                       n_dp, (long long)n_big, (long long)cl.n_med, (long long)cl.n_s32, (long long)cl.n_s16, rounds, t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
     return MAUVE_OK;
 }
 

@@ -137,6 +137,46 @@ def test_dp_subwave_groups(ctx):
     _check_dp(ctx, many)
 
 
+ROUNDS_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from mauvealigner_amd import _lib, synth
+from oracle import pyoracle as O
+rng = np.random.default_rng(8)
+ivs = []
+for k in range(40):                      # long, ragged intervals: 40 x (300 .. 900)^2 cells of traceback
+    base = rng.integers(0, 4, int(rng.integers(300, 900)), dtype=np.uint8)
+    ivs.append([synth.mutate(base, 0.1, rng, indel_frac=0.3) for _ in range(3)])
+ctx = _lib.Context(0)
+cols, score = ctx.dp_batch(ivs)
+for iv, c, s in zip(ivs, cols, score):
+    ec, es = O.align_interval(iv)
+    assert np.array_equal(c, ec) and int(s) == es
+gs = synth.make_config("C3", scale=0.02)
+ctx.set_genomes(gs)
+r = ctx.align(_lib.default_params())
+e = O.align(gs, O.default_params())["aln"]
+for k in ("cols", "col_off", "dp_score", "anchor_start"):
+    assert np.array_equal(r[k], e[k]), k
+print("OK")
+"""
+
+
+def test_dp_rounds_under_a_traceback_budget():
+    """A batch whose traceback exceeds the budget runs in rounds over one buffer (both front ends: mauve_dp_batch and
+    mauve_align), with the same results; one interval beyond the budget is refused with MAUVE_ERR_LIMIT."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MAUVE_DP_TB_BUDGET=str(3 << 20), MAUVE_TRACE="1")
+    r = subprocess.run([sys.executable, "-c", ROUNDS_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr[-3000:]
+    rounds = [int(l.split(" round(s)")[0].rsplit(" ", 1)[1]) for l in r.stderr.splitlines() if " round(s)" in l]
+    assert rounds and max(rounds) > 1, r.stderr[-2000:]
+    env["MAUVE_DP_TB_BUDGET"] = str(1 << 16)
+    r = subprocess.run([sys.executable, "-c", ROUNDS_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "(-4)" in r.stderr and "MAUVE_DP_TB_BUDGET" in r.stderr
+
+
 def test_lcb_extension(ctx):
     """S10 (lcb_extension): masked re-search of the regions outside every LCB with lighter seeds; bit-exact against
     the oracle, and it only ever adds anchored columns."""
