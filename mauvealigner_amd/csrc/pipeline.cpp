@@ -13,7 +13,7 @@
 
 namespace {
 
-inline uint8_t base_at(const std::vector<uint64_t> &w, int64_t i) { return (uint8_t)((w[(size_t)(i >> 5)] >> (2 * (i & 31))) & 3); }
+inline uint8_t base_at(const uint64_t *w, int64_t i) { return (uint8_t)((w[(size_t)(i >> 5)] >> (2 * (i & 31))) & 3); }
 
 // inter-anchor interval of genome g between anchors a (left in genome-0 order) and b, LCB orientation
 inline void gap_of(const int64_t *a, const int64_t *b, int g, int64_t &lo, int64_t &len, bool &rev)
@@ -691,7 +691,7 @@ int mauve_write_xmfa(mauve_ctx *c, const char *const *names, char *buf, int64_t 
             const bool rev = R.iv_reverse[(size_t)iv * N + g] != 0;
             int64_t nxt = rev ? re : le;
             row.resize((size_t)nc);
-            const auto &w = c->host_packed[g];
+            const uint64_t *w = c->host_packed[(size_t)g];
             for (int64_t k = 0; k < nc; k++) {
                 if (R.cols[(size_t)(c0 + k)] >> g & 1) {
                     uint8_t b = base_at(w, nxt - 1);

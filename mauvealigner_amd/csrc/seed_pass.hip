@@ -12,6 +12,7 @@
 // All kernels are HBM-bound integer work: coalesced 4/8-byte streams, LDS staging for
 // the scatter, wave64 ballots for ranking and for the extension walk.  No MFMA by design.
 #include "common.hpp"
+#include "dev_scan.hpp"
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -767,6 +768,62 @@ __global__ void __launch_bounds__(256) join_pair(const uint32_t *__restrict__ va
 }
 
 // ------------------------------------------------------------------------------------------------
+// SeedMatchEnumerator on the device (SeedMatchEnumerator.h:59-141): the sorted mer list of ONE sequence is cut into
+// runs of identical mers; a run of m occurrences, min_multi <= m <= max_multi, becomes one match of m components in
+// position order (the stable sort keeps them so), 1-based, a component negative when its strand flag differs from
+// the first component's (SetDirection, :127-141); with direct_only a run that has reverse components keeps only the
+// forward ones, if two or more remain (:88-117).  Output CSR: mult[r], start_off[r], starts[].
+//   enum_runs  : the head of every run walks it and notes how many starts it will emit (0: no match)
+//   vscan_*    : start offsets; cmp_* (EnumRuns): the emitting runs in list order -> mult / start_off
+//   enum_write : the heads walk again and write the starts
+// ------------------------------------------------------------------------------------------------
+template <typename KeyT>
+__global__ void __launch_bounds__(256) enum_runs(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t n, int64_t min_multi,
+                                                 int64_t max_multi, int direct_only, uint32_t *__restrict__ emit)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const KeyT k = keys[i];
+    uint32_t e = 0;
+    if (i == 0 || keys[i - 1] != k) {
+        const uint32_t ref = vals[i] >> 31;
+        uint32_t j = i, kept = 0; bool found_rev = false;
+        while (j < n && keys[j] == k) { if ((vals[j] >> 31) != ref) found_rev = true; else kept++; j++; }
+        const int64_t m = (int64_t)(j - i);
+        if (m >= 2 && m >= min_multi && m <= max_multi) e = (direct_only && found_rev) ? (kept > 1 ? kept : 0u) : (uint32_t)m;
+    }
+    emit[i] = e;
+}
+struct EmitVal { const uint32_t *e; __device__ int64_t value(uint32_t i) const { return e[i]; } };
+struct EnumRuns {
+    const uint32_t *cnt; const int64_t *soff; uint32_t n; int64_t *mult, *start_off; int64_t *tot /* [0] runs, [1] starts */;
+    __device__ uint32_t domain(int) const { return n; }
+    __device__ bool flag(uint32_t i, int) const { return cnt[i] != 0; }
+    __device__ void each(uint32_t, uint32_t, bool, int) const {}
+    __device__ void emit(uint32_t i, uint32_t r, int) const { mult[r] = cnt[i]; start_off[r] = soff[i]; }
+    __device__ void total(uint32_t runs, int) const { tot[0] = runs; start_off[runs] = soff[n]; }
+};
+template <typename KeyT>
+__global__ void __launch_bounds__(256) enum_write(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t n, int direct_only,
+                                                  const uint32_t *__restrict__ emit, const int64_t *__restrict__ soff, uint32_t gpos0,
+                                                  int64_t *__restrict__ starts)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n || emit[i] == 0) return;
+    const KeyT k = keys[i];
+    const uint32_t ref = vals[i] >> 31;
+    uint32_t j = i; bool found_rev = false;
+    while (j < n && keys[j] == k) { if ((vals[j] >> 31) != ref) found_rev = true; j++; }
+    int64_t o = soff[i];
+    for (uint32_t t = i; t < j; t++) {
+        const bool rv = (vals[t] >> 31) != ref;
+        const int64_t p1 = (int64_t)((vals[t] & 0x7fffffffu) - gpos0) + 1;
+        if (direct_only && found_rev) { if (!rv) starts[o++] = p1; }
+        else starts[o++] = rv ? -p1 : p1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // extension.  A hit fixes a generalized diagonal: component c moves +k (same strand as the
 // anchor) or -k (opposite strand) when the anchor moves +k.  Offset k "agrees" when the masked windows of
 // all components are equal there.  Agreeing offsets at most `span` apart chain into a cluster; the match
@@ -1147,7 +1204,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     // slices join_hash hands back.  MAUVE_OLD_JOIN forces the second (A/B switch).
     static const bool force_old_join = getenv("MAUVE_OLD_JOIN") != nullptr;
     const HostHits *hh = ctx->host_hits;                      // mauve_extend_hits: the hits come from the host, no sort, no join
-    const bool hash_path = !hh && mode != MAUVE_MODE_PAIRWISE && !out_keys && only_seq < 0 && !force_old_join && !(masked && SEG);
+    const bool hash_path = !hh && mode != MAUVE_MODE_PAIRWISE && !out_keys && !ctx->enum_req && only_seq < 0 && !force_old_join && !(masked && SEG);
     // segmented keys: segment id above the mer; ids 0 .. nseg-1, the all-ones id is left to the invalid (all-ones) key
     int segbits = 0;
     if (SEG) while (segbits < 32 && (1ull << segbits) <= (uint64_t)nseg) segbits++;
@@ -1219,7 +1276,39 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     if (rc) return rc;
     TRACE(ctx, "sort");
 
-    if (out_keys) {   // sorted-mer-list export / SeedMatchEnumerator path: hand the sorted pairs to the host
+    if (ctx->enum_req) {   // SeedMatchEnumerator: runs -> matches on the device, only the CSR result goes to the host
+        EnumRequest &q = *ctx->enum_req;
+        using namespace devscan;
+        const uint32_t nb = (sorted_n + TILE - 1) / TILE, blocks = (sorted_n + 255) / 256;
+        HIPCHK(ctx, ctx->run_sum.ensure((size_t)sorted_n * 4 + 64 + ((size_t)sorted_n + 2) * 8 * 3 + (size_t)nb * 16 + 256));
+        uint32_t *emit = ctx->run_sum.as<uint32_t>();
+        int64_t *soff = reinterpret_cast<int64_t *>(ctx->run_sum.as<char>() + (((size_t)sorted_n * 4 + 63) & ~(size_t)63));
+        int64_t *d_mult = soff + sorted_n + 2, *d_off = d_mult + sorted_n + 2, *bsum = d_off + sorted_n + 2, *tot = bsum + nb + 2;
+        uint32_t *bcnt = reinterpret_cast<uint32_t *>(tot + 4);
+        hipLaunchKernelGGL((enum_runs<KeyT>), dim3(blocks), dim3(256), 0, ctx->stream, keys, vals, sorted_n, q.min_multi, q.max_multi, q.direct_only, emit);
+        hipLaunchKernelGGL((vscan_partial<int64_t, EmitVal>), dim3(nb), dim3(256), 0, ctx->stream, EmitVal{emit}, sorted_n, bsum);
+        hipLaunchKernelGGL((vscan_write<int64_t, EmitVal>), dim3(nb), dim3(256), 0, ctx->stream, EmitVal{emit}, sorted_n, bsum, soff, tot + 1);
+        const EnumRuns er{emit, soff, sorted_n, d_mult, d_off, tot};
+        hipLaunchKernelGGL((cmp_count<EnumRuns>), dim3(nb), dim3(256), 0, ctx->stream, er, bcnt);
+        hipLaunchKernelGGL((cmp_write<EnumRuns>), dim3(nb), dim3(256), 0, ctx->stream, er, bcnt);
+        HIPCHK(ctx, hipGetLastError());
+        int64_t ht[2] = {0, 0};
+        HIPCHK(ctx, hipMemcpyAsync(ht, tot, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        q.n = ht[0]; q.ns = ht[1];
+        if (q.starts) {
+            HIPCHK(ctx, ctx->sorted_rec.ensure(((size_t)q.ns + 1) * 8));
+            hipLaunchKernelGGL((enum_write<KeyT>), dim3(blocks), dim3(256), 0, ctx->stream, keys, vals, sorted_n, q.direct_only, emit, soff,
+                               tab.gpos_off[only_seq], ctx->sorted_rec.as<int64_t>());
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemcpyAsync(q.mult, d_mult, (size_t)q.n * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(q.start_off, d_off, ((size_t)q.n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(q.starts, ctx->sorted_rec.p, (size_t)q.ns * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return MAUVE_OK;
+    }
+    if (out_keys) {   // sorted-mer-list export: hand the sorted pairs to the host
         std::vector<KeyT> hk(sorted_n);
         out_vals->resize(sorted_n);
         HIPCHK(ctx, hipMemcpyAsync(hk.data(), keys, (size_t)sorted_n * sizeof(KeyT), hipMemcpyDeviceToHost, ctx->stream));
@@ -1550,6 +1639,24 @@ int seedpass_from_hits(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, co
     ctx->host_hits = &hits;
     rc = seedpass_impl<uint32_t, false>(ctx, gs, sh, tab, total, MAUVE_MODE_MEM, 0, extend, -1, nullptr, 0, n_matches, nullptr, nullptr);
     ctx->host_hits = nullptr;
+    return rc;
+}
+
+// SeedMatchEnumerator::FindMatches of sequence `seq` on the device; q carries the rule in and the CSR result out
+int seedpass_enumerate(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t pattern, EnumRequest &q)
+{
+    SeedShape sh;
+    if (!make_seed_shape(pattern, &sh)) { ctx->err = "seed pattern must be palindromic, span <= 49, weight <= 31"; return MAUVE_ERR_ARG; }
+    if (seq < 0 || seq >= gs.nseq) { ctx->err = "sequence index out of range"; return MAUVE_ERR_ARG; }
+    GenomeTab tab; int64_t total = 0;
+    int rc = build_tab(ctx, gs, sh.span, &tab, &total);
+    if (rc) return rc;
+    q.n = 0; q.ns = 0;
+    if (tab.nwin[seq] == 0) { if (q.start_off) q.start_off[0] = 0; return MAUVE_OK; }
+    ctx->enum_req = &q;
+    if (2 * sh.weight <= 32) rc = seedpass_impl<uint32_t, false>(ctx, gs, sh, tab, total, 0, 0, 0, seq, nullptr, 0, nullptr, nullptr, nullptr);
+    else rc = seedpass_impl<uint64_t, false>(ctx, gs, sh, tab, total, 0, 0, 0, seq, nullptr, 0, nullptr, nullptr, nullptr);
+    ctx->enum_req = nullptr;
     return rc;
 }
 
