@@ -116,6 +116,8 @@ public:
     void SetMinRecursionGapLength(gnSeqI n) { p_.min_recursive_gap = (int64_t)n; }     // :670-672
     void SetGappedAligner(GappedAligner &ga) { gal_ = &ga; }                            // :674
     void SetMaxGappedAlignmentLength(gnSeqI n) { p_.max_gapped_len = (int64_t)n; }     // :675-676
+    // no reference counterpart: gaps above the limit and up to n go through the banded DP instead of staying unaligned
+    void SetMaxBandedAlignmentLength(gnSeqI n) { p_.max_banded_len = (int64_t)n; }
     void SetMaxExtensionIterations(uint n) { p_.max_extension_iters = (int32_t)n; }      // :687-690 (LCB extension)
     void SetSeedPattern(int64 seed) { p_.seed_pattern = (uint64_t)seed; }
     void SetScoring(const PairwiseScoringScheme &pss)

@@ -63,6 +63,9 @@ typedef struct {
     int64_t min_recursive_gap;    /* Aligner::SetMinRecursionGapLength, default 200 (:670-672,899) */
     int64_t max_gapped_len;       /* Aligner::SetMaxGappedAlignmentLength (:674-676), default 10000 */
     mauve_scoring scoring;
+    int64_t max_banded_len;       /* no reference counterpart (its aligner leaves intervals above max_gapped_len unaligned): intervals
+                                     whose longest sequence is in (max_gapped_len, max_banded_len] are aligned by the banded DP
+                                     (DESIGN.md S7b); default 0 = off */
 } mauve_params;
 
 /* sizes of the result of mauve_align(), for the caller to allocate the fill buffers */
@@ -164,6 +167,12 @@ int mauve_lcb_chain(int nseq, int64_t n, const int64_t *length, const int64_t *s
 int mauve_dp_batch(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
                    const int64_t *seq_off, const mauve_scoring *sc, uint32_t *cols,
                    int64_t *col_off, int64_t *score);
+/* The same seam for long intervals (GappedAligner::SetMaxAlignmentLength, GappedAligner.h: the reference's aligners
+   refuse what is longer; this one bands it): an interval whose longest sequence is above band_from runs every
+   progressive step inside the band |j - floor(i*n/m)| <= 128 + |n-m| + (m+n)/64; the others in full. */
+int mauve_dp_batch_banded(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
+                          const int64_t *seq_off, const mauve_scoring *sc, int64_t band_from,
+                          uint32_t *cols, int64_t *col_off, int64_t *score);
 
 /* ---- whole path: doAlignment's hot section (mauveAligner.cpp:523-531,585,629-698,746-760):
         multi-MUMs -> N-way filter -> overlap elimination -> LCBs -> recursive anchoring -> gapped

@@ -23,7 +23,7 @@ EXPORTS = [
     "mauve_default_params", "mauve_packed_words", "mauve_pack_ascii", "mauve_pack_codes", "mauve_set_genomes", "mauve_set_genomes_contigs",
     "mauve_ambiguity_bitmap",
     "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_extend_hits", "mauve_seed_match_enumerate",
-    "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_align", "mauve_align_fetch",
+    "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_dp_batch_banded", "mauve_align", "mauve_align_fetch",
     "mauve_align_matches", "mauve_align_begin", "mauve_align_begin_matches", "mauve_align_dp_anchors", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
     "mauve_guide_tree", "mauve_progressive_align",
     "mauve_write_xmfa", "mauve_profile_enable", "mauve_profile_reset", "mauve_profile_get", "mauve_last_stage_times",
@@ -39,7 +39,8 @@ class Params(C.Structure):
                 ("mode", C.c_int32), ("lcb_weight", C.c_int64), ("collinear", C.c_int32),
                 ("recursive", C.c_int32), ("gapped", C.c_int32), ("add_unaligned", C.c_int32),
                 ("extend_lcbs", C.c_int32), ("max_extension_iters", C.c_int32),
-                ("min_recursive_gap", C.c_int64), ("max_gapped_len", C.c_int64), ("scoring", Scoring)]
+                ("min_recursive_gap", C.c_int64), ("max_gapped_len", C.c_int64), ("scoring", Scoring),
+                ("max_banded_len", C.c_int64)]
 
 
 class AlignSizes(C.Structure):
@@ -295,8 +296,9 @@ class Context:
                                                     _p(st, C.c_int64)), "seed_match_enumerate")
         return mult, off, st
 
-    def dp_batch(self, intervals, scoring=None):
-        """intervals: list of lists of code arrays (nseq each).  -> (cols list, scores)"""
+    def dp_batch(self, intervals, scoring=None, band_from=None):
+        """intervals: list of lists of code arrays (nseq each).  -> (cols list, scores).  band_from: intervals whose
+        longest sequence is above it run the banded DP (mauve_dp_batch_banded)."""
         sc = scoring or default_scoring()
         n_iv = len(intervals)
         nseq = len(intervals[0]) if n_iv else 1
@@ -312,9 +314,14 @@ class Context:
         cols = np.zeros(max(int(off[-1]), 1), np.uint32)
         col_off = np.zeros(n_iv + 1, np.int64)
         score = np.zeros(max(n_iv, 1), np.int64)
-        self._chk(self.L.mauve_dp_batch(self.h, nseq, C.c_int64(n_iv), _p(codes, C.c_uint8), _p(off, C.c_int64),
-                                        C.byref(sc), _p(cols, C.c_uint32), _p(col_off, C.c_int64), _p(score, C.c_int64)),
-                  "mauve_dp_batch")
+        if band_from is None:
+            self._chk(self.L.mauve_dp_batch(self.h, nseq, C.c_int64(n_iv), _p(codes, C.c_uint8), _p(off, C.c_int64),
+                                            C.byref(sc), _p(cols, C.c_uint32), _p(col_off, C.c_int64), _p(score, C.c_int64)),
+                      "mauve_dp_batch")
+        else:
+            self._chk(self.L.mauve_dp_batch_banded(self.h, nseq, C.c_int64(n_iv), _p(codes, C.c_uint8), _p(off, C.c_int64),
+                                                   C.byref(sc), C.c_int64(int(band_from)), _p(cols, C.c_uint32),
+                                                   _p(col_off, C.c_int64), _p(score, C.c_int64)), "mauve_dp_batch_banded")
         return [cols[col_off[i]:col_off[i + 1]].copy() for i in range(n_iv)], score[:n_iv].copy()
 
     def align(self, params=None, fetch=True, names=None, want_xmfa=False):

@@ -224,6 +224,7 @@ struct mauve_ctx {
     DevBuf dp_desc, dp_list, dp_codes, dp_off, dp_prof_cnt, dp_prof_mask, dp_prof2_cnt, dp_prof2_mask, dp_tb, dp_meta, dp_score,
         dp_cols, dp_rows;
 
+    int64_t dp_band_from = INT64_MAX;     // intervals whose longest sequence exceeds this run the banded DP (dp_batch.hip)
     DevBuf dpf_anch, dpf_work, dpf_tot;   // device front end of the DP stage (dp_run_from_anchors)
 
     // profiling
@@ -313,6 +314,10 @@ void lcb_greedy(int N, int32_t K, int64_t *weight, const uint32_t *orient_bits, 
 // DP (dp_batch.hip)
 int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *sc,
                       uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells);
+// gapped-alignment eligibility of an inter-anchor interval by its longest sequence: full DP up to max_gapped_len, banded
+// DP above it up to max_banded_len
+inline int64_t dp_len_limit(const mauve_params *p) { return p->max_banded_len > p->max_gapped_len ? p->max_banded_len : p->max_gapped_len; }
+inline int64_t dp_band_from_of(const mauve_params *p) { return p->max_banded_len > p->max_gapped_len ? p->max_gapped_len : INT64_MAX; }
 int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na, const int32_t *h_len, const int32_t *h_st, const int32_t *h_lcb, int gapped,
                         int64_t max_gapped_len, const mauve_scoring *scoring, int32_t *gapcode, int64_t *n_dp_out, int64_t *code_total_out,
                         PinnedBuf *dcols, std::vector<int64_t> &dcol_off, std::vector<int64_t> &dscore, int64_t *cells);

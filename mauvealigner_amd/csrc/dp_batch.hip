@@ -38,6 +38,56 @@ struct DpMeta {
 
 struct DpScoring { int32_t go, ge; int32_t s[4][4]; };
 
+// ---- banded steps: intervals whose longest sequence exceeds max_gapped_len run every progressive step
+// inside the band |j - c(i)| <= W around the scaled diagonal c(i) = floor(i * n / m), W = 128 + |n - m| + (m + n) / 64:
+// cells outside are minus infinity.  Only the band is swept and only its traceback is stored: stripe s covers the
+// columns J0(s) .. J1(s), its traceback stride is dp_stride(m, n, banded) steps (uniform over the stripes).
+__host__ __device__ __forceinline__ int64_t dp_band_w(int64_t m, int64_t n) { return 128 + (m > n ? m - n : n - m) + (m + n) / 64; }
+__host__ __device__ __forceinline__ int64_t dp_stride(int64_t m, int64_t n, bool banded)
+{
+    const int64_t full = n + 64;
+    if (!banded || m < 1) return full;
+    const int64_t b = (63 * n) / m + 2 * dp_band_w(m, n) + 72;
+    return b < full ? b : full;
+}
+__host__ __device__ __forceinline__ int64_t dp_diag(int64_t i, int64_t m, int64_t n) { return (i * n) / m; }
+// first column of stripe s's sweep: one left of its first row's band, so that the diagonal input of the band's first
+// cell (row above, one column left -- in that row's band whenever c() steps there) has been seen
+__host__ __device__ __forceinline__ int32_t dp_j0(int32_t s, int64_t m, int64_t n, bool banded)
+{
+    if (!banded) return 0;
+    const int64_t j = dp_diag((int64_t)s * 64 + 1, m, n) - dp_band_w(m, n) - 1;
+    return (int32_t)(j > 0 ? j : 0);
+}
+// traceback bytes an interval step may need when only bounds of the profile length are known (mmin <= m <= mmax)
+__host__ __device__ __forceinline__ int64_t dp_tb_need(int64_t mmin, int64_t mmax, int64_t n, bool banded)
+{
+    const int64_t stripes = (mmax + 63) / 64;
+    int64_t stride = n + 64;
+    if (banded && mmin >= 1) {
+        const int64_t d0 = n > mmin ? n - mmin : mmin - n, d1 = n > mmax ? n - mmax : mmax - n;
+        const int64_t wmax = 128 + (d0 > d1 ? d0 : d1) + (mmax + n) / 64;
+        const int64_t b = (63 * n) / mmin + 2 * wmax + 72;
+        if (b < stride) stride = b;
+    }
+    return stripes * stride * 64;
+}
+
+// cells a step evaluates: m x n, or the band's share of it (rows 1..m, columns max(1, blo)..bhi); every lane returns the total
+__device__ __forceinline__ int64_t dp_step_cells(int32_t m, int32_t n, bool banded, int lane)
+{
+    if (!banded) return (int64_t)m * n;
+    const int64_t W = dp_band_w(m, n);
+    int64_t acc = 0;
+    for (int64_t i = 1 + lane; i <= m; i += 64) {
+        const int64_t c = dp_diag(i, m, n);
+        const int64_t lo = c - W > 1 ? c - W : 1, hi = c + W < n ? c + W : n;
+        if (hi >= lo) acc += hi - lo + 1;
+    }
+    for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+    return acc;
+}
+
 // lane l receives lane l-1's value, lane 0 keeps its own (gfx9 DPP wave_shr:1)
 __device__ __forceinline__ int32_t wave_shr1(int32_t v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
 
@@ -54,6 +104,7 @@ __device__ __forceinline__ void max3(int32_t a, int32_t b, int32_t c, int32_t &b
 // unconditional and its wait lands a round later, and handed to lane 0 with v_readlane.
 struct DpStripe {
     int32_t s, i, m, n, steps, gyo, gye, gxo, gxe, sub0, sub1, sub2, sub3;
+    int32_t j0, blo, bhi, plo, phi;          // first column of the stripe's sweep; this row's band; the band of the row above the stripe
     bool active, park;
     const uint8_t *seq; const int32_t *rin; int32_t *rout; uint8_t *tbs;
     int32_t Mc, Xc, Yc, Md, Xd, Yd;
@@ -61,6 +112,7 @@ struct DpStripe {
     int32_t bM_cur, bX_cur, bY_cur, bM_nxt, bX_nxt, bY_nxt;
 };
 
+template <bool BANDED>
 __device__ __forceinline__ void dp_stripe_begin(DpStripe &S, int32_t s, int lane, int32_t m, int32_t n, int32_t nstripes,
                                                 const uint32_t *Pc, const uint8_t *seq, const DpScoring &sc, int32_t krows,
                                                 int32_t *rowbuf, uint8_t *tbp, int32_t T)
@@ -82,36 +134,52 @@ __device__ __forceinline__ void dp_stripe_begin(DpStripe &S, int32_t s, int lane
     S.rin = rowbuf + (size_t)((s & 1) ^ 1) * 3 * (n + 1);      // written by stripe s-1
     S.rout = rowbuf + (size_t)(s & 1) * 3 * (n + 1);
     S.park = s + 1 < nstripes;
-    S.steps = n + min(64, m - s * 64);                          // t = 0 .. n + rows_here - 1
+    const int32_t rows_here = min(64, m - s * 64);
+    if (BANDED) {
+        const int64_t W = dp_band_w(m, n);
+        const int64_t ci = dp_diag(S.active ? S.i : m, m, n);
+        S.blo = (int32_t)max((int64_t)0, ci - W); S.bhi = (int32_t)min((int64_t)n, ci + W);
+        const int64_t cp = dp_diag((int64_t)s * 64, m, n);
+        S.plo = (int32_t)max((int64_t)0, cp - W); S.phi = (int32_t)min((int64_t)n, cp + W);
+        S.j0 = dp_j0(s, m, n, true);
+        const int32_t j1 = (int32_t)min((int64_t)n, dp_diag((int64_t)s * 64 + rows_here, m, n) + W);
+        S.steps = (j1 - S.j0 + 1) + rows_here - 1;
+    } else {
+        S.blo = 0; S.bhi = n; S.plo = 0; S.phi = n; S.j0 = 0;
+        S.steps = n + rows_here;                                // t = 0 .. n + rows_here - 1
+    }
     S.tbs = tbp + (size_t)s * T * 64 + lane;
     S.Mc = S.Xc = S.Yc = S.Md = S.Xd = S.Yd = DP_NEG_INF;
     S.bcur = 0;
 }
 
 // chunk k of lane 0's inputs: base t-1 and boundary column t for t = 64k + lane
+template <bool BANDED>
 __device__ __forceinline__ void dp_stripe_chunk(const DpStripe &S, int32_t k, int lane, uint32_t &sq, int32_t &bM, int32_t &bX, int32_t &bY)
 {
-    const int32_t col = 64 * k + lane;
+    const int32_t col = (BANDED ? S.j0 : 0) + 64 * k + lane;
     sq = (uint32_t)S.seq[min(max(col - 1, 0), S.n - 1)];
+    const bool inr = !BANDED || (col >= S.plo && col <= S.phi);               // inside the band of the row above (always, unbanded)
     if (S.s == 0) {
         bM = col == 0 ? 0 : DP_NEG_INF; bX = DP_NEG_INF;
-        bY = col == 0 ? DP_NEG_INF : S.gyo + (col - 1) * S.gye;
+        bY = (col == 0 || !inr) ? DP_NEG_INF : S.gyo + (col - 1) * S.gye;
     } else {
         const int32_t cc = min(col, S.n);
-        bM = S.rin[cc]; bX = S.rin[(S.n + 1) + cc]; bY = S.rin[2 * (S.n + 1) + cc];
+        bM = inr ? S.rin[cc] : DP_NEG_INF; bX = inr ? S.rin[(S.n + 1) + cc] : DP_NEG_INF; bY = inr ? S.rin[2 * (S.n + 1) + cc] : DP_NEG_INF;
     }
 }
 
 // round c: steps t = 64c .. min(64c + 63, steps - 1).  Branch-free cell update; (fM, fX, fY) catch cell (m, n).
+template <bool BANDED>
 __device__ __forceinline__ void dp_stripe_round(DpStripe &S, int32_t c, int lane, int32_t &fM, int32_t &fX, int32_t &fY)
 {
-    if (c == 0) dp_stripe_chunk(S, 0, lane, S.sq_cur, S.bM_cur, S.bX_cur, S.bY_cur);
+    if (c == 0) dp_stripe_chunk<BANDED>(S, 0, lane, S.sq_cur, S.bM_cur, S.bX_cur, S.bY_cur);
     else { S.sq_cur = S.sq_nxt; S.bM_cur = S.bM_nxt; S.bX_cur = S.bX_nxt; S.bY_cur = S.bY_nxt; }
-    dp_stripe_chunk(S, c + 1, lane, S.sq_nxt, S.bM_nxt, S.bX_nxt, S.bY_nxt);
+    dp_stripe_chunk<BANDED>(S, c + 1, lane, S.sq_nxt, S.bM_nxt, S.bX_nxt, S.bY_nxt);
     const int32_t t_end = min(64 * c + 64, S.steps);
     const bool lane0 = lane == 0, last_lane = S.park && lane == 63;
     for (int32_t t = 64 * c; t < t_end; t++) {
-        const int32_t j = t - lane;
+        const int32_t j = (BANDED ? S.j0 : 0) + t - lane;
         // (i-1, j): lane-1's newest values (DPP wave shift); lane 0 takes the stripe's upper boundary row
         int32_t Mu = wave_shr1(S.Mc), Xu = wave_shr1(S.Xc), Yu = wave_shr1(S.Yc);
         uint32_t bnext = (uint32_t)wave_shr1((int32_t)S.bcur);
@@ -131,10 +199,12 @@ __device__ __forceinline__ void dp_stripe_round(DpStripe &S, int32_t c, int lane
         int32_t Yn = max(best, DP_NEG_INF);
         Mn = j1 ? Mn : DP_NEG_INF; Yn = j1 ? Yn : DP_NEG_INF; pm = j1 ? pm : 0u; py = j1 ? py : 0u;
         if (on) {
-            S.Mc = Mn; S.Xc = Xn; S.Yc = Yn;
-            S.tbs[(size_t)t * 64] = (uint8_t)(pm | (px << 2) | (py << 4));
-            if (last_lane) { S.rout[j] = Mn; S.rout[(S.n + 1) + j] = Xn; S.rout[2 * (S.n + 1) + j] = Yn; }
-            if (S.i == S.m && j == S.n) { fM = Mn; fX = Xn; fY = Yn; }
+            if (!BANDED || (j >= S.blo && j <= S.bhi)) {
+                S.Mc = Mn; S.Xc = Xn; S.Yc = Yn;
+                S.tbs[(size_t)t * 64] = (uint8_t)(pm | (px << 2) | (py << 4));
+                if (last_lane) { S.rout[j] = Mn; S.rout[(S.n + 1) + j] = Xn; S.rout[2 * (S.n + 1) + j] = Yn; }
+                if (S.i == S.m && j == S.n) { fM = Mn; fX = Xn; fY = Yn; }
+            } else { S.Mc = DP_NEG_INF; S.Xc = DP_NEG_INF; S.Yc = DP_NEG_INF; }     // outside the band: minus infinity for whoever reads it
         }
         S.Md = Mu; S.Xd = Xu; S.Yd = Yu;
     }
@@ -149,11 +219,58 @@ __device__ __forceinline__ void dp_stripe_round(DpStripe &S, int32_t c, int lane
 constexpr int DP_MW_LAG = 3;
 constexpr int DP_MW_WAVES = 16;            // 1024 threads: four waves per SIMD of one CU
 
+// the pipeline over the stripes of one step (all waves of the workgroup call it together)
+template <bool BANDED>
+__device__ __forceinline__ void dp_mw_sweep(int32_t *s_stripe, int32_t *s_round, int32_t *s_fin, int lane, int wv, int32_t m, int32_t n,
+                                        int32_t nstripes, const uint32_t *Pc, const uint8_t *seq, const DpScoring &sc, int32_t krows,
+                                        int32_t *rowbuf, uint8_t *tbp, int32_t T)
+{
+    constexpr int W = DP_MW_WAVES;
+    int32_t my_s = wv, my_c = 0;
+    if (lane == 0) { s_stripe[wv] = wv; s_round[wv] = 0; }
+    __syncthreads();
+    DpStripe S;                                       // the stripe this wave is in the middle of
+    int32_t nrounds = 0;
+    int32_t fM = DP_NEG_INF, fX = DP_NEG_INF, fY = DP_NEG_INF;
+    // every stripe runs at most (n + 64) / 64 + 1 rounds; a fully serial schedule is the upper bound
+    const int64_t guard_max = (int64_t)nstripes * ((T + 64) / 64 + 2) + 16;
+    for (int64_t guard = 0; guard < guard_max; guard++) {
+        int32_t lo = s_stripe[0];
+#pragma unroll
+        for (int w = 1; w < W; w++) lo = min(lo, s_stripe[w]);
+        if (lo >= nstripes) break;
+        bool can = my_s < nstripes;
+        if (can && my_s > 0) {
+            const int pw = (my_s - 1) % W;
+            const int32_t ps = s_stripe[pw], pr = s_round[pw];
+            // a banded stripe starts its sweep further right than the one above: that many more of the rounds above must be done
+            const int32_t dj = BANDED ? (dp_j0(my_s, m, n, true) - dp_j0(my_s - 1, m, n, true) + 63) / 64 : 0;
+            can = ps > my_s - 1 || (ps == my_s - 1 && pr >= my_c + DP_MW_LAG + dj);
+        }
+        __syncthreads();               // every wave has read this round's state before anyone updates it
+        if (can) {
+            if (my_c == 0) {
+                dp_stripe_begin<BANDED>(S, my_s, lane, m, n, nstripes, Pc, seq, sc, krows, rowbuf, tbp, T);
+                nrounds = (S.steps + 63) / 64;
+            }
+            dp_stripe_round<BANDED>(S, my_c, lane, fM, fX, fY);
+            my_c++;
+            if (my_c == nrounds) {
+                if (my_s == nstripes - 1 && lane == ((m - 1) & 63)) { s_fin[0] = fM; s_fin[1] = fX; s_fin[2] = fY; }
+                my_s += W; my_c = 0;
+            }
+            __threadfence_block();     // parked row and traceback bytes before the progress counters
+            if (lane == 0) { s_stripe[wv] = my_s; s_round[wv] = my_c; }
+        }
+        __syncthreads();
+    }
+}
+
 __device__ void dp_interval_mw(int nseq, int64_t iv, const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
                                DpMeta *__restrict__ meta, uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
                                uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB, uint8_t *__restrict__ tb,
                                const int64_t *__restrict__ tb_off, int32_t *__restrict__ rows,
-                               const int64_t *__restrict__ rows_off, uint8_t *__restrict__ ops, const DpScoring &sc)
+                               const int64_t *__restrict__ rows_off, uint8_t *__restrict__ ops, const DpScoring &sc, int64_t band_from)
 {
     __shared__ int32_t s_stripe[DP_MW_WAVES], s_round[DP_MW_WAVES], s_fin[3];
     constexpr int W = DP_MW_WAVES;
@@ -161,6 +278,9 @@ __device__ void dp_interval_mw(int nseq, int64_t iv, const uint8_t *__restrict__
     const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
     const int64_t base = seq_off[iv * nseq];
+    int64_t longest = 0;
+    for (int g = 0; g < nseq; g++) longest = max(longest, seq_off[iv * nseq + g + 1] - seq_off[iv * nseq + g]);
+    const bool banded = longest > band_from;
     for (int g = 0; g < nseq; g++) {
         const int64_t so = seq_off[iv * nseq + g];
         const int32_t n = (int32_t)(seq_off[iv * nseq + g + 1] - so);
@@ -176,48 +296,15 @@ __device__ void dp_interval_mw(int nseq, int64_t iv, const uint8_t *__restrict__
             continue;
         }
         const int32_t m = mt.m;
-        const int32_t T = n + 64;
+        const int32_t T = (int32_t)dp_stride(m, n, banded);
+        auto j0_of = [&](int32_t st) -> int32_t { return dp_j0(st, m, n, banded); };
         uint8_t *tbp = tb + tb_off[iv];
         int32_t *rowbuf = rows + rows_off[iv];
         const int32_t nstripes = (m + 63) / 64;
 
-        // ---- pipeline over stripes ----
-        int32_t my_s = wv, my_c = 0;
-        if (lane == 0) { s_stripe[wv] = wv; s_round[wv] = 0; }
-        __syncthreads();
-        DpStripe S;                                       // the stripe this wave is in the middle of
-        int32_t nrounds = 0;
-        int32_t fM = DP_NEG_INF, fX = DP_NEG_INF, fY = DP_NEG_INF;
-        // every stripe runs at most (n + 64) / 64 + 1 rounds; a fully serial schedule is the upper bound
-        const int64_t guard_max = (int64_t)nstripes * ((n + 64) / 64 + 2) + 16;
-        for (int64_t guard = 0; guard < guard_max; guard++) {
-            int32_t lo = s_stripe[0];
-#pragma unroll
-            for (int w = 1; w < W; w++) lo = min(lo, s_stripe[w]);
-            if (lo >= nstripes) break;
-            bool can = my_s < nstripes;
-            if (can && my_s > 0) {
-                const int pw = (my_s - 1) % W;
-                const int32_t ps = s_stripe[pw], pr = s_round[pw];
-                can = ps > my_s - 1 || (ps == my_s - 1 && pr >= my_c + DP_MW_LAG);
-            }
-            __syncthreads();               // every wave has read this round's state before anyone updates it
-            if (can) {
-                if (my_c == 0) {
-                    dp_stripe_begin(S, my_s, lane, m, n, nstripes, Pc, seq, sc, mt.krows, rowbuf, tbp, T);
-                    nrounds = (S.steps + 63) / 64;
-                }
-                dp_stripe_round(S, my_c, lane, fM, fX, fY);
-                my_c++;
-                if (my_c == nrounds) {
-                    if (my_s == nstripes - 1 && lane == ((m - 1) & 63)) { s_fin[0] = fM; s_fin[1] = fX; s_fin[2] = fY; }
-                    my_s += W; my_c = 0;
-                }
-                __threadfence_block();     // parked row and traceback bytes before the progress counters
-                if (lane == 0) { s_stripe[wv] = my_s; s_round[wv] = my_c; }
-            }
-            __syncthreads();
-        }
+        if (banded) dp_mw_sweep<true>(s_stripe, s_round, s_fin, lane, wv, m, n, nstripes, Pc, seq, sc, mt.krows, rowbuf, tbp, T);
+        else dp_mw_sweep<false>(s_stripe, s_round, s_fin, lane, wv, m, n, nstripes, Pc, seq, sc, mt.krows, rowbuf, tbp, T);
+        int32_t fM, fX, fY;
         fM = s_fin[0]; fX = s_fin[1]; fY = s_fin[2];
         int32_t best = fM; int state = 0;
         if (fX > best) { best = fX; state = 1; }
@@ -225,13 +312,14 @@ __device__ void dp_interval_mw(int nseq, int64_t iv, const uint8_t *__restrict__
 
         // ---- traceback: every wave walks the same path (uniform control flow), wave 0 records it ----
         uint8_t *opr = ops + base;
-        int32_t ti = m, tj = n, len = 0;
+        int32_t ti = m, tj = n, len = 0, ws = -1, wj0 = 0;
         while (ti > 0 || tj > 0) {
             uint32_t op, nstate;
             if (ti == 0) { op = 2; nstate = (tj == 1) ? 0 : 2; }
             else {
                 const int32_t s = (ti - 1) >> 6, l = (ti - 1) & 63;
-                const uint8_t bt = tbp[((size_t)s * T + (tj + l)) * 64 + l];
+                if (s != ws) { ws = s; wj0 = j0_of(s); }
+                const uint8_t bt = tbp[((size_t)s * T + (tj - wj0 + l)) * 64 + l];
                 if (state == 0) { op = 3; nstate = bt & 3; }
                 else if (state == 1) { op = 1; nstate = (bt >> 2) & 3; }
                 else { op = 2; nstate = (bt >> 4) & 3; }
@@ -260,7 +348,7 @@ __device__ void dp_interval_mw(int nseq, int64_t iv, const uint8_t *__restrict__
             }
             carry_p += (int32_t)__popcll(bp); carry_s += (int32_t)__popcll(bs);
         }
-        mt.cells += (int64_t)m * n; mt.score += best; mt.m = len; mt.krows += 1; mt.cur ^= 1;
+        mt.cells += dp_step_cells(m, n, banded, lane); mt.score += best; mt.m = len; mt.krows += 1; mt.cur ^= 1;
         __threadfence_block();
         __syncthreads();
     }
@@ -419,9 +507,9 @@ __global__ void __launch_bounds__(64 * DP_MW_WAVES) dp_step_big(int nseq, const 
                                                uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
                                                uint8_t *__restrict__ tb, const int64_t *__restrict__ tb_off,
                                                int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
-                                               uint8_t *__restrict__ ops, DpScoring sc)
+                                               uint8_t *__restrict__ ops, DpScoring sc, int64_t band_from)
 {
-    dp_interval_mw(nseq, list[blockIdx.x], codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, sc);
+    dp_interval_mw(nseq, list[blockIdx.x], codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, sc, band_from);
 }
 
 struct DpClasses { int64_t first_med, n_med, first_s32, n_s32, first_s16, n_s16; uint32_t blocks_med, blocks_s32; };
@@ -482,9 +570,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 
         for (int32_t s = 0; s < nstripes; s++) {
             DpStripe S;
-            dp_stripe_begin(S, s, lane, m, n, nstripes, Pc, seq, sc, mt.krows, rowbuf, tbp, T);
+            dp_stripe_begin<false>(S, s, lane, m, n, nstripes, Pc, seq, sc, mt.krows, rowbuf, tbp, T);
             const int32_t nrounds = (S.steps + 63) / 64;
-            for (int32_t c = 0; c < nrounds; c++) dp_stripe_round(S, c, lane, fM, fX, fY);
+            for (int32_t c = 0; c < nrounds; c++) dp_stripe_round<false>(S, c, lane, fM, fX, fY);
             __threadfence_block();   // the parked row / traceback bytes are read back by this wave
         }
         // result lives in the lane that owns row m
@@ -581,7 +669,7 @@ __global__ void __launch_bounds__(256) dp_gather_codes(const uint64_t *__restric
 // over the positions [a, b) of the launch list [workgroup | one wave | two per wave | four per wave]; tb_base is
 // subtracted from the traceback offsets (rounds, below)
 static int dp_launch_steps(mauve_ctx *ctx, int nseq, int64_t a, int64_t b, int64_t n_big, const DpClasses &full, const int64_t *d_seq_off,
-                           const int64_t *d_tb_off, const int64_t *d_rows_off, const DpScoring &sc, int64_t tb_base)
+                           const int64_t *d_tb_off, const int64_t *d_rows_off, const DpScoring &sc, int64_t tb_base, int64_t band_from)
 {
     auto clip = [&](int64_t first, int64_t n, int64_t &f2, int64_t &n2) { f2 = std::max(first, a); n2 = std::max<int64_t>(0, std::min(first + n, b) - f2); };
     int64_t bf, bn;
@@ -602,7 +690,7 @@ static int dp_launch_steps(mauve_ctx *ctx, int nseq, int64_t a, int64_t b, int64
                            ctx->dp_list.as<int64_t>() + bf, ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(),
                            ctx->dp_prof_cnt.as<uint32_t>(), ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
                            ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(),
-                           d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
+                           d_rows_off, ctx->dp_score.as<uint8_t>(), sc, band_from);
         HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
     }
     if (blocks)
@@ -625,7 +713,8 @@ static int64_t dp_tb_budget()
     return std::max<int64_t>(b, 1 << 16);
 }
 static int dp_launch_rounds(mauve_ctx *ctx, int nseq, int64_t n_iv, int64_t n_big, const DpClasses &cl, const int64_t *d_seq_off,
-                            const int64_t *d_tb_off, const int64_t *d_rows_off, const DpScoring &sc, const int64_t *tb_list, int *rounds_out)
+                            const int64_t *d_tb_off, const int64_t *d_rows_off, const DpScoring &sc, const int64_t *tb_list, int *rounds_out,
+                            int64_t band_from)
 {
     const int64_t budget = dp_tb_budget();
     int rounds = 0;
@@ -635,7 +724,7 @@ static int dp_launch_rounds(mauve_ctx *ctx, int nseq, int64_t n_iv, int64_t n_bi
             if (tb_list[a + 1] - tb_list[a] > budget) { ctx->err = "dp: one interval needs more traceback than MAUVE_DP_TB_BUDGET allows"; return MAUVE_ERR_LIMIT; }
             while (b < n_iv && tb_list[b + 1] - tb_list[a] <= budget) b++;
         } else b = n_iv;
-        int rc = dp_launch_steps(ctx, nseq, a, b, n_big, cl, d_seq_off, d_tb_off, d_rows_off, sc, tb_list ? tb_list[a] : 0);
+        int rc = dp_launch_steps(ctx, nseq, a, b, n_big, cl, d_seq_off, d_tb_off, d_rows_off, sc, tb_list ? tb_list[a] : 0, band_from);
         if (rc) return rc;
         rounds++;
         a = b;
@@ -662,6 +751,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     tb_off.resize((size_t)n_iv + 1); rows_off.resize((size_t)n_iv + 1);
     is_big.assign((size_t)n_iv, 0); est.assign((size_t)n_iv, 0);
     int64_t est_total = 0;
+    const int64_t band_from = ctx->dp_band_from;
     static const bool no_mw = getenv("MAUVE_DP_ONE_WAVE") != nullptr;     // A/B switch for the workgroup path
     static const bool no_groups = getenv("MAUVE_DP_NO_GROUPS") != nullptr; // A/B switch for the sub-wave path
     std::vector<uint8_t> &cls = H.cls; cls.assign((size_t)n_iv, 1);
@@ -671,23 +761,27 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     need_v.resize((size_t)n_iv); nmax_v.resize((size_t)n_iv);
     ctx->pool->parallel_for(n_iv, 2048, [&](int64_t b, int64_t e) {
         for (int64_t iv = b; iv < e; iv++) {
-            int64_t mmax = 0, need = 0, nmax = 0, es = 0, mbound = 0, steps_max = 0; bool first = true; uint8_t big = 0;
+            int64_t mmax = 0, mmin = 0, need = 0, nmax = 0, es = 0, mbound = 0, steps_max = 0, longest = 0; bool first = true; uint8_t big = 0;
+            for (int g = 0; g < nseq; g++) longest = std::max(longest, seq_off[iv * nseq + g + 1] - seq_off[iv * nseq + g]);
+            const bool banded = longest > band_from;
             for (int g = 0; g < nseq; g++) {
                 const int64_t n = seq_off[iv * nseq + g + 1] - seq_off[iv * nseq + g];
                 if (n == 0) continue;
-                if (first) { first = false; mmax = n; continue; }
-                need = std::max(need, ((mmax + 63) / 64) * (n + 64) * 64);
+                if (first) { first = false; mmax = mmin = n; continue; }
+                const int64_t tbn = dp_tb_need(mmin, mmax, n, banded);  // the profile is at least as long as its longest member
+                need = std::max(need, tbn);
                 nmax = std::max(nmax, n);
                 // a step with >= 3 stripes against >= 256 columns pipelines over several waves
                 if (mmax > 128 && n >= 256 && !no_mw) big = 1;
-                es += ((mmax + 63) / 64) * (n + 64);                   // systolic steps of a single wave
+                es += tbn / 64;                                        // systolic steps of a single wave
                 mbound = std::max(mbound, mmax); steps_max = std::max(steps_max, mmax + n);
-                mmax += n;
+                mmax += n; mmin = std::max(mmin, n);
             }
+            if (banded && nmax) big = 2;                               // banded steps exist only in the workgroup kernel
             need_v[(size_t)iv] = need; nmax_v[(size_t)iv] = nmax; est[(size_t)iv] = es; is_big[(size_t)iv] = big;
             // sub-wave classes: every profile the interval will see fits G rows, every step fits the LDS slice
             uint8_t k = 1;
-            if (!no_groups && steps_max <= DP_GRP_TMAX) k = mbound <= 16 ? 3 : (mbound <= 32 ? 2 : 1);
+            if (!no_groups && !banded && steps_max <= DP_GRP_TMAX) k = mbound <= 16 ? 3 : (mbound <= 32 ? 2 : 1);
             cls[(size_t)iv] = k;
         }
     });
@@ -716,8 +810,8 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
         const int64_t balanced = est_total / 3072;
         for (int64_t k = 0; k < n_iv; k++) {          // lst is largest first
             uint8_t &b = is_big[(size_t)lst[(size_t)k]];
-            if (b && (n_big >= 128 || est[(size_t)lst[(size_t)k]] <= 4 * balanced)) b = 0;
-            n_big += b;
+            if (b == 1 && (n_big >= 128 || est[(size_t)lst[(size_t)k]] <= 4 * balanced)) b = 0;
+            n_big += b != 0;
         }
     }
     // list = [workgroup path | one wave | two per wave | four per wave], each class still largest first
@@ -784,7 +878,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     memcpy(pin_list, lst.data(), (size_t)n_iv * 8);
     HIPCHK(ctx, hipMemcpyAsync(ctx->dp_list.p, pin_list, (size_t)n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
     int rounds = 1;
-    { int rcl = dp_launch_rounds(ctx, nseq, n_iv, n_big, cl, d_seq_off, d_tb_off, d_rows_off, sc, one_round ? nullptr : tb_list.data(), &rounds); if (rcl) return rcl; }
+    { int rcl = dp_launch_rounds(ctx, nseq, n_iv, n_big, cl, d_seq_off, d_tb_off, d_rows_off, sc, one_round ? nullptr : tb_list.data(), &rounds, band_from); if (rcl) return rcl; }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // host work while the DP kernels run
     HIPCHK(ctx, ctx->pin_meta.ensure((size_t)n_iv * sizeof(DpMeta)));
@@ -883,29 +977,37 @@ __global__ void __launch_bounds__(256) dpf_desc(const int32_t *__restrict__ alen
                                                 const uint32_t *__restrict__ anchor_of, const DpFrontTotals *__restrict__ tot,
                                                 DpSeqDesc *__restrict__ desc, int64_t *__restrict__ need, int64_t *__restrict__ rowsn,
                                                 int64_t *__restrict__ est, uint8_t *__restrict__ cand, uint8_t *__restrict__ cls,
-                                                uint32_t *__restrict__ sizekey, uint32_t *__restrict__ slotval, int no_mw, int no_groups)
+                                                uint32_t *__restrict__ sizekey, uint32_t *__restrict__ slotval, int no_mw, int no_groups, int64_t band_from)
 {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
     if (s >= (uint32_t)tot->n_dp) return;
     const uint32_t k = anchor_of[s];
-    int64_t mmax = 0, nd = 0, nmax = 0, es = 0, mbound = 0, steps_max = 0; bool first = true; uint8_t big = 0;
+    int64_t mmax = 0, mmin = 0, nd = 0, nmax = 0, es = 0, mbound = 0, steps_max = 0, longest = 0; bool first = true; uint8_t big = 0;
+    for (int g = 0; g < N; g++) {
+        int64_t lo, n; bool rv;
+        dpf_gap(alen, ast, N, k, g, lo, n, rv);
+        longest = max(longest, n);
+    }
+    const bool banded = longest > band_from;
     for (int g = 0; g < N; g++) {
         int64_t lo, n; bool rv;
         dpf_gap(alen, ast, N, k, g, lo, n, rv);
         DpSeqDesc d; d.genome = g; d.rev = rv; d.lo0 = lo - 1; d.len = n;
         desc[(size_t)s * N + g] = d;
         if (n == 0) continue;
-        if (first) { first = false; mmax = n; continue; }
-        nd = max(nd, ((mmax + 63) / 64) * (n + 64) * 64);
+        if (first) { first = false; mmax = mmin = n; continue; }
+        const int64_t tbn = dp_tb_need(mmin, mmax, n, banded);
+        nd = max(nd, tbn);
         nmax = max(nmax, n);
         if (mmax > 128 && n >= 256 && !no_mw) big = 1;       // a step with >= 3 stripes against >= 256 columns pipelines over several waves
-        es += ((mmax + 63) / 64) * (n + 64);
+        es += tbn / 64;
         mbound = max(mbound, mmax); steps_max = max(steps_max, mmax + n);
-        mmax += n;
+        mmax += n; mmin = max(mmin, n);
     }
+    if (banded && nmax) big = 2;                             // banded steps exist only in the workgroup kernel
     need[s] = nd; rowsn[s] = 6 * (nmax + 1); est[s] = es; cand[s] = big;
     uint8_t kc = 1;
-    if (!no_groups && steps_max <= DP_GRP_TMAX) kc = mbound <= 16 ? 3 : (mbound <= 32 ? 2 : 1);
+    if (!no_groups && !banded && steps_max <= DP_GRP_TMAX) kc = mbound <= 16 ? 3 : (mbound <= 32 ? 2 : 1);
     cls[s] = kc;
     int c = 0; for (int64_t f = nd; f > 1; f >>= 1) c++;
     sizekey[s] = (uint32_t)(63 - c);                         // largest traceback footprint first
@@ -925,8 +1027,8 @@ __global__ void __launch_bounds__(256) dpf_tb_scatter(const int64_t *__restrict_
 struct DpBigPick {
     const uint32_t *order; const uint8_t *cand, *cls; const int64_t *est; const DpFrontTotals *tot; uint32_t *key2;
     __device__ uint32_t domain(int) const { return (uint32_t)tot->n_dp; }
-    __device__ bool flag(uint32_t j, int) const { const uint32_t s = order[j]; return cand[s] && est[s] > 4 * (tot->est / 3072); }
-    __device__ void each(uint32_t j, uint32_t before, bool fl, int) const { key2[j] = (fl && before < 128) ? 0u : (uint32_t)cls[order[j]]; }
+    __device__ bool flag(uint32_t j, int) const { const uint32_t s = order[j]; return cand[s] == 1 && est[s] > 4 * (tot->est / 3072); }
+    __device__ void each(uint32_t j, uint32_t before, bool fl, int) const { key2[j] = ((fl && before < 128) || cand[order[j]] == 2) ? 0u : (uint32_t)cls[order[j]]; }
     __device__ void emit(uint32_t, uint32_t, int) const {}
     __device__ void total(uint32_t, int) const {}
 };
@@ -1000,7 +1102,7 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     hipLaunchKernelGGL((cmp_count<DpSlots>), dim3(nb), dim3(256), 0, ctx->stream, sl, bcnt);
     hipLaunchKernelGGL((cmp_write<DpSlots>), dim3(nb), dim3(256), 0, ctx->stream, sl, bcnt);
     hipLaunchKernelGGL(dpf_desc, dim3(blocks), dim3(256), 0, ctx->stream, alen, ast, N, anchor_of, tot, desc, need, rowsn, est, cand, cls, k1, v1,
-                       (int)no_mw, (int)no_groups);
+                       (int)no_mw, (int)no_groups, ctx->dp_band_from);
     // the counts below are device values; the launches cover na (>= n_dp) entries and the kernels stop at n_dp.
     // Offsets: the value functors return 0 beyond n_dp because the arrays there are never read -- so clear them first.
     // (need / rows / est / desc of slots >= n_dp are not written: scan over exactly n_dp needs the count -> two-phase:
@@ -1078,7 +1180,7 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     }
     DpScoring sc; sc.go = scoring->gap_open; sc.ge = scoring->gap_extend; memcpy(sc.s, scoring->matrix, sizeof sc.s);
     int rounds = 1;
-    rc = dp_launch_rounds(ctx, N, n_dp, n_big, cl, d_seq_off, d_tb_off, d_rows_off, sc, tb_list.empty() ? nullptr : tb_list.data(), &rounds);
+    rc = dp_launch_rounds(ctx, N, n_dp, n_big, cl, d_seq_off, d_tb_off, d_rows_off, sc, tb_list.empty() ? nullptr : tb_list.data(), &rounds, ctx->dp_band_from);
     if (rc) return rc;
     // results: column offsets, scores and the cell count by scans over the per-interval records; the columns compacted
     const DpMeta *meta = ctx->dp_meta.as<DpMeta>();
@@ -1141,5 +1243,18 @@ extern "C" int mauve_dp_batch(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint
         ctx->err = "dp_batch: bad argument"; return MAUVE_ERR_ARG;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->dp_band_from = INT64_MAX;          // the GappedAligner seam aligns what it is given in full
+    return dp_batch_run(ctx, nseq, n_iv, codes, seq_off, sc, cols, col_off, score, nullptr);
+}
+
+extern "C" int mauve_dp_batch_banded(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,
+                                     const mauve_scoring *sc, int64_t band_from, uint32_t *cols, int64_t *col_off, int64_t *score)
+{
+    if (!ctx) return MAUVE_ERR_ARG;
+    if (nseq < 1 || nseq > MAUVE_MAX_SEQ || n_iv < 0 || !seq_off || !sc || !col_off || (n_iv && !cols) || band_from < 0) {
+        ctx->err = "dp_batch_banded: bad argument"; return MAUVE_ERR_ARG;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->dp_band_from = band_from;
     return dp_batch_run(ctx, nseq, n_iv, codes, seq_off, sc, cols, col_off, score, nullptr);
 }

@@ -283,7 +283,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
             }
             if (tot == 0) continue;
             AlignState::GapRef gr; gr.lcb = l; gr.idx = (int64_t)i; gr.dp = false; gr.dp_slot = -1; gr.tot = tot;
-            if (p->gapped && nonempty >= 2 && mx <= p->max_gapped_len) {
+            if (p->gapped && nonempty >= 2 && mx <= dp_len_limit(p)) {
                 gr.dp = true; gr.dp_slot = S.n_dp++;
                 for (int g = 0; g < N; g++) {
                     DpSeqDesc d; d.genome = g; d.rev = rv[g]; d.lo0 = lo[g] - 1; d.len = ln[g];
@@ -305,6 +305,7 @@ static int align_dp(mauve_ctx *c, const int64_t *idx, int64_t n, uint32_t *cols,
 {
     AlignState &S = c->ast;
     const int N = S.N;
+    c->dp_band_from = dp_band_from_of(&S.p);
     if (!idx) return dp_batch_run_desc(c, N, S.n_dp, S.desc.data(), &S.p.scoring, cols, col_off, score, cells);
     std::vector<DpSeqDesc> sub((size_t)n * N);
     for (int64_t k = 0; k < n; k++) {
@@ -509,7 +510,8 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
         }
     }
     if (!no_shadow && na) c->shadow = [c]() { fill_anchor_table(c); };               // runs while the DP kernels do
-    rc = dp_run_from_anchors(c, N, na, h_len, h_st, h_lcb, S.p.gapped, S.p.max_gapped_len, &S.p.scoring, gapcode, &S.n_dp, &S.code_total,
+    c->dp_band_from = dp_band_from_of(&S.p);
+    rc = dp_run_from_anchors(c, N, na, h_len, h_st, h_lcb, S.p.gapped, dp_len_limit(&S.p), &S.p.scoring, gapcode, &S.n_dp, &S.code_total,
                              &c->pin_dcols, S.dcol_off, S.dscore, &cells);
     c->shadow = nullptr;
     if (rc) return rc;

@@ -219,6 +219,7 @@ int prog_node(Prog &P, int node)
     uint32_t *dcols = c->pin_dcols.as<uint32_t>();
     std::vector<int64_t> dcol_off((size_t)n_dp + 1, 0), dscore((size_t)n_dp + 1, 0);
     int64_t cells = 0;
+    c->dp_band_from = INT64_MAX;            // the progressive path splits long intervals instead
     rc = dp_batch_run_desc(c, n, n_dp, desc.data(), &p->scoring, dcols, dcol_off.data(), dscore.data(), &cells);
     if (rc) return rc;
     P.n_gap_dp += n_dp; P.n_cells += cells;

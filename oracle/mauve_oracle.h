@@ -84,6 +84,7 @@ typedef struct {
     int64_t min_recursive_gap;/* default 200 (mauveAligner.cpp:899) */
     int64_t max_gapped_len;   /* default 10000 */
     orc_scoring scoring;
+    int64_t max_banded_len;   /* banded DP for intervals in (max_gapped_len, max_banded_len]; default 0 = off */
 } orc_params;
 
 /* ---- seeds ---------------------------------------------------------------------------------- */
@@ -129,6 +130,12 @@ void orc_free_lcbs(orc_lcbs *l);
 /* ---- gapped DP -------------------------------------------------------------------------------- */
 /* progressive N-way alignment of one inter-anchor interval; seqs[g] are codes already in LCB
    orientation; cols_out must hold sum(lens) entries; returns number of columns, score in *score */
+/* banded variants: cells outside |j - floor(i*n/m)| <= 128 + |n-m| + (m+n)/64 are minus infinity */
+int64_t orc_profile_dp_band(int64_t m, const uint8_t *cnt, int k_rows, int64_t n, const uint8_t *seq,
+                            const orc_scoring *sc, uint8_t *ops_out, int64_t *score, int banded);
+int64_t orc_align_interval_band(int nseq, const uint8_t *const *seqs, const int64_t *lens,
+                                const orc_scoring *sc, uint32_t *cols_out, int64_t *score, int64_t *cells, int banded);
+int64_t orc_band_cells(int64_t m, int64_t n, int banded);
 int64_t orc_align_interval(int nseq, const uint8_t *const *seqs, const int64_t *lens,
                            const orc_scoring *sc, uint32_t *cols_out, int64_t *score,
                            int64_t *cells);

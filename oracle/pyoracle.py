@@ -50,7 +50,8 @@ class Params(C.Structure):
                 ("mode", C.c_int32), ("lcb_weight", C.c_int64), ("collinear", C.c_int32),
                 ("recursive", C.c_int32), ("gapped", C.c_int32), ("add_unaligned", C.c_int32),
                 ("extend_lcbs", C.c_int32), ("max_extension_iters", C.c_int32),
-                ("min_recursive_gap", C.c_int64), ("max_gapped_len", C.c_int64), ("scoring", Scoring)]
+                ("min_recursive_gap", C.c_int64), ("max_gapped_len", C.c_int64), ("scoring", Scoring),
+                ("max_banded_len", C.c_int64)]
 
 
 def build(force=False):
@@ -74,6 +75,10 @@ def lib():
         L.orc_sorted_mer_list.restype = C.c_int64
         L.orc_align_interval.restype = C.c_int64
         L.orc_profile_dp.restype = C.c_int64
+        L.orc_profile_dp_band.restype = C.c_int64
+        L.orc_align_interval_band.restype = C.c_int64
+        L.orc_band_cells.restype = C.c_int64
+        L.orc_band_cells.argtypes = [C.c_int64, C.c_int64, C.c_int]
         L.orc_write_xmfa.restype = C.c_void_p
         L.orc_free.argtypes = [C.c_void_p]
         _LIB = L
@@ -274,27 +279,29 @@ def compute_lcbs(length, start, min_weight, collinear=False):
     return d
 
 
-def profile_dp(cnt, k_rows, seq, scoring=None):
+def profile_dp(cnt, k_rows, seq, scoring=None, banded=False):
     sc = scoring or default_scoring()
     cnt = np.ascontiguousarray(cnt, dtype=np.uint8).reshape(-1, 4)
     seq = np.ascontiguousarray(seq, dtype=np.uint8)
     m, n = len(cnt), len(seq)
     ops = np.zeros(m + n + 1, dtype=np.uint8)
     score = C.c_int64()
-    L = lib().orc_profile_dp(C.c_int64(m), _u8p(cnt), k_rows, C.c_int64(n), _u8p(seq), C.byref(sc), _u8p(ops),
-                             C.byref(score))
+    L = lib().orc_profile_dp_band(C.c_int64(m), _u8p(cnt), k_rows, C.c_int64(n), _u8p(seq), C.byref(sc), _u8p(ops),
+                                  C.byref(score), int(bool(banded)))
     return ops[:L].copy(), int(score.value)
 
 
-def align_interval(seqs, scoring=None):
+def align_interval(seqs, scoring=None, banded=False, want_cells=False):
     sc = scoring or default_scoring()
     seqs, arr, lens = _seq_args(seqs)
     total = sum(len(s) for s in seqs)
     cols = np.zeros(max(total, 1), dtype=np.uint32)
     score = C.c_int64()
     cells = C.c_int64()
-    nc = lib().orc_align_interval(len(seqs), arr, lens, C.byref(sc), cols.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                  C.byref(score), C.byref(cells))
+    nc = lib().orc_align_interval_band(len(seqs), arr, lens, C.byref(sc), cols.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       C.byref(score), C.byref(cells), int(bool(banded)))
+    if want_cells:
+        return cols[:nc].copy(), int(score.value), int(cells.value)
     return cols[:nc].copy(), int(score.value)
 
 

@@ -177,6 +177,85 @@ def test_dp_rounds_under_a_traceback_budget():
     assert r.returncode != 0 and "(-4)" in r.stderr and "MAUVE_DP_TB_BUDGET" in r.stderr
 
 
+def _check_dp_banded(ctx, intervals, band_from):
+    widths = sorted({len(iv) for iv in intervals})
+    if len(widths) > 1:                                        # one launch per number of sequences
+        for w in widths:
+            _check_dp_banded(ctx, [iv for iv in intervals if len(iv) == w], band_from)
+        return
+    cols, score = ctx.dp_batch(intervals, band_from=band_from)
+    for iv, c, s in zip(intervals, cols, score):
+        banded = max(len(x) for x in iv) > band_from
+        ec, es = O.align_interval(iv, banded=banded)
+        assert len(c) == len(ec)
+        assert np.array_equal(c, ec)
+        assert int(s) == es
+
+
+def _long_gap_pair(rng, L, shift, div=0.05):
+    """Two related sequences whose optimal alignment leaves the band: `shift` extra bases early in b, `shift` bases
+    dropped later (the lengths stay close, so the band does not widen with them)."""
+    a = rng.integers(0, 4, L, dtype=np.uint8)
+    b = a.copy()
+    mut = rng.random(L) < div
+    b[mut] = (b[mut] + 1) % 4
+    b = np.concatenate([b[:L // 6], rng.integers(0, 4, shift, dtype=np.uint8), b[L // 6:L // 2], b[L // 2 + shift:]])
+    return [a, b]
+
+
+def test_dp_banded(ctx):
+    """Banded steps against the oracle's banded DP: a path that the band cuts (the result differs from the
+    full DP, so the band is what is being tested), unequal lengths, three sequences, the smallest shapes with every
+    interval banded, and banded + full intervals in one launch."""
+    rng = np.random.default_rng(11)
+    cut = _long_gap_pair(rng, 6000, 900)
+    full = O.align_interval(cut)
+    band = O.align_interval(cut, banded=True)
+    assert band[1] < full[1]                                   # the band is live on this input
+    _check_dp_banded(ctx, [cut], 1000)
+    ivs = [_long_gap_pair(rng, 3000, 500), [rng.integers(0, 4, 500, dtype=np.uint8), rng.integers(0, 4, 5000, dtype=np.uint8)],
+           [rng.integers(0, 4, 5000, dtype=np.uint8), rng.integers(0, 4, 300, dtype=np.uint8)],
+           _rand_interval(rng, 3, 2500, 0.2, 0.0), _rand_interval(rng, 4, 1300, 0.15, 0.2),
+           _long_gap_pair(rng, 64 * 30, 400) + [rng.integers(0, 4, 700, dtype=np.uint8)]]
+    ivs += [_rand_interval(rng, 2, int(rng.integers(1, 400)), 0.1, 0.1) for _ in range(60)]
+    _check_dp_banded(ctx, ivs, 1000)                           # long ones banded, the rest in full, one launch
+    _check_dp_banded(ctx, ivs[1:], 0)                          # every interval banded, down to single bases
+    edge = [[np.array([1], np.uint8), np.array([2], np.uint8)], [np.zeros(0, np.uint8), rng.integers(0, 4, 9, dtype=np.uint8)],
+            [rng.integers(0, 4, 64, dtype=np.uint8), rng.integers(0, 4, 65, dtype=np.uint8)],
+            [rng.integers(0, 4, 129, dtype=np.uint8), rng.integers(0, 4, 1, dtype=np.uint8)]]
+    _check_dp_banded(ctx, edge, 0)
+
+
+def _genomes_with_long_gaps(seed=5):
+    rng = np.random.default_rng(seed)
+    base = synth.random_genome(40000, rng)
+    gs = []
+    for g in range(3):
+        x = synth.mutate(base, 0.04, rng, indel_frac=0.1)
+        # a divergent stretch (no anchors inside) and a genome-specific insertion
+        p = 9000 + 3000 * g
+        x = np.concatenate([x[:p], rng.integers(0, 4, 1500 + 400 * g, dtype=np.uint8), x[p + 1200:]])
+        gs.append(x.astype(np.uint8))
+    return gs
+
+
+def test_align_banded_long_gaps(ctx):
+    """max_banded_len: inter-anchor intervals above max_gapped_len are aligned by the banded DP instead of staying
+    unaligned -- whole path against the oracle, device front end and the host one (sharded phases)."""
+    from mauvealigner_amd import _lib, parallel
+    gs = _genomes_with_long_gaps()
+    _same_align(ctx, gs, max_gapped_len=400, max_banded_len=20000)
+    # without recursive anchoring the three 1.5 - 2.3 kb stretches stay whole: banded intervals well above the limit
+    off = _same_align(ctx, gs, max_gapped_len=400, recursive=0)
+    on = _same_align(ctx, gs, max_gapped_len=400, max_banded_len=20000, recursive=0)
+    assert on["n_gap_dp"] > off["n_gap_dp"] and on["n_cols"] < off["n_cols"] and on["n_dp_cells"] > 10 * off["n_dp_cells"]
+    names = ["g%d" % i for i in range(len(gs))]
+    sh = parallel.align_sharded(ctx, _lib.default_params(max_gapped_len=400, max_banded_len=20000, recursive=0), None, names=names, want_xmfa=True)
+    for k in ("cols", "col_off", "left", "right", "reverse", "dp_score"):
+        assert np.array_equal(on[k], sh[k]), k
+    assert on["xmfa"] == sh["xmfa"] and on["n_dp_cells"] == sh["n_dp_cells"]
+
+
 def test_lcb_extension(ctx):
     """S10 (lcb_extension): masked re-search of the regions outside every LCB with lighter seeds; bit-exact against
     the oracle, and it only ever adds anchored columns."""

@@ -112,3 +112,37 @@ def test_c5_full_size_properties(ctx):
     sizes2 = ctx.align(p)
     for k in KEYS:
         assert np.array_equal(r[k], sizes2[k]), k
+
+
+def test_banded_long_intervals(ctx):
+    """Long gaps through the banded DP at lengths the full DP has no traceback memory for: a 60 kb pair
+    bit-exact against the oracle's banded DP, a 150 kb pair through properties (every base spelled once and in
+    order; the score is at least that of the gap-free diagonal walk plus the end gap, which lies inside the band)."""
+    import time
+    rng = np.random.default_rng(31)
+
+    def pair(L):
+        a = rng.integers(0, 4, L, dtype=np.uint8)
+        b = synth.mutate(a, 0.08, rng, indel_frac=0.2)
+        return [a, b]
+    iv = pair(60000)
+    t0 = time.time()
+    cols, score = ctx.dp_batch([iv], band_from=10000)
+    t1 = time.time()
+    ec, es = O.align_interval(iv, banded=True)
+    assert int(score[0]) == es and np.array_equal(cols[0], ec)
+    big = pair(150000)
+    t2 = time.time()
+    cols, score = ctx.dp_batch([big], band_from=10000)
+    t3 = time.time()
+    c = cols[0]
+    for k, s in enumerate(big):
+        assert int(((c >> np.uint32(k)) & np.uint32(1)).sum()) == len(s)
+    assert np.all(c != 0)
+    sc = O.default_scoring()
+    m, n = len(big[0]), len(big[1])
+    k = min(m, n)
+    mat = np.array([[sc.matrix[i][j] for j in range(4)] for i in range(4)], dtype=np.int64)
+    diag = int(mat[big[0][:k], big[1][:k]].sum()) + (sc.gap_open + (abs(m - n) - 1) * sc.gap_extend if m != n else 0)
+    assert int(score[0]) >= diag
+    print("banded 60k: %.3f s, 150k: %.3f s" % (t1 - t0, t3 - t2))

@@ -486,3 +486,28 @@ def test_golden_progressive_fixture_reproduces():
         assert np.array_equal(r["aln"][k], z[k]), k
     with open(os.path.join(GOLDEN, "g4x3k_tree.xmfa")) as f:
         assert f.read() == r["xmfa"]
+
+
+def test_banded_dp_oracle():
+    """Banded profile DP: equal to the full DP while the band covers the matrix, never better than it,
+    cut by a shift larger than the band, and the cell count is the band's area."""
+    rng = np.random.default_rng(21)
+    for _ in range(30):
+        a = rng.integers(0, 4, int(rng.integers(1, 129)), dtype=np.uint8)
+        b = rng.integers(0, 4, int(rng.integers(1, 129)), dtype=np.uint8)
+        f, g = O.align_interval([a, b]), O.align_interval([a, b], banded=True)
+        assert np.array_equal(f[0], g[0]) and f[1] == g[1]
+    L, shift = 4000, 700
+    a = rng.integers(0, 4, L, dtype=np.uint8)
+    b = np.concatenate([a[:600], rng.integers(0, 4, shift, dtype=np.uint8), a[600:2000], a[2000 + shift:]])
+    f = O.align_interval([a, b], want_cells=True)
+    g = O.align_interval([a, b], banded=True, want_cells=True)
+    assert g[1] < f[1] and f[2] == L * L
+    W = 128 + 0 + (2 * L) // 64
+    assert g[2] == sum(min(L, (i * L) // L + W) - max(1, (i * L) // L - W) + 1 for i in range(1, L + 1))
+    # every sequence is spelled out once, in order, whatever the band did
+    for k, s in enumerate((a, b)):
+        assert int(((g[0] >> k) & 1).sum()) == len(s)
+    # a small shift stays inside the band: same optimum
+    b2 = np.concatenate([a[:600], rng.integers(0, 4, 60, dtype=np.uint8), a[600:]])
+    assert O.align_interval([a, b2])[1] == O.align_interval([a, b2], banded=True)[1]
