@@ -1,0 +1,249 @@
+// assemble_dev.hip -- the interval table of mauve_align assembled on the device.
+//
+// GappedMatchRecord::finalize's last step (MatchRecord.h:323-345: the anchors and the aligned stretches between them are
+// spliced into one alignment per LCB) and addUnalignedIntervals (mauveAligner.cpp:748), frozen layout DESIGN.md S6:
+// per LCB the columns of anchor 0, the stretch behind it, anchor 1, ... ; then the single-genome islands.
+//
+// When the chains never left the device (chain_order_device) and the DP results stayed there (dp_run_from_anchors with
+// stay_on_device), nothing of the result has to cross PCIe for the pass to finish: the column array (the bulk: one
+// uint32 per alignment column) is written here by a wave per anchor, the per-LCB rows of the interval table (column
+// offsets, extents, DP score sums) come back in one small copy, and the columns and the anchor table are copied to the
+// host only when the caller fetches them (materialize_result).
+#include "common.hpp"
+#include "dev_scan.hpp"
+#include <cstring>
+#include <cstdlib>
+#include <algorithm>
+
+namespace {
+using namespace devscan;
+
+// the stretch between anchor k and k + 1 of one chain in genome g (same arithmetic as gap_of, pipeline.cpp / dpf_gap)
+__device__ __forceinline__ int64_t as_gap_len(const int32_t *__restrict__ alen, const int32_t *__restrict__ ast, int N, uint32_t k, int g)
+{
+    const int64_t sa = ast[(size_t)k * N + g], sb = ast[(size_t)(k + 1) * N + g];
+    int64_t lo, hi;
+    if (sa > 0) { lo = sa + alen[k]; hi = sb - 1; }
+    else { lo = -sb + alen[k + 1]; hi = -sa - 1; }
+    const int64_t ln = hi - lo + 1;
+    return ln < 0 ? 0 : ln;
+}
+
+// columns of anchor a and of the stretch behind it
+struct AsWidth {
+    const int32_t *alen, *ast, *gapcode; const int64_t *dcol_off; int N;
+    __device__ int64_t value(uint32_t a) const
+    {
+        int64_t w = alen[a];
+        const int32_t code = gapcode[a];
+        if (code >= 0) w += dcol_off[code + 1] - dcol_off[code];
+        else if (code == -2) for (int g = 0; g < N; g++) w += as_gap_len(alen, ast, N, a, g);
+        return w;
+    }
+};
+
+// first / last anchor of every LCB, the LCB's first column, its DP score sum
+__global__ void __launch_bounds__(256) as_lcb(const int32_t *__restrict__ alcb, const int32_t *__restrict__ gapcode, const int64_t *__restrict__ dscore,
+                                              const int64_t *__restrict__ col0, uint32_t na, uint32_t *__restrict__ first_a, uint32_t *__restrict__ last_a,
+                                              int64_t *__restrict__ lcb_col, unsigned long long *__restrict__ lcb_score)
+{
+    const uint32_t a = blockIdx.x * 256u + threadIdx.x;
+    const bool in = a < na;
+    const int32_t l = in ? alcb[a] : 0;
+    const int32_t code = in ? gapcode[a] : -1;
+    wave_keyed_add(lcb_score, code >= 0, (uint32_t)l, code >= 0 ? (unsigned long long)dscore[code] : 0ull);
+    if (!in) return;
+    if (a == 0 || alcb[a - 1] != l) { first_a[l] = a; lcb_col[l] = col0[a]; }
+    if (a + 1 == na || alcb[a + 1] != l) last_a[l] = a;
+}
+
+// LCB extents: the anchors of a chain are ordered, so the ends come from its first and last anchor (signed: negative = reverse)
+__global__ void __launch_bounds__(256) as_extents(const int32_t *__restrict__ alen, const int32_t *__restrict__ ast, int N, uint32_t nl,
+                                                  const uint32_t *__restrict__ first_a, const uint32_t *__restrict__ last_a,
+                                                  int64_t *__restrict__ left, int64_t *__restrict__ right)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= nl * (uint32_t)N) return;
+    const uint32_t l = t / (uint32_t)N; const int g = (int)(t % (uint32_t)N);
+    const uint32_t a0 = first_a[l], a1 = last_a[l];
+    const int64_t s0 = ast[(size_t)a0 * N + g], s1 = ast[(size_t)a1 * N + g];
+    int64_t le, re;
+    if (s0 > 0) { le = s0; re = s1 + alen[a1] - 1; }
+    else { le = -s1; re = -s0 + alen[a0] - 1; }
+    left[t] = s0 < 0 ? -le : le; right[t] = s0 < 0 ? -re : re;
+}
+
+// one wave per anchor: its own columns (every genome present), then the stretch behind it -- the DP's columns, or, for a
+// stretch that was not aligned, its bases genome by genome
+__global__ void __launch_bounds__(256) as_fill(const int32_t *__restrict__ alen, const int32_t *__restrict__ ast, const int32_t *__restrict__ gapcode,
+                                               const int64_t *__restrict__ dcol_off, const uint32_t *__restrict__ dcols,
+                                               const int64_t *__restrict__ col0, uint32_t na, int N, uint32_t full, uint32_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nw = (gridDim.x * 256u) >> 6;
+    for (uint32_t a = wave; a < na; a += nw) {
+        uint32_t *o = out + col0[a];
+        const int32_t ln = alen[a];
+        for (int32_t c = lane; c < ln; c += 64) o[c] = full;
+        o += ln;
+        const int32_t code = gapcode[a];
+        if (code >= 0) {
+            const int64_t s0 = dcol_off[code], n = dcol_off[code + 1] - s0;
+            for (int64_t c = lane; c < n; c += 64) o[c] = dcols[s0 + c];
+        } else if (code == -2) {
+            for (int g = 0; g < N; g++) {
+                const int64_t n = as_gap_len(alen, ast, N, a, g);
+                for (int64_t c = lane; c < n; c += 64) o[c] = 1u << g;
+                o += n;
+            }
+        }
+    }
+}
+
+struct Island { int64_t col, len; uint32_t bit, pad; };
+__global__ void __launch_bounds__(256) as_islands(const Island *__restrict__ isl, uint32_t n, uint32_t *__restrict__ out)
+{
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const Island is = isl[k];
+        uint32_t *o = out + is.col;
+        for (int64_t c = threadIdx.x; c < is.len; c += 256) o[c] = is.bit;
+    }
+}
+
+}  // namespace
+
+// Everything of align_finish, from the device-side chains and DP results.  The host receives the per-LCB rows; the
+// columns and the anchor table stay in c->res_cols / c->res_anch until materialize_result.
+int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes *sizes)
+{
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    AlignState &S = c->ast; AlignResult &R = c->res;
+    const int N = S.N; const int64_t nl = S.nl; const uint32_t na = (uint32_t)na64;
+    const mauve_ctx::DpFrontOut &fo = c->dpf_out;
+    const double t0 = now_ms();
+    c->stage.dp_ms = t0 - S.t_dp0;
+    const uint32_t nb = (na + TILE - 1) / TILE, blocks = (na + 255) / 256;
+    // work area: col0[na + 1], tile sums, per LCB: first / last anchor, first column, extents, score
+    auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    const size_t o_bsum = ((size_t)na + 1) * 8, o_first = o_bsum + ((size_t)nb + 8) * 8, o_last = up8(o_first + (size_t)nl * 4),
+                 o_col = up8(o_last + (size_t)nl * 4), o_left = o_col + ((size_t)nl + 1) * 8, o_right = o_left + (size_t)nl * N * 8,
+                 o_score = o_right + (size_t)nl * N * 8, w_total = o_score + (size_t)nl * 8;
+    HIPCHK(c, c->as_work.ensure(w_total + 64));
+    HIPCHK(c, c->res_cols.ensure(((size_t)S.sum + 64) * 4));          // every column holds a base, every base sits in one column
+    HIPCHK(c, c->res_anch.ensure((size_t)na * (2 + (size_t)N) * 4 + 64));
+    char *wk = c->as_work.as<char>();
+    int64_t *col0 = reinterpret_cast<int64_t *>(wk), *bsum = reinterpret_cast<int64_t *>(wk + o_bsum);
+    uint32_t *first_a = reinterpret_cast<uint32_t *>(wk + o_first), *last_a = reinterpret_cast<uint32_t *>(wk + o_last);
+    int64_t *lcb_col = reinterpret_cast<int64_t *>(wk + o_col), *left = reinterpret_cast<int64_t *>(wk + o_left),
+            *right = reinterpret_cast<int64_t *>(wk + o_right);
+    unsigned long long *score = reinterpret_cast<unsigned long long *>(wk + o_score);
+    uint32_t *out = c->res_cols.as<uint32_t>();
+    HIPCHK(c, hipMemsetAsync(score, 0, (size_t)nl * 8, c->stream));
+    // the DP front end may have found no interval: its offset / score arrays are then not set up
+    const AsWidth wf{fo.alen, fo.ast, fo.gapcode, fo.col_off, N};
+    hipLaunchKernelGGL((vscan_partial<int64_t, AsWidth>), dim3(nb), dim3(256), 0, c->stream, wf, na, bsum);
+    hipLaunchKernelGGL((vscan_write<int64_t, AsWidth>), dim3(nb), dim3(256), 0, c->stream, wf, na, bsum, col0, (int64_t *)nullptr);
+    hipLaunchKernelGGL(as_lcb, dim3(blocks), dim3(256), 0, c->stream, fo.alcb, fo.gapcode, fo.score, col0, na, first_a, last_a, lcb_col, score);
+    hipLaunchKernelGGL(as_extents, dim3(((uint32_t)nl * N + 255) / 256), dim3(256), 0, c->stream, fo.alen, fo.ast, N, (uint32_t)nl, first_a, last_a, left, right);
+    HIPCHK(c, hipGetLastError());
+    // per-LCB rows to the host: first columns, extents, scores, weights, and the number of LCB columns
+    const size_t rows_bytes = ((size_t)nl + 1) * 8 + 2 * (size_t)nl * N * 8 + (size_t)nl * 8;
+    HIPCHK(c, c->pin_asm.ensure(64 + rows_bytes + (size_t)nl * 8));
+    int64_t *h_tot = c->pin_asm.as<int64_t>(), *h_rows = h_tot + 8, *h_lw = h_rows + rows_bytes / 8;
+    HIPCHK(c, hipMemcpyAsync(h_tot, col0 + na, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_rows, lcb_col, rows_bytes, hipMemcpyDeviceToHost, c->stream));       // lcb_col .. score are adjacent
+    HIPCHK(c, hipMemcpyAsync(h_lw, c->ch_lw.p, (size_t)nl * 8, hipMemcpyDeviceToHost, c->stream));
+    {
+        const uint32_t fb = (uint32_t)std::min<int64_t>(((int64_t)na + 3) / 4, 256 * 8);
+        hipLaunchKernelGGL(as_fill, dim3(fb), dim3(256), 0, c->stream, fo.alen, fo.ast, fo.gapcode, fo.col_off, fo.cols, col0, na, N, S.full, out);
+    }
+    // the anchor table for a later fetch (the DP front end's arrays are overwritten by the next DP launch of any kind)
+    HIPCHK(c, hipMemcpyAsync(c->res_anch.p, fo.alen, (size_t)na * (2 + (size_t)N) * 4, hipMemcpyDeviceToDevice, c->stream));   // alen, ast, alcb are adjacent
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double t1 = now_ms();
+    const int64_t lcb_cols = h_tot[0];
+    const int64_t *h_col = h_rows, *h_left = h_col + nl + 1, *h_right = h_left + nl * N, *h_score = h_right + nl * N;
+    R.col_off.assign(h_col, h_col + nl);
+    R.lcb_left.assign(h_left, h_left + nl * N); R.lcb_right.assign(h_right, h_right + nl * N);
+    R.dp_score.assign(h_score, h_score + nl);
+    R.lcb_weight.assign(h_lw, h_lw + nl);
+    R.iv_left.assign((size_t)nl * N, 0); R.iv_right.assign((size_t)nl * N, 0); R.iv_reverse.assign((size_t)nl * N, 0);
+    for (int64_t i = 0; i < nl * N; i++) {
+        R.iv_left[(size_t)i] = std::llabs(R.lcb_left[(size_t)i]);
+        R.iv_right[(size_t)i] = std::llabs(R.lcb_right[(size_t)i]);
+        R.iv_reverse[(size_t)i] = R.lcb_left[(size_t)i] < 0;
+    }
+    int64_t ncols = lcb_cols, niv = nl;
+    if (S.p.add_unaligned) {
+        // islands: same sweep as align_finish; the columns are filled on the device from a small table
+        std::vector<Island> isl;
+        for (int g = 0; g < N; g++) {
+            std::vector<std::pair<int64_t, int64_t>> sp;
+            for (int64_t l = 0; l < nl; l++) if (R.iv_left[(size_t)l * N + g]) sp.push_back({R.iv_left[(size_t)l * N + g], R.iv_right[(size_t)l * N + g]});
+            std::sort(sp.begin(), sp.end());
+            int64_t cur = 1;
+            for (size_t i = 0; i <= sp.size(); i++) {
+                const int64_t lo = cur, hi = i < sp.size() ? sp[i].first - 1 : c->lens[(size_t)g];
+                if (hi >= lo) {
+                    R.col_off.push_back(ncols);
+                    Island is; is.col = ncols; is.len = hi - lo + 1; is.bit = 1u << g; is.pad = 0;
+                    isl.push_back(is);
+                    ncols += hi - lo + 1;
+                    for (int h = 0; h < N; h++) { R.iv_left.push_back(h == g ? lo : 0); R.iv_right.push_back(h == g ? hi : 0); R.iv_reverse.push_back(0); }
+                    R.dp_score.push_back(0);
+                    niv++;
+                }
+                if (i < sp.size() && sp[i].second + 1 > cur) cur = sp[i].second + 1;
+            }
+        }
+        if (ncols > S.sum) { c->err = "assemble_device: more columns than bases (internal error)"; return MAUVE_ERR_HIP; }
+        if (!isl.empty()) {
+            const size_t ib = isl.size() * sizeof(Island);
+            HIPCHK(c, c->pin_asm.ensure(64 + rows_bytes + (size_t)nl * 8 + ib + 64));
+            char *pi = c->pin_asm.as<char>() + 64 + rows_bytes + (size_t)nl * 8;
+            memcpy(pi, isl.data(), ib);
+            HIPCHK(c, c->as_isl.ensure(ib + 64));
+            HIPCHK(c, hipMemcpyAsync(c->as_isl.p, pi, ib, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(as_islands, dim3((uint32_t)std::min<size_t>(isl.size(), 1024)), dim3(256), 0, c->stream,
+                               c->as_isl.as<Island>(), (uint32_t)isl.size(), out);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(c->stream));            // pin_asm is reused by the next call
+        }
+    }
+    R.col_off.push_back(ncols);
+    R.n_cols = (size_t)ncols;
+    R.dev_pending = true; R.dev_na = na; R.cols_ext = nullptr;
+    R.cols_fill = 0; R.cols_dirty.clear();                       // the host column buffer no longer holds the "all anchors" state
+    R.sz.n_mums = S.nm; R.sz.n_lcb = nl; R.sz.n_anchor = na; R.sz.n_iv = niv; R.sz.n_cols = ncols;
+    R.sz.n_gap_dp = fo.n_dp; R.sz.n_dp_cells = cells;
+    *sizes = R.sz;
+    const double t2 = now_ms();
+    if (trace) fprintf(stderr, "[trace] assemble (device): layout+fill %.3f ms, islands+tables %.3f\n", t1 - t0, t2 - t1);
+    c->stage.assemble_ms = t2 - t0;
+    c->stage.total_ms = t2 - S.t0;
+    S.open = false;
+    return MAUVE_OK;
+}
+
+// columns and anchor table of a device-assembled result -> host (page-locked staging); idempotent
+int materialize_result(mauve_ctx *c)
+{
+    AlignResult &R = c->res;
+    if (!R.dev_pending) return MAUVE_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int N = c->ast.N; const size_t na = R.dev_na;
+    const size_t cb = R.n_cols * 4, ab = na * (2 + (size_t)N) * 4;
+    HIPCHK(c, c->pin_cols.ensure(cb + ab + 64));
+    char *pc = c->pin_cols.as<char>();
+    if (cb) HIPCHK(c, hipMemcpyAsync(pc, c->res_cols.p, cb, hipMemcpyDeviceToHost, c->stream));
+    if (ab) HIPCHK(c, hipMemcpyAsync(pc + cb, c->res_anch.p, ab, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    R.cols_ext = reinterpret_cast<const uint32_t *>(pc);
+    const int32_t *hl = reinterpret_cast<const int32_t *>(pc + cb), *hs = hl + na, *hb = hs + na * N;
+    R.anchor_length.resize(na); R.anchor_start.resize(na * N); R.anchor_lcb.resize(na);
+    for (size_t a = 0; a < na; a++) { R.anchor_length[a] = hl[a]; R.anchor_lcb[a] = hb[a]; }
+    for (size_t i = 0; i < na * N; i++) R.anchor_start[i] = hs[i];
+    R.dev_pending = false;
+    return MAUVE_OK;
+}

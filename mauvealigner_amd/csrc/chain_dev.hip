@@ -267,9 +267,88 @@ __global__ void __launch_bounds__(256) ch_label(const int32_t *__restrict__ len,
     lcb[i] = len[i] > 0 ? final_id[node_of[i]] : -1;
 }
 
+// ---- the chains on the device (align_device_tail, pipeline.cpp) ---------------------------------------------------
+// chain order = LCB by LCB, canonical (genome-0) order inside: a stable sort of the labelled matches by LCB id
+__global__ void __launch_bounds__(256) co_keys(const int32_t *__restrict__ lcb, uint32_t n, uint32_t nl, uint32_t *__restrict__ key,
+                                               uint32_t *__restrict__ val)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const int32_t l = lcb[i];
+    key[i] = l >= 0 ? (uint32_t)l : nl;                      // dead / eliminated: behind every LCB
+    val[i] = i;
+}
+
+// anchors in chain order (alen[cap], ast[cap * N], alcb[cap]), their number, LCB weights (sum of length * N), and the
+// number of inter-anchor gaps the recursion would have to look at (longest side above min_gap; gap_weight, recursive.cpp)
+__global__ void __launch_bounds__(256) co_gather(const uint32_t *__restrict__ key, const uint32_t *__restrict__ val, uint32_t n, uint32_t nl, int N,
+                                                 const int32_t *__restrict__ len, const int32_t *__restrict__ st, int64_t min_gap,
+                                                 int32_t *__restrict__ alen, int32_t *__restrict__ ast, int32_t *__restrict__ alcb,
+                                                 unsigned long long *__restrict__ lw, uint32_t *__restrict__ out)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t l = j < n ? key[j] : nl;
+    const bool alive = l < nl;
+    const uint32_t i = alive ? val[j] : 0u;
+    const int32_t ln = alive ? len[i] : 0;
+    wave_keyed_add(lw, alive, l, (unsigned long long)((int64_t)ln * N));
+    if (!alive) return;
+    alen[j] = ln; alcb[j] = (int32_t)l;
+    for (int g = 0; g < N; g++) ast[(size_t)j * N + g] = st[(size_t)i * N + g];
+    const bool last = j + 1 == n || key[j + 1] >= nl;
+    if (last) out[0] = j + 1;                                // the labelled matches are the first na entries of the order
+    if (!last && key[j + 1] == l) {
+        const uint32_t i2 = val[j + 1];
+        const int32_t ln2 = len[i2];
+        int64_t mx = 0;
+        for (int g = 0; g < N; g++) {
+            const int64_t sa = st[(size_t)i * N + g], sb = st[(size_t)i2 * N + g];
+            int64_t lo, hi;
+            if (sa > 0) { lo = sa + ln; hi = sb - 1; } else { lo = -sb + ln2; hi = -sa - 1; }
+            mx = max(mx, hi - lo + 1);
+        }
+        if (mx > min_gap) atomicAdd(&out[1], 1u);
+    }
+}
+
 }  // namespace
 
-int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchVec &m, std::vector<int64_t> &match_lcb, int64_t &n_lcb)
+// The chains stay on the device: anchors in chain order in c->ch_anch (capacity layout: alen[n], ast[n * N], alcb[n]),
+// LCB weights in c->ch_lw.  Out: number of anchors, number of gaps the recursion would look at.
+int chain_order_device(mauve_ctx *c, int N, int64_t nl, int64_t min_gap, int64_t *na_out, int64_t *n_rec_out)
+{
+    const uint32_t n = (uint32_t)c->dev_rec_n;
+    *na_out = 0; *n_rec_out = 0;
+    if (nl <= 0) return MAUVE_OK;
+    const int32_t *len = c->ch_len.as<int32_t>(), *lcb = len + 2 * (size_t)n;
+    const int32_t *st = c->ch_st.as<int32_t>();
+    uint32_t *k1 = c->ch_ent.as<uint32_t>(), *v1 = k1 + n, *k2 = v1 + n, *v2 = k2 + n;
+    HIPCHK(c, c->ch_anch.ensure((size_t)n * (2 + (size_t)N) * 4 + 64));
+    HIPCHK(c, c->ch_lw.ensure((size_t)nl * 8 + 64));
+    int32_t *alen = c->ch_anch.as<int32_t>(), *ast = alen + n, *alcb = ast + (size_t)n * N;
+    unsigned long long *lw = c->ch_lw.as<unsigned long long>();
+    uint32_t *cnt = c->ch_cnt.as<uint32_t>();
+    const uint32_t blocks = (n + 255) / 256;
+    int bits = 1; while ((1LL << bits) <= nl) bits++;
+    HIPCHK(c, hipMemsetAsync(lw, 0, (size_t)nl * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(cnt + 16, 0, 8, c->stream));
+    hipLaunchKernelGGL(co_keys, dim3(blocks), dim3(256), 0, c->stream, lcb, n, (uint32_t)nl, k1, v1);
+    uint32_t *kk = k1, *vv = v1;
+    int rc = sort_pairs_u32(c, n, bits, &kk, &vv, k2, v2, MAUVE_K_MISC);
+    if (rc) return rc;
+    hipLaunchKernelGGL(co_gather, dim3(blocks), dim3(256), 0, c->stream, kk, vv, n, (uint32_t)nl, N, len, st, min_gap, alen, ast, alcb, lw, cnt + 16);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, c->pin_chain.ensure(256));
+    HIPCHK(c, hipMemcpyAsync(c->pin_chain.p, cnt + 16, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *na_out = c->pin_chain.as<uint32_t>()[0];
+    *n_rec_out = c->pin_chain.as<uint32_t>()[1];
+    return MAUVE_OK;
+}
+
+// Elimination, LCB graph, greedy breakpoint elimination, labels: everything stays on the device (cropped records in
+// c->ch_len / c->ch_st, final LCB id per match behind them).  chain_device_copy_back brings them to the host.
+int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, int64_t &n_lcb)
 {
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     const double t0 = now_ms();
@@ -341,7 +420,6 @@ int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchV
     if (hc[3]) { c->err = "chain_device: overlap cluster beyond the per-thread limit"; return MAUVE_ERR_LIMIT; }      // caller falls back to the host chain
     const uint32_t na = hc[0], K = hc[1];
     const double t1 = now_ms();
-    match_lcb.assign((size_t)n, -1);
     n_lcb = 0;
     std::vector<int64_t> final_id;
     if (K) {
@@ -368,8 +446,19 @@ int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchV
     } else {
         HIPCHK(c, hipMemsetAsync(lcb, 0xff, (size_t)n * 4, c->stream));
     }
+    if (trace) fprintf(stderr, "[trace] chain (device): eliminate+nodes %.3f ms (na=%u K=%u), links+greedy+labels %.3f\n", t1 - t0, na, K, now_ms() - t1);
+    return MAUVE_OK;
+}
+
+// the cropped list and its labels back to the host (dead records stay in the list with length 0 / LCB -1)
+int chain_device_copy_back(mauve_ctx *c, int N, MatchVec &m, std::vector<int64_t> &match_lcb)
+{
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     const double t2 = now_ms();
-    // the cropped list and its labels back to the host (dead records stay in the list with length 0 / LCB -1)
+    const uint32_t n = (uint32_t)c->dev_rec_n;
+    const int32_t *len = c->ch_len.as<int32_t>(), *lcb = len + 2 * (size_t)n;
+    const int32_t *st = c->ch_st.as<int32_t>();
+    match_lcb.assign((size_t)n, -1);
     const size_t rb = (size_t)n * 4 * (2 + (size_t)N);
     HIPCHK(c, c->pin_chain.ensure(256 + rb));
     int32_t *hl = reinterpret_cast<int32_t *>(c->pin_chain.as<char>() + 256), *hs = hl + n, *hb = hs + (size_t)n * N;
@@ -389,7 +478,13 @@ int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchV
         }
         match_lcb[i] = hb[i];
     }
-    if (trace) fprintf(stderr, "[trace] chain (device): eliminate+nodes %.3f ms (na=%u K=%u), links+greedy+labels %.3f, copy back %.3f\n",
-                       t1 - t0, na, K, t2 - t1, now_ms() - t2);
+    if (trace) fprintf(stderr, "[trace] chain (device): copy back %.3f ms\n", now_ms() - t2);
     return MAUVE_OK;
+}
+
+int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchVec &m, std::vector<int64_t> &match_lcb, int64_t &n_lcb)
+{
+    int rc = chain_device_core(c, N, min_weight, collinear, n_lcb);
+    if (rc) return rc;
+    return chain_device_copy_back(c, N, m, match_lcb);
 }

@@ -127,6 +127,11 @@ struct AlignResult {
     uint32_t cols_fill = 0;            // value every word outside cols_dirty holds (0 = no such invariant)
     std::vector<std::pair<size_t, size_t>> cols_dirty;   // (offset, length) ranges holding gap columns
     std::vector<int64_t> dp_score;
+    // device-assembled result (assemble_dev.hip): the columns and the anchor table are still in HBM (res_cols / res_anch)
+    bool dev_pending = false;
+    size_t dev_na = 0;
+    const uint32_t *cols_ext = nullptr;      // the columns in page-locked staging after materialize_result (else: cols)
+    const uint32_t *cols_data() const { return cols_ext ? cols_ext : cols.data(); }
 };
 
 // N-way match list in flat records of (1 + N) int64: length, signed 1-based starts (libMems Match layout).
@@ -156,6 +161,7 @@ struct AlignState {
     struct Item { int64_t lcb; uint32_t idx; int64_t col0; int64_t gap; };
     bool open = false;
     bool anchor_table_done = false;     // anchor_length/start/lcb already filled (in the DP kernel's shadow)
+    bool dev_tail = false;              // the chains stayed on the device: DP front end and assembly run there (mauve_align)
     mauve_params p{};
     int N = 0; uint32_t full = 0;
     int64_t sum = 0, nm = 0, nl = 0, n_dp = 0, code_total = 0, n_anchor = 0, anchor_cols = 0;
@@ -172,7 +178,7 @@ struct AlignState {
     // start a new alignment: scalars to zero, vectors emptied but not released
     void reset()
     {
-        open = false; anchor_table_done = false; p = mauve_params(); N = 0; full = 0;
+        open = false; anchor_table_done = false; dev_tail = false; p = mauve_params(); N = 0; full = 0;
         sum = nm = nl = n_dp = code_total = n_anchor = anchor_cols = 0; t0 = t_dp0 = 0;
         gaps.clear(); desc.clear(); dcol_off.clear(); dscore.clear();
         match_lcb.clear(); items.clear();
@@ -208,6 +214,9 @@ struct mauve_ctx {
     DevBuf join_bound;                   // join_hash: first bucket boundary at or after every chunk edge
     DevBuf join_ovf;                     // join_hash: [count, pad, (lo, hi) ...] ranges handed back to the full sort + serial join
     DevBuf ch_len, ch_st, ch_crop, ch_ent, ch_ord, ch_rank, ch_node, ch_graph, ch_cnt;   // device chain (chain_dev.hip)
+    DevBuf ch_anch, ch_lw;               // the chains in chain order and the LCB weights (chain_order_device)
+    DevBuf as_work, as_isl, res_cols, res_anch;      // device assembly (assemble_dev.hip): work area, islands, result columns, anchor table
+    PinnedBuf pin_asm, pin_cols;         // ... its per-LCB rows coming back; the columns and anchors on their way to a fetch
     PinnedBuf pin_chain;
     DevBuf run_sum;                      // pairwise finder: run list (start, length, exactly-once genome set)
     DevBuf rec_vinv, rec_vcm;            // ... and their ambiguity / contig bitmaps, when the resident genomes have them
@@ -224,6 +233,8 @@ struct mauve_ctx {
     DevBuf dp_desc, dp_list, dp_codes, dp_off, dp_prof_cnt, dp_prof_mask, dp_prof2_cnt, dp_prof2_mask, dp_tb, dp_meta, dp_score,
         dp_cols, dp_rows;
 
+    // where dp_run_from_anchors left its device-side results (valid until the next DP launch)
+    struct DpFrontOut { const int32_t *alen, *ast, *alcb, *gapcode; const int64_t *col_off, *score; const uint32_t *cols; int64_t n_dp, n_cols; } dpf_out{};
     int64_t dp_band_from = INT64_MAX;     // intervals whose longest sequence exceeds this run the banded DP (dp_batch.hip)
     DevBuf dpf_anch, dpf_work, dpf_tot;   // device front end of the DP stage (dp_run_from_anchors)
 
@@ -300,6 +311,9 @@ int sort_pairs_u32(mauve_ctx *ctx, uint32_t n, int key_bits, uint32_t **keys_io,
                    int timer_id);
 // device chain (chain_dev.hip): EliminateOverlaps + LCBs of the N-way list the seed pass left in ctx->sorted_rec
 int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchVec &m, std::vector<int64_t> &match_lcb, int64_t &n_lcb);
+int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, int64_t &n_lcb);
+int chain_device_copy_back(mauve_ctx *c, int N, MatchVec &m, std::vector<int64_t> &match_lcb);
+int chain_order_device(mauve_ctx *c, int N, int64_t nl, int64_t min_gap, int64_t *na_out, int64_t *n_rec_out);
 
 // host chaining (chain_host.cpp)
 struct ChainOrders { std::vector<std::vector<uint32_t>> ord; bool sparse = false; };   // per genome: match indices in left-end order;
@@ -320,6 +334,8 @@ inline int64_t dp_len_limit(const mauve_params *p) { return p->max_banded_len > 
 inline int64_t dp_band_from_of(const mauve_params *p) { return p->max_banded_len > p->max_gapped_len ? p->max_gapped_len : INT64_MAX; }
 int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na, const int32_t *h_len, const int32_t *h_st, const int32_t *h_lcb, int gapped,
                         int64_t max_gapped_len, const mauve_scoring *scoring, int32_t *gapcode, int64_t *n_dp_out, int64_t *code_total_out,
-                        PinnedBuf *dcols, std::vector<int64_t> &dcol_off, std::vector<int64_t> &dscore, int64_t *cells);
+                        PinnedBuf *dcols, std::vector<int64_t> &dcol_off, std::vector<int64_t> &dscore, int64_t *cells, bool stay_on_device = false);
+int assemble_device(mauve_ctx *c, int64_t na, int64_t cells, mauve_align_sizes *sizes);
+int materialize_result(mauve_ctx *c);
 int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,
                  const mauve_scoring *sc, uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells);

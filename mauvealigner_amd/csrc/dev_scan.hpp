@@ -53,6 +53,22 @@ __device__ __forceinline__ void tiles_before_add(const uint32_t *__restrict__ v,
     *before = tb; *all = ta;
 }
 
+// arr[l] += v for the active lanes of a wave, which mostly share one key l (entries sorted by key): then the wave adds up
+// first and issues one atomic instead of 64 on the same address.  Every lane of the wave must make the call.
+__device__ __forceinline__ void wave_keyed_add(unsigned long long *arr, bool active, uint32_t l, unsigned long long v)
+{
+    const uint64_t act = __ballot(active);
+    if (!act) return;
+    const int first = __ffsll((unsigned long long)act) - 1;
+    const uint32_t l0 = (uint32_t)__shfl((int)l, first);
+    if (__ballot(active && l == l0) == act) {
+        unsigned long long s = active ? v : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if ((int)(threadIdx.x & 63) == first) atomicAdd(&arr[l0], s);
+    } else if (active) atomicAdd(&arr[l], v);
+}
+
 // ---- flag compaction over the tiles: cmp_count (flags per tile) + cmp_write (every workgroup sums the tiles before it) ----
 // F: domain(y) entries; flag(r, y); each(r, exclusive count, flag, y) for every entry; emit(r, slot, y) for the flagged;
 // total(count, y) once.

@@ -1056,16 +1056,18 @@ __global__ void __launch_bounds__(256) dpf_scores(const DpMeta *__restrict__ met
 
 // anchors: na records in chain order (LCB by LCB, genome-0 order inside), host arrays (page-locked).  Out: gapcode[na]
 // (-1 / -2 / DP slot), n_dp, the DP columns in *dcols (page-locked, grown here), dcol_off[n_dp + 1], dscore[n_dp].
+// stay_on_device: the anchor arrays are device pointers and nothing but the totals comes back -- the gap codes, column
+// offsets, scores and columns are left where ctx->dpf_out says, for the device assembly (assemble_dev.hip).
 int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_len, const int32_t *h_st, const int32_t *h_lcb, int gapped,
                         int64_t max_gapped_len, const mauve_scoring *scoring, int32_t *gapcode, int64_t *n_dp_out, int64_t *code_total_out,
-                        PinnedBuf *dcols, std::vector<int64_t> &dcol_off, std::vector<int64_t> &dscore, int64_t *cells)
+                        PinnedBuf *dcols, std::vector<int64_t> &dcol_off, std::vector<int64_t> &dscore, int64_t *cells, bool stay_on_device)
 {
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     static const bool no_mw = getenv("MAUVE_DP_ONE_WAVE") != nullptr, no_groups = getenv("MAUVE_DP_NO_GROUPS") != nullptr;
     const double t0 = now_ms();
     *n_dp_out = 0; *code_total_out = 0; if (cells) *cells = 0;
     dcol_off.assign(1, 0); dscore.clear();
-    if (na64 < 2) { for (int64_t k = 0; k < na64; k++) gapcode[k] = -1; return MAUVE_OK; }
+    if (na64 < 2) { if (stay_on_device) { ctx->err = "dp: device tail needs two anchors"; return MAUVE_ERR_STATE; } for (int64_t k = 0; k < na64; k++) gapcode[k] = -1; return MAUVE_OK; }
     if (na64 >= (1LL << 31)) { ctx->err = "dp: too many anchors"; return MAUVE_ERR_LIMIT; }
     const uint32_t na = (uint32_t)na64, nb = (na + TILE - 1) / TILE, blocks = (na + 255) / 256;
     // device arrays sized by na (an upper bound of n_dp)
@@ -1094,9 +1096,10 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     int64_t *d_seq_off = ctx->dp_off.as<int64_t>();
     int64_t *d_tb_off = d_seq_off + ((size_t)na * N + 1), *d_rows_off = d_tb_off + (na + 1), *d_col_off = d_rows_off + (na + 1);
     HIPCHK(ctx, hipMemsetAsync(tot, 0, 256, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(alen, h_len, (size_t)na * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ast, h_st, (size_t)na * N * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(alcb, h_lcb, (size_t)na * 4, hipMemcpyHostToDevice, ctx->stream));
+    const hipMemcpyKind up = stay_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIPCHK(ctx, hipMemcpyAsync(alen, h_len, (size_t)na * 4, up, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ast, h_st, (size_t)na * N * 4, up, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(alcb, h_lcb, (size_t)na * 4, up, ctx->stream));
     hipLaunchKernelGGL(dpf_gap_flags, dim3(blocks), dim3(256), 0, ctx->stream, alen, ast, alcb, na, N, gapped, max_gapped_len, d_gapcode);
     const DpSlots sl{d_gapcode, na, anchor_of, tot};
     hipLaunchKernelGGL((cmp_count<DpSlots>), dim3(nb), dim3(256), 0, ctx->stream, sl, bcnt);
@@ -1112,11 +1115,13 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     DpFrontTotals *ht = ctx->pin_dp_in.as<DpFrontTotals>();
     int32_t *h_gapcode = reinterpret_cast<int32_t *>(ctx->pin_dp_in.as<char>() + 256);
     HIPCHK(ctx, hipMemcpyAsync(ht, tot, sizeof(DpFrontTotals), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h_gapcode, d_gapcode, (size_t)na * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (!stay_on_device) HIPCHK(ctx, hipMemcpyAsync(h_gapcode, d_gapcode, (size_t)na * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t n_dp = (uint32_t)ht->n_dp;
-    memcpy(gapcode, h_gapcode, (size_t)na * 4);
+    if (!stay_on_device) memcpy(gapcode, h_gapcode, (size_t)na * 4);
     *n_dp_out = n_dp;
+    mauve_ctx::DpFrontOut &fo = ctx->dpf_out;
+    fo.alen = alen; fo.ast = ast; fo.alcb = alcb; fo.gapcode = d_gapcode; fo.col_off = d_col_off; fo.score = need; fo.cols = nullptr; fo.n_dp = n_dp; fo.n_cols = 0;
     const double t1 = now_ms();
     if (n_dp == 0) return MAUVE_OK;
     const uint32_t nbd = (n_dp + TILE - 1) / TILE, nbs = (n_dp * (uint32_t)N + TILE - 1) / TILE, blk_d = (n_dp + 255) / 256;
@@ -1197,6 +1202,15 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // host work while the DP kernels run
+    if (stay_on_device) {
+        HIPCHK(ctx, hipMemcpyAsync(ht, tot, sizeof(DpFrontTotals), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (cells) *cells = ht->cells;
+        fo.cols = ctx->dp_cols.as<uint32_t>(); fo.n_cols = ht->cols;
+        if (trace) fprintf(stderr, "[trace] dp (device front, results stay): %u intervals (%lld workgroup, %lld one-wave, %lld two/wave, %lld four/wave), %d round(s); gaps+slots %.3f ms, sizing+order %.3f, kernels+offsets %.3f\n",
+                           n_dp, (long long)n_big, (long long)cl.n_med, (long long)cl.n_s32, (long long)cl.n_s16, rounds, t1 - t0, t2 - t1, now_ms() - t2);
+        return MAUVE_OK;
+    }
     dcol_off.resize((size_t)n_dp + 1); dscore.resize((size_t)n_dp);
     HIPCHK(ctx, ctx->pin_meta.ensure(((size_t)n_dp * 2 + 2) * 8));
     int64_t *p_off = ctx->pin_meta.as<int64_t>(), *p_score = p_off + n_dp + 1;

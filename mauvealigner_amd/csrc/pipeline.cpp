@@ -132,7 +132,7 @@ static int extend_lcbs(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
 // begin : seed pass, chaining, recursive anchoring, interval descriptors        (every rank, deterministic)
 // dp    : gapped alignment of a subset of the intervals                         (each rank its share)
 // finish: assembly of the interval table from the columns of ALL intervals      (every rank)
-static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = false, const MatchVec *given = nullptr)
+static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = false, const MatchVec *given = nullptr, bool want_tail = false)
 {
     const int N = c->nseq;
     AlignState &S = c->ast;
@@ -145,6 +145,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
     R.mum_length.clear(); R.mum_start.clear(); R.lcb_left.clear(); R.lcb_right.clear(); R.lcb_weight.clear();
     R.anchor_length.clear(); R.anchor_start.clear(); R.anchor_lcb.clear(); R.iv_left.clear(); R.iv_right.clear();
     R.iv_reverse.clear(); R.col_off.clear(); R.n_cols = 0; R.dp_score.clear();
+    R.dev_pending = false; R.dev_na = 0; R.cols_ext = nullptr;
     memset(&c->stage, 0, sizeof c->stage);
 
     int64_t sum = 0; for (int g = 0; g < N; g++) sum += c->lens[g];
@@ -216,9 +217,31 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
     bool on_device = !host_chain && nm > 0 && c->dev_rec_n == nm;
     double t1b = t1;
     if (on_device) {
-        rc = chain_device(c, N, lcbw, p->collinear != 0, m, match_lcb, nl);
+        rc = chain_device_core(c, N, lcbw, p->collinear != 0, nl);
         if (rc == MAUVE_ERR_LIMIT) on_device = false;
         else if (rc) return rc;
+        else {
+            // The chains can stay on the device when nothing on the host has to look at them: no LCB extension, and no
+            // inter-anchor gap long enough for the recursion (counted on the device).  The DP front end and the assembly
+            // then run there too (mauve_align), and the host sees only the per-LCB rows.
+            static const bool host_tail = getenv("MAUVE_HOST_TAIL") != nullptr;      // A/B switch
+            if (want_tail && !host_tail && !p->extend_lcbs && nl > 0) {
+                int64_t na = 0, nrec = 0;
+                rc = chain_order_device(c, N, nl, p->min_recursive_gap, &na, &nrec);
+                if (rc) return rc;
+                if (na >= 2 && (!p->recursive || nrec == 0)) {
+                    S.nl = nl; S.n_anchor = na; S.dev_tail = true;
+                    const double t2 = now_ms();
+                    c->stage.chain_ms = t2 - t1;
+                    if (getenv("MAUVE_TRACE")) fprintf(stderr, "[trace] chain: on the device %.3f ms, %lld anchors in %lld LCBs stay there\n", t2 - t1, (long long)na, (long long)nl);
+                    S.t_dp0 = t2;
+                    S.open = true;
+                    return MAUVE_OK;
+                }
+            }
+            rc = chain_device_copy_back(c, N, m, match_lcb);
+            if (rc) return rc;
+        }
         t1b = now_ms();
     }
     if (!on_device) {
@@ -480,10 +503,20 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     HIPCHK(c, hipSetDevice(c->device));
     static const bool host_front = getenv("MAUVE_HOST_DP_FRONT") != nullptr;      // A/B switch
     static const bool no_shadow = getenv("MAUVE_NO_SHADOW") != nullptr;
-    int rc = align_begin(c, p, !host_front);
+    int rc = align_begin(c, p, !host_front, nullptr, !host_front);
     if (rc) return rc;
     AlignState &S = c->ast;
     int64_t cells = 0;
+    if (S.dev_tail) {
+        // chains, DP and assembly on the device: anchors from chain_order_device, results left in HBM until they are fetched
+        const uint32_t cap = (uint32_t)c->dev_rec_n;
+        const int32_t *d_len = c->ch_anch.as<int32_t>(), *d_st = d_len + cap, *d_lcb = d_st + (size_t)cap * S.N;
+        c->dp_band_from = dp_band_from_of(&S.p);
+        rc = dp_run_from_anchors(c, S.N, S.n_anchor, d_len, d_st, d_lcb, S.p.gapped, dp_len_limit(&S.p), &S.p.scoring, nullptr, &S.n_dp, &S.code_total,
+                                 nullptr, S.dcol_off, S.dscore, &cells, true);
+        if (rc) return rc;
+        return assemble_device(c, S.n_anchor, cells, sizes);
+    }
     if (host_front) {
         HIPCHK(c, c->pin_dcols.ensure(((size_t)S.code_total + 1) * sizeof(uint32_t)));
         uint32_t *dcols = c->pin_dcols.as<uint32_t>();
@@ -657,13 +690,14 @@ int mauve_align_fetch(mauve_ctx *c, int64_t *mum_length, int64_t *mum_start, int
                       int64_t *dp_score)
 {
     if (!c) return MAUVE_ERR_ARG;
+    { int rcm = materialize_result(c); if (rcm) return rcm; }
     const AlignResult &R = c->res;
     CPY(mum_length, R.mum_length); CPY(mum_start, R.mum_start);
     CPY(lcb_left, R.lcb_left); CPY(lcb_right, R.lcb_right); CPY(lcb_weight, R.lcb_weight);
     CPY(anchor_length, R.anchor_length); CPY(anchor_start, R.anchor_start); CPY(anchor_lcb, R.anchor_lcb);
     CPY(iv_left, R.iv_left); CPY(iv_right, R.iv_right); CPY(iv_reverse, R.iv_reverse);
     CPY(col_off, R.col_off); CPY(dp_score, R.dp_score);
-    if (cols && R.n_cols) memcpy(cols, R.cols.data(), R.n_cols * sizeof(uint32_t));
+    if (cols && R.n_cols) memcpy(cols, R.cols_data(), R.n_cols * sizeof(uint32_t));
     return MAUVE_OK;
 }
 
@@ -672,8 +706,10 @@ int mauve_align_fetch(mauve_ctx *c, int64_t *mum_length, int64_t *mum_start, int
 int mauve_write_xmfa(mauve_ctx *c, const char *const *names, char *buf, int64_t *len)
 {
     if (!c || !len) return MAUVE_ERR_ARG;
+    { int rcm = materialize_result(c); if (rcm) return rcm; }
     const AlignResult &R = c->res;
     const int N = c->nseq;
+    const uint32_t *rcols = R.cols_data();
     static const char B[4] = {'A', 'C', 'G', 'T'};
     std::string out;
     out.reserve(R.n_cols * (size_t)N / 2 + 4096);
@@ -695,7 +731,7 @@ int mauve_write_xmfa(mauve_ctx *c, const char *const *names, char *buf, int64_t 
             row.resize((size_t)nc);
             const uint64_t *w = c->host_packed[(size_t)g];
             for (int64_t k = 0; k < nc; k++) {
-                if (R.cols[(size_t)(c0 + k)] >> g & 1) {
+                if (rcols[(size_t)(c0 + k)] >> g & 1) {
                     uint8_t b = base_at(w, nxt - 1);
                     row[(size_t)k] = rev ? B[3 - b] : B[b];
                     if (c->has_invalid && (c->h_invalid[c->base_mask_off[(size_t)g] + (size_t)((nxt - 1) >> 6)] >> ((nxt - 1) & 63) & 1)) row[(size_t)k] = 'N';

@@ -177,6 +177,60 @@ def test_dp_rounds_under_a_traceback_budget():
     assert r.returncode != 0 and "(-4)" in r.stderr and "MAUVE_DP_TB_BUDGET" in r.stderr
 
 
+TAIL_SCRIPT = r"""
+import sys, json, hashlib, numpy as np
+sys.path.insert(0, %(root)r)
+from mauvealigner_amd import _lib, synth
+from oracle import pyoracle as O
+ctx = _lib.Context(0)
+out = {}
+cases = [("C3", 0.04, dict(recursive=0)), ("C3", 0.04, dict(recursive=0, add_unaligned=0)), ("C2", 0.03, dict(recursive=0, gapped=0)),
+         ("C3", 0.04, dict()), ("C1", 0.3, dict(recursive=0, max_gapped_len=40))]
+def long_gaps():
+    rng = np.random.default_rng(5)
+    base = synth.random_genome(30000, rng)
+    gs = []
+    for g in range(3):
+        x = synth.mutate(base, 0.04, rng, indel_frac=0.1)
+        p = 9000 + 3000 * g
+        gs.append(np.concatenate([x[:p], rng.integers(0, 4, 1500, dtype=np.uint8), x[p + 1200:]]).astype(np.uint8))
+    return gs
+cases.append(("long gaps", 0, dict()))                 # the recursion has work: the chains go back to the host
+for cfg, scale, kw in cases:
+    gs = long_gaps() if cfg == "long gaps" else synth.make_config(cfg, scale=scale)
+    ctx.set_genomes(gs)
+    names = ["g%%d" %% i for i in range(len(gs))]
+    n0 = ctx.align(_lib.default_params(**kw), fetch=False)          # sizes alone, nothing fetched
+    r = ctx.align(_lib.default_params(**kw), names=names, want_xmfa=True)
+    e = O.align(gs, O.default_params(**kw), names=names, want_xmfa=True)
+    a = e["aln"]
+    assert n0["n_cols"] == r["n_cols"] == len(a["cols"]) and n0["n_iv"] == a["n_iv"] and n0["n_anchor"] == len(a["anchor_length"])
+    for k in ("anchor_length", "anchor_start", "anchor_lcb", "left", "right", "reverse", "col_off", "cols", "dp_score"):
+        assert np.array_equal(r[k], a[k]), (cfg, kw, k)
+    assert np.array_equal(r["lcb_weight"], e["lcbs"]["weight"]) and r["n_dp_cells"] == a["n_dp_cells"] and r["xmfa"] == e["xmfa"]
+print("OK")
+"""
+
+
+def test_device_tail_equals_host_tail_and_oracle():
+    """mauve_align keeps the chains, the DP results and the assembly on the device when no gap needs the recursion
+    (chain_order_device / assemble_dev.hip): same bytes as the oracle, with and without islands, without DP, with gaps
+    emitted unaligned, and sizes available before anything is fetched.  The trace shows which tail ran; MAUVE_HOST_TAIL
+    forces the host tail on the same inputs."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MAUVE_TRACE="1", MAUVE_CANON_DEVICE_MIN="1")      # small lists, too, are sorted and chained on the device
+    r = subprocess.run([sys.executable, "-c", TAIL_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr[-3000:]
+    stay = [l for l in r.stderr.splitlines() if "stay there" in l]
+    back = [l for l in r.stderr.splitlines() if "copy back" in l]
+    assert len(stay) >= 8 and back, r.stderr[-2000:]          # recursion-free cases stay; the one with long gaps goes back
+    env["MAUVE_HOST_TAIL"] = "1"
+    r = subprocess.run([sys.executable, "-c", TAIL_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr[-3000:]
+    assert not [l for l in r.stderr.splitlines() if "stay there" in l]
+
+
 def _check_dp_banded(ctx, intervals, band_from):
     widths = sorted({len(iv) for iv in intervals})
     if len(widths) > 1:                                        # one launch per number of sequences
