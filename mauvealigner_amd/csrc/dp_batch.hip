@@ -88,8 +88,17 @@ __device__ __forceinline__ int64_t dp_step_cells(int32_t m, int32_t n, bool band
     return acc;
 }
 
-// lane l receives lane l-1's value, lane 0 keeps its own (gfx9 DPP wave_shr:1)
+// lane l receives lane l-1's value; wave_shr1z: lane 0 receives 0 (its caller puts the real input there), wave_shr1: lane 0
+// keeps its own (gfx9 DPP wave_shr:1)
+__device__ __forceinline__ int32_t wave_shr1z(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
 __device__ __forceinline__ int32_t wave_shr1(int32_t v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+
+// v with lane 0 replaced by the wave-uniform value x (v_writelane_b32; this compiler has no builtin for it)
+__device__ __forceinline__ int32_t lane0_set(int32_t v, int32_t x)
+{
+    asm("v_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(x));
+    return v;
+}
 
 __device__ __forceinline__ void max3(int32_t a, int32_t b, int32_t c, int32_t &best, uint32_t &p)
 {
@@ -169,24 +178,32 @@ __device__ __forceinline__ void dp_stripe_chunk(const DpStripe &S, int32_t k, in
     }
 }
 
-// round c: steps t = 64c .. min(64c + 63, steps - 1).  Branch-free cell update; (fM, fX, fY) catch cell (m, n).
+// round c: steps t = 64c .. min(64c + 63, steps - 1).  The cell update is straight-line code: the state moves only where
+// the lane has a cell (and, banded, the cell is inside the band), the traceback byte is stored unconditionally -- the
+// slot (t, lane) belongs to this lane and this step alone and is only ever read for real cells -- and the value at
+// (m, n) is simply what the lane of row m holds when the sweep is over.  Lane 0's inputs arrive by v_readlane from the
+// chunk registers and are put in place by v_writelane; the loop counter and bounds are wave-uniform (scalar branch).
 template <bool BANDED>
-__device__ __forceinline__ void dp_stripe_round(DpStripe &S, int32_t c, int lane, int32_t &fM, int32_t &fX, int32_t &fY)
+__device__ __forceinline__ void dp_stripe_round(DpStripe &S, int32_t c, int lane)
 {
     if (c == 0) dp_stripe_chunk<BANDED>(S, 0, lane, S.sq_cur, S.bM_cur, S.bX_cur, S.bY_cur);
     else { S.sq_cur = S.sq_nxt; S.bM_cur = S.bM_nxt; S.bX_cur = S.bX_nxt; S.bY_cur = S.bY_nxt; }
     dp_stripe_chunk<BANDED>(S, c + 1, lane, S.sq_nxt, S.bM_nxt, S.bX_nxt, S.bY_nxt);
-    const int32_t t_end = min(64 * c + 64, S.steps);
-    const bool lane0 = lane == 0, last_lane = S.park && lane == 63;
-    for (int32_t t = 64 * c; t < t_end; t++) {
-        const int32_t j = (BANDED ? S.j0 : 0) + t - lane;
+    const int32_t t0 = __builtin_amdgcn_readfirstlane(64 * c), t_end = __builtin_amdgcn_readfirstlane(min(64 * c + 64, S.steps));
+    const bool park = __builtin_amdgcn_readfirstlane((int)S.park) != 0;
+    const int32_t jbase = (BANDED ? S.j0 : 0) - lane;
+    uint8_t *tbw = S.tbs + (size_t)t0 * 64;
+    for (int32_t t = t0; t < t_end; t++, tbw += 64) {
+        const int32_t j = jbase + t;
         // (i-1, j): lane-1's newest values (DPP wave shift); lane 0 takes the stripe's upper boundary row
-        int32_t Mu = wave_shr1(S.Mc), Xu = wave_shr1(S.Xc), Yu = wave_shr1(S.Yc);
-        uint32_t bnext = (uint32_t)wave_shr1((int32_t)S.bcur);
-        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int32_t)S.sq_cur, t & 63);
-        const int32_t M0 = __builtin_amdgcn_readlane(S.bM_cur, t & 63), X0 = __builtin_amdgcn_readlane(S.bX_cur, t & 63),
-                      Y0 = __builtin_amdgcn_readlane(S.bY_cur, t & 63);
-        Mu = lane0 ? M0 : Mu; Xu = lane0 ? X0 : Xu; Yu = lane0 ? Y0 : Yu; bnext = lane0 ? b0 : bnext;
+        int32_t Mu = wave_shr1z(S.Mc), Xu = wave_shr1z(S.Xc), Yu = wave_shr1z(S.Yc);
+        int32_t bn = wave_shr1z((int32_t)S.bcur);
+        const int sel = t & 63;
+        Mu = lane0_set(Mu, __builtin_amdgcn_readlane(S.bM_cur, sel));
+        Xu = lane0_set(Xu, __builtin_amdgcn_readlane(S.bX_cur, sel));
+        Yu = lane0_set(Yu, __builtin_amdgcn_readlane(S.bY_cur, sel));
+        bn = lane0_set(bn, __builtin_amdgcn_readlane((int32_t)S.sq_cur, sel));
+        const uint32_t bnext = (uint32_t)bn;
         S.bcur = bnext;
         const bool on = S.active && (uint32_t)j <= (uint32_t)S.n, j1 = j >= 1;
         int32_t best; uint32_t pm, px, py;
@@ -198,14 +215,12 @@ __device__ __forceinline__ void dp_stripe_round(DpStripe &S, int32_t c, int lane
         max3(S.Mc + S.gyo, S.Xc + S.gyo, S.Yc + S.gye, best, py);    // (i, j-1): own previous column
         int32_t Yn = max(best, DP_NEG_INF);
         Mn = j1 ? Mn : DP_NEG_INF; Yn = j1 ? Yn : DP_NEG_INF; pm = j1 ? pm : 0u; py = j1 ? py : 0u;
-        if (on) {
-            if (!BANDED || (j >= S.blo && j <= S.bhi)) {
-                S.Mc = Mn; S.Xc = Xn; S.Yc = Yn;
-                S.tbs[(size_t)t * 64] = (uint8_t)(pm | (px << 2) | (py << 4));
-                if (last_lane) { S.rout[j] = Mn; S.rout[(S.n + 1) + j] = Xn; S.rout[2 * (S.n + 1) + j] = Yn; }
-                if (S.i == S.m && j == S.n) { fM = Mn; fX = Xn; fY = Yn; }
-            } else { S.Mc = DP_NEG_INF; S.Xc = DP_NEG_INF; S.Yc = DP_NEG_INF; }     // outside the band: minus infinity for whoever reads it
-        }
+        *tbw = (uint8_t)(pm | (px << 2) | (py << 4));
+        const bool upd = on && (!BANDED || (j >= S.blo && j <= S.bhi));
+        if (park) { if (upd && lane == 63) { S.rout[j] = Mn; S.rout[(S.n + 1) + j] = Xn; S.rout[2 * (S.n + 1) + j] = Yn; } }
+        if (BANDED) {                                                  // outside the band: minus infinity for whoever reads it
+            S.Mc = upd ? Mn : (on ? DP_NEG_INF : S.Mc); S.Xc = upd ? Xn : (on ? DP_NEG_INF : S.Xc); S.Yc = upd ? Yn : (on ? DP_NEG_INF : S.Yc);
+        } else { S.Mc = upd ? Mn : S.Mc; S.Xc = upd ? Xn : S.Xc; S.Yc = upd ? Yn : S.Yc; }
         S.Md = Mu; S.Xd = Xu; S.Yd = Yu;
     }
 }
@@ -217,6 +232,7 @@ __device__ __forceinline__ void dp_stripe_round(DpStripe &S, int32_t c, int lane
 // round; a wave whose dependency is not met sits the round out.  Same recurrences, same traceback bytes, same
 // results as the one-wave path -- only the schedule differs.
 constexpr int DP_MW_LAG = 3;
+constexpr int DP_MW_WIN = 256;             // steps of traceback the walk keeps in LDS (16 KB)
 constexpr int DP_MW_WAVES = 16;            // 1024 threads: four waves per SIMD of one CU
 
 // the pipeline over the stripes of one step (all waves of the workgroup call it together)
@@ -231,7 +247,6 @@ __device__ __forceinline__ void dp_mw_sweep(int32_t *s_stripe, int32_t *s_round,
     __syncthreads();
     DpStripe S;                                       // the stripe this wave is in the middle of
     int32_t nrounds = 0;
-    int32_t fM = DP_NEG_INF, fX = DP_NEG_INF, fY = DP_NEG_INF;
     // every stripe runs at most (n + 64) / 64 + 1 rounds; a fully serial schedule is the upper bound
     const int64_t guard_max = (int64_t)nstripes * ((T + 64) / 64 + 2) + 16;
     for (int64_t guard = 0; guard < guard_max; guard++) {
@@ -253,10 +268,10 @@ __device__ __forceinline__ void dp_mw_sweep(int32_t *s_stripe, int32_t *s_round,
                 dp_stripe_begin<BANDED>(S, my_s, lane, m, n, nstripes, Pc, seq, sc, krows, rowbuf, tbp, T);
                 nrounds = (S.steps + 63) / 64;
             }
-            dp_stripe_round<BANDED>(S, my_c, lane, fM, fX, fY);
+            dp_stripe_round<BANDED>(S, my_c, lane);
             my_c++;
             if (my_c == nrounds) {
-                if (my_s == nstripes - 1 && lane == ((m - 1) & 63)) { s_fin[0] = fM; s_fin[1] = fX; s_fin[2] = fY; }
+                if (my_s == nstripes - 1 && lane == ((m - 1) & 63)) { s_fin[0] = S.Mc; s_fin[1] = S.Xc; s_fin[2] = S.Yc; }   // the lane of row m holds (m, n)
                 my_s += W; my_c = 0;
             }
             __threadfence_block();     // parked row and traceback bytes before the progress counters
@@ -273,6 +288,7 @@ __device__ void dp_interval_mw(int nseq, int64_t iv, const uint8_t *__restrict__
                                const int64_t *__restrict__ rows_off, uint8_t *__restrict__ ops, const DpScoring &sc, int64_t band_from)
 {
     __shared__ int32_t s_stripe[DP_MW_WAVES], s_round[DP_MW_WAVES], s_fin[3];
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[DP_MW_WIN * 64];     // traceback window of the walk
     constexpr int W = DP_MW_WAVES;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
@@ -312,14 +328,25 @@ __device__ void dp_interval_mw(int nseq, int64_t iv, const uint8_t *__restrict__
 
         // ---- traceback: every wave walks the same path (uniform control flow), wave 0 records it ----
         uint8_t *opr = ops + base;
-        int32_t ti = m, tj = n, len = 0, ws = -1, wj0 = 0;
+        // through a window in LDS that the whole workgroup refills (see the one-wave walker in dp_step)
+        int32_t ti = m, tj = n, len = 0, ws = -1, wj0 = 0, wlo = 0;
         while (ti > 0 || tj > 0) {
             uint32_t op, nstate;
             if (ti == 0) { op = 2; nstate = (tj == 1) ? 0 : 2; }
             else {
                 const int32_t s = (ti - 1) >> 6, l = (ti - 1) & 63;
-                if (s != ws) { ws = s; wj0 = j0_of(s); }
-                const uint8_t bt = tbp[((size_t)s * T + (tj - wj0 + l)) * 64 + l];
+                if (s != ws) wj0 = j0_of(s);
+                const int32_t t = tj - wj0 + l;
+                if (s != ws || t < wlo) {                  // the same for every wave: the barriers are uniform
+                    ws = s; wlo = max(0, t - (DP_MW_WIN - 1));
+                    const uint8_t *src = tbp + ((size_t)s * T + wlo) * 64;
+                    const int32_t nbytes = (t - wlo + 1) * 64;
+                    __syncthreads();                       // nobody still reads the old window
+                    for (int32_t o = threadIdx.x * 16; o < nbytes; o += 64 * W * 16)
+                        *reinterpret_cast<uint4 *>(s_win + o) = *reinterpret_cast<const uint4 *>(src + o);
+                    __syncthreads();
+                }
+                const uint8_t bt = s_win[(size_t)(t - wlo) * 64 + l];
                 if (state == 0) { op = 3; nstate = bt & 3; }
                 else if (state == 1) { op = 1; nstate = (bt >> 2) & 3; }
                 else { op = 2; nstate = (bt >> 4) & 3; }
@@ -412,7 +439,6 @@ __device__ void dp_groups(int nseq, const int64_t *__restrict__ list, int64_t fi
 #pragma unroll
                 for (int k = 0; k < GROUPS; k++) tmax = max(tmax, __builtin_amdgcn_readlane(steps, k * G));
                 int32_t Mc = DP_NEG_INF, Xc = DP_NEG_INF, Yc = DP_NEG_INF, Md = DP_NEG_INF, Xd = DP_NEG_INF, Yd = DP_NEG_INF;
-                int32_t fM = DP_NEG_INF, fX = DP_NEG_INF, fY = DP_NEG_INF;
                 uint32_t bcur = 0;
                 // chunk k of the group's sequence: lane ql holds base k*G - 1 + ql (column t = k*G + ql reads base t-1)
                 auto chunk = [&](int32_t k) -> uint32_t { return nn > 0 ? (uint32_t)seq[min(max(k * G - 1 + ql, 0), nn - 1)] : 0u; };
@@ -420,8 +446,8 @@ __device__ void dp_groups(int nseq, const int64_t *__restrict__ list, int64_t fi
                 for (int32_t t = 0; t < tmax; t++) {
                     if (t > 0 && (t & (G - 1)) == 0) { sq_cur = sq_nxt; sq_nxt = chunk(t / G + 1); }
                     const int32_t j = t - ql;
-                    int32_t Mu = wave_shr1(Mc), Xu = wave_shr1(Xc), Yu = wave_shr1(Yc);
-                    uint32_t bnext = (uint32_t)wave_shr1((int32_t)bcur);
+                    int32_t Mu = wave_shr1z(Mc), Xu = wave_shr1z(Xc), Yu = wave_shr1z(Yc);      // the leaders override what they receive
+                    uint32_t bnext = (uint32_t)wave_shr1z((int32_t)bcur);
                     const uint32_t b0 = (uint32_t)lane_read((int32_t)sq_cur, gbase + (t & (G - 1)));
                     const int32_t M0 = t == 0 ? 0 : DP_NEG_INF, Y0 = t == 0 ? DP_NEG_INF : gyo + (t - 1) * gye;
                     Mu = leader ? M0 : Mu; Xu = leader ? DP_NEG_INF : Xu; Yu = leader ? Y0 : Yu; bnext = leader ? b0 : bnext;
@@ -436,16 +462,15 @@ __device__ void dp_groups(int nseq, const int64_t *__restrict__ list, int64_t fi
                     max3(Mc + gyo, Xc + gyo, Yc + gye, best, py);
                     int32_t Yn = max(best, DP_NEG_INF);
                     Mn = j1 ? Mn : DP_NEG_INF; Yn = j1 ? Yn : DP_NEG_INF; pm = j1 ? pm : 0u; py = j1 ? py : 0u;
-                    if (on) {
-                        Mc = Mn; Xc = Xn; Yc = Yn;
-                        tbq[t * G + ql] = (uint8_t)(pm | (px << 2) | (py << 4));
-                        if (i == m && j == nn) { fM = Mn; fX = Xn; fY = Yn; }
-                    }
+                    // straight-line: the slot (t, lane) is this lane's alone and is read only for real cells; the state moves
+                    // only where the lane has a cell, so the lane of row m ends up holding (m, n)
+                    tbq[t * G + ql] = (uint8_t)(pm | (px << 2) | (py << 4));
+                    Mc = on ? Mn : Mc; Xc = on ? Xn : Xc; Yc = on ? Yn : Yc;
                     Md = Mu; Xd = Xu; Yd = Yu;
                 }
                 __threadfence_block();                       // traceback bytes: written by the lanes, read by the leader
                 const int owner = gbase + max(m, 1) - 1;
-                fM = lane_read(fM, owner); fX = lane_read(fX, owner); fY = lane_read(fY, owner);
+                const int32_t fM = lane_read(Mc, owner), fX = lane_read(Xc, owner), fY = lane_read(Yc, owner);
                 int32_t best = fM; int state = 0;
                 if (fX > best) { best = fX; state = 1; }
                 if (fY > best) { best = fY; state = 2; }
@@ -524,7 +549,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 {
     // Small steps (one stripe, m + n <= 128) keep their traceback bytes and reversed ops in LDS: the traceback
     // walk is a chain of dependent 1-byte loads, ~100 cycles each from LDS against >1000 from L2/HBM.
-    __shared__ uint8_t s_tb[4][DP_LDS_TB];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tb[4][DP_LDS_TB];
     __shared__ uint8_t s_ops[4][DP_LDS_OPS];
     // The list is [dp_step_big's entries | one-wave | two per wave (m <= 32) | four per wave (m <= 16)], each class
     // largest first; the block ranges follow the same order so the long ones start first.
@@ -572,8 +597,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             DpStripe S;
             dp_stripe_begin<false>(S, s, lane, m, n, nstripes, Pc, seq, sc, mt.krows, rowbuf, tbp, T);
             const int32_t nrounds = (S.steps + 63) / 64;
-            for (int32_t c = 0; c < nrounds; c++) dp_stripe_round<false>(S, c, lane, fM, fX, fY);
+            for (int32_t c = 0; c < nrounds; c++) dp_stripe_round<false>(S, c, lane);
             __threadfence_block();   // the parked row / traceback bytes are read back by this wave
+            if (s == nstripes - 1) { fM = S.Mc; fX = S.Xc; fY = S.Yc; }      // the lane of row m holds (m, n)
         }
         // result lives in the lane that owns row m
         const int owner = (m - 1) & 63;
@@ -584,13 +610,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 
         // ---- traceback (wave-uniform walk; bytes were written by this wave) ----
         uint8_t *opr = in_lds ? s_ops[wv] : ops + base;   // reversed ops, capacity m + n
-        int32_t ti = m, tj = n, len = 0;
+        // A step whose traceback went to global memory is walked through a window in the wave's LDS slice: the walk is a
+        // chain of dependent one-byte loads (m + n of them), so each would pay a full L2 round trip; inside a stripe the
+        // step index t = tj + l only falls (by 1 or 2 per op), so the DP_LDS_TB / 64 steps below the current one are
+        // fetched at once with 16-byte loads and serve at least half as many ops.
+        int32_t ti = m, tj = n, len = 0, ws = -1, wlo = 0;
+        uint8_t *win = s_tb[wv];
         while (ti > 0 || tj > 0) {
             uint32_t op, nstate;
             if (ti == 0) { op = 2; nstate = (tj == 1) ? 0 : 2; }
             else {
                 const int32_t s = (ti - 1) >> 6, l = (ti - 1) & 63;
-                const uint8_t bt = tbp[((size_t)s * T + (tj + l)) * 64 + l];
+                const int32_t t = tj + l;
+                uint8_t bt;
+                if (in_lds) bt = win[(size_t)t * 64 + l];
+                else {
+                    if (s != ws || t < wlo) {
+                        ws = s; wlo = max(0, t - (DP_LDS_TB / 64 - 1));
+                        const uint8_t *src = tbp + ((size_t)s * T + wlo) * 64;
+                        const int32_t nbytes = (t - wlo + 1) * 64;
+                        for (int32_t o = lane * 16; o < nbytes; o += 1024)
+                            *reinterpret_cast<uint4 *>(win + o) = *reinterpret_cast<const uint4 *>(src + o);
+                        __threadfence_block();             // the window is read by every lane
+                    }
+                    bt = win[(size_t)(t - wlo) * 64 + l];
+                }
                 if (state == 0) { op = 3; nstate = bt & 3; }
                 else if (state == 1) { op = 1; nstate = (bt >> 2) & 3; }
                 else { op = 2; nstate = (bt >> 4) & 3; }
@@ -664,6 +708,11 @@ __global__ void __launch_bounds__(256) dp_gather_codes(const uint64_t *__restric
         }
     }
 }
+
+// Which intervals get a workgroup (dp_step_big) instead of a wave: candidates whose single-wave estimate exceeds
+// factor x the balanced share of a wave slot, at most max of them (MAUVE_DP_BIG_FACTOR4 = 4 x factor, MAUVE_DP_BIG_MAX).
+static int64_t dp_big_factor4() { static const int64_t f = getenv("MAUVE_DP_BIG_FACTOR4") ? atoll(getenv("MAUVE_DP_BIG_FACTOR4")) : 16; return f; }
+static int64_t dp_big_max() { static const int64_t m = getenv("MAUVE_DP_BIG_MAX") ? atoll(getenv("MAUVE_DP_BIG_MAX")) : 128; return m; }
 
 // the two DP launches: dp_step_big (workgroup per interval, second stream) beside dp_step (wave / sub-wave per interval),
 // over the positions [a, b) of the launch list [workgroup | one wave | two per wave | four per wave]; tb_base is
@@ -810,7 +859,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
         const int64_t balanced = est_total / 3072;
         for (int64_t k = 0; k < n_iv; k++) {          // lst is largest first
             uint8_t &b = is_big[(size_t)lst[(size_t)k]];
-            if (b == 1 && (n_big >= 128 || est[(size_t)lst[(size_t)k]] <= 4 * balanced)) b = 0;
+            if (b == 1 && (n_big >= dp_big_max() || est[(size_t)lst[(size_t)k]] * 4 <= dp_big_factor4() * balanced)) b = 0;
             n_big += b != 0;
         }
     }
@@ -1025,10 +1074,10 @@ __global__ void __launch_bounds__(256) dpf_tb_scatter(const int64_t *__restrict_
 
 // workgroup-pipeline entries: candidates well above a balanced one-wave share, the first 128 of them in size order
 struct DpBigPick {
-    const uint32_t *order; const uint8_t *cand, *cls; const int64_t *est; const DpFrontTotals *tot; uint32_t *key2;
+    const uint32_t *order; const uint8_t *cand, *cls; const int64_t *est; const DpFrontTotals *tot; uint32_t *key2; int64_t factor4; uint32_t maxn;
     __device__ uint32_t domain(int) const { return (uint32_t)tot->n_dp; }
-    __device__ bool flag(uint32_t j, int) const { const uint32_t s = order[j]; return cand[s] == 1 && est[s] > 4 * (tot->est / 3072); }
-    __device__ void each(uint32_t j, uint32_t before, bool fl, int) const { key2[j] = ((fl && before < 128) || cand[order[j]] == 2) ? 0u : (uint32_t)cls[order[j]]; }
+    __device__ bool flag(uint32_t j, int) const { const uint32_t s = order[j]; return cand[s] == 1 && est[s] * 4 > factor4 * (tot->est / 3072); }
+    __device__ void each(uint32_t j, uint32_t before, bool fl, int) const { key2[j] = ((fl && before < maxn) || cand[order[j]] == 2) ? 0u : (uint32_t)cls[order[j]]; }
     __device__ void emit(uint32_t, uint32_t, int) const {}
     __device__ void total(uint32_t, int) const {}
 };
@@ -1136,7 +1185,7 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     int rc = sort_pairs_u32(ctx, n_dp, 6, &ok, &ov, k2, v2, MAUVE_K_MISC);
     if (rc) return rc;
     uint32_t *fk = ok == k1 ? k2 : k1, *fv = ov == v1 ? v2 : v1;        // free pair
-    const DpBigPick bp{ov, cand, cls, est, tot, fk};
+    const DpBigPick bp{ov, cand, cls, est, tot, fk, dp_big_factor4(), (uint32_t)dp_big_max()};
     hipLaunchKernelGGL((cmp_count<DpBigPick>), dim3(nbd), dim3(256), 0, ctx->stream, bp, bcnt);
     hipLaunchKernelGGL((cmp_write<DpBigPick>), dim3(nbd), dim3(256), 0, ctx->stream, bp, bcnt);
     uint32_t *ck = fk, *cv = ov;
