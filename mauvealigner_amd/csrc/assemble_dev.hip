@@ -157,6 +157,14 @@ int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes
         const uint32_t fb = (uint32_t)std::min<int64_t>(((int64_t)na + 3) / 4, 256 * 8);
         hipLaunchKernelGGL(as_fill, dim3(fb), dim3(256), 0, c->stream, fo.alen, fo.ast, fo.gapcode, fo.col_off, fo.cols, col0, na, N, S.full, out);
     }
+    // the match list, if the seed pass left it on the device only
+    R.dev_nm = 0;
+    if (c->matches_pending) {
+        const size_t mb = (size_t)c->n_matches * (1 + (size_t)N) * 8;
+        HIPCHK(c, c->res_mums.ensure(mb + 64));
+        HIPCHK(c, hipMemcpyAsync(c->res_mums.p, c->sorted_rec.p, mb, hipMemcpyDeviceToDevice, c->stream));
+        R.dev_nm = (size_t)c->n_matches;
+    }
     // the anchor table for a later fetch (the DP front end's arrays are overwritten by the next DP launch of any kind)
     HIPCHK(c, hipMemcpyAsync(c->res_anch.p, fo.alen, (size_t)na * (2 + (size_t)N) * 4, hipMemcpyDeviceToDevice, c->stream));   // alen, ast, alcb are adjacent
     HIPCHK(c, hipGetLastError());
@@ -233,12 +241,18 @@ int materialize_result(mauve_ctx *c)
     if (!R.dev_pending) return MAUVE_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->ast.N; const size_t na = R.dev_na;
-    const size_t cb = R.n_cols * 4, ab = na * (2 + (size_t)N) * 4;
-    HIPCHK(c, c->pin_cols.ensure(cb + ab + 64));
+    const size_t cb = (R.n_cols * 4 + 63) & ~(size_t)63, ab = (na * (2 + (size_t)N) * 4 + 63) & ~(size_t)63, mb = R.dev_nm * (1 + (size_t)N) * 8;
+    HIPCHK(c, c->pin_cols.ensure(cb + ab + mb + 64));
     char *pc = c->pin_cols.as<char>();
-    if (cb) HIPCHK(c, hipMemcpyAsync(pc, c->res_cols.p, cb, hipMemcpyDeviceToHost, c->stream));
-    if (ab) HIPCHK(c, hipMemcpyAsync(pc + cb, c->res_anch.p, ab, hipMemcpyDeviceToHost, c->stream));
+    if (cb) HIPCHK(c, hipMemcpyAsync(pc, c->res_cols.p, R.n_cols * 4, hipMemcpyDeviceToHost, c->stream));
+    if (ab) HIPCHK(c, hipMemcpyAsync(pc + cb, c->res_anch.p, na * (2 + (size_t)N) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (mb) HIPCHK(c, hipMemcpyAsync(pc + cb + ab, c->res_mums.p, mb, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (mb) {
+        const int64_t *hm = reinterpret_cast<const int64_t *>(pc + cb + ab);
+        R.mum_length.assign(hm, hm + R.dev_nm); R.mum_start.assign(hm + R.dev_nm, hm + R.dev_nm * (1 + (size_t)N));
+        R.dev_nm = 0;
+    }
     R.cols_ext = reinterpret_cast<const uint32_t *>(pc);
     const int32_t *hl = reinterpret_cast<const int32_t *>(pc + cb), *hs = hl + na, *hb = hs + na * N;
     R.anchor_length.resize(na); R.anchor_start.resize(na * N); R.anchor_lcb.resize(na);

@@ -129,7 +129,7 @@ struct AlignResult {
     std::vector<int64_t> dp_score;
     // device-assembled result (assemble_dev.hip): the columns and the anchor table are still in HBM (res_cols / res_anch)
     bool dev_pending = false;
-    size_t dev_na = 0;
+    size_t dev_na = 0, dev_nm = 0;          // anchors; matches still on the device (0: mum_* are filled)
     const uint32_t *cols_ext = nullptr;      // the columns in page-locked staging after materialize_result (else: cols)
     const uint32_t *cols_data() const { return cols_ext ? cols_ext : cols.data(); }
 };
@@ -215,7 +215,7 @@ struct mauve_ctx {
     DevBuf join_ovf;                     // join_hash: [count, pad, (lo, hi) ...] ranges handed back to the full sort + serial join
     DevBuf ch_len, ch_st, ch_crop, ch_ent, ch_ord, ch_rank, ch_node, ch_graph, ch_cnt;   // device chain (chain_dev.hip)
     DevBuf ch_anch, ch_lw;               // the chains in chain order and the LCB weights (chain_order_device)
-    DevBuf as_work, as_isl, res_cols, res_anch;      // device assembly (assemble_dev.hip): work area, islands, result columns, anchor table
+    DevBuf as_work, as_isl, res_cols, res_anch, res_mums;      // device assembly (assemble_dev.hip): work area, islands, result columns, anchor table
     PinnedBuf pin_asm, pin_cols;         // ... its per-LCB rows coming back; the columns and anchors on their way to a fetch
     PinnedBuf pin_chain;
     DevBuf run_sum;                      // pairwise finder: run list (start, length, exactly-once genome set)
@@ -233,6 +233,9 @@ struct mauve_ctx {
     DevBuf dp_desc, dp_list, dp_codes, dp_off, dp_prof_cnt, dp_prof_mask, dp_prof2_cnt, dp_prof2_mask, dp_tb, dp_meta, dp_score,
         dp_cols, dp_rows;
 
+    // the seed pass may leave its match list on the device only (sorted_rec) when the caller says so: mauve_align's device tail
+    bool lazy_matches_ok = false, matches_pending = false;
+    int match_nseq = 0;
     // where dp_run_from_anchors left its device-side results (valid until the next DP launch)
     struct DpFrontOut { const int32_t *alen, *ast, *alcb, *gapcode; const int64_t *col_off, *score; const uint32_t *cols; int64_t n_dp, n_cols; } dpf_out{};
     int64_t dp_band_from = INT64_MAX;     // intervals whose longest sequence exceeds this run the banded DP (dp_batch.hip)
@@ -337,5 +340,6 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na, const int32_t *h_len,
                         PinnedBuf *dcols, std::vector<int64_t> &dcol_off, std::vector<int64_t> &dscore, int64_t *cells, bool stay_on_device = false);
 int assemble_device(mauve_ctx *c, int64_t na, int64_t cells, mauve_align_sizes *sizes);
 int materialize_result(mauve_ctx *c);
+int seed_matches_to_host(mauve_ctx *ctx);
 int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,
                  const mauve_scoring *sc, uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells);

@@ -145,7 +145,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
     R.mum_length.clear(); R.mum_start.clear(); R.lcb_left.clear(); R.lcb_right.clear(); R.lcb_weight.clear();
     R.anchor_length.clear(); R.anchor_start.clear(); R.anchor_lcb.clear(); R.iv_left.clear(); R.iv_right.clear();
     R.iv_reverse.clear(); R.col_off.clear(); R.n_cols = 0; R.dp_score.clear();
-    R.dev_pending = false; R.dev_na = 0; R.cols_ext = nullptr;
+    R.dev_pending = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr;
     memset(&c->stage, 0, sizeof c->stage);
 
     int64_t sum = 0; for (int g = 0; g < N; g++) sum += c->lens[g];
@@ -198,12 +198,15 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
         }
         c->n_matches = nm; c->dev_rec_n = -1;
     } else {
+        static const bool host_tail_env = getenv("MAUVE_HOST_TAIL") != nullptr;
+        c->lazy_matches_ok = want_tail && !host_tail_env && !p->extend_lcbs;     // the list may stay in HBM (device tail below)
         rc = seedpass_run(c, main_genome_set(c), pat, p->mode, full, 1, nullptr, 0, &nm);
+        c->lazy_matches_ok = false;
         c->shadow = nullptr;
         if (rc) return rc;
     }
     S.nm = nm;
-    R.mum_length = c->match_len; R.mum_start = c->match_start;
+    if (!c->matches_pending) { R.mum_length = c->match_len; R.mum_start = c->match_start; }
     const double t1 = now_ms();
     c->stage.seed_ms = t1 - S.t0;
 
@@ -239,10 +242,20 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
                     return MAUVE_OK;
                 }
             }
+            if (c->matches_pending) {                    // the host goes on: it needs its copy of the list after all
+                rc = seed_matches_to_host(c);
+                if (rc) return rc;
+                R.mum_length = c->match_len; R.mum_start = c->match_start;
+            }
             rc = chain_device_copy_back(c, N, m, match_lcb);
             if (rc) return rc;
         }
         t1b = now_ms();
+    }
+    if (c->matches_pending) {                            // device chain gave up: host chain on the host copy
+        rc = seed_matches_to_host(c);
+        if (rc) return rc;
+        R.mum_length = c->match_len; R.mum_start = c->match_start;
     }
     if (!on_device) {
         m.resize((size_t)nm);

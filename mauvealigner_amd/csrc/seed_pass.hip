@@ -1086,12 +1086,19 @@ __global__ void __launch_bounds__(256) canon_keys(const int32_t *__restrict__ ml
     if (b && (threadIdx.x & 63) == (uint32_t)(__ffsll((unsigned long long)b) - 1)) atomicAdd(n_valid, (uint32_t)__popcll(b));
 }
 
+// The number of surviving records is still on the device (*n_valid): the launch covers all candidates, the output is
+// out[0 .. nm) lengths followed by nm * nseq starts.  Two neighbours with the same key (first component, start) are a
+// tie the key alone does not order: *ties is raised and the host finishes the order (rare).
 __global__ void __launch_bounds__(256) canon_gather(const int32_t *__restrict__ mlen, const int32_t *__restrict__ mstart,
-                                                    const uint32_t *__restrict__ vals, uint32_t nm, int nseq,
-                                                    int64_t *__restrict__ out_len, int64_t *__restrict__ out_start)
+                                                    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                    const uint32_t *__restrict__ n_valid, int nseq, int64_t *__restrict__ out,
+                                                    uint32_t *__restrict__ ties)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nm = *n_valid;
     if (r >= nm) return;
+    int64_t *out_len = out, *out_start = out + nm;
+    if (r > 0 && keys[r] == keys[r - 1]) atomicOr(ties, 1u);
     const uint32_t src = vals[r];
     out_len[r] = mlen[src];
     for (int g = 0; g < nseq; g++) out_start[(size_t)r * nseq + g] = mstart[(size_t)src * nseq + g];
@@ -1331,7 +1338,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     if (mode == MAUVE_MODE_PAIRWISE) {
         for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++) passes.push_back({(1u << i) | (1u << j), (1u << i) | (1u << j), MAUVE_MODE_MEM});
     } else passes.push_back({0xffffffffu, (uint32_t)mask, mode});
-    ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear();
+    ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear(); ctx->matches_pending = false;
     if (n_matches) *n_matches = 0;
     // one record slot per candidate of every pass; length 0 = not a leftmost hit (host scratch kept across calls)
     std::vector<int32_t> &hl = ctx->sdh.hl, &hs = ctx->sdh.hs; hl.clear(); hs.clear();
@@ -1474,18 +1481,29 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         HIPCHK(ctx, hipGetLastError());
         int rc2 = sort_pairs<uint64_t>(ctx, ncand, pos_bits + fbits, &ck, &cv, ck2, cv2, false, MAUVE_K_CANON);
         if (rc2) return rc2;
+        HIPCHK(ctx, ctx->sorted_rec.ensure((size_t)ncand * (1 + N) * 8 + 64));
+        hipLaunchKernelGGL(canon_gather, dim3((ncand + 255) / 256), dim3(256), 0, ctx->stream, ctx->mlen.as<int32_t>(),
+                           ctx->mstart.as<int32_t>(), ck, cv, ctx->counters.as<uint32_t>() + 3, N, ctx->sorted_rec.as<int64_t>(),
+                           ctx->counters.as<uint32_t>() + 4);
+        HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, ctx->pin_seed.ensure(64));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 32, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t nm = ctx->pin_seed.as<uint32_t>()[3];
+        const bool dev_ties = ctx->pin_seed.as<uint32_t>()[4] != 0;
+        if (ctx->lazy_matches_ok && nm && !dev_ties) {
+            // the caller keeps working on the device copy (sorted_rec); the host copy is made when somebody asks for it
+            ctx->match_len.clear(); ctx->match_start.clear();
+            ctx->matches_pending = true; ctx->match_nseq = N;
+            ctx->n_matches = nm; ctx->dev_rec_n = (int64_t)nm;
+            if (n_matches) *n_matches = nm;
+            TRACE(ctx, "canonical sort (device, list stays)");
+            return MAUVE_OK;
+        }
         ctx->match_len.resize(nm); ctx->match_start.resize((size_t)nm * N);
         bool canon_ties = false;
         if (nm) {
-            HIPCHK(ctx, ctx->sorted_rec.ensure((size_t)nm * (1 + N) * 8));
-            int64_t *ol = ctx->sorted_rec.as<int64_t>(), *os = ol + nm;
-            hipLaunchKernelGGL(canon_gather, dim3((nm + 255) / 256), dim3(256), 0, ctx->stream, ctx->mlen.as<int32_t>(),
-                               ctx->mstart.as<int32_t>(), cv, nm, N, ol, os);
-            HIPCHK(ctx, hipGetLastError());
+            int64_t *ol = ctx->sorted_rec.as<int64_t>();
             // through page-locked staging: a pageable destination of tens of MB copies at a fraction of the link rate
             const size_t rbytes = (size_t)nm * (1 + N) * 8;
             HIPCHK(ctx, ctx->pin_seed.ensure(64 + rbytes));
@@ -1614,7 +1632,7 @@ int seedpass_run(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, int mode
     GenomeTab tab; int64_t total = 0;
     int rc = build_tab(ctx, gs, sh.span, &tab, &total);
     if (rc) return rc;
-    ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear();
+    ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear(); ctx->matches_pending = false;
     ctx->dev_rec_n = -1;
     if (n_matches) *n_matches = 0;
     if (total == 0) return MAUVE_OK;
@@ -1632,7 +1650,7 @@ int seedpass_from_hits(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, co
     GenomeTab tab; int64_t total = 0;
     int rc = build_tab(ctx, gs, sh.span, &tab, &total);
     if (rc) return rc;
-    ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear();
+    ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear(); ctx->matches_pending = false;
     ctx->dev_rec_n = -1;
     if (n_matches) *n_matches = 0;
     if (total == 0 || hits.n == 0) return MAUVE_OK;
@@ -1677,5 +1695,22 @@ int seedpass_sorted_list(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t 
     if (rc) return rc;
     // vals carry global window indices; make them local to the genome
     for (auto &v : *vals) v = ((v & 0x7fffffffu) - tab.gpos_off[seq]) | (v & 0x80000000u);
+    return MAUVE_OK;
+}
+
+// host copy of a match list the seed pass left on the device only (seedpass_impl with lazy_matches_ok)
+int seed_matches_to_host(mauve_ctx *ctx)
+{
+    if (!ctx->matches_pending) return MAUVE_OK;
+    const size_t nm = (size_t)ctx->n_matches; const int N = ctx->match_nseq;
+    const size_t rbytes = nm * (1 + (size_t)N) * 8;
+    HIPCHK(ctx, ctx->pin_seed.ensure(64 + rbytes));
+    char *pin = ctx->pin_seed.as<char>() + 64;
+    HIPCHK(ctx, hipMemcpyAsync(pin, ctx->sorted_rec.p, rbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->match_len.resize(nm); ctx->match_start.resize(nm * N);
+    memcpy(ctx->match_len.data(), pin, nm * 8);
+    memcpy(ctx->match_start.data(), pin + nm * 8, nm * N * 8);
+    ctx->matches_pending = false;
     return MAUVE_OK;
 }
