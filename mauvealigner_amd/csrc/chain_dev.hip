@@ -383,8 +383,8 @@ int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, i
     for (int g = 0; g < N; g++) {
         hipLaunchKernelGGL(ch_keys, dim3(blocks), dim3(256), 0, c->stream, len, st, n, N, g, dead_key, k1, v1);
         uint32_t *kk = k1, *vv = v1;
-        int rc = sort_pairs_u32(c, n, pos_bits + 1, &kk, &vv, k2, v2, MAUVE_K_MISC);
-        if (rc) return rc;
+        // genome 0: the list is in canonical order, i.e. already ordered by its left ends there (no ties: dev_rec_n), nobody is dead yet
+        if (g > 0) { int rc = sort_pairs_u32(c, n, pos_bits + 1, &kk, &vv, k2, v2, MAUVE_K_MISC); if (rc) return rc; }
         hipLaunchKernelGGL(cl_partial, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive);
         hipLaunchKernelGGL(cl_flags, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive, nb, cflag, cnt);
         const ClusterStarts cs{cflag, n, sl, cnt};
