@@ -8,16 +8,17 @@
 namespace mems {
 
 // ---- ProgressiveAligner: setters and align() as called at progressiveMauve.cpp:575-710 -------------------
-// The guide tree and the progressive anchoring run on the device (mauve_progressive_align).  The
-// setters that tune libMems' sum-of-pairs LCB scoring have no counterpart in the frozen replacement; they are
-// accepted so that the call site compiles, and documented as inert.
+// The guide tree and the progressive anchoring run on the device (mauve_progressive_align); the extant
+// sum-of-pairs LCB scoring is DESIGN.md S11.  The setters that tune libMems' penalty scaling and refinement have no
+// counterpart in the frozen replacement; they are accepted so that the call site compiles, and documented as inert.
 class ProgressiveAligner {
 public:
     explicit ProgressiveAligner(uint seq_count) : seq_count_(seq_count), tree_left_(2 * seq_count - 1, -1), tree_right_(2 * seq_count - 1, -1)
     {
         mauve_default_params(&p_);
     }
-    void setBreakpointPenalty(double w) { if (w >= 0) p_.lcb_weight = (int64_t)w * (int64_t)seq_count_; }   // --weight, :584-593
+    // --weight, :584-593: a length (x seq_count) under LengthScoring, a score under the sum-of-pairs scheme
+    void setBreakpointPenalty(double w) { if (w >= 0) bp_penalty_ = w; }
     void setMinimumBreakpointPenalty(double) {}
     void setCollinear(boolean c) { p_.collinear = c; }                        // :594-597
     void setGappedAlignment(boolean g) { p_.gapped = g; }                     // --skip-gapped-alignment
@@ -29,7 +30,11 @@ public:
         for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) p_.scoring.matrix[i][j] = pss.matrix[i][j];
         p_.scoring.gap_open = pss.gap_open; p_.scoring.gap_extend = pss.gap_extend;
     }
-    void setLcbScoringScheme(int) {}                                          // :611-625 (ExtantSumOfPairs...: inert)
+    // :611-625.  ExtantSumOfPairsScoring (the call site's default, :625) scores LCBs by the sum-of-pairs score of their
+    // anchors (MAUVE_LCB_SCORE_SP); the two ancestral schemes need libMems' ancestral sequence
+    // reconstruction and fall back to it as well.  LengthScoring (not in libMems) keeps the Aligner::align weights.
+    enum LcbScoringScheme { AncestralScoring, AncestralSumOfPairsScoring, ExtantSumOfPairsScoring, LengthScoring };
+    void setLcbScoringScheme(int s) { p_.lcb_scoring = s == LengthScoring ? MAUVE_LCB_SCORE_LENGTH : MAUVE_LCB_SCORE_SP; score_set_ = true; }
     void setUseLcbWeightScaling(boolean) {}                                   // :626-642
     void setBpDistEstimateMinScore(double) {}
     void setUseSeedFamilies(boolean) {}
@@ -42,6 +47,7 @@ public:
     void align(std::vector<genome::gnSequence *> &seq_table, IntervalList &il)
     {
         if (seq_table.size() != seq_count_) throw genome::gnException("ProgressiveAligner::align: sequence count mismatch");
+        if (bp_penalty_ >= 0) p_.lcb_weight = p_.lcb_scoring == MAUVE_LCB_SCORE_SP ? (int64_t)bp_penalty_ : (int64_t)bp_penalty_ * (int64_t)seq_count_;
         HipContext &hc = HipContext::global();
         MatchList tmp; tmp.seq_table = seq_table;
         tmp.upload(hc);
@@ -55,6 +61,8 @@ public:
 private:
     uint seq_count_;
     mauve_params p_;
+    double bp_penalty_ = -1;
+    bool score_set_ = false;
     std::vector<int32_t> tree_left_, tree_right_;
 };
 

@@ -40,6 +40,9 @@ extern "C" {
 #define MAUVE_MODE_PAIRWISE 2 /* mems::PairwiseMatchFinder (progressiveMauve.cpp:496-501): MemHash on every genome
                                 pair separately; matches have exactly two components; mask is ignored */
 
+#define MAUVE_LCB_SCORE_LENGTH 0
+#define MAUVE_LCB_SCORE_SP 1
+
 typedef struct mauve_ctx mauve_ctx;
 
 typedef struct {
@@ -66,6 +69,10 @@ typedef struct {
     int64_t max_banded_len;       /* no reference counterpart (its aligner leaves intervals above max_gapped_len unaligned): intervals
                                      whose longest sequence is in (max_gapped_len, max_banded_len] are aligned by the banded DP
                                      (DESIGN.md S7b); default 0 = off */
+    int32_t lcb_scoring;          /* ProgressiveAligner::setLcbScoringScheme (progressiveMauve.cpp:611-625): MAUVE_LCB_SCORE_LENGTH
+                                     (0, default: weight = sum of length * n, the Aligner::align rule) or MAUVE_LCB_SCORE_SP (1: extant
+                                     sum-of-pairs score of the anchors); lcb_weight is then a score */
+    int32_t reserved0;
 } mauve_params;
 
 /* sizes of the result of mauve_align(), for the caller to allocate the fill buffers */
@@ -173,6 +180,13 @@ int mauve_dp_batch(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
 int mauve_dp_batch_banded(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
                           const int64_t *seq_off, const mauve_scoring *sc, int64_t band_from,
                           uint32_t *cols, int64_t *col_off, int64_t *score);
+
+/* ---- extant sum-of-pairs score of ungapped matches: the anchor score behind ProgressiveAligner::setLcbScoringScheme(
+        ExtantSumOfPairsScoring) (progressiveMauve.cpp:611-625; libMems-internal, frozen form DESIGN.md S11): for every column of a
+        match and every pair of its components, the substitution score of the two bases.  length[n], start[n*nseq] signed
+        1-based on the resident genomes, scores[n] out. ---- */
+int mauve_match_sp_scores(mauve_ctx *ctx, int64_t n, const int64_t *length, const int64_t *start, const mauve_scoring *sc,
+                          int64_t *scores);
 
 /* ---- whole path: doAlignment's hot section (mauveAligner.cpp:523-531,585,629-698,746-760):
         multi-MUMs -> N-way filter -> overlap elimination -> LCBs -> recursive anchoring -> gapped

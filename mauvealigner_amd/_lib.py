@@ -23,7 +23,7 @@ EXPORTS = [
     "mauve_default_params", "mauve_packed_words", "mauve_pack_ascii", "mauve_pack_codes", "mauve_set_genomes", "mauve_set_genomes_contigs",
     "mauve_ambiguity_bitmap",
     "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_extend_hits", "mauve_seed_match_enumerate",
-    "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_dp_batch_banded", "mauve_align", "mauve_align_fetch",
+    "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_dp_batch_banded", "mauve_match_sp_scores", "mauve_align", "mauve_align_fetch",
     "mauve_align_matches", "mauve_align_begin", "mauve_align_begin_matches", "mauve_align_dp_anchors", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
     "mauve_guide_tree", "mauve_progressive_align",
     "mauve_write_xmfa", "mauve_profile_enable", "mauve_profile_reset", "mauve_profile_get", "mauve_last_stage_times",
@@ -40,7 +40,7 @@ class Params(C.Structure):
                 ("recursive", C.c_int32), ("gapped", C.c_int32), ("add_unaligned", C.c_int32),
                 ("extend_lcbs", C.c_int32), ("max_extension_iters", C.c_int32),
                 ("min_recursive_gap", C.c_int64), ("max_gapped_len", C.c_int64), ("scoring", Scoring),
-                ("max_banded_len", C.c_int64)]
+                ("max_banded_len", C.c_int64), ("lcb_scoring", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class AlignSizes(C.Structure):
@@ -323,6 +323,16 @@ class Context:
                                                    C.byref(sc), C.c_int64(int(band_from)), _p(cols, C.c_uint32),
                                                    _p(col_off, C.c_int64), _p(score, C.c_int64)), "mauve_dp_batch_banded")
         return [cols[col_off[i]:col_off[i + 1]].copy() for i in range(n_iv)], score[:n_iv].copy()
+
+    def match_sp_scores(self, length, start, scoring=None):
+        """extant sum-of-pairs scores of ungapped matches on the resident genomes (mauve_match_sp_scores)"""
+        sc = scoring or default_scoring()
+        length = np.ascontiguousarray(length, dtype=np.int64)
+        start = np.ascontiguousarray(start, dtype=np.int64).reshape(len(length), self.nseq)
+        out = np.zeros(max(len(length), 1), np.int64)
+        self._chk(self.L.mauve_match_sp_scores(self.h, C.c_int64(len(length)), _p(length, C.c_int64), _p(start, C.c_int64),
+                                               C.byref(sc), _p(out, C.c_int64)), "mauve_match_sp_scores")
+        return out[:len(length)].copy()
 
     def align(self, params=None, fetch=True, names=None, want_xmfa=False):
         p = params or default_params()

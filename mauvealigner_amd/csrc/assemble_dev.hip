@@ -110,7 +110,78 @@ __global__ void __launch_bounds__(256) as_islands(const Island *__restrict__ isl
     }
 }
 
+// ---- extant sum-of-pairs score of ungapped matches ---------------------------------------------------------
+// One wave per match: a lane takes every 64th column, reads the base of every present component from the packed genomes
+// (a reverse component from its right end, complemented), adds the substitution scores of all pairs; wave reduction.
+struct SpGenomes { uint64_t word_off[MAUVE_MAX_SEQ]; int32_t s[4][4]; };
+__global__ void __launch_bounds__(256) sp_score_matches(const uint64_t *__restrict__ packed, SpGenomes G, int n, const int64_t *__restrict__ rec,
+                                                        uint32_t nm, int64_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nw = (gridDim.x * 256u) >> 6;
+    for (uint32_t i = wave; i < nm; i += nw) {
+        const int64_t *r = rec + (size_t)i * (1 + n);
+        const int64_t len = r[0];
+        int64_t acc = 0;
+        for (int64_t c = lane; c < len; c += 64) {
+            uint32_t have = 0, bases = 0;                      // 2 bits per component
+            for (int g = 0; g < n; g++) {
+                const int64_t st = r[1 + g];
+                if (!st) continue;
+                const int64_t p = st > 0 ? st - 1 + c : -st - 1 + (len - 1 - c);
+                uint32_t b = (uint32_t)(packed[G.word_off[g] + (uint64_t)(p >> 5)] >> (2 * (p & 31))) & 3u;
+                if (st < 0) b = 3u - b;
+                have |= 1u << g; bases |= b << (2 * g);          // n <= 16 (checked on the host)
+            }
+            for (int x = 0; x < n; x++) {
+                if (!(have >> x & 1)) continue;
+                const uint32_t bx = (bases >> (2 * x)) & 3u;
+                for (int y = x + 1; y < n; y++) if (have >> y & 1) acc += G.s[bx][(bases >> (2 * y)) & 3u];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) out[i] = acc;
+    }
+}
+
 }  // namespace
+
+int64_t sp_default_min_weight(int w, int n, const mauve_scoring *sc)
+{
+    int32_t d = sc->matrix[0][0];
+    for (int a = 1; a < 4; a++) d = std::min(d, sc->matrix[a][a]);
+    return (int64_t)3 * w * ((int64_t)n * (n - 1) / 2) * d;
+}
+
+int match_sp_scores(mauve_ctx *c, const MatchVec &m, const int *gmap, const mauve_scoring *sc, std::vector<int64_t> &out)
+{
+    const int n = m.N; const size_t nm = m.size();
+    out.assign(nm, 0);
+    if (nm == 0) return MAUVE_OK;
+    if (n > 16) { c->err = "sum-of-pairs LCB scoring: at most 16 genomes"; return MAUVE_ERR_LIMIT; }
+    for (size_t i = 0; i < nm; i++)
+        for (int g = 0; g < n; g++) {
+            const int64_t st = m.st(i)[g], L = c->lens[(size_t)(gmap ? gmap[g] : g)];
+            if (st && m.len(i) > 0 && std::llabs(st) + m.len(i) - 1 > L) { c->err = "sp scores: match outside its genome"; return MAUVE_ERR_ARG; }   // (records of length <= 0 score 0)
+        }
+    SpGenomes G; memset(&G, 0, sizeof G);
+    for (int g = 0; g < n; g++) G.word_off[g] = c->word_off[(size_t)(gmap ? gmap[g] : g)];
+    memcpy(G.s, sc->matrix, sizeof G.s);
+    const size_t rb = nm * (1 + (size_t)n) * 8;
+    HIPCHK(c, c->as_work.ensure(rb + nm * 8 + 64));
+    HIPCHK(c, c->pin_asm.ensure(rb + nm * 8 + 64));
+    int64_t *d_rec = c->as_work.as<int64_t>(), *d_out = d_rec + nm * (1 + (size_t)n);
+    memcpy(c->pin_asm.p, m.d.data(), rb);
+    HIPCHK(c, hipMemcpyAsync(d_rec, c->pin_asm.p, rb, hipMemcpyHostToDevice, c->stream));
+    const uint32_t blocks = (uint32_t)std::min<size_t>((nm + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL(sp_score_matches, dim3(blocks), dim3(256), 0, c->stream, c->genomes.as<uint64_t>(), G, n, d_rec, (uint32_t)nm, d_out);
+    HIPCHK(c, hipGetLastError());
+    int64_t *h_out = reinterpret_cast<int64_t *>(c->pin_asm.as<char>() + rb);
+    HIPCHK(c, hipMemcpyAsync(h_out, d_out, nm * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(out.data(), h_out, nm * 8);
+    return MAUVE_OK;
+}
 
 // Everything of align_finish, from the device-side chains and DP results.  The host receives the per-LCB rows; the
 // columns and the anchor table stay in c->res_cols / c->res_anch until materialize_result.

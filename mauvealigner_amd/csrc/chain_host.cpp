@@ -308,7 +308,7 @@ void lcb_greedy(int N, int32_t K, int64_t *weight, const uint32_t *orient_bits, 
 // Greedy breakpoint elimination over the compact LCB graph.  `orders` (optional): the
 // per-genome (left end, index) order of m as produced by host_eliminate_overlaps; sorted here otherwise.
 void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb,
-                    const ChainOrders *orders)
+                    const ChainOrders *orders, const int64_t *match_weight)
 {
     const int N = m.N;
     const size_t n = m.size();
@@ -361,7 +361,7 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
         }
         if (!join) { weight.push_back(0); node_first.push_back(i); }
         node_of[i] = (int32_t)weight.size() - 1;
-        weight.back() += m.len(i) * N;
+        weight.back() += match_weight ? match_weight[i] : m.len(i) * N;       // sum-of-pairs anchor scores instead
     }
     const int32_t K = (int32_t)weight.size();
     // per-genome doubly linked lists of nodes, flat [K][N]

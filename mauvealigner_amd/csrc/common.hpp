@@ -174,6 +174,7 @@ struct AlignState {
     // megabyte-sized vector per stage and call costs more in page faults than the stage itself
     MatchVec m;
     std::vector<int64_t> match_lcb;
+    std::vector<int64_t> match_weight;  // sum-of-pairs scores of the matches (lcb_scoring = SP), else empty
     std::vector<Item> items;
     // start a new alignment: scalars to zero, vectors emptied but not released
     void reset()
@@ -181,7 +182,7 @@ struct AlignState {
         open = false; anchor_table_done = false; dev_tail = false; p = mauve_params(); N = 0; full = 0;
         sum = nm = nl = n_dp = code_total = n_anchor = anchor_cols = 0; t0 = t_dp0 = 0;
         gaps.clear(); desc.clear(); dcol_off.clear(); dscore.clear();
-        match_lcb.clear(); items.clear();
+        match_lcb.clear(); match_weight.clear(); items.clear();
     }
 };
 
@@ -323,7 +324,10 @@ struct ChainOrders { std::vector<std::vector<uint32_t>> ord; bool sparse = false
                                                                                         // sparse: the list still holds dead records (not named here)
 void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders = nullptr, bool compact = true);
 void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb,
-                    const ChainOrders *orders = nullptr);
+                    const ChainOrders *orders = nullptr, const int64_t *match_weight = nullptr);
+// extant sum-of-pairs scores of the matches of m (n components; gmap: their genomes, nullptr = 0..n-1), assemble_dev.hip
+int match_sp_scores(mauve_ctx *c, const MatchVec &m, const int *gmap, const mauve_scoring *sc, std::vector<int64_t> &out);
+int64_t sp_default_min_weight(int w, int n, const mauve_scoring *sc);
 
 void lcb_greedy(int N, int32_t K, int64_t *weight, const uint32_t *orient_bits, int32_t *prevv, int32_t *nextv, int64_t min_weight,
                 bool collinear, std::vector<int64_t> &final_id, int64_t &n_lcb);

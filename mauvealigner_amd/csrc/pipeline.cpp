@@ -217,7 +217,9 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
     const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight : (int64_t)3 * w * N;
     std::vector<int64_t> &match_lcb = S.match_lcb; int64_t nl = 0;
     static const bool host_chain = getenv("MAUVE_HOST_CHAIN") != nullptr;
-    bool on_device = !host_chain && nm > 0 && c->dev_rec_n == nm;
+    if (p->lcb_scoring != MAUVE_LCB_SCORE_LENGTH && p->lcb_scoring != MAUVE_LCB_SCORE_SP) { c->err = "align: unknown lcb_scoring"; return MAUVE_ERR_ARG; }
+    if (p->lcb_scoring == MAUVE_LCB_SCORE_SP && p->extend_lcbs) { c->err = "align: lcb_scoring and extend_lcbs cannot be combined"; return MAUVE_ERR_ARG; }
+    bool on_device = !host_chain && nm > 0 && c->dev_rec_n == nm && p->lcb_scoring == MAUVE_LCB_SCORE_LENGTH;   // score weights: host chain
     double t1b = t1;
     if (on_device) {
         rc = chain_device_core(c, N, lcbw, p->collinear != 0, nl);
@@ -267,6 +269,14 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
         static const bool elim_compact = getenv("MAUVE_ELIM_COMPACT") != nullptr;       // A/B switch
         host_eliminate_overlaps(m, &orders, elim_compact);           // default: dead records stay in m, with lcb -1 below
         t1b = now_ms();
+        if (p->lcb_scoring == MAUVE_LCB_SCORE_SP) {              // LCB weight = sum-of-pairs score of its anchors
+            std::vector<int64_t> mw;
+            rc = match_sp_scores(c, m, nullptr, &p->scoring, mw);
+            if (rc) return rc;
+            const int64_t minw = p->lcb_weight >= 0 ? p->lcb_weight : sp_default_min_weight(w, N, &p->scoring);
+            host_lcb_chain(m, minw, p->collinear != 0, match_lcb, nl, &orders, mw.data());
+            S.match_weight.swap(mw);
+        } else
         host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl, &orders);
     }
     if (p->extend_lcbs) {
@@ -281,7 +291,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
     for (size_t i = 0; i < m.size(); i++) {
         int64_t l = match_lcb[i]; if (l < 0) continue;
         chains[(size_t)l].push(m.rec(i));              // m is sorted by genome-0 start (canonical order)
-        R.lcb_weight[(size_t)l] += m.len(i) * N;
+        R.lcb_weight[(size_t)l] += S.match_weight.empty() ? m.len(i) * N : S.match_weight[i];
     }
     const double t2 = now_ms();
     c->stage.chain_ms = t2 - t1;
@@ -594,6 +604,21 @@ static int given_matches(mauve_ctx *c, int64_t n, const int64_t *length, const i
             mv.st((size_t)i)[g] = s;
         }
     }
+    return MAUVE_OK;
+}
+
+int mauve_match_sp_scores(mauve_ctx *c, int64_t n, const int64_t *length, const int64_t *start, const mauve_scoring *sc, int64_t *scores)
+{
+    if (!c || !sc || n < 0 || (n && (!length || !start || !scores))) return MAUVE_ERR_ARG;
+    if (c->nseq < 2) { c->err = "match_sp_scores: at least two genomes required"; return MAUVE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int N = c->nseq;
+    MatchVec m(N); m.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) { m.len((size_t)i) = length[i]; std::copy(start + i * N, start + (i + 1) * N, m.st((size_t)i)); }
+    std::vector<int64_t> out;
+    int rc = match_sp_scores(c, m, nullptr, sc, out);
+    if (rc) return rc;
+    std::copy(out.begin(), out.end(), scores);
     return MAUVE_OK;
 }
 

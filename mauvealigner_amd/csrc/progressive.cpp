@@ -154,6 +154,15 @@ int prog_node(Prog &P, int node)
     host_eliminate_overlaps(m, &orders);
     const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight * n / P.N : (int64_t)3 * w * n;
     std::vector<int64_t> match_lcb; int64_t nl = 0;
+    if (p->lcb_scoring == MAUVE_LCB_SCORE_SP) {
+        std::vector<int64_t> mw;
+        rc = match_sp_scores(c, m, gm.data(), &p->scoring, mw);
+        if (rc) return rc;
+        // a given score threshold is for all N genomes: scaled by the node's share of the pairs
+        const int64_t minw = p->lcb_weight >= 0 ? p->lcb_weight * ((int64_t)n * (n - 1) / 2) / ((int64_t)P.N * (P.N - 1) / 2)
+                                                : sp_default_min_weight(w, n, &p->scoring);
+        host_lcb_chain(m, minw, p->collinear != 0, match_lcb, nl, &orders, mw.data());
+    } else
     host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl, &orders);
     if (trace) {
         int64_t surv = 0; for (size_t i = 0; i < m.size(); i++) if (match_lcb[i] >= 0) surv++;
@@ -319,6 +328,7 @@ int mauve_progressive_align(mauve_ctx *c, const mauve_params *p, mauve_align_siz
 {
     if (!c || !p || !sizes) return MAUVE_ERR_ARG;
     if (c->nseq < 2) { c->err = "progressive_align: at least two genomes required"; return MAUVE_ERR_STATE; }
+    if (p->lcb_scoring != MAUVE_LCB_SCORE_LENGTH && p->lcb_scoring != MAUVE_LCB_SCORE_SP) { c->err = "progressive_align: unknown lcb_scoring"; return MAUVE_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     const double t0 = now_ms();
     const int N = c->nseq;

@@ -85,6 +85,8 @@ typedef struct {
     int64_t max_gapped_len;   /* default 10000 */
     orc_scoring scoring;
     int64_t max_banded_len;   /* banded DP for intervals in (max_gapped_len, max_banded_len]; default 0 = off */
+    int32_t lcb_scoring;      /* 0 = length weights (Aligner::align), 1 = extant sum-of-pairs anchor scores */
+    int32_t reserved0;
 } orc_params;
 
 /* ---- seeds ---------------------------------------------------------------------------------- */
@@ -124,6 +126,8 @@ void orc_free(void *p);
 /* ---- LCBs ------------------------------------------------------------------------------------ */
 int orc_multiplicity_filter(const orc_matches *in, int mult, orc_matches *out);
 int orc_eliminate_overlaps(orc_matches *m);   /* in place, N-way input */
+int orc_compute_lcbs_w(const orc_matches *m, const int64_t *match_weight, int64_t min_weight, int collinear, orc_lcbs *out);
+void orc_match_sp_scores(int nseq, const uint8_t *const *codes, const orc_matches *m, const orc_scoring *sc, int64_t *out);
 int orc_compute_lcbs(const orc_matches *m, int64_t min_weight, int collinear, orc_lcbs *out);
 void orc_free_lcbs(orc_lcbs *l);
 

@@ -51,7 +51,7 @@ class Params(C.Structure):
                 ("recursive", C.c_int32), ("gapped", C.c_int32), ("add_unaligned", C.c_int32),
                 ("extend_lcbs", C.c_int32), ("max_extension_iters", C.c_int32),
                 ("min_recursive_gap", C.c_int64), ("max_gapped_len", C.c_int64), ("scoring", Scoring),
-                ("max_banded_len", C.c_int64)]
+                ("max_banded_len", C.c_int64), ("lcb_scoring", C.c_int32), ("reserved0", C.c_int32)]
 
 
 def build(force=False):
@@ -277,6 +277,16 @@ def compute_lcbs(length, start, min_weight, collinear=False):
     d = _lcbs_to_dict(out, len(keep[0]))
     lib().orc_free_lcbs(C.byref(out))
     return d
+
+
+def match_sp_scores(seqs, length, start, scoring=None):
+    """extant sum-of-pairs score of every (ungapped) match, DESIGN.md S11"""
+    sc = scoring or default_scoring()
+    seqs, arr, lens = _seq_args(seqs)
+    m, keep = _np_to_matches(length, start)
+    out = np.zeros(max(len(keep[0]), 1), np.int64)
+    lib().orc_match_sp_scores(len(seqs), arr, C.byref(m), C.byref(sc), out.ctypes.data_as(C.POINTER(C.c_int64)))
+    return out[:len(keep[0])].copy()
 
 
 def profile_dp(cnt, k_rows, seq, scoring=None, banded=False):

@@ -310,6 +310,24 @@ def test_align_banded_long_gaps(ctx):
     assert on["xmfa"] == sh["xmfa"] and on["n_dp_cells"] == sh["n_dp_cells"]
 
 
+def test_sp_lcb_scoring(ctx):
+    """lcb_scoring = sum-of-pairs (ProgressiveAligner::setLcbScoringScheme, DESIGN.md S11): the device's anchor scores equal
+    the oracle's, and mauve_align / mauve_progressive_align with score-weighted LCBs equal the oracle's results."""
+    from mauvealigner_amd import _lib
+    gs = synth.make_config("C3", scale=0.03)
+    ctx.set_genomes(gs)
+    r = ctx.align(_lib.default_params())
+    sc = ctx.match_sp_scores(r["anchor_length"], r["anchor_start"])
+    assert np.array_equal(sc, O.match_sp_scores(gs, r["anchor_length"], r["anchor_start"]))
+    assert sc.min() > 0
+    _same_align(ctx, gs, lcb_scoring=1)
+    _same_align(ctx, gs, lcb_scoring=1, lcb_weight=200000)        # a breakpoint penalty as a score
+    gs4 = synth.make_config("C4", scale=0.01)
+    _same_progressive(ctx, gs4, lcb_scoring=1)
+    with pytest.raises(RuntimeError):
+        ctx.align(_lib.default_params(lcb_scoring=1, extend_lcbs=1))
+
+
 def test_lcb_extension(ctx):
     """S10 (lcb_extension): masked re-search of the regions outside every LCB with lighter seeds; bit-exact against
     the oracle, and it only ever adds anchored columns."""

@@ -511,3 +511,28 @@ def test_banded_dp_oracle():
     # a small shift stays inside the band: same optimum
     b2 = np.concatenate([a[:600], rng.integers(0, 4, 60, dtype=np.uint8), a[600:]])
     assert O.align_interval([a, b2])[1] == O.align_interval([a, b2], banded=True)[1]
+
+
+def test_sp_scoring_oracle():
+    """Extant sum-of-pairs anchor scores: by hand on a tiny case, and through the LCB computation."""
+    sc = O.default_scoring()
+    M = np.array([[sc.matrix[i][j] for j in range(4)] for i in range(4)], dtype=np.int64)
+    A, C_, G, T = 0, 1, 2, 3
+    g0 = np.array([A, C_, G, T, A, A], np.uint8)
+    g1 = np.array([T, A, C_, G, A, A], np.uint8)                  # g0[0:3] = g1[1:4]
+    g2 = np.array([T, T, C_, G, T, G], np.uint8)                  # reverse complement of g2[1:4] = (C, G, A) -> rc = T C G ... checked below
+    # match of length 3: g0 at 1, g1 at 2, g2 reverse at 2 (covers g2[1:4] = T C G, read backwards and complemented: C G A)
+    s = O.match_sp_scores([g0, g1, g2], [3], [[1, 2, -2]])
+    cols = [(g0[0 + c], g1[1 + c], 3 - g2[1 + (2 - c)]) for c in range(3)]
+    want = sum(int(M[a][b] + M[a][d] + M[b][d]) for a, b, d in cols)
+    assert int(s[0]) == want
+    # an absent component drops its pairs
+    s2 = O.match_sp_scores([g0, g1, g2], [3], [[1, 2, 0]])
+    assert int(s2[0]) == sum(int(M[a][b]) for a, b, _ in cols)
+    # whole path: SP scoring keeps fewer or equal LCBs than no threshold and reports score weights
+    gs = synth.make_config("C3", scale=0.02)
+    e0 = O.align(gs, O.default_params())
+    e1 = O.align(gs, O.default_params(lcb_scoring=1))
+    assert e1["lcbs"]["n_lcb"] >= 1
+    ml, ms = e1["aln"]["anchor_length"], e1["aln"]["anchor_start"]
+    assert int(e1["lcbs"]["weight"].sum()) > int(e0["lcbs"]["weight"].sum())       # scores (~95 per pair and column) against lengths
