@@ -88,6 +88,27 @@ __device__ __forceinline__ int64_t dp_step_cells(int32_t m, int32_t n, bool band
     return acc;
 }
 
+// Kernel class of an interval from an ESTIMATE of its profile lengths: aligning a profile with one more sequence rarely
+// makes it much longer than the longest sequence so far, while the safe bound is the SUM of the lengths -- which puts
+// nearly every 5-way interval of ~20-base gaps into the one-wave class.  est(m) = min(bound, longest + longest / 8 + 2);
+// the kernels check the real lengths and fall back (dp_groups).  3: four per wave (rows <= 16), 2: two per wave
+// (rows <= 32), 1: a wave of its own.
+struct DpClassEst {
+    int64_t mbound = 0, longest = 0, rows = 0, steps = 0; bool first = true;
+    int mode = 0;                     // 0: the estimate; 1: the safe bound (MAUVE_DP_CLASS=bound); 2: half the longest (=wild: tests the fallback)
+    __host__ __device__ void add(int64_t n)
+    {
+        if (n == 0) return;
+        if (first) { first = false; mbound = longest = n; return; }
+        int64_t e = mode == 1 ? mbound : (mode == 2 ? longest / 2 + 1 : longest + longest / 8 + 2);
+        if (e > mbound) e = mbound;
+        if (e > rows) rows = e;
+        if (e + n > steps) steps = e + n;
+        mbound += n; if (n > longest) longest = n;
+    }
+    __host__ __device__ int klass(int tmax) const { return steps <= tmax ? (rows <= 16 ? 3 : (rows <= 32 ? 2 : 1)) : 1; }
+};
+
 // lane l receives lane l-1's value; wave_shr1z: lane 0 receives 0 (its caller puts the real input there), wave_shr1: lane 0
 // keeps its own (gfx9 DPP wave_shr:1)
 __device__ __forceinline__ int32_t wave_shr1z(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
@@ -414,9 +435,14 @@ __device__ void dp_groups(int nseq, const int64_t *__restrict__ list, int64_t fi
         const int64_t iv = have ? list[first + li0 + q] : 0;
         DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
         const int64_t base = have ? seq_off[iv * nseq] : 0;
+        // The class of an interval comes from an ESTIMATE of its profile lengths (dp_class_of): a group whose profile
+        // outgrows its G rows, or whose step outgrows the LDS slice, gives the interval up (mt.m = -1) and the wave
+        // runs it through the one-wave path afterwards (dp_step).
+        bool dead = false;
         for (int g = 0; g < nseq; g++) {
             int64_t so = 0; int32_t n = 0;
-            if (have) { so = seq_off[iv * nseq + g]; n = (int32_t)(seq_off[iv * nseq + g + 1] - so); }
+            if (have && !dead) { so = seq_off[iv * nseq + g]; n = (int32_t)(seq_off[iv * nseq + g + 1] - so); }
+            if (n > 0 && mt.krows > 0 && (mt.m > G || mt.m + n > DP_GRP_TMAX)) { dead = true; n = 0; }
             const uint8_t *seq = codes + so;
             uint32_t *Pc = (mt.cur ? cntB : cntA) + base, *Pm = (mt.cur ? maskB : maskA) + base;
             uint32_t *Qc = (mt.cur ? cntA : cntB) + base, *Qm = (mt.cur ? maskA : maskB) + base;
@@ -522,6 +548,7 @@ __device__ void dp_groups(int nseq, const int64_t *__restrict__ list, int64_t fi
             if (init) { mt.m = n; mt.krows = 1; }
             __threadfence_block();       // profiles written by some lanes are read by others in the next step
         }
+        if (dead) mt.m = -1;
         if (have && leader) meta[iv] = mt;
     }
 }
@@ -554,6 +581,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     // The list is [dp_step_big's entries | one-wave | two per wave (m <= 32) | four per wave (m <= 16)], each class
     // largest first; the block ranges follow the same order so the long ones start first.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int per = 1; bool only_failed = false;
+    int64_t pos0, pstep, pend;
     if (blockIdx.x >= cl.blocks_med) {
         const bool s32 = blockIdx.x < cl.blocks_med + cl.blocks_s32;
         const uint32_t b0 = s32 ? cl.blocks_med : cl.blocks_med + cl.blocks_s32;
@@ -561,14 +590,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         const int64_t widx = (int64_t)(blockIdx.x - b0) * 4 + wv, nw = (int64_t)nb * 4;
         if (s32) dp_groups<32>(nseq, list, cl.first_s32, cl.n_s32, widx, nw, codes, seq_off, meta, cntA, maskA, cntB, maskB, s_tb[wv], s_ops[wv], sc);
         else dp_groups<16>(nseq, list, cl.first_s16, cl.n_s16, widx, nw, codes, seq_off, meta, cntA, maskA, cntB, maskB, s_tb[wv], s_ops[wv], sc);
-        return;
+        // second look at this wave's own list positions: what a group gave up is aligned below, one interval per wave
+        per = s32 ? 2 : 4; only_failed = true;
+        pos0 = (s32 ? cl.first_s32 : cl.first_s16) + widx * per; pstep = nw * per; pend = (s32 ? cl.first_s32 + cl.n_s32 : cl.first_s16 + cl.n_s16);
+        __threadfence_block();
+    } else {
+        pos0 = cl.first_med + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); pstep = ((int64_t)cl.blocks_med * blockDim.x) >> 6;
+        pend = cl.first_med + cl.n_med;
     }
-    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)cl.blocks_med * blockDim.x) >> 6;
     const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
 
-    for (int64_t li = cl.first_med + wave_global; li < cl.first_med + cl.n_med; li += nwaves) {
-      const int64_t iv = list[li];
+    for (int64_t lb = pos0; lb < pend; lb += pstep)
+    for (int q = 0; q < per && lb + q < pend; q++) {
+      const int64_t iv = list[lb + q];
+      if (only_failed && meta[iv].m != -1) continue;
       // all progressive steps of one interval run back to back in this wave (they only depend on each other)
       DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
       const int64_t base = seq_off[iv * nseq];
@@ -711,6 +746,11 @@ __global__ void __launch_bounds__(256) dp_gather_codes(const uint64_t *__restric
 
 // Which intervals get a workgroup (dp_step_big) instead of a wave: candidates whose single-wave estimate exceeds
 // factor x the balanced share of a wave slot, at most max of them (MAUVE_DP_BIG_FACTOR4 = 4 x factor, MAUVE_DP_BIG_MAX).
+static int dp_class_mode()
+{
+    static const int m = []() { const char *e = getenv("MAUVE_DP_CLASS"); return !e ? 0 : (!strcmp(e, "bound") ? 1 : (!strcmp(e, "wild") ? 2 : 0)); }();
+    return m;
+}
 static int64_t dp_big_factor4() { static const int64_t f = getenv("MAUVE_DP_BIG_FACTOR4") ? atoll(getenv("MAUVE_DP_BIG_FACTOR4")) : 16; return f; }
 static int64_t dp_big_max() { static const int64_t m = getenv("MAUVE_DP_BIG_MAX") ? atoll(getenv("MAUVE_DP_BIG_MAX")) : 128; return m; }
 
@@ -810,11 +850,13 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     need_v.resize((size_t)n_iv); nmax_v.resize((size_t)n_iv);
     ctx->pool->parallel_for(n_iv, 2048, [&](int64_t b, int64_t e) {
         for (int64_t iv = b; iv < e; iv++) {
-            int64_t mmax = 0, mmin = 0, need = 0, nmax = 0, es = 0, mbound = 0, steps_max = 0, longest = 0; bool first = true; uint8_t big = 0;
+            int64_t mmax = 0, mmin = 0, need = 0, nmax = 0, es = 0, longest = 0; bool first = true; uint8_t big = 0;
+            DpClassEst ce; ce.mode = dp_class_mode();
             for (int g = 0; g < nseq; g++) longest = std::max(longest, seq_off[iv * nseq + g + 1] - seq_off[iv * nseq + g]);
             const bool banded = longest > band_from;
             for (int g = 0; g < nseq; g++) {
                 const int64_t n = seq_off[iv * nseq + g + 1] - seq_off[iv * nseq + g];
+                ce.add(n);
                 if (n == 0) continue;
                 if (first) { first = false; mmax = mmin = n; continue; }
                 const int64_t tbn = dp_tb_need(mmin, mmax, n, banded);  // the profile is at least as long as its longest member
@@ -823,14 +865,13 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
                 // a step with >= 3 stripes against >= 256 columns pipelines over several waves
                 if (mmax > 128 && n >= 256 && !no_mw) big = 1;
                 es += tbn / 64;                                        // systolic steps of a single wave
-                mbound = std::max(mbound, mmax); steps_max = std::max(steps_max, mmax + n);
                 mmax += n; mmin = std::max(mmin, n);
             }
             if (banded && nmax) big = 2;                               // banded steps exist only in the workgroup kernel
             need_v[(size_t)iv] = need; nmax_v[(size_t)iv] = nmax; est[(size_t)iv] = es; is_big[(size_t)iv] = big;
             // sub-wave classes: every profile the interval will see fits G rows, every step fits the LDS slice
             uint8_t k = 1;
-            if (!no_groups && !banded && steps_max <= DP_GRP_TMAX) k = mbound <= 16 ? 3 : (mbound <= 32 ? 2 : 1);
+            if (!no_groups && !banded) k = (uint8_t)ce.klass(DP_GRP_TMAX);
             cls[(size_t)iv] = k;
         }
     });
@@ -1026,12 +1067,13 @@ __global__ void __launch_bounds__(256) dpf_desc(const int32_t *__restrict__ alen
                                                 const uint32_t *__restrict__ anchor_of, const DpFrontTotals *__restrict__ tot,
                                                 DpSeqDesc *__restrict__ desc, int64_t *__restrict__ need, int64_t *__restrict__ rowsn,
                                                 int64_t *__restrict__ est, uint8_t *__restrict__ cand, uint8_t *__restrict__ cls,
-                                                uint32_t *__restrict__ sizekey, uint32_t *__restrict__ slotval, int no_mw, int no_groups, int64_t band_from)
+                                                uint32_t *__restrict__ sizekey, uint32_t *__restrict__ slotval, int no_mw, int no_groups, int64_t band_from, int class_mode)
 {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
     if (s >= (uint32_t)tot->n_dp) return;
     const uint32_t k = anchor_of[s];
-    int64_t mmax = 0, mmin = 0, nd = 0, nmax = 0, es = 0, mbound = 0, steps_max = 0, longest = 0; bool first = true; uint8_t big = 0;
+    int64_t mmax = 0, mmin = 0, nd = 0, nmax = 0, es = 0, longest = 0; bool first = true; uint8_t big = 0;
+    DpClassEst ce; ce.mode = class_mode;
     for (int g = 0; g < N; g++) {
         int64_t lo, n; bool rv;
         dpf_gap(alen, ast, N, k, g, lo, n, rv);
@@ -1043,6 +1085,7 @@ __global__ void __launch_bounds__(256) dpf_desc(const int32_t *__restrict__ alen
         dpf_gap(alen, ast, N, k, g, lo, n, rv);
         DpSeqDesc d; d.genome = g; d.rev = rv; d.lo0 = lo - 1; d.len = n;
         desc[(size_t)s * N + g] = d;
+        ce.add(n);
         if (n == 0) continue;
         if (first) { first = false; mmax = mmin = n; continue; }
         const int64_t tbn = dp_tb_need(mmin, mmax, n, banded);
@@ -1050,13 +1093,12 @@ __global__ void __launch_bounds__(256) dpf_desc(const int32_t *__restrict__ alen
         nmax = max(nmax, n);
         if (mmax > 128 && n >= 256 && !no_mw) big = 1;       // a step with >= 3 stripes against >= 256 columns pipelines over several waves
         es += tbn / 64;
-        mbound = max(mbound, mmax); steps_max = max(steps_max, mmax + n);
         mmax += n; mmin = max(mmin, n);
     }
     if (banded && nmax) big = 2;                             // banded steps exist only in the workgroup kernel
     need[s] = nd; rowsn[s] = 6 * (nmax + 1); est[s] = es; cand[s] = big;
     uint8_t kc = 1;
-    if (!no_groups && !banded && steps_max <= DP_GRP_TMAX) kc = mbound <= 16 ? 3 : (mbound <= 32 ? 2 : 1);
+    if (!no_groups && !banded) kc = (uint8_t)ce.klass(DP_GRP_TMAX);
     cls[s] = kc;
     int c = 0; for (int64_t f = nd; f > 1; f >>= 1) c++;
     sizekey[s] = (uint32_t)(63 - c);                         // largest traceback footprint first
@@ -1154,7 +1196,7 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     hipLaunchKernelGGL((cmp_count<DpSlots>), dim3(nb), dim3(256), 0, ctx->stream, sl, bcnt);
     hipLaunchKernelGGL((cmp_write<DpSlots>), dim3(nb), dim3(256), 0, ctx->stream, sl, bcnt);
     hipLaunchKernelGGL(dpf_desc, dim3(blocks), dim3(256), 0, ctx->stream, alen, ast, N, anchor_of, tot, desc, need, rowsn, est, cand, cls, k1, v1,
-                       (int)no_mw, (int)no_groups, ctx->dp_band_from);
+                       (int)no_mw, (int)no_groups, ctx->dp_band_from, dp_class_mode());
     // the counts below are device values; the launches cover na (>= n_dp) entries and the kernels stop at n_dp.
     // Offsets: the value functors return 0 beyond n_dp because the arrays there are never read -- so clear them first.
     // (need / rows / est / desc of slots >= n_dp are not written: scan over exactly n_dp needs the count -> two-phase:

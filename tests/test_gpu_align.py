@@ -231,6 +231,45 @@ def test_device_tail_equals_host_tail_and_oracle():
     assert not [l for l in r.stderr.splitlines() if "stay there" in l]
 
 
+CLASS_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from mauvealigner_amd import _lib, synth
+from oracle import pyoracle as O
+rng = np.random.default_rng(12)
+ctx = _lib.Context(0)
+for nseq in (2, 3, 5):
+    ivs = []
+    for k in range(400):
+        base = rng.integers(0, 4, int(rng.integers(1, 60)), dtype=np.uint8)
+        ivs.append([synth.mutate(base, 0.2, rng, indel_frac=0.5) if rng.random() > 0.1 else np.zeros(0, np.uint8) for _ in range(nseq)])
+    cols, score = ctx.dp_batch(ivs)
+    for iv, c, s in zip(ivs, cols, score):
+        ec, es = O.align_interval(iv)
+        assert np.array_equal(c, ec) and int(s) == es
+gs = synth.make_config("C3", scale=0.03)
+ctx.set_genomes(gs)
+r = ctx.align(_lib.default_params())
+e = O.align(gs, O.default_params())["aln"]
+for k in ("cols", "col_off", "dp_score"):
+    assert np.array_equal(r[k], e[k]), k
+assert r["n_dp_cells"] == e["n_dp_cells"]
+print("OK")
+"""
+
+
+def test_dp_class_estimate_and_fallback():
+    """Intervals are put into the sub-wave classes by an estimate of their profile lengths; a group whose profile outgrows
+    its rows hands the interval to the one-wave path.  MAUVE_DP_CLASS=wild underestimates on purpose (half the longest
+    sequence), so most groups fall back; =bound is the safe worst-case classing.  Same results in all three."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("wild", "bound", "estimate"):
+        env = dict(os.environ, MAUVE_DP_CLASS=mode)
+        r = subprocess.run([sys.executable, "-c", CLASS_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), mode + "\n" + r.stdout + r.stderr[-3000:]
+
+
 def _check_dp_banded(ctx, intervals, band_from):
     widths = sorted({len(iv) for iv in intervals})
     if len(widths) > 1:                                        # one launch per number of sequences
