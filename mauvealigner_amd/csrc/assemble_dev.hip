@@ -58,13 +58,18 @@ __global__ void __launch_bounds__(256) as_lcb(const int32_t *__restrict__ alcb, 
 }
 
 // LCB extents: the anchors of a chain are ordered, so the ends come from its first and last anchor (signed: negative = reverse)
+// (also: the LCB weights and the total number of LCB columns into the block of rows that goes to the host in one copy)
 __global__ void __launch_bounds__(256) as_extents(const int32_t *__restrict__ alen, const int32_t *__restrict__ ast, int N, uint32_t nl,
                                                   const uint32_t *__restrict__ first_a, const uint32_t *__restrict__ last_a,
-                                                  int64_t *__restrict__ left, int64_t *__restrict__ right)
+                                                  int64_t *__restrict__ left, int64_t *__restrict__ right,
+                                                  const unsigned long long *__restrict__ lw, int64_t *__restrict__ lw_row,
+                                                  const int64_t *__restrict__ total_cols, int64_t *__restrict__ total_row)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= nl * (uint32_t)N) return;
     const uint32_t l = t / (uint32_t)N; const int g = (int)(t % (uint32_t)N);
+    if (g == 0) lw_row[l] = (int64_t)lw[l];
+    if (t == 0) *total_row = *total_cols;
     const uint32_t a0 = first_a[l], a1 = last_a[l];
     const int64_t s0 = ast[(size_t)a0 * N + g], s1 = ast[(size_t)a1 * N + g];
     int64_t le, re;
@@ -184,7 +189,7 @@ int match_sp_scores(mauve_ctx *c, const MatchVec &m, const int *gmap, const mauv
 }
 
 // Everything of align_finish, from the device-side chains and DP results.  The host receives the per-LCB rows; the
-// columns and the anchor table stay in c->res_cols / c->res_anch until materialize_result.
+// columns stay in c->res_cols, the anchor table where the chain stage left it, until materialize_result.
 int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes *sizes)
 {
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
@@ -198,16 +203,16 @@ int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes
     auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
     const size_t o_bsum = ((size_t)na + 1) * 8, o_first = o_bsum + ((size_t)nb + 8) * 8, o_last = up8(o_first + (size_t)nl * 4),
                  o_col = up8(o_last + (size_t)nl * 4), o_left = o_col + ((size_t)nl + 1) * 8, o_right = o_left + (size_t)nl * N * 8,
-                 o_score = o_right + (size_t)nl * N * 8, w_total = o_score + (size_t)nl * 8;
+                 o_score = o_right + (size_t)nl * N * 8, o_lw = o_score + (size_t)nl * 8, o_tot = o_lw + (size_t)nl * 8, w_total = o_tot + 8;
     HIPCHK(c, c->as_work.ensure(w_total + 64));
     HIPCHK(c, c->res_cols.ensure(((size_t)S.sum + 64) * 4));          // every column holds a base, every base sits in one column
-    HIPCHK(c, c->res_anch.ensure((size_t)na * (2 + (size_t)N) * 4 + 64));
     char *wk = c->as_work.as<char>();
     int64_t *col0 = reinterpret_cast<int64_t *>(wk), *bsum = reinterpret_cast<int64_t *>(wk + o_bsum);
     uint32_t *first_a = reinterpret_cast<uint32_t *>(wk + o_first), *last_a = reinterpret_cast<uint32_t *>(wk + o_last);
     int64_t *lcb_col = reinterpret_cast<int64_t *>(wk + o_col), *left = reinterpret_cast<int64_t *>(wk + o_left),
             *right = reinterpret_cast<int64_t *>(wk + o_right);
     unsigned long long *score = reinterpret_cast<unsigned long long *>(wk + o_score);
+    int64_t *lw_row = reinterpret_cast<int64_t *>(wk + o_lw), *tot_row = reinterpret_cast<int64_t *>(wk + o_tot);
     uint32_t *out = c->res_cols.as<uint32_t>();
     HIPCHK(c, hipMemsetAsync(score, 0, (size_t)nl * 8, c->stream));
     // the DP front end may have found no interval: its offset / score arrays are then not set up
@@ -215,34 +220,27 @@ int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes
     hipLaunchKernelGGL((vscan_partial<int64_t, AsWidth>), dim3(nb), dim3(256), 0, c->stream, wf, na, bsum);
     hipLaunchKernelGGL((vscan_write<int64_t, AsWidth>), dim3(nb), dim3(256), 0, c->stream, wf, na, bsum, col0, (int64_t *)nullptr);
     hipLaunchKernelGGL(as_lcb, dim3(blocks), dim3(256), 0, c->stream, fo.alcb, fo.gapcode, fo.score, col0, na, first_a, last_a, lcb_col, score);
-    hipLaunchKernelGGL(as_extents, dim3(((uint32_t)nl * N + 255) / 256), dim3(256), 0, c->stream, fo.alen, fo.ast, N, (uint32_t)nl, first_a, last_a, left, right);
+    hipLaunchKernelGGL(as_extents, dim3(((uint32_t)nl * N + 255) / 256), dim3(256), 0, c->stream, fo.alen, fo.ast, N, (uint32_t)nl, first_a, last_a, left, right,
+                       c->ch_lw.as<unsigned long long>(), lw_row, col0 + na, tot_row);
     HIPCHK(c, hipGetLastError());
     // per-LCB rows to the host: first columns, extents, scores, weights, and the number of LCB columns
-    const size_t rows_bytes = ((size_t)nl + 1) * 8 + 2 * (size_t)nl * N * 8 + (size_t)nl * 8;
-    HIPCHK(c, c->pin_asm.ensure(64 + rows_bytes + (size_t)nl * 8));
-    int64_t *h_tot = c->pin_asm.as<int64_t>(), *h_rows = h_tot + 8, *h_lw = h_rows + rows_bytes / 8;
-    HIPCHK(c, hipMemcpyAsync(h_tot, col0 + na, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(h_rows, lcb_col, rows_bytes, hipMemcpyDeviceToHost, c->stream));       // lcb_col .. score are adjacent
-    HIPCHK(c, hipMemcpyAsync(h_lw, c->ch_lw.p, (size_t)nl * 8, hipMemcpyDeviceToHost, c->stream));
+    const size_t rows_bytes = ((size_t)nl + 1) * 8 + 2 * (size_t)nl * N * 8 + 2 * (size_t)nl * 8 + 8;
+    HIPCHK(c, c->pin_asm.ensure(64 + rows_bytes));
+    int64_t *h_rows = c->pin_asm.as<int64_t>() + 8;
+    HIPCHK(c, hipMemcpyAsync(h_rows, lcb_col, rows_bytes, hipMemcpyDeviceToHost, c->stream));       // lcb_col .. total are adjacent
     {
         const uint32_t fb = (uint32_t)std::min<int64_t>(((int64_t)na + 3) / 4, 256 * 8);
         hipLaunchKernelGGL(as_fill, dim3(fb), dim3(256), 0, c->stream, fo.alen, fo.ast, fo.gapcode, fo.col_off, fo.cols, col0, na, N, S.full, out);
     }
-    // the match list, if the seed pass left it on the device only
-    R.dev_nm = 0;
-    if (c->matches_pending) {
-        const size_t mb = (size_t)c->n_matches * (1 + (size_t)N) * 8;
-        HIPCHK(c, c->res_mums.ensure(mb + 64));
-        HIPCHK(c, hipMemcpyAsync(c->res_mums.p, c->sorted_rec.p, mb, hipMemcpyDeviceToDevice, c->stream));
-        R.dev_nm = (size_t)c->n_matches;
-    }
-    // the anchor table for a later fetch (the DP front end's arrays are overwritten by the next DP launch of any kind)
-    HIPCHK(c, hipMemcpyAsync(c->res_anch.p, fo.alen, (size_t)na * (2 + (size_t)N) * 4, hipMemcpyDeviceToDevice, c->stream));   // alen, ast, alcb are adjacent
+    // The match list (if the seed pass left it on the device only: sorted_rec) and the anchor table (ch_anch) are
+    // fetched from where they are: both stay untouched until this context's next seed pass / chain.
+    R.dev_nm = c->matches_pending ? (size_t)c->n_matches : 0;
+    R.dev_alen = fo.alen; R.dev_ast = fo.ast; R.dev_alcb = fo.alcb;
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const double t1 = now_ms();
-    const int64_t lcb_cols = h_tot[0];
-    const int64_t *h_col = h_rows, *h_left = h_col + nl + 1, *h_right = h_left + nl * N, *h_score = h_right + nl * N;
+    const int64_t *h_col = h_rows, *h_left = h_col + nl + 1, *h_right = h_left + nl * N, *h_score = h_right + nl * N, *h_lw = h_score + nl;
+    const int64_t lcb_cols = h_lw[nl];
     R.col_off.assign(h_col, h_col + nl);
     R.lcb_left.assign(h_left, h_left + nl * N); R.lcb_right.assign(h_right, h_right + nl * N);
     R.dp_score.assign(h_score, h_score + nl);
@@ -279,8 +277,8 @@ int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes
         if (ncols > S.sum) { c->err = "assemble_device: more columns than bases (internal error)"; return MAUVE_ERR_HIP; }
         if (!isl.empty()) {
             const size_t ib = isl.size() * sizeof(Island);
-            HIPCHK(c, c->pin_asm.ensure(64 + rows_bytes + (size_t)nl * 8 + ib + 64));
-            char *pi = c->pin_asm.as<char>() + 64 + rows_bytes + (size_t)nl * 8;
+            HIPCHK(c, c->pin_asm.ensure(64 + rows_bytes + ib + 64));
+            char *pi = c->pin_asm.as<char>() + 64 + rows_bytes;
             memcpy(pi, isl.data(), ib);
             HIPCHK(c, c->as_isl.ensure(ib + 64));
             HIPCHK(c, hipMemcpyAsync(c->as_isl.p, pi, ib, hipMemcpyHostToDevice, c->stream));
@@ -316,8 +314,13 @@ int materialize_result(mauve_ctx *c)
     HIPCHK(c, c->pin_cols.ensure(cb + ab + mb + 64));
     char *pc = c->pin_cols.as<char>();
     if (cb) HIPCHK(c, hipMemcpyAsync(pc, c->res_cols.p, R.n_cols * 4, hipMemcpyDeviceToHost, c->stream));
-    if (ab) HIPCHK(c, hipMemcpyAsync(pc + cb, c->res_anch.p, na * (2 + (size_t)N) * 4, hipMemcpyDeviceToHost, c->stream));
-    if (mb) HIPCHK(c, hipMemcpyAsync(pc + cb + ab, c->res_mums.p, mb, hipMemcpyDeviceToHost, c->stream));
+    if (ab) {
+        char *pa = pc + cb;
+        HIPCHK(c, hipMemcpyAsync(pa, R.dev_alen, na * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(pa + na * 4, R.dev_ast, na * N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(pa + na * 4 * (1 + (size_t)N), R.dev_alcb, na * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (mb) HIPCHK(c, hipMemcpyAsync(pc + cb + ab, c->sorted_rec.p, mb, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (mb) {
         const int64_t *hm = reinterpret_cast<const int64_t *>(pc + cb + ab);

@@ -258,6 +258,19 @@ __global__ void __launch_bounds__(256) ch_cluster_pass(int32_t *__restrict__ len
     for (int q = s; q < s0; q++) eleft[a + q] = dead_key;
 }
 
+// the compact graph for the host's greedy elimination, in one piece: weight[K] (8 B), orient[K], prev[K*N], next[K*N], check word
+__global__ void __launch_bounds__(256) ch_pack_graph(uint32_t K, int N, const unsigned long long *__restrict__ weight, const uint32_t *__restrict__ orient,
+                                                     const int32_t *__restrict__ prevv, const int32_t *__restrict__ nextv, const uint32_t *__restrict__ cnt,
+                                                     unsigned long long *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(out + K);
+    int32_t *op = reinterpret_cast<int32_t *>(o32 + K), *on = op + (size_t)K * N;
+    if (i < K) { out[i] = weight[i]; o32[i] = orient[i]; }
+    if (i < K * (uint32_t)N) { op[i] = prevv[i]; on[i] = nextv[i]; }
+    if (i == 0) reinterpret_cast<uint32_t *>(on + (size_t)K * N)[0] = cnt[2];
+}
+
 // final LCB id of every match (-1: dead, or its LCB was eliminated)
 __global__ void __launch_bounds__(256) ch_label(const int32_t *__restrict__ len, uint32_t n, const int32_t *__restrict__ node_of,
                                                 const int32_t *__restrict__ final_id, int32_t *__restrict__ lcb)
@@ -399,7 +412,7 @@ int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, i
     hipLaunchKernelGGL((cmp_count<FinalRanks>), dim3(nb, N), dim3(256), 0, c->stream, fr, bcnt);
     hipLaunchKernelGGL((cmp_write<FinalRanks>), dim3(nb, N), dim3(256), 0, c->stream, fr, bcnt);
     // the graph arrays are sized for the worst case K = n
-    HIPCHK(c, c->ch_graph.ensure((size_t)n * (8 + 4 + (size_t)N * 4 * 3 + 4)));
+    HIPCHK(c, c->ch_graph.ensure((size_t)n * (8 + 4 + (size_t)N * 4 * 3 + 4) + 8 + (size_t)n * (8 + 4 + (size_t)N * 8) + 64));     // the arrays + their packed copy
     unsigned long long *weight = c->ch_graph.as<unsigned long long>();
     uint32_t *orient = reinterpret_cast<uint32_t *>(weight + n);
     int32_t *prevv = reinterpret_cast<int32_t *>(orient + n), *nextv = prevv + (size_t)n * N, *seq = nextv + (size_t)n * N;
@@ -430,13 +443,13 @@ int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, i
         int64_t *hw = reinterpret_cast<int64_t *>(pg);
         uint32_t *ho = reinterpret_cast<uint32_t *>(hw + K);
         int32_t *hp = reinterpret_cast<int32_t *>(ho + K), *hn = hp + (size_t)K * N;
-        HIPCHK(c, hipMemcpyAsync(hw, weight, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(ho, orient, (size_t)K * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hp, prevv, (size_t)K * N * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hn, nextv, (size_t)K * N * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->pin_chain.p, cnt, 16, hipMemcpyDeviceToHost, c->stream));
+        // packed on the device (the arrays are K-prefixes of capacity-n arrays), one copy
+        const size_t pbytes = (size_t)K * (8 + 4 + (size_t)N * 8) + 4;
+        unsigned long long *pack = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(final_dev + n) + 7) & ~(uintptr_t)7);   // behind the graph arrays
+        hipLaunchKernelGGL(ch_pack_graph, dim3((K * (uint32_t)N + 255) / 256), dim3(256), 0, c->stream, K, N, weight, orient, prevv, nextv, cnt, pack);
+        HIPCHK(c, hipMemcpyAsync(pg, pack, pbytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->pin_chain.as<uint32_t>()[2]) { c->err = "chain_device: node lists inconsistent"; return MAUVE_ERR_LIMIT; }
+        if (*reinterpret_cast<uint32_t *>(hn + (size_t)K * N)) { c->err = "chain_device: node lists inconsistent"; return MAUVE_ERR_LIMIT; }
         lcb_greedy(N, (int32_t)K, hw, ho, hp, hn, min_weight, collinear, final_id, n_lcb);
         int32_t *hf = reinterpret_cast<int32_t *>(pg + gbytes);
         for (uint32_t i = 0; i < K; i++) hf[i] = (int32_t)final_id[i];

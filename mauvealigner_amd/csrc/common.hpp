@@ -127,9 +127,10 @@ struct AlignResult {
     uint32_t cols_fill = 0;            // value every word outside cols_dirty holds (0 = no such invariant)
     std::vector<std::pair<size_t, size_t>> cols_dirty;   // (offset, length) ranges holding gap columns
     std::vector<int64_t> dp_score;
-    // device-assembled result (assemble_dev.hip): the columns and the anchor table are still in HBM (res_cols / res_anch)
+    // device-assembled result (assemble_dev.hip): the columns (res_cols), the anchor table and maybe the match list are still in HBM
     bool dev_pending = false;
     size_t dev_na = 0, dev_nm = 0;          // anchors; matches still on the device (0: mum_* are filled)
+    const int32_t *dev_alen = nullptr, *dev_ast = nullptr, *dev_alcb = nullptr;     // ... where the anchors are (chain_order_device's arrays)
     const uint32_t *cols_ext = nullptr;      // the columns in page-locked staging after materialize_result (else: cols)
     const uint32_t *cols_data() const { return cols_ext ? cols_ext : cols.data(); }
 };
@@ -216,7 +217,7 @@ struct mauve_ctx {
     DevBuf join_ovf;                     // join_hash: [count, pad, (lo, hi) ...] ranges handed back to the full sort + serial join
     DevBuf ch_len, ch_st, ch_crop, ch_ent, ch_ord, ch_rank, ch_node, ch_graph, ch_cnt;   // device chain (chain_dev.hip)
     DevBuf ch_anch, ch_lw;               // the chains in chain order and the LCB weights (chain_order_device)
-    DevBuf as_work, as_isl, res_cols, res_anch, res_mums;      // device assembly (assemble_dev.hip): work area, islands, result columns, anchor table
+    DevBuf as_work, as_isl, res_cols;    // device assembly (assemble_dev.hip): work area, islands, result columns
     PinnedBuf pin_asm, pin_cols;         // ... its per-LCB rows coming back; the columns and anchors on their way to a fetch
     PinnedBuf pin_chain;
     DevBuf run_sum;                      // pairwise finder: run list (start, length, exactly-once genome set)

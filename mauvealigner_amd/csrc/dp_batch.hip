@@ -1176,6 +1176,9 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     HIPCHK(ctx, ctx->dpf_tot.ensure(256));
     int32_t *alen = ctx->dpf_anch.as<int32_t>(), *ast = alen + na, *alcb = ast + (size_t)na * N, *d_gapcode = alcb + na;
     uint32_t *anchor_of = reinterpret_cast<uint32_t *>(d_gapcode + na);
+    if (stay_on_device) {            // the anchors are device arrays already: used where they are (no copy)
+        alen = const_cast<int32_t *>(h_len); ast = const_cast<int32_t *>(h_st); alcb = const_cast<int32_t *>(h_lcb);
+    }
     DpSeqDesc *desc = ctx->dp_desc.as<DpSeqDesc>();
     char *wk = ctx->dpf_work.as<char>();
     int64_t *need = reinterpret_cast<int64_t *>(wk), *rowsn = need + na, *est = rowsn + na;
@@ -1187,10 +1190,11 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     int64_t *d_seq_off = ctx->dp_off.as<int64_t>();
     int64_t *d_tb_off = d_seq_off + ((size_t)na * N + 1), *d_rows_off = d_tb_off + (na + 1), *d_col_off = d_rows_off + (na + 1);
     HIPCHK(ctx, hipMemsetAsync(tot, 0, 256, ctx->stream));
-    const hipMemcpyKind up = stay_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    HIPCHK(ctx, hipMemcpyAsync(alen, h_len, (size_t)na * 4, up, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ast, h_st, (size_t)na * N * 4, up, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(alcb, h_lcb, (size_t)na * 4, up, ctx->stream));
+    if (!stay_on_device) {
+        HIPCHK(ctx, hipMemcpyAsync(alen, h_len, (size_t)na * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ast, h_st, (size_t)na * N * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(alcb, h_lcb, (size_t)na * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     hipLaunchKernelGGL(dpf_gap_flags, dim3(blocks), dim3(256), 0, ctx->stream, alen, ast, alcb, na, N, gapped, max_gapped_len, d_gapcode);
     const DpSlots sl{d_gapcode, na, anchor_of, tot};
     hipLaunchKernelGGL((cmp_count<DpSlots>), dim3(nb), dim3(256), 0, ctx->stream, sl, bcnt);

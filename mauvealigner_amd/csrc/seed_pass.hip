@@ -579,7 +579,7 @@ template <typename KeyT, bool WIDE, int VARIANT>
 __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t n,
                                                  const uint32_t *__restrict__ bound, GenomeTab tab, int mode, uint32_t want_mask,
                                                  uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos,
-                                                 uint32_t *__restrict__ ovf, uint32_t P)
+                                                 uint32_t *__restrict__ ovf_cnt, uint32_t *__restrict__ ovf, uint32_t P)
 {
     __shared__ KeyT skey[HJ_SLOTS];
     __shared__ uint32_t som[HJ_SLOTS];                       // once (low half) | multi (high half); WIDE: once only
@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, 
     if (lo >= hi) return;                                     // no bucket starts in this chunk
     if (hi > cs + (uint32_t)HJ_CAP) {                         // oversize: hand the range to the host
         if (tid == 0) {
-            const uint32_t o = atomicAdd(&ovf[0], 1u);
+            const uint32_t o = atomicAdd(&ovf_cnt[0], 1u);
             if (o < (uint32_t)HJ_OVF_CAP) { ovf[2 + 2 * o] = lo; ovf[3 + 2 * o] = hi; }
         }
         return;
@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, 
     for (int r = 0; r < HJ_ROWS; r++) {
         if (!mm[r]) continue;
         const uint32_t ap = (uint32_t)skey[slot[r]] & 0x7fffffffu;
-        if (ap >= P) { atomicAdd(&ovf[1], 1u); continue; }   // cannot happen; a wild store could take the device down
+        if (ap >= P) { atomicAdd(&ovf_cnt[1], 1u); continue; }   // cannot happen; a wild store could take the device down
         if (VARIANT == 1) continue;
         tpos[(size_t)ap * tab.nseq + (__ffs(gbit[r]) - 1)] = v[r];
         if ((mm[r] & (0u - mm[r])) == gbit[r]) tmask[ap] = mm[r];
@@ -1377,15 +1377,14 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
                                    __builtin_ctz(fp.consider), 31 - __builtin_clz(fp.consider), tmask, tpos);
         } else if (hash_path) {
             const uint32_t nchunk = (ns + HJ_T - 1) / HJ_T;
-            HIPCHK(ctx, ctx->join_ovf.ensure((2 + 2 * (size_t)HJ_OVF_CAP) * 4));
-            HIPCHK(ctx, hipMemsetAsync(ctx->join_ovf.p, 0, 8, ctx->stream));
+            HIPCHK(ctx, ctx->join_ovf.ensure((2 + 2 * (size_t)HJ_OVF_CAP) * 4));        // the ranges; their count sits in the counter block (words 8, 9)
             KernelTimer t(ctx, MAUVE_K_JOIN, ns);
             static const int jv = getenv("MAUVE_JH_VARIANT") ? atoi(getenv("MAUVE_JH_VARIANT")) : 0;
             HIPCHK(ctx, ctx->join_bound.ensure(((size_t)nchunk + 2) * 4));
             hipLaunchKernelGGL((join_bounds<KeyT>), dim3((nchunk + 1 + 3) / 4), dim3(256), 0, ctx->stream, keys, ns, L, nchunk,
                                ctx->join_bound.as<uint32_t>());
 #define JH_LAUNCH(W, V) hipLaunchKernelGGL((join_hash<KeyT, W, V>), dim3(nchunk), dim3(256), 0, ctx->stream, keys, vals, ns, \
-                                           ctx->join_bound.as<uint32_t>(), tab, fp.rule, fp.want, tmask, tpos, ctx->join_ovf.as<uint32_t>(), P)
+                                           ctx->join_bound.as<uint32_t>(), tab, fp.rule, fp.want, tmask, tpos, ctx->counters.as<uint32_t>() + 8, ctx->join_ovf.as<uint32_t>(), P)
             if (N > 16) JH_LAUNCH(true, 0);
             else if (jv == 1) JH_LAUNCH(false, 1);
             else if (jv == 2) JH_LAUNCH(false, 2);
@@ -1405,8 +1404,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         HIPCHK(ctx, hipGetLastError());
         if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // the kernels above are still running
         HIPCHK(ctx, ctx->pin_seed.ensure(64));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-        if (hash_path) HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.as<char>() + 32, ctx->join_ovf.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 48, hipMemcpyDeviceToHost, ctx->stream));     // run counters + join_hash's overflow count
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         uint32_t nc = ctx->pin_seed.as<uint32_t>()[1];
         const uint32_t novf = hash_path ? ctx->pin_seed.as<uint32_t>()[8] : 0u;
