@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) as_extents(const int32_t *__restrict__ al
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= nl * (uint32_t)N) return;
     const uint32_t l = t / (uint32_t)N; const int g = (int)(t % (uint32_t)N);
-    if (g == 0) lw_row[l] = (int64_t)lw[l];
+    if (g == 0) lw_row[l] = lw ? (int64_t)lw[l] : 0;
     if (t == 0) *total_row = *total_cols;
     const uint32_t a0 = first_a[l], a1 = last_a[l];
     const int64_t s0 = ast[(size_t)a0 * N + g], s1 = ast[(size_t)a1 * N + g];
@@ -190,7 +190,7 @@ int match_sp_scores(mauve_ctx *c, const MatchVec &m, const int *gmap, const mauv
 
 // Everything of align_finish, from the device-side chains and DP results.  The host receives the per-LCB rows; the
 // columns stay in c->res_cols, the anchor table where the chain stage left it, until materialize_result.
-int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes *sizes)
+int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes *sizes, bool host_chains)
 {
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     AlignState &S = c->ast; AlignResult &R = c->res;
@@ -221,7 +221,7 @@ int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes
     hipLaunchKernelGGL((vscan_write<int64_t, AsWidth>), dim3(nb), dim3(256), 0, c->stream, wf, na, bsum, col0, (int64_t *)nullptr);
     hipLaunchKernelGGL(as_lcb, dim3(blocks), dim3(256), 0, c->stream, fo.alcb, fo.gapcode, fo.score, col0, na, first_a, last_a, lcb_col, score);
     hipLaunchKernelGGL(as_extents, dim3(((uint32_t)nl * N + 255) / 256), dim3(256), 0, c->stream, fo.alen, fo.ast, N, (uint32_t)nl, first_a, last_a, left, right,
-                       c->ch_lw.as<unsigned long long>(), lw_row, col0 + na, tot_row);
+                       host_chains ? (const unsigned long long *)nullptr : c->ch_lw.as<unsigned long long>(), lw_row, col0 + na, tot_row);
     HIPCHK(c, hipGetLastError());
     // per-LCB rows to the host: first columns, extents, scores, weights, and the number of LCB columns
     const size_t rows_bytes = ((size_t)nl + 1) * 8 + 2 * (size_t)nl * N * 8 + 2 * (size_t)nl * 8 + 8;
@@ -234,7 +234,8 @@ int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes
     }
     // The match list (if the seed pass left it on the device only: sorted_rec) and the anchor table (ch_anch) are
     // fetched from where they are: both stay untouched until this context's next seed pass / chain.
-    R.dev_nm = c->matches_pending ? (size_t)c->n_matches : 0;
+    // (host_chains: both are on the host already -- the chains came from there)
+    R.dev_nm = !host_chains && c->matches_pending ? (size_t)c->n_matches : 0;
     R.dev_alen = fo.alen; R.dev_ast = fo.ast; R.dev_alcb = fo.alcb;
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -244,7 +245,7 @@ int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes
     R.col_off.assign(h_col, h_col + nl);
     R.lcb_left.assign(h_left, h_left + nl * N); R.lcb_right.assign(h_right, h_right + nl * N);
     R.dp_score.assign(h_score, h_score + nl);
-    R.lcb_weight.assign(h_lw, h_lw + nl);
+    if (!host_chains) R.lcb_weight.assign(h_lw, h_lw + nl);              // (host chains: filled by align_begin)
     R.iv_left.assign((size_t)nl * N, 0); R.iv_right.assign((size_t)nl * N, 0); R.iv_reverse.assign((size_t)nl * N, 0);
     for (int64_t i = 0; i < nl * N; i++) {
         R.iv_left[(size_t)i] = std::llabs(R.lcb_left[(size_t)i]);
@@ -290,7 +291,18 @@ int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes
     }
     R.col_off.push_back(ncols);
     R.n_cols = (size_t)ncols;
-    R.dev_pending = true; R.dev_na = na; R.cols_ext = nullptr;
+    if (host_chains && !S.anchor_table_done) {                       // anchor_length / _start / _lcb straight from the host chains
+        R.anchor_length.resize((size_t)na); R.anchor_start.resize((size_t)na * N); R.anchor_lcb.resize((size_t)na);
+        size_t a = 0;
+        for (int64_t l = 0; l < nl; l++) {
+            const MatchVec &ch = S.chains[(size_t)l];
+            for (size_t i = 0; i < ch.size(); i++, a++) {
+                R.anchor_length[a] = ch.len(i); R.anchor_lcb[a] = l;
+                std::copy(ch.st(i), ch.st(i) + N, &R.anchor_start[a * N]);
+            }
+        }
+    }
+    R.dev_pending = true; R.dev_na = host_chains ? 0 : na; R.cols_ext = nullptr;
     R.cols_fill = 0; R.cols_dirty.clear();                       // the host column buffer no longer holds the "all anchors" state
     R.sz.n_mums = S.nm; R.sz.n_lcb = nl; R.sz.n_anchor = na; R.sz.n_iv = niv; R.sz.n_cols = ncols;
     R.sz.n_gap_dp = fo.n_dp; R.sz.n_dp_cells = cells;
@@ -329,9 +341,11 @@ int materialize_result(mauve_ctx *c)
     }
     R.cols_ext = reinterpret_cast<const uint32_t *>(pc);
     const int32_t *hl = reinterpret_cast<const int32_t *>(pc + cb), *hs = hl + na, *hb = hs + na * N;
-    R.anchor_length.resize(na); R.anchor_start.resize(na * N); R.anchor_lcb.resize(na);
-    for (size_t a = 0; a < na; a++) { R.anchor_length[a] = hl[a]; R.anchor_lcb[a] = hb[a]; }
-    for (size_t i = 0; i < na * N; i++) R.anchor_start[i] = hs[i];
+    if (na) {                                                    // (0: the anchor table came from host chains and is filled)
+        R.anchor_length.resize(na); R.anchor_start.resize(na * N); R.anchor_lcb.resize(na);
+        for (size_t a = 0; a < na; a++) { R.anchor_length[a] = hl[a]; R.anchor_lcb[a] = hb[a]; }
+        for (size_t i = 0; i < na * N; i++) R.anchor_start[i] = hs[i];
+    }
     R.dev_pending = false;
     return MAUVE_OK;
 }

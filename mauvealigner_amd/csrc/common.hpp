@@ -342,8 +342,8 @@ inline int64_t dp_len_limit(const mauve_params *p) { return p->max_banded_len > 
 inline int64_t dp_band_from_of(const mauve_params *p) { return p->max_banded_len > p->max_gapped_len ? p->max_gapped_len : INT64_MAX; }
 int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na, const int32_t *h_len, const int32_t *h_st, const int32_t *h_lcb, int gapped,
                         int64_t max_gapped_len, const mauve_scoring *scoring, int32_t *gapcode, int64_t *n_dp_out, int64_t *code_total_out,
-                        PinnedBuf *dcols, std::vector<int64_t> &dcol_off, std::vector<int64_t> &dscore, int64_t *cells, bool stay_on_device = false);
-int assemble_device(mauve_ctx *c, int64_t na, int64_t cells, mauve_align_sizes *sizes);
+                        PinnedBuf *dcols, std::vector<int64_t> &dcol_off, std::vector<int64_t> &dscore, int64_t *cells, int stay = 0);
+int assemble_device(mauve_ctx *c, int64_t na, int64_t cells, mauve_align_sizes *sizes, bool host_chains = false);
 int materialize_result(mauve_ctx *c);
 int seed_matches_to_host(mauve_ctx *ctx);
 int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,

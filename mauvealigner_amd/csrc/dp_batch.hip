@@ -1151,8 +1151,10 @@ __global__ void __launch_bounds__(256) dpf_scores(const DpMeta *__restrict__ met
 // offsets, scores and columns are left where ctx->dpf_out says, for the device assembly (assemble_dev.hip).
 int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_len, const int32_t *h_st, const int32_t *h_lcb, int gapped,
                         int64_t max_gapped_len, const mauve_scoring *scoring, int32_t *gapcode, int64_t *n_dp_out, int64_t *code_total_out,
-                        PinnedBuf *dcols, std::vector<int64_t> &dcol_off, std::vector<int64_t> &dscore, int64_t *cells, bool stay_on_device)
+                        PinnedBuf *dcols, std::vector<int64_t> &dcol_off, std::vector<int64_t> &dscore, int64_t *cells, int stay)
 {
+    // stay: 0 = host anchors, results to the host; 1 = device anchors used in place, results stay; 2 = host anchors, results stay
+    const bool stay_on_device = stay != 0, anchors_in_place = stay == 1;
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     static const bool no_mw = getenv("MAUVE_DP_ONE_WAVE") != nullptr, no_groups = getenv("MAUVE_DP_NO_GROUPS") != nullptr;
     const double t0 = now_ms();
@@ -1176,7 +1178,7 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     HIPCHK(ctx, ctx->dpf_tot.ensure(256));
     int32_t *alen = ctx->dpf_anch.as<int32_t>(), *ast = alen + na, *alcb = ast + (size_t)na * N, *d_gapcode = alcb + na;
     uint32_t *anchor_of = reinterpret_cast<uint32_t *>(d_gapcode + na);
-    if (stay_on_device) {            // the anchors are device arrays already: used where they are (no copy)
+    if (anchors_in_place) {          // the anchors are device arrays already: used where they are (no copy)
         alen = const_cast<int32_t *>(h_len); ast = const_cast<int32_t *>(h_st); alcb = const_cast<int32_t *>(h_lcb);
     }
     DpSeqDesc *desc = ctx->dp_desc.as<DpSeqDesc>();
@@ -1190,7 +1192,7 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     int64_t *d_seq_off = ctx->dp_off.as<int64_t>();
     int64_t *d_tb_off = d_seq_off + ((size_t)na * N + 1), *d_rows_off = d_tb_off + (na + 1), *d_col_off = d_rows_off + (na + 1);
     HIPCHK(ctx, hipMemsetAsync(tot, 0, 256, ctx->stream));
-    if (!stay_on_device) {
+    if (!anchors_in_place) {
         HIPCHK(ctx, hipMemcpyAsync(alen, h_len, (size_t)na * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(ast, h_st, (size_t)na * N * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(alcb, h_lcb, (size_t)na * 4, hipMemcpyHostToDevice, ctx->stream));

@@ -536,7 +536,7 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
         const int32_t *d_len = c->ch_anch.as<int32_t>(), *d_st = d_len + cap, *d_lcb = d_st + (size_t)cap * S.N;
         c->dp_band_from = dp_band_from_of(&S.p);
         rc = dp_run_from_anchors(c, S.N, S.n_anchor, d_len, d_st, d_lcb, S.p.gapped, dp_len_limit(&S.p), &S.p.scoring, nullptr, &S.n_dp, &S.code_total,
-                                 nullptr, S.dcol_off, S.dscore, &cells, true);
+                                 nullptr, S.dcol_off, S.dscore, &cells, 1);
         if (rc) return rc;
         return assemble_device(c, S.n_anchor, cells, sizes);
     }
@@ -567,6 +567,16 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     }
     if (!no_shadow && na) c->shadow = [c]() { fill_anchor_table(c); };               // runs while the DP kernels do
     c->dp_band_from = dp_band_from_of(&S.p);
+    static const bool host_tail = getenv("MAUVE_HOST_TAIL") != nullptr;
+    if (!host_tail && na >= 2) {
+        // The chains were on the host (recursion, LCB extension, a small or tied list), but nothing after them has to be:
+        // the anchors go up, the DP results stay in HBM and the interval table is assembled there (assemble_dev.hip).
+        rc = dp_run_from_anchors(c, N, na, h_len, h_st, h_lcb, S.p.gapped, dp_len_limit(&S.p), &S.p.scoring, nullptr, &S.n_dp, &S.code_total,
+                                 nullptr, S.dcol_off, S.dscore, &cells, 2);
+        if (c->shadow) { std::function<void()> f; f.swap(c->shadow); f(); }
+        if (rc) return rc;
+        return assemble_device(c, na, cells, sizes, true);
+    }
     rc = dp_run_from_anchors(c, N, na, h_len, h_st, h_lcb, S.p.gapped, dp_len_limit(&S.p), &S.p.scoring, gapcode, &S.n_dp, &S.code_total,
                              &c->pin_dcols, S.dcol_off, S.dscore, &cells);
     c->shadow = nullptr;
