@@ -34,6 +34,25 @@ __global__ void __launch_bounds__(256) ch_init(const int64_t *__restrict__ rlen,
     crop[2 * (size_t)i] = 0; crop[2 * (size_t)i + 1] = 0;
 }
 
+// the same for the N-way list of a recursion batch (virtual genomes = the gaps of the batch, concatenated): only
+// all-forward matches take part, and every match gets the id of its gap -- the segment of genome 0 its
+// start lies in (seg0: K + 1 segment starts)
+__global__ void __launch_bounds__(256) ch_init_seg(const int64_t *__restrict__ rlen, const int64_t *__restrict__ rst, uint32_t n, int N,
+                                                   const uint32_t *__restrict__ seg0, uint32_t K, int32_t *__restrict__ len, int32_t *__restrict__ st,
+                                                   uint32_t *__restrict__ crop, uint32_t *__restrict__ gapid)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    bool fwd = true;
+    for (int g = 0; g < N; g++) { const int64_t s = rst[(size_t)i * N + g]; st[(size_t)i * N + g] = (int32_t)s; fwd &= s > 0; }
+    len[i] = fwd ? (int32_t)rlen[i] : 0;
+    crop[2 * (size_t)i] = 0; crop[2 * (size_t)i + 1] = 0;
+    const uint32_t p0 = (uint32_t)(rst[(size_t)i * N] > 0 ? rst[(size_t)i * N] - 1 : 0);
+    uint32_t lo = 0, hi = K;                                     // last k with seg0[k] <= p0
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (seg0[mid] <= p0) lo = mid; else hi = mid; }
+    gapid[i] = lo;
+}
+
 // sort keys of genome g: left end of every alive match (dead ones sort behind everything), value = match index
 __global__ void __launch_bounds__(256) ch_keys(const int32_t *__restrict__ len, const int32_t *__restrict__ st, uint32_t n, int N, int g,
                                                uint32_t dead_key, uint32_t *__restrict__ key, uint32_t *__restrict__ val)
@@ -141,12 +160,13 @@ struct FinalRanks {                         // y = genome: its order without the
 // they have the same orientation and are neighbours there too (next if forward, previous if reverse)
 struct LcbNodes {
     const int32_t *len, *st; uint32_t n; int N; const uint32_t *ordc, *rank; uint32_t *cnt; int32_t *node_of;
-    unsigned long long *weight; uint32_t *orient;
+    unsigned long long *weight; uint32_t *orient; const uint32_t *gapid;        // gapid (recursion batches): a node never spans two gaps
     __device__ uint32_t domain(int) const { return cnt[0]; }
     __device__ bool flag(uint32_t k, int) const
     {
         if (k == 0) return true;
         const uint32_t i = ordc[k], p = ordc[k - 1];
+        if (gapid && gapid[i] != gapid[p]) return true;
         for (int g = 1; g < N; g++) {
             const bool oi = st[(size_t)i * N + g] < 0, op = st[(size_t)p * N + g] < 0;
             if (oi != op) return true;
@@ -192,20 +212,12 @@ __global__ void __launch_bounds__(256) ch_links(int N, const uint32_t *__restric
 
 // ch_cluster_pass: thread j runs every pass of cluster j.  Entries come back in (left end, index) order, the dead
 // behind them as dead_key; the survivors' crops are applied to the match records (all genomes) at the end.
-__global__ void __launch_bounds__(256) ch_cluster_pass(int32_t *__restrict__ len, int32_t *__restrict__ st, int N, int g, uint32_t dead_key,
-                                                       uint32_t *__restrict__ eleft, uint32_t *__restrict__ eidx,
-                                                       const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ cnt_in,
-                                                       uint32_t *__restrict__ fail)
+// all passes of one cluster (entries a .. a + s of the genome's order); the working arrays hold s entries each
+__device__ __forceinline__ void ch_cluster_run(int32_t *__restrict__ len, int32_t *__restrict__ st, int N, int g, uint32_t dead_key,
+                                               uint32_t *__restrict__ eleft, uint32_t *__restrict__ eidx, uint32_t a, int s,
+                                               uint32_t *L, uint32_t *Ln, uint32_t *I, uint32_t *CF, uint32_t *CL, uint32_t *pf, uint32_t *pl, uint8_t *F)
 {
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= cnt_in[0]) return;
-    const uint32_t a = cstart[j];
-    int s = (int)(cstart[j + 1] - a);
-    if (s < 2) return;
-    if (s > CH_CL_MAX) { *fail = 1; return; }
     // entry state: left end in g, length, index, forward in g, crops so far at the match's first / last column side
-    uint32_t L[CH_CL_MAX], Ln[CH_CL_MAX], I[CH_CL_MAX], CF[CH_CL_MAX], CL[CH_CL_MAX], pf[CH_CL_MAX], pl[CH_CL_MAX];
-    uint8_t F[CH_CL_MAX];
     for (int q = 0; q < s; q++) {
         L[q] = eleft[a + q]; I[q] = eidx[a + q]; Ln[q] = (uint32_t)len[I[q]]; F[q] = st[(size_t)I[q] * N + g] > 0;
         CF[q] = 0; CL[q] = 0;
@@ -256,6 +268,41 @@ __global__ void __launch_bounds__(256) ch_cluster_pass(int32_t *__restrict__ len
         }
     }
     for (int q = s; q < s0; q++) eleft[a + q] = dead_key;
+}
+
+// big == nullptr: a cluster beyond CH_CL_MAX entries raises *fail (the caller chains on the host instead).
+__global__ void __launch_bounds__(256) ch_cluster_pass(int32_t *__restrict__ len, int32_t *__restrict__ st, int N, int g, uint32_t dead_key,
+                                                       uint32_t *__restrict__ eleft, uint32_t *__restrict__ eidx,
+                                                       const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ cnt_in,
+                                                       uint32_t *__restrict__ fail, int leave_big, int cl_max)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= cnt_in[0]) return;
+    const uint32_t a = cstart[j];
+    const int s = (int)(cstart[j + 1] - a);
+    if (s < 2) return;
+    if (s > cl_max) { if (!leave_big) *fail = 1; return; }
+    uint32_t L[CH_CL_MAX], Ln[CH_CL_MAX], I[CH_CL_MAX], CF[CH_CL_MAX], CL[CH_CL_MAX], pf[CH_CL_MAX], pl[CH_CL_MAX];
+    uint8_t F[CH_CL_MAX];
+    ch_cluster_run(len, st, N, g, dead_key, eleft, eidx, a, s, L, Ln, I, CF, CL, pf, pl, F);
+}
+
+// The clusters ch_cluster_pass left alone (recursion batches: light seeds in divergent stretches give repeat-like families of
+// overlapping matches): the same passes with the working arrays in global memory (ws: 7 words + 1 byte per list entry,
+// a cluster uses the slice of its own entries), still one thread per cluster -- they are few.
+__global__ void __launch_bounds__(64) ch_cluster_pass_big(int32_t *__restrict__ len, int32_t *__restrict__ st, int N, int g, uint32_t dead_key,
+                                                          uint32_t *__restrict__ eleft, uint32_t *__restrict__ eidx,
+                                                          const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ cnt_in,
+                                                          uint32_t *__restrict__ ws, uint32_t n, int cl_max)
+{
+    const uint32_t j = blockIdx.x * 64u + threadIdx.x;
+    if (j >= cnt_in[0]) return;
+    const uint32_t a = cstart[j];
+    const int s = (int)(cstart[j + 1] - a);
+    if (s <= cl_max) return;
+    uint32_t *L = ws + a, *Ln = L + n, *I = Ln + n, *CF = I + n, *CL = CF + n, *pf = CL + n, *pl = pf + n;
+    uint8_t *F = reinterpret_cast<uint8_t *>(ws + 7 * (size_t)n) + a;
+    ch_cluster_run(len, st, N, g, dead_key, eleft, eidx, a, s, L, Ln, I, CF, CL, pf, pl, F);
 }
 
 // the compact graph for the host's greedy elimination, in one piece: weight[K] (8 B), orient[K], prev[K*N], next[K*N], check word
@@ -359,19 +406,20 @@ int chain_order_device(mauve_ctx *c, int N, int64_t nl, int64_t min_gap, int64_t
     return MAUVE_OK;
 }
 
-// Elimination, LCB graph, greedy breakpoint elimination, labels: everything stays on the device (cropped records in
-// c->ch_len / c->ch_st, final LCB id per match behind them).  chain_device_copy_back brings them to the host.
-int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, int64_t &n_lcb)
+// Elimination and LCB graph of the device-resident list (cropped records in c->ch_len / c->ch_st, node of every match behind
+// the lengths).  The compact graph arrives on the host in c->pin_chain (ChainGraphHost): weight[K], orient[K], prev[K*N],
+// next[K*N].  seg0 != nullptr: a recursion batch (forward matches only, nodes confined to their gaps).
+int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *seg0, uint32_t nseg, ChainGraphHost *G)
 {
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     const double t0 = now_ms();
     const int64_t nm = c->dev_rec_n;
     if (nm <= 0 || nm >= (1LL << 31)) { c->err = "chain_device: no device-resident match list"; return MAUVE_ERR_STATE; }
     const uint32_t n = (uint32_t)nm;
-    int64_t maxlen = 1; for (int g = 0; g < N; g++) maxlen = std::max<int64_t>(maxlen, c->lens[(size_t)g]);
+    int64_t maxlen = std::max<int64_t>(1, maxlen_in);
     int pos_bits = 1; while (pos_bits < 31 && (1LL << pos_bits) <= maxlen) pos_bits++;
     const uint32_t dead_key = 1u << pos_bits;                      // one above every left end
-    HIPCHK(c, c->ch_len.ensure((size_t)n * 4 * 3));               // len, node_of, lcb
+    HIPCHK(c, c->ch_len.ensure((size_t)n * 4 * 4));               // len, node_of, lcb, gap id
     HIPCHK(c, c->ch_st.ensure((size_t)n * N * 4));
     HIPCHK(c, c->ch_crop.ensure((size_t)n * 8));
     const uint32_t nb = (n + CH_TILE - 1) / CH_TILE;
@@ -379,7 +427,9 @@ int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, i
     HIPCHK(c, c->ch_ord.ensure((size_t)n * N * 4 * 2));           // ord[N][n], ordc[N][n]
     HIPCHK(c, c->ch_rank.ensure((size_t)n * N * 4));
     HIPCHK(c, c->ch_cnt.ensure(256));
-    int32_t *len = c->ch_len.as<int32_t>(), *node_of = len + n, *lcb = node_of + n;
+    if (seg0) HIPCHK(c, c->ch_big.ensure((size_t)n * 29 + 64));   // working arrays of the big clusters
+    int32_t *len = c->ch_len.as<int32_t>(), *node_of = len + n;
+    uint32_t *gapid = seg0 ? reinterpret_cast<uint32_t *>(len + 3 * (size_t)n) : nullptr;
     int32_t *st = c->ch_st.as<int32_t>();
     uint32_t *crop = c->ch_crop.as<uint32_t>();
     uint32_t *k1 = c->ch_ent.as<uint32_t>(), *v1 = k1 + n, *k2 = v1 + n, *v2 = k2 + n, *sl = v2 + n;     // sl: cluster starts (up to n + 1)
@@ -391,19 +441,24 @@ int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, i
                                                                   // [8+g] survivors of genome g
     const int64_t *rlen = c->sorted_rec.as<int64_t>(), *rst = rlen + n;
     const uint32_t blocks = (n + 255) / 256;
+    static const int cl_max = []() { const char *e = getenv("MAUVE_CH_CL_MAX"); const int v = e ? atoi(e) : CH_CL_MAX; return v < 1 ? 1 : (v > CH_CL_MAX ? CH_CL_MAX : v); }();   // (tests lower it)
     HIPCHK(c, hipMemsetAsync(cnt, 0, 256, c->stream));
-    hipLaunchKernelGGL(ch_init, dim3(blocks), dim3(256), 0, c->stream, rlen, rst, n, N, len, st, crop);
+    if (seg0) hipLaunchKernelGGL(ch_init_seg, dim3(blocks), dim3(256), 0, c->stream, rlen, rst, n, N, seg0, nseg, len, st, crop, gapid);
+    else hipLaunchKernelGGL(ch_init, dim3(blocks), dim3(256), 0, c->stream, rlen, rst, n, N, len, st, crop);
     for (int g = 0; g < N; g++) {
         hipLaunchKernelGGL(ch_keys, dim3(blocks), dim3(256), 0, c->stream, len, st, n, N, g, dead_key, k1, v1);
         uint32_t *kk = k1, *vv = v1;
         // genome 0: the list is in canonical order, i.e. already ordered by its left ends there (no ties: dev_rec_n), nobody is dead yet
-        if (g > 0) { int rc = sort_pairs_u32(c, n, pos_bits + 1, &kk, &vv, k2, v2, MAUVE_K_MISC); if (rc) return rc; }
+        // (a recursion batch starts with its non-forward matches dead: sorted like any other genome)
+        if (g > 0 || seg0) { int rc = sort_pairs_u32(c, n, pos_bits + 1, &kk, &vv, k2, v2, MAUVE_K_MISC); if (rc) return rc; }
         hipLaunchKernelGGL(cl_partial, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive);
         hipLaunchKernelGGL(cl_flags, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive, nb, cflag, cnt);
         const ClusterStarts cs{cflag, n, sl, cnt};
         hipLaunchKernelGGL((cmp_count<ClusterStarts>), dim3(nb), dim3(256), 0, c->stream, cs, bcnt);
         hipLaunchKernelGGL((cmp_write<ClusterStarts>), dim3(nb), dim3(256), 0, c->stream, cs, bcnt);
-        hipLaunchKernelGGL(ch_cluster_pass, dim3(blocks), dim3(256), 0, c->stream, len, st, N, g, dead_key, kk, vv, sl, cnt + 4, cnt + 3);
+        hipLaunchKernelGGL(ch_cluster_pass, dim3(blocks), dim3(256), 0, c->stream, len, st, N, g, dead_key, kk, vv, sl, cnt + 4, cnt + 3, seg0 ? 1 : 0, cl_max);
+        if (seg0) hipLaunchKernelGGL(ch_cluster_pass_big, dim3((n + 63) / 64), dim3(64), 0, c->stream, len, st, N, g, dead_key, kk, vv, sl, cnt + 4,
+                                     c->ch_big.as<uint32_t>(), n, cl_max);
         const GenomeOrder go{dead_key, kk, vv, cnt, ord + (size_t)g * n, cnt + 8 + g};
         hipLaunchKernelGGL((cmp_count<GenomeOrder>), dim3(nb), dim3(256), 0, c->stream, go, bcnt);
         hipLaunchKernelGGL((cmp_write<GenomeOrder>), dim3(nb), dim3(256), 0, c->stream, go, bcnt);
@@ -418,7 +473,7 @@ int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, i
     int32_t *prevv = reinterpret_cast<int32_t *>(orient + n), *nextv = prevv + (size_t)n * N, *seq = nextv + (size_t)n * N;
     int32_t *final_dev = seq + (size_t)n * N;
     HIPCHK(c, hipMemsetAsync(weight, 0, (size_t)n * 8, c->stream));
-    const LcbNodes ln{len, st, n, N, ordc, rank, cnt, node_of, weight, orient};
+    const LcbNodes ln{len, st, n, N, ordc, rank, cnt, node_of, weight, orient, gapid};
     hipLaunchKernelGGL((cmp_count<LcbNodes>), dim3(nb), dim3(256), 0, c->stream, ln, bcnt);
     hipLaunchKernelGGL((cmp_write<LcbNodes>), dim3(nb), dim3(256), 0, c->stream, ln, bcnt);
     const NodeSeq ns{n, ordc, cnt, node_of, seq};
@@ -432,9 +487,7 @@ int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, i
     const uint32_t *hc = c->pin_chain.as<uint32_t>();
     if (hc[3]) { c->err = "chain_device: overlap cluster beyond the per-thread limit"; return MAUVE_ERR_LIMIT; }      // caller falls back to the host chain
     const uint32_t na = hc[0], K = hc[1];
-    const double t1 = now_ms();
-    n_lcb = 0;
-    std::vector<int64_t> final_id;
+    G->na = na; G->K = K; G->weight = nullptr; G->orient = nullptr; G->prev = nullptr; G->next = nullptr; G->final_stage = nullptr; G->final_dev = final_dev;
     if (K) {
         // graph to the host: weight[K], orient[K], prev[K*N], next[K*N]
         const size_t gbytes = (size_t)K * (8 + 4 + (size_t)N * 8) + 64;
@@ -450,16 +503,100 @@ int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, i
         HIPCHK(c, hipMemcpyAsync(pg, pack, pbytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (*reinterpret_cast<uint32_t *>(hn + (size_t)K * N)) { c->err = "chain_device: node lists inconsistent"; return MAUVE_ERR_LIMIT; }
-        lcb_greedy(N, (int32_t)K, hw, ho, hp, hn, min_weight, collinear, final_id, n_lcb);
-        int32_t *hf = reinterpret_cast<int32_t *>(pg + gbytes);
-        for (uint32_t i = 0; i < K; i++) hf[i] = (int32_t)final_id[i];
-        HIPCHK(c, hipMemcpyAsync(final_dev, hf, (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(ch_label, dim3(blocks), dim3(256), 0, c->stream, len, n, node_of, final_dev, lcb);
+        G->weight = hw; G->orient = ho; G->prev = hp; G->next = hn; G->final_stage = reinterpret_cast<int32_t *>(pg + gbytes);
+    }
+    if (trace) fprintf(stderr, "[trace] chain (device): eliminate+nodes+graph %.3f ms (na=%u K=%u)\n", now_ms() - t0, na, K);
+    return MAUVE_OK;
+}
+
+// Elimination, LCB graph, greedy breakpoint elimination, labels: everything stays on the device (cropped records in
+// c->ch_len / c->ch_st, final LCB id per match behind them).  chain_device_copy_back brings them to the host.
+int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, int64_t &n_lcb)
+{
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    int64_t maxlen = 1; for (int g = 0; g < N; g++) maxlen = std::max<int64_t>(maxlen, c->lens[(size_t)g]);
+    ChainGraphHost G;
+    int rc = chain_device_graph(c, N, maxlen, nullptr, 0, &G);
+    if (rc) return rc;
+    const double t1 = now_ms();
+    const uint32_t n = (uint32_t)c->dev_rec_n, K = G.K, blocks = (n + 255) / 256;
+    int32_t *len = c->ch_len.as<int32_t>(), *node_of = len + n, *lcb = node_of + n;
+    n_lcb = 0;
+    if (K) {
+        std::vector<int64_t> final_id;
+        lcb_greedy(N, (int32_t)K, G.weight, G.orient, G.prev, G.next, min_weight, collinear, final_id, n_lcb);
+        for (uint32_t i = 0; i < K; i++) G.final_stage[i] = (int32_t)final_id[i];
+        HIPCHK(c, hipMemcpyAsync(G.final_dev, G.final_stage, (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(ch_label, dim3(blocks), dim3(256), 0, c->stream, len, n, node_of, G.final_dev, lcb);
         HIPCHK(c, hipGetLastError());
     } else {
         HIPCHK(c, hipMemsetAsync(lcb, 0xff, (size_t)n * 4, c->stream));
     }
-    if (trace) fprintf(stderr, "[trace] chain (device): eliminate+nodes %.3f ms (na=%u K=%u), links+greedy+labels %.3f\n", t1 - t0, na, K, now_ms() - t1);
+    if (trace) fprintf(stderr, "[trace] chain (device): greedy+labels %.3f ms\n", now_ms() - t1);
+    return MAUVE_OK;
+}
+
+// A recursion batch chained on the device (recursive.cpp): the N-way forward matches of ALL gaps of the batch as one
+// list on the virtual genomes.  Overlap elimination of the whole list equals the elimination gap by gap (matches of
+// different gaps lie in different segments of every virtual genome, so they never share an overlap cluster), the LCB
+// nodes are confined to their gaps, and the collinear rule (one collinear chain per gap) runs on the host
+// per gap over the compact graph -- nearly every gap has a single node.  Out: cropped records (hl, hs: int32, list
+// order) and survive[i] for every match of the list.
+int chain_device_gaps(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0_dev, uint32_t nseg, const int32_t **hl_out, const int32_t **hs_out,
+                      std::vector<uint8_t> &survive)
+{
+    ChainGraphHost G;
+    {   // page-locked room for the graph (at most one node per match) AND the records behind it, before the graph lands there
+        const size_t n0 = (size_t)c->dev_rec_n;
+        HIPCHK(c, c->pin_chain.ensure(256 + n0 * (8 + 4 + (size_t)N * 8) + 64 + n0 * 4 + 64 + n0 * 4 * (3 + (size_t)N) + 64));
+    }
+    int rc = chain_device_graph(c, N, maxlen, seg0_dev, nseg, &G);
+    if (rc) return rc;
+    const uint32_t n = (uint32_t)c->dev_rec_n, K = G.K;
+    const int32_t *len = c->ch_len.as<int32_t>(), *node_of = len + n;
+    const uint32_t *gapid = reinterpret_cast<const uint32_t *>(len + 3 * (size_t)n);
+    const int32_t *st = c->ch_st.as<int32_t>();
+    // the graph is consumed before pin_chain is reused for the records
+    std::vector<uint8_t> node_ok((size_t)K, 1);
+    std::vector<int64_t> w; std::vector<uint32_t> o; std::vector<int32_t> pv, nx; std::vector<int64_t> final_id;
+    // records, nodes and gap ids of the matches
+    std::vector<int32_t> g_of_node((size_t)K, -1);
+    {
+        // node -> gap needs the per-match arrays: fetch them behind the graph block
+        const size_t gbytes = (size_t)K * (8 + 4 + (size_t)N * 8) + 64 + (size_t)K * 4;
+        char *pg = c->pin_chain.as<char>() + 256;
+        int32_t *hl = reinterpret_cast<int32_t *>(pg + ((gbytes + 63) & ~(size_t)63)), *hs = hl + n, *hnode = hs + (size_t)n * N;
+        uint32_t *hgap = reinterpret_cast<uint32_t *>(hnode + n);
+        HIPCHK(c, hipMemcpyAsync(hl, len, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hs, st, (size_t)n * N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hnode, node_of, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hgap, gapid, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (uint32_t i = 0; i < n; i++) if (hl[i] > 0) g_of_node[(size_t)hnode[i]] = (int32_t)hgap[i];
+        // per gap: its nodes are consecutive (genome-0 order); more than one -> the collinear rule on the sub-graph
+        for (uint32_t n0 = 0; n0 < K;) {
+            uint32_t n1 = n0 + 1;
+            while (n1 < K && g_of_node[n1] == g_of_node[n0]) n1++;
+            const int32_t kk = (int32_t)(n1 - n0);
+            if (kk > 1) {
+                w.assign(G.weight + n0, G.weight + n1); o.assign(G.orient + n0, G.orient + n1);
+                pv.resize((size_t)kk * N); nx.resize((size_t)kk * N);
+                for (int32_t j = 0; j < kk; j++)
+                    for (int g = 0; g < N; g++) {
+                        const int32_t p = G.prev[(size_t)(n0 + j) * N + g], q = G.next[(size_t)(n0 + j) * N + g];
+                        pv[(size_t)j * N + g] = (p >= (int32_t)n0 && p < (int32_t)n1) ? p - (int32_t)n0 : -1;
+                        nx[(size_t)j * N + g] = (q >= (int32_t)n0 && q < (int32_t)n1) ? q - (int32_t)n0 : -1;
+                    }
+                int64_t nl = 0;
+                lcb_greedy(N, kk, w.data(), o.data(), pv.data(), nx.data(), 0, true, final_id, nl);
+                for (int32_t j = 0; j < kk; j++) node_ok[(size_t)n0 + j] = final_id[(size_t)j] >= 0;
+            }
+            n0 = n1;
+        }
+        survive.assign((size_t)n, 0);
+        for (uint32_t i = 0; i < n; i++) survive[i] = hl[i] > 0 && node_ok[(size_t)hnode[i]];
+        *hl_out = hl; *hs_out = hs;
+    }
     return MAUVE_OK;
 }
 

@@ -216,6 +216,7 @@ struct mauve_ctx {
     DevBuf join_bound;                   // join_hash: first bucket boundary at or after every chunk edge
     DevBuf join_ovf;                     // join_hash: [count, pad, (lo, hi) ...] ranges handed back to the full sort + serial join
     DevBuf ch_len, ch_st, ch_crop, ch_ent, ch_ord, ch_rank, ch_node, ch_graph, ch_cnt;   // device chain (chain_dev.hip)
+    DevBuf ch_big;                       // working arrays of overlap clusters beyond the per-thread limit (recursion batches)
     DevBuf ch_anch, ch_lw;               // the chains in chain order and the LCB weights (chain_order_device)
     DevBuf as_work, as_isl, res_cols;    // device assembly (assemble_dev.hip): work area, islands, result columns
     PinnedBuf pin_asm, pin_cols;         // ... its per-LCB rows coming back; the columns and anchors on their way to a fetch
@@ -316,7 +317,11 @@ int sort_pairs_u32(mauve_ctx *ctx, uint32_t n, int key_bits, uint32_t **keys_io,
                    int timer_id);
 // device chain (chain_dev.hip): EliminateOverlaps + LCBs of the N-way list the seed pass left in ctx->sorted_rec
 int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchVec &m, std::vector<int64_t> &match_lcb, int64_t &n_lcb);
+struct ChainGraphHost { uint32_t na, K; int64_t *weight; uint32_t *orient; int32_t *prev, *next; int32_t *final_stage; int32_t *final_dev; };
+int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0, uint32_t nseg, ChainGraphHost *G);
 int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, int64_t &n_lcb);
+int chain_device_gaps(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0_dev, uint32_t nseg, const int32_t **hl_out, const int32_t **hs_out,
+                      std::vector<uint8_t> &survive);
 int chain_device_copy_back(mauve_ctx *c, int N, MatchVec &m, std::vector<int64_t> &match_lcb);
 int chain_order_device(mauve_ctx *c, int N, int64_t nl, int64_t min_gap, int64_t *na_out, int64_t *n_rec_out);
 

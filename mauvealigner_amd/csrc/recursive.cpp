@@ -235,11 +235,32 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
             MatchVec loc(N), glob(N);            // reused from gap to gap (thousands of gaps per batch)
             ChainOrders orders;
             std::vector<int64_t> ml;
+            // Large batches are chained on the device, all gaps at once (chain_device_gaps); the host loop below then only
+            // maps the survivors back.  Small batches (host-sorted lists), ties in the canonical order and clusters beyond
+            // the device kernel's limit are chained here, gap by gap.  MAUVE_HOST_GAP_CHAIN: A/B switch.
+            static const bool host_gaps = getenv("MAUVE_HOST_GAP_CHAIN") != nullptr;
+            bool dev_chain = false;
+            const int32_t *dl = nullptr, *ds = nullptr; std::vector<uint8_t> survive;
+            if (!host_gaps && nm > 0 && c->dev_rec_n == nm) {
+                int64_t maxlen = 1; for (int g = 0; g < N; g++) maxlen = std::max(maxlen, vs.lens[(size_t)g]);
+                const int rcg = chain_device_gaps(c, N, maxlen, c->rec_seg.as<uint32_t>(), K, &dl, &ds, survive);
+                if (rcg == MAUVE_OK) dev_chain = true;
+                else if (rcg != MAUVE_ERR_LIMIT) return rcg;
+            }
             while (i < nm) {
                 const int64_t s0 = c->match_start[(size_t)i * N];      // genome 0 is always forward
                 const uint32_t k = (uint32_t)(std::upper_bound(seg0, seg0 + K + 1, (uint32_t)(s0 - 1)) - seg0) - 1;
                 loc.d.clear();
                 while (i < nm && (uint32_t)(c->match_start[(size_t)i * N] - 1) < seg0[k + 1]) {
+                    if (dev_chain) {                                   // the device's verdict and its cropped record
+                        if (survive[(size_t)i]) {
+                            int64_t rec[1 + MAUVE_MAX_SEQ]; rec[0] = dl[(size_t)i];
+                            for (int g = 0; g < N; g++) rec[1 + g] = (int64_t)ds[(size_t)i * N + g] - seg[(size_t)g * (K + 1) + k];
+                            loc.push(rec);
+                        }
+                        i++;
+                        continue;
+                    }
                     bool fwd = true;
                     int64_t rec[1 + MAUVE_MAX_SEQ]; rec[0] = c->match_len[(size_t)i];
                     for (int g = 0; g < N; g++) {
@@ -251,12 +272,15 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                     i++;
                 }
                 if (loc.empty()) continue;
+                if (dev_chain) ml.assign(loc.size(), 0);
+                else {
                 const double te0 = trace ? now_ms() : 0;
                 host_eliminate_overlaps(loc, &orders);
                 const double te1 = trace ? now_ms() : 0;
                 int64_t nl = 0;
                 host_lcb_chain(loc, 0, true, ml, nl, &orders);
                 if (trace) { t_elim += te1 - te0; t_lcb += now_ms() - te1; }
+                }
                 const size_t wi = ids[k];
                 const int64_t *A = work.a(wi);
                 glob.d.clear();
@@ -277,7 +301,7 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                     next.push(lcb, w, q == 0 ? work.a(wi) : glob.rec(q - 1), q == glob.size() ? work.b(wi) : glob.rec(q));
                 for (size_t q = 0; q < glob.size(); q++) found[(size_t)lcb].push(glob.rec(q));
             }
-            if (trace) fprintf(stderr, "[trace]   per-gap chaining %.3f ms (eliminate %.3f, lcb %.3f)\n", now_ms() - tch0, t_elim, t_lcb);
+            if (trace) fprintf(stderr, "[trace]   per-gap chaining %.3f ms (%s; eliminate %.3f, lcb %.3f)\n", now_ms() - tch0, dev_chain ? "device" : "host", t_elim, t_lcb);
         }
         work.d.swap(next.d);
     }

@@ -1545,7 +1545,15 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             }
         }
         ctx->n_matches = nm;
-        ctx->dev_rec_n = canon_ties ? -1 : (int64_t)nm;      // sorted_rec holds the list in canonical order (no host fix-up was needed)
+        if (canon_ties && nm) {
+            // the host finished the order inside the tie groups: the device copy follows (the chaining stages read it)
+            char *pin = ctx->pin_seed.as<char>() + 64;
+            memcpy(pin, ctx->match_len.data(), (size_t)nm * 8);
+            memcpy(pin + (size_t)nm * 8, ctx->match_start.data(), (size_t)nm * N * 8);
+            HIPCHK(ctx, hipMemcpyAsync(ctx->sorted_rec.p, pin, (size_t)nm * (1 + N) * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        ctx->dev_rec_n = (int64_t)nm;                          // sorted_rec holds the list in canonical order
         if (n_matches) *n_matches = nm;
         TRACE(ctx, "canonical sort (device)");
         return MAUVE_OK;

@@ -482,6 +482,64 @@ def test_align_recursion_hyperdivergent(ctx):
     assert r1["n_anchor"] > r0["n_anchor"]
 
 
+GAPCHAIN_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from mauvealigner_amd import _lib, synth
+from oracle import pyoracle as O
+ctx = _lib.Context(0)
+rng = np.random.default_rng(21)
+anc = rng.integers(0, 4, 60000, dtype=np.uint8)
+hyper = []
+for g in range(3):
+    b = synth.mutate(anc, 0.01, rng)
+    if g:
+        b[10000:14000] = synth.mutate(b[10000:14000], 0.33, rng, indel_frac=0.0)[:4000]
+        b[30000:42000] = synth.mutate(b[30000:42000], 0.30, rng, indel_frac=0.0)[:12000]
+    hyper.append(b)
+sets = [hyper, synth.make_config("C5", scale=0.004), synth.make_config("C3", scale=0.02)]
+base = rng.integers(0, 4, 40000, dtype=np.uint8)                   # a repeat family inside a divergent stretch: overlapping matches in a gap
+rep = rng.integers(0, 4, 300, dtype=np.uint8)
+fam = []
+for g in range(3):
+    x = synth.mutate(base, 0.02, rng)
+    mid = np.concatenate([synth.mutate(rep, 0.03, rng) for _ in range(6)] + [rng.integers(0, 4, 200, dtype=np.uint8)])
+    fam.append(np.concatenate([x[:15000], mid, x[15000:]]).astype(np.uint8))
+sets.append(fam)
+for gs in sets:
+    ctx.set_genomes(gs)
+    r = ctx.align(_lib.default_params())
+    e = O.align(gs, O.default_params())["aln"]
+    for k in ("anchor_length", "anchor_start", "anchor_lcb", "cols", "col_off", "dp_score"):
+        assert np.array_equal(r[k], e[k]), k
+print("OK")
+"""
+
+
+def test_recursion_gaps_chained_on_the_device():
+    """The N-way matches of a whole recursion batch are overlap-eliminated and reduced to one collinear chain per gap on
+    the device (chain_device_gaps), with the per-gap greedy step on the compact graph; MAUVE_HOST_GAP_CHAIN keeps the
+    host loop.  MAUVE_CANON_DEVICE_MIN=1 sends small lists down the device path too."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MAUVE_TRACE="1", MAUVE_CANON_DEVICE_MIN="1")
+    r = subprocess.run([sys.executable, "-c", GAPCHAIN_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr[-3000:]
+    dev = [l for l in r.stderr.splitlines() if "per-gap chaining" in l and "(device" in l]
+    assert len(dev) >= 4, r.stderr[-3000:]
+    # overlap clusters beyond the per-thread limit: the global-memory kernel in the recursion batches, the host chain for the
+    # main list -- with the limit lowered to 2 nearly every cluster takes those paths
+    env["MAUVE_CH_CL_MAX"] = "2"
+    r = subprocess.run([sys.executable, "-c", GAPCHAIN_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr[-3000:]
+    assert [l for l in r.stderr.splitlines() if "per-gap chaining" in l and "(device" in l]
+    del env["MAUVE_CH_CL_MAX"]
+    env["MAUVE_HOST_GAP_CHAIN"] = "1"
+    r = subprocess.run([sys.executable, "-c", GAPCHAIN_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr[-3000:]
+    assert not [l for l in r.stderr.splitlines() if "per-gap chaining" in l and "(device" in l]
+
+
 def test_align_matches_given_list(ctx):
     """Aligner::align(MatchList&, ...) (mauveAligner.cpp:698): the caller's match list is chained, not re-found.
     The finder's own N-way list reproduces mauve_align; order, subset matches and duplicates-free shuffles do not
