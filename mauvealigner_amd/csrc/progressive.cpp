@@ -15,39 +15,39 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector<MatchVec> &chains, int N, const int *gmap);
 
 namespace {
 
-struct IvList {                       // 1-based inclusive, sorted, disjoint, non-adjacent
-    std::vector<int64_t> lo, hi;
-    void push(int64_t l, int64_t h)
+// The bases of one genome that no block has taken yet: an ordered map start -> end of free stretches (1-based,
+// inclusive, disjoint).  Blocks are carved out one by one; a position is identified by the start of the stretch it lies
+// in (0 = placed already).
+struct FreePool {
+    std::map<int64_t, int64_t> free_;
+    void reset(int64_t len) { free_.clear(); if (len >= 1) free_[1] = len; }
+    bool whole(int64_t len) const { return free_.size() == 1 && free_.begin()->first == 1 && free_.begin()->second == len; }
+    int64_t bases() const { int64_t t = 0; for (const auto &kv : free_) t += kv.second - kv.first + 1; return t; }
+    int64_t stretch_of(int64_t pos) const
+    {
+        auto it = free_.upper_bound(pos);
+        if (it == free_.begin()) return 0;
+        --it;
+        return pos <= it->second ? it->first : 0;
+    }
+    void carve(int64_t l, int64_t h)              // free minus [l, h]
     {
         if (h < l) return;
-        if (!lo.empty() && hi.back() + 1 >= l) { hi.back() = std::max(hi.back(), h); return; }
-        lo.push_back(l); hi.push_back(h);
-    }
-    int64_t find(int64_t pos) const    // index of the interval holding pos, -1 = placed already
-    {
-        size_t k = std::upper_bound(lo.begin(), lo.end(), pos) - lo.begin();
-        if (k == 0) return -1;
-        return pos <= hi[k - 1] ? (int64_t)k - 1 : -1;
-    }
-    void subtract(std::vector<std::pair<int64_t, int64_t>> r)      // minus the union of the ranges
-    {
-        std::sort(r.begin(), r.end());
-        IvList out; size_t k = 0;
-        for (size_t i = 0; i < lo.size(); i++) {
-            int64_t cur = lo[i];
-            while (k < r.size() && r[k].second < cur) k++;
-            for (size_t q = k; q < r.size() && r[q].first <= hi[i]; q++) {
-                if (r[q].first > cur) out.push(cur, r[q].first - 1);
-                cur = std::max(cur, r[q].second + 1);
-            }
-            if (cur <= hi[i]) out.push(cur, hi[i]);
+        auto it = free_.upper_bound(l);
+        if (it != free_.begin()) --it;
+        while (it != free_.end() && it->first <= h) {
+            const int64_t a = it->first, e = it->second;
+            if (e < l) { ++it; continue; }
+            it = free_.erase(it);
+            if (a < l) free_[a] = l - 1;
+            if (e > h) { free_[h + 1] = e; break; }
         }
-        *this = out;
     }
 };
 
@@ -63,7 +63,7 @@ inline void gap_of(const int64_t *a, const int64_t *b, int g, int64_t &lo, int64
 struct Prog {
     mauve_ctx *c; const mauve_params *p; int N;
     std::vector<int32_t> left, right;
-    std::vector<IvList> rest;          // per genome: bases not placed in any block yet
+    std::vector<FreePool> rest;        // per genome: bases not placed in any block yet
     AlignResult *R;
     int64_t n_gap_dp = 0, n_cells = 0, n_anchor = 0, n_multi = 0;
 };
@@ -84,10 +84,9 @@ int upload_mask(Prog &P, const std::vector<int> &gm, GenomeSet &gs)
     std::vector<uint64_t> bits(words, ~0ULL);
     for (size_t j = 0; j < gm.size(); j++) {
         uint64_t *M = bits.data() + gs.mask_off[j];
-        const IvList &L = P.rest[gm[j]];
-        for (size_t k = 0; k < L.lo.size(); k++)
-            for (int64_t b = L.lo[k] - 1; b < L.hi[k];) {           // clear [lo-1, hi) word-wise
-                const int64_t w = b >> 6, e = std::min<int64_t>(L.hi[k], (w + 1) << 6);
+        for (const auto &fr : P.rest[gm[j]].free_)
+            for (int64_t b = fr.first - 1; b < fr.second;) {        // clear [lo-1, hi) word-wise
+                const int64_t w = b >> 6, e = std::min<int64_t>(fr.second, (w + 1) << 6);
                 const int n = (int)(e - b), sh = (int)(b & 63);
                 const uint64_t m = (n == 64 ? ~0ULL : ((1ULL << n) - 1ULL)) << sh;
                 M[w] &= ~m; b = e;
@@ -126,7 +125,7 @@ int prog_node(Prog &P, int node)
     AlignResult &R = *P.R;
 
     int64_t rest_len = 0;
-    for (int j = 0; j < n; j++) for (size_t k = 0; k < P.rest[gm[j]].lo.size(); k++) rest_len += P.rest[gm[j]].hi[k] - P.rest[gm[j]].lo[k] + 1;
+    for (int j = 0; j < n; j++) rest_len += P.rest[gm[j]].bases();
     int w = p->seed_weight > 0 ? p->seed_weight : mauve_default_seed_weight(rest_len / n);
     uint64_t pat = p->seed_pattern ? p->seed_pattern : mauve_get_seed(w, p->seed_rank);
     if (!pat) { c->err = "progressive_align: no seed pattern for this weight/rank"; return MAUVE_ERR_ARG; }
@@ -136,7 +135,7 @@ int prog_node(Prog &P, int node)
     GenomeSet gs; gs.buf = &c->genomes; gs.nseq = n;
     for (int j = 0; j < n; j++) { gs.lens.push_back(c->lens[gm[j]]); gs.word_off.push_back(c->word_off[gm[j]]); }
     bool any_placed = false;
-    for (int j = 0; j < n; j++) { const IvList &L = P.rest[gm[j]]; if (!(L.lo.size() == 1 && L.lo[0] == 1 && L.hi[0] == c->lens[gm[j]])) any_placed = true; }
+    for (int j = 0; j < n; j++) if (!P.rest[gm[j]].whole(c->lens[gm[j]])) any_placed = true;
     if (any_placed) { int rc = upload_mask(P, gm, gs); if (rc) return rc; }
 
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
@@ -180,7 +179,7 @@ int prog_node(Prog &P, int node)
             const MatchVec &last = pieces.back();
             const int64_t *a = last.st(last.size() - 1);
             for (int j = 0; j < n && !newp; j++)
-                if (P.rest[gm[j]].find(std::llabs(a[j])) != P.rest[gm[j]].find(std::llabs(m.st(i)[j]))) newp = true;
+                if (P.rest[gm[j]].stretch_of(std::llabs(a[j])) != P.rest[gm[j]].stretch_of(std::llabs(m.st(i)[j]))) newp = true;
         }
         if (newp) { pieces.emplace_back(n); cur_lcb = l; }
         pieces.back().push(m.rec(i));
@@ -275,7 +274,7 @@ int prog_node(Prog &P, int node)
             placed[(size_t)j].push_back({le, re});
         }
     }
-    for (int j = 0; j < n; j++) P.rest[gm[j]].subtract(placed[(size_t)j]);
+    for (int j = 0; j < n; j++) for (const auto &pl : placed[(size_t)j]) P.rest[gm[j]].carve(pl.first, pl.second);
     if (trace) fprintf(stderr, "[trace] node %d: blocks %.1f ms\n", node, now_ms() - tb0);
     rc = prog_node(P, P.left[node]);
     if (rc) return rc;
@@ -353,8 +352,8 @@ int mauve_progressive_align(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     R.dev_pending = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr; R.cols_fill = 0; R.cols_dirty.clear();
     R.cols_fill = 0; R.cols_dirty.clear();           // mauve_align's prefilled-buffer invariant no longer holds
     P.R = &R;
-    P.rest.assign((size_t)N, IvList());
-    for (int g = 0; g < N; g++) P.rest[(size_t)g].push(1, c->lens[g]);
+    P.rest.assign((size_t)N, FreePool());
+    for (int g = 0; g < N; g++) P.rest[(size_t)g].reset(c->lens[g]);
     rc = prog_node(P, 2 * N - 2);
     if (rc) return rc;
     const double tg2 = now_ms();
@@ -362,8 +361,8 @@ int mauve_progressive_align(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     const int64_t n_multi = P.n_multi;
     if (p->add_unaligned)
         for (int g = 0; g < N; g++)
-            for (size_t k = 0; k < P.rest[(size_t)g].lo.size(); k++) {
-                const int64_t lo = P.rest[(size_t)g].lo[k], hi = P.rest[(size_t)g].hi[k];
+            for (const auto &fr : P.rest[(size_t)g].free_) {
+                const int64_t lo = fr.first, hi = fr.second;
                 R.col_off.push_back((int64_t)R.cols.size());
                 R.cols.insert(R.cols.end(), (size_t)(hi - lo + 1), 1u << g);
                 for (int h = 0; h < N; h++) { R.iv_left.push_back(h == g ? lo : 0); R.iv_right.push_back(h == g ? hi : 0); R.iv_reverse.push_back(0); }
