@@ -3,6 +3,7 @@
 #ifndef MAUVE_HIP_MATCHLIST_H
 #define MAUVE_HIP_MATCHLIST_H
 
+#include <fstream>
 #include <sstream>
 #include "Match.h"
 #include "MatchProjectionAdapter.h"      // in-tree code reaches it through this header (SeedMatchEnumerator.h:98)
@@ -106,6 +107,46 @@ inline void ReadList(MatchList &ml, std::istream &is)
         for (size_t g = 0; g < N; g++) { if (!(is >> st)) { m->Free(); throw genome::gnException("ReadList: truncated match row"); } m->SetStart((uint)g, st); }
         ml.push_back(m);
     }
+}
+
+// LoadSequences(list, log) (mauveAligner.cpp:454,463; addUnalignedIntervals.cpp:23; getAlignmentWindows.cpp:58 ...): one
+// gnSequence per entry of seq_filename into seq_table (FastA; a multi-record file is one genome of several contigs).
+// Works on anything with seq_filename / seq_table (MatchList, IntervalList).
+template <class ListT>
+inline void LoadSequences(ListT &list, std::ostream *log)
+{
+    for (size_t i = 0; i < list.seq_table.size(); i++) delete list.seq_table[i];
+    list.seq_table.clear();
+    for (size_t i = 0; i < list.seq_filename.size(); i++) {
+        genome::gnSequence *s = new genome::gnSequence();
+        s->LoadSource(list.seq_filename[i]);
+        list.seq_table.push_back(s);
+        if (log) *log << "Sequence loaded successfully.\n" << list.seq_filename[i] << " " << s->length() << " base pairs.\n";
+    }
+}
+
+// LoadMFASequences(list, mfa_file, log) (alignmentProjector.cpp:55, evd.cpp:97): every record of ONE multi-FastA file
+// becomes a genome of its own; seq_filename gets the file name once per record.
+template <class ListT>
+inline void LoadMFASequences(ListT &list, const std::string &mfa_filename, std::ostream *log)
+{
+    std::ifstream in(mfa_filename.c_str());
+    if (!in) throw genome::gnException("LoadMFASequences: cannot open " + mfa_filename);
+    for (size_t i = 0; i < list.seq_table.size(); i++) delete list.seq_table[i];
+    list.seq_table.clear(); list.seq_filename.clear();
+    std::string line, cur; bool have = false;
+    auto flush = [&]() {
+        if (!have) return;
+        list.seq_table.push_back(new genome::gnSequence(cur)); list.seq_filename.push_back(mfa_filename);
+        if (log) *log << "Sequence loaded successfully.\n" << mfa_filename << " " << cur.size() << " base pairs.\n";
+        cur.clear();
+    };
+    while (std::getline(in, line)) {
+        if (!line.empty() && line[0] == '>') { flush(); have = true; continue; }
+        if (!have) continue;
+        for (char ch : line) if (ch != '\r' && ch != ' ') cur.push_back(ch);
+    }
+    flush();
 }
 
 }  // namespace mems

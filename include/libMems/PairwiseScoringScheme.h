@@ -5,6 +5,8 @@
 #define MAUVE_HIP_PAIRWISESCORINGSCHEME_H
 
 #include <istream>
+#include <string>
+#include <vector>
 #include "AbstractMatch.h"
 
 namespace mems {
@@ -39,6 +41,32 @@ inline void readSubstitutionMatrix(std::istream &is, score_t matrix[4][4])
         matrix[got / 4][got % 4] = (score_t)v; got++;
     }
     if (got != 16) throw genome::gnException("readSubstitutionMatrix: expected 16 scores");
+}
+
+// computeSPScore (repeatoire.cpp:2527: `computeSPScore(alignment, pss, scores_final, score_final)`): sum-of-pairs score
+// of a gapped alignment given as one text row per sequence ('-' = gap).  libMems-internal [EXT]; frozen form, the pair
+// scoring of DESIGN.md S7: for every pair of rows, a column with two bases scores matrix[a][b] (bases outside ACGT
+// score as A, S1), a base against a gap opens (gap_open) or continues (gap_extend) a gap run of that pair, two gaps
+// score nothing and do not interrupt a run.  scores[c] = the column's sum over the pairs, score = their total.
+inline void computeSPScore(const std::vector<std::string> &alignment, const PairwiseScoringScheme &pss,
+                           std::vector<score_t> &scores, score_t &score)
+{
+    const size_t R = alignment.size(), C = R ? alignment[0].size() : 0;
+    for (size_t r = 1; r < R; r++) if (alignment[r].size() != C) throw genome::gnException("computeSPScore: ragged alignment");
+    auto code = [](char ch) { switch (ch) { case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 0; } };
+    scores.assign(C, 0); score = 0;
+    for (size_t x = 0; x < R; x++)
+        for (size_t y = x + 1; y < R; y++) {
+            int open = 0;                                  // 1: a run with row x gapped is open, 2: row y gapped
+            for (size_t c = 0; c < C; c++) {
+                const bool gx = alignment[x][c] == '-', gy = alignment[y][c] == '-';
+                if (gx && gy) continue;
+                score_t v;
+                if (!gx && !gy) { v = pss.matrix[code(alignment[x][c])][code(alignment[y][c])]; open = 0; }
+                else { const int side = gx ? 1 : 2; v = open == side ? pss.gap_extend : pss.gap_open; open = side; }
+                scores[c] += v; score += v;
+            }
+        }
 }
 
 }  // namespace mems

@@ -128,6 +128,8 @@ static int extend_lcbs(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
     return MAUVE_OK;
 }
 
+static const bool g_trace_pipeline = getenv("MAUVE_TRACE") != nullptr;     // read once, not in the timed path
+
 // ---- the whole path in three phases, so that the DP intervals of one alignment can be sharded over ranks ----
 // begin : seed pass, chaining, recursive anchoring, interval descriptors        (every rank, deterministic)
 // dp    : gapped alignment of a subset of the intervals                         (each rank its share)
@@ -238,7 +240,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
                     S.nl = nl; S.n_anchor = na; S.dev_tail = true;
                     const double t2 = now_ms();
                     c->stage.chain_ms = t2 - t1;
-                    if (getenv("MAUVE_TRACE")) fprintf(stderr, "[trace] chain: on the device %.3f ms, %lld anchors in %lld LCBs stay there\n", t2 - t1, (long long)na, (long long)nl);
+                    if (g_trace_pipeline) fprintf(stderr, "[trace] chain: on the device %.3f ms, %lld anchors in %lld LCBs stay there\n", t2 - t1, (long long)na, (long long)nl);
                     S.t_dp0 = t2;
                     S.open = true;
                     return MAUVE_OK;
@@ -295,7 +297,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
     }
     const double t2 = now_ms();
     c->stage.chain_ms = t2 - t1;
-    if (getenv("MAUVE_TRACE")) fprintf(stderr, "[trace] chain: eliminate_overlaps %.3f ms, lcb %.3f ms\n", t1b - t1, t2 - t1b);
+    if (g_trace_pipeline) fprintf(stderr, "[trace] chain: eliminate_overlaps %.3f ms, lcb %.3f ms\n", t1b - t1, t2 - t1b);
 
     // ---- recursive anchoring ----
     if (p->recursive) {
@@ -341,7 +343,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
         }
     }
     S.t_dp0 = now_ms();
-    if (getenv("MAUVE_TRACE")) fprintf(stderr, "[trace] interval table: %.3f ms (%lld gaps, %lld dp)\n", S.t_dp0 - t3, (long long)S.gaps.size(), (long long)S.n_dp);
+    if (g_trace_pipeline) fprintf(stderr, "[trace] interval table: %.3f ms (%lld gaps, %lld dp)\n", S.t_dp0 - t3, (long long)S.gaps.size(), (long long)S.n_dp);
     S.open = true;
     return MAUVE_OK;
 }
@@ -510,7 +512,7 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
     R.sz.n_gap_dp = n_dp; R.sz.n_dp_cells = cells;
     *sizes = R.sz;
     const double t5 = now_ms();
-    if (getenv("MAUVE_TRACE")) fprintf(stderr, "[trace] assemble: layout %.3f ms, restore %.3f, anchors+gaps %.3f, unaligned+sizes %.3f\n", ta1 - t4, ta2 - ta1, ta3 - ta2, t5 - ta3);
+    if (g_trace_pipeline) fprintf(stderr, "[trace] assemble: layout %.3f ms, restore %.3f, anchors+gaps %.3f, unaligned+sizes %.3f\n", ta1 - t4, ta2 - ta1, ta3 - ta2, t5 - ta3);
     c->stage.assemble_ms = t5 - t4;
     c->stage.total_ms = t5 - S.t0;
     S.open = false;

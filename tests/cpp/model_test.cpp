@@ -1,5 +1,6 @@
 // Host-side data model of the mirror (include/libMems): the shapes the in-tree tools use, checked on small hand cases.
 #include <cassert>
+#include <fstream>
 #include <iostream>
 #include <sstream>
 #include "libMems/mems_hip.h"
@@ -79,5 +80,25 @@ int main()
     threw = false; try { IntervalList x; x.ReadStandardAlignment(bigdef); } catch (genome::gnException &) { threw = true; }
     assert(threw);
     std::cout << "OK" << std::endl;
+    // ---- computeSPScore (repeatoire.cpp:2527), LoadSequences / LoadMFASequences (addUnalignedIntervals.cpp:23, evd.cpp:97) ----
+    {
+        PairwiseScoringScheme pss;                      // HOXD70, -400 / -30
+        std::vector<std::string> aln; aln.push_back("AC--GT"); aln.push_back("ACTTGT"); aln.push_back("A---GA");
+        std::vector<score_t> colscore; score_t total = 0;
+        computeSPScore(aln, pss, colscore, total);
+        // pairs (0,1): A/A C/C open ext G/G T/T; (0,2): A/A, C vs gap opens, two gap-gap columns, G/G, T/A; (1,2): A/A, open ext ext, G/G, T/A
+        const score_t want = (91 + 100 - 400 - 30 + 100 + 91) + (91 - 400 + 100 - 123) + (91 - 400 - 30 - 30 + 100 - 123);
+        assert(total == want && colscore.size() == 6 && colscore[0] == 3 * 91 && colscore[2] == -400 - 30);
+        score_t s2 = 0; for (size_t c = 0; c < colscore.size(); c++) s2 += colscore[c];
+        assert(s2 == total);
+        const char *mfa = "/tmp/mauve_hip_model_test.mfa";
+        { std::ofstream f(mfa); f << ">one\nACGT\nAC\n>two\nGGTT\n"; }
+        MatchList ml2; LoadMFASequences(ml2, mfa, nullptr);
+        assert(ml2.seq_table.size() == 2 && ml2.seq_table[0]->length() == 6 && ml2.seq_table[1]->ToString() == "GGTT" && ml2.seq_filename.size() == 2);
+        IntervalList il2; il2.seq_filename.push_back(mfa); LoadSequences(il2, nullptr);
+        assert(il2.seq_table.size() == 1 && il2.seq_table[0]->length() == 10 && il2.seq_table[0]->contigListSize() == 2);
+        for (size_t i2 = 0; i2 < ml2.seq_table.size(); i2++) delete ml2.seq_table[i2];
+        delete il2.seq_table[0];
+    }
     return 0;
 }
