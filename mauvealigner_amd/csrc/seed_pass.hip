@@ -434,7 +434,10 @@ __device__ __forceinline__ void rs_scatter_tile(const KeyT *__restrict__ keys_in
     }
 }
 
-template <typename KeyT>
+// RAW: `hist` holds the raw per-tile digit counts (no rs_rowscan ran): every workgroup sums its digit's row for itself --
+// the sorts of the chain / DP front / canonical order have at most a few dozen tiles, where the row scan is one more
+// launch of pure latency.
+template <typename KeyT, bool RAW = false>
 __global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict__ keys_in,
                                                          const uint32_t *__restrict__ vals_in,
                                                          KeyT *__restrict__ keys_out,
@@ -455,7 +458,13 @@ __global__ void __launch_bounds__(RS_THREADS) rs_scatter(const KeyT *__restrict_
 
     for (int w = 0; w < RS_WAVES; w++) wcount[w][tid] = 0;
     // digit base = exclusive scan of the digit totals
-    {
+    if (RAW) {
+        const uint32_t *row = hist + (size_t)tid * nblk;
+        uint32_t tot = 0, before = 0;
+        for (uint32_t t = 0; t < nblk; t++) { const uint32_t c = row[t]; tot += c; before += t < blockIdx.x ? c : 0u; }
+        uint32_t dummy;
+        gbase[tid] = block_excl_scan(tot, &dummy, scan) + before;
+    } else {
         uint32_t dummy;
         const uint32_t tot = totals[tid];
         gbase[tid] = block_excl_scan(tot, &dummy, scan) + hist[(size_t)tid * nblk + blockIdx.x];
@@ -1170,6 +1179,14 @@ static int sort_pairs(mauve_ctx *ctx, uint32_t n, int key_bits, KeyT **keys_io, 
         if (!(shift == shift_lo && have_hist0)) { KernelTimer t(ctx, k_hist, n);
           hipLaunchKernelGGL(rs_hist<KeyT>, dim3(nblk), dim3(RS_THREADS), 0, ctx->stream, kin, n, shift,
                              ctx->hist.as<uint32_t>(), nblk); }
+        static const bool no_raw = getenv("MAUVE_SORT_ROWSCAN") != nullptr;        // A/B switch
+        if (nblk <= 64 && !no_raw) {      // small sort: no row scan launch, the scatter reads the raw tile histograms
+            KernelTimer t(ctx, k_scat, n);
+            hipLaunchKernelGGL((rs_scatter<KeyT, true>), dim3(nblk), dim3(RS_THREADS), 0, ctx->stream, kin, vin, kout, vout, n,
+                               shift, ctx->hist.as<uint32_t>(), ctx->totals.as<uint32_t>(), nblk);
+            std::swap(kin, kout); std::swap(vin, vout);
+            continue;
+        }
         { KernelTimer t(ctx, k_scan, n);
           hipLaunchKernelGGL(rs_rowscan, dim3(256), dim3(256), 0, ctx->stream, ctx->hist.as<uint32_t>(), nblk,
                              ctx->totals.as<uint32_t>()); }
