@@ -584,7 +584,7 @@ __global__ void __launch_bounds__(256) join_bounds(const KeyT *__restrict__ keys
     if ((threadIdx.x & 63) == 0) bound[c] = res;
 }
 
-template <typename KeyT, bool WIDE, int VARIANT>
+template <typename KeyT, bool WIDE>
 __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t n,
                                                  const uint32_t *__restrict__ bound, GenomeTab tab, int mode, uint32_t want_mask,
                                                  uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos,
@@ -624,36 +624,9 @@ __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, 
         }
         if (idx < lo || idx >= hi) k[r] = EMPTY;
     }
-    // ---- pass 1: group by mer.  The LDS operations of all rows are issued phase by phase (first probes, collision
-    // walks, genome-set updates), so that their latencies overlap instead of adding up row by row ----
-    if (VARIANT == 2) return;
+    // ---- pass 1: group by mer: claim a slot (compare-and-swap on the key word, linear probing), then OR the entry's genome
+    // into the slot's once / multi sets ----
     uint32_t slot[HJ_ROWS]; uint32_t gbit[HJ_ROWS];
-    if (false) {
-    KeyT seen[HJ_ROWS];
-#pragma unroll
-    for (int r = 0; r < HJ_ROWS; r++) {
-        slot[r] = ((uint32_t)k[r] ^ (uint32_t)((uint64_t)k[r] >> 32)) * 0x9E3779B1u >> 20;         // 12 bits
-        gbit[r] = 1u << genome_of(v[r] & 0x7fffffffu, tab);
-        seen[r] = k[r];
-        if (k[r] != EMPTY) seen[r] = atomicCAS(&skey[slot[r]], EMPTY, k[r]);                       // EMPTY: beyond the range, or an invalid window
-    }
-#pragma unroll
-    for (int r = 0; r < HJ_ROWS; r++) {
-        if (k[r] == EMPTY) { slot[r] = HJ_NONE; gbit[r] = 0; continue; }
-        uint32_t s = slot[r]; KeyT old = seen[r];
-        while (!(old == EMPTY || old == k[r])) {
-            s = (s + 1) & (HJ_SLOTS - 1);
-            old = atomicCAS(&skey[s], EMPTY, k[r]);
-        }
-        slot[r] = s;
-    }
-    uint32_t prev[HJ_ROWS];
-#pragma unroll
-    for (int r = 0; r < HJ_ROWS; r++) prev[r] = slot[r] != HJ_NONE ? atomicOr(&som[slot[r]], gbit[r]) : 0u;
-#pragma unroll
-    for (int r = 0; r < HJ_ROWS; r++)
-        if (prev[r] & gbit[r]) { if (WIDE) atomicOr(&som2[slot[r]], gbit[r]); else atomicOr(&som[slot[r]], gbit[r] << 16); }
-    } else {
 #pragma unroll
     for (int r = 0; r < HJ_ROWS; r++) {
         slot[r] = HJ_NONE; gbit[r] = 0;
@@ -668,7 +641,6 @@ __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, 
         const uint32_t old = atomicOr(&som[s], bit);
         if (old & bit) { if (WIDE) atomicOr(&som2[s], bit); else atomicOr(&som[s], bit << 16); }
         slot[r] = s; gbit[r] = bit;
-    }
     }
     __syncthreads();
     // ---- pass 2: the finder rule per mer; the entry of the lowest component genome is the anchor ----
@@ -691,7 +663,6 @@ __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, 
         if (!mm[r]) continue;
         const uint32_t ap = (uint32_t)skey[slot[r]] & 0x7fffffffu;
         if (ap >= P) { atomicAdd(&ovf_cnt[1], 1u); continue; }   // cannot happen; a wild store could take the device down
-        if (VARIANT == 1) continue;
         tpos[(size_t)ap * tab.nseq + (__ffs(gbit[r]) - 1)] = v[r];
         if ((mm[r] & (0u - mm[r])) == gbit[r]) tmask[ap] = mm[r];
     }
@@ -1396,16 +1367,13 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             const uint32_t nchunk = (ns + HJ_T - 1) / HJ_T;
             HIPCHK(ctx, ctx->join_ovf.ensure((2 + 2 * (size_t)HJ_OVF_CAP) * 4));        // the ranges; their count sits in the counter block (words 8, 9)
             KernelTimer t(ctx, MAUVE_K_JOIN, ns);
-            static const int jv = getenv("MAUVE_JH_VARIANT") ? atoi(getenv("MAUVE_JH_VARIANT")) : 0;
             HIPCHK(ctx, ctx->join_bound.ensure(((size_t)nchunk + 2) * 4));
             hipLaunchKernelGGL((join_bounds<KeyT>), dim3((nchunk + 1 + 3) / 4), dim3(256), 0, ctx->stream, keys, ns, L, nchunk,
                                ctx->join_bound.as<uint32_t>());
-#define JH_LAUNCH(W, V) hipLaunchKernelGGL((join_hash<KeyT, W, V>), dim3(nchunk), dim3(256), 0, ctx->stream, keys, vals, ns, \
+#define JH_LAUNCH(W) hipLaunchKernelGGL((join_hash<KeyT, W>), dim3(nchunk), dim3(256), 0, ctx->stream, keys, vals, ns, \
                                            ctx->join_bound.as<uint32_t>(), tab, fp.rule, fp.want, tmask, tpos, ctx->counters.as<uint32_t>() + 8, ctx->join_ovf.as<uint32_t>(), P)
-            if (N > 16) JH_LAUNCH(true, 0);
-            else if (jv == 1) JH_LAUNCH(false, 1);
-            else if (jv == 2) JH_LAUNCH(false, 2);
-            else JH_LAUNCH(false, 0);
+            if (N > 16) JH_LAUNCH(true);
+            else JH_LAUNCH(false);
 #undef JH_LAUNCH
         } else
         { KernelTimer t(ctx, MAUVE_K_JOIN, ns);
