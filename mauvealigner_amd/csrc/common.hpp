@@ -237,6 +237,8 @@ struct mauve_ctx {
         dp_cols, dp_rows;
 
     // the seed pass may leave its match list on the device only (sorted_rec) when the caller says so: mauve_align's device tail
+    bool pair_sums_only = false;          // seed pass for the guide tree: per-pair length sums instead of the match list
+    std::vector<int64_t> pair_sums;
     bool lazy_matches_ok = false, matches_pending = false;
     int match_nseq = 0;
     // where dp_run_from_anchors left its device-side results (valid until the next DP launch)

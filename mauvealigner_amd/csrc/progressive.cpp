@@ -293,14 +293,14 @@ int mauve_guide_tree(mauve_ctx *c, uint64_t pattern, int64_t *dist, int32_t *lef
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->nseq, M = 2 * N - 1;
     int64_t nm = 0;
+    // similarity = sum of the pairwise match lengths per genome pair: summed on the device, the matches themselves stay there
+    c->pair_sums_only = true;
     int rc = seedpass_run(c, main_genome_set(c), pattern, MAUVE_MODE_PAIRWISE, 0, 1, nullptr, 0, &nm);
+    c->pair_sums_only = false;
     if (rc) return rc;
     std::vector<int64_t> S((size_t)N * N, 0);
-    for (int64_t k = 0; k < nm; k++) {
-        int a = -1, b = -1;
-        for (int g = 0; g < N; g++) if (c->match_start[(size_t)k * N + g]) { if (a < 0) a = g; else b = g; }
-        S[(size_t)a * N + b] += c->match_len[(size_t)k]; S[(size_t)b * N + a] += c->match_len[(size_t)k];
-    }
+    if (c->pair_sums.size() == (size_t)N * N)
+        for (int a = 0; a < N; a++) for (int b = a + 1; b < N; b++) { S[(size_t)a * N + b] = S[(size_t)b * N + a] = c->pair_sums[(size_t)a * N + b]; }
     std::vector<int64_t> D((size_t)M * M, 0), size((size_t)M, 0);
     std::vector<char> active((size_t)M, 0);
     for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) {

@@ -1045,6 +1045,25 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
 // (dropped candidates get first component = nseq and sort behind everything), the radix sort above on
 // (key, candidate index), then a gather of the surviving records as int64 in sorted order.
 // ------------------------------------------------------------------------------------------------
+// guide tree (progressive.cpp): all it needs of the pairwise matches is the sum of their lengths per genome pair -- no
+// canonical order, no copy of the (hundreds of thousands of) records.  Block-level sums in LDS, then one atomic per pair.
+__global__ void __launch_bounds__(256) pair_length_sums(const int32_t *__restrict__ mlen, const int32_t *__restrict__ mstart, uint32_t ncand,
+                                                        int nseq, unsigned long long *__restrict__ sums)
+{
+    __shared__ unsigned long long s[MAUVE_MAX_SEQ * MAUVE_MAX_SEQ];
+    for (int i = threadIdx.x; i < nseq * nseq; i += 256) s[i] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ncand; i += gridDim.x * 256u) {
+        const int32_t len = mlen[i];
+        if (len == 0) continue;
+        int a = -1, b = -1;
+        for (int g = 0; g < nseq; g++) if (mstart[(size_t)i * nseq + g]) { if (a < 0) a = g; else if (b < 0) b = g; }
+        if (b >= 0) atomicAdd(&s[a * nseq + b], (unsigned long long)len);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nseq * nseq; i += 256) if (s[i]) atomicAdd(&sums[i], s[i]);
+}
+
 __global__ void __launch_bounds__(256) canon_keys(const int32_t *__restrict__ mlen, const int32_t *__restrict__ mstart, uint32_t ncand,
                                                   int nseq, int pos_bits, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                   uint32_t *__restrict__ n_valid)
@@ -1444,6 +1463,23 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         TRACE(ctx, "extend");
     }
     const uint32_t ncand = cand_total;
+    if (ctx->pair_sums_only) {                   // the guide tree's view of the pairwise matches
+        ctx->pair_sums.assign((size_t)N * N, 0);
+        if (ncand) {
+            HIPCHK(ctx, ctx->run_sum.ensure((size_t)N * N * 8 + 64));
+            unsigned long long *d = ctx->run_sum.as<unsigned long long>();
+            HIPCHK(ctx, hipMemsetAsync(d, 0, (size_t)N * N * 8, ctx->stream));
+            hipLaunchKernelGGL(pair_length_sums, dim3(std::min<uint32_t>((ncand + 255) / 256, 1024)), dim3(256), 0, ctx->stream, ctx->mlen.as<int32_t>(),
+                               ctx->mstart.as<int32_t>(), ncand, N, d);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, ctx->pin_seed.ensure(64 + (size_t)N * N * 8));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.as<char>() + 64, d, (size_t)N * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            memcpy(ctx->pair_sums.data(), ctx->pin_seed.as<char>() + 64, (size_t)N * N * 8);
+        }
+        TRACE(ctx, "pair length sums");
+        return MAUVE_OK;
+    }
     if (ncand == 0) return MAUVE_OK;
     // ---- canonical order (first component, |start|, mask, starts, length) ----
     static const uint32_t dev_sort_min = getenv("MAUVE_CANON_DEVICE_MIN") ? (uint32_t)atol(getenv("MAUVE_CANON_DEVICE_MIN")) : 16384u;
