@@ -8,6 +8,7 @@
 #include "GappedAligner.h"
 #include "IntervalList.h"
 #include "MatchList.h"
+#include <fstream>
 
 namespace mems {
 
@@ -110,6 +111,24 @@ inline void transposeMatches(MatchList &ml, uint seqI, std::vector<int64> &start
     for (const Match *m : ml) starts.push_back(m->Start(seqI));
 }
 
+// One set of LCBs as a signed permutation per sequence: the LCB ids (1-based, numbered along sequence 0) in the order
+// their left ends occur in that sequence, negative where the LCB lies reversed -- the rows toGrimmFormat.cpp:58-77 prints,
+// tab-separated, one line per sequence, a blank line after the set.
+inline void WritePermutation(std::ostream &os, uint N, int64_t K, const std::vector<int64_t> &left_end, const std::vector<int64_t> &left_adj, const std::vector<int64_t> &right_adj)
+{
+    for (uint g = 0; g < N; g++) {
+        int64_t l = 0;
+        while (l < K && left_adj[(size_t)l * N + g] != NO_ADJACENCY) l++;
+        for (bool first = true; l >= 0 && l < K; l = right_adj[(size_t)l * N + g], first = false) {
+            if (!first) os << '\t';
+            if (left_end[(size_t)l * N + g] < 0) os << '-';
+            os << l + 1;
+        }
+        os << '\n';
+    }
+    os << '\n';
+}
+
 class Aligner {
 public:
     explicit Aligner(uint seq_count) : seq_count_(seq_count), gal_(nullptr) { mauve_default_params(&p_); }
@@ -120,6 +139,10 @@ public:
     void SetMaxBandedAlignmentLength(gnSeqI n) { p_.max_banded_len = (int64_t)n; }
     void SetMaxExtensionIterations(uint n) { p_.max_extension_iters = (int32_t)n; }      // :687-690 (LCB extension)
     void SetSeedPattern(int64 seed) { p_.seed_pattern = (uint64_t)seed; }
+    // :678-686 (--permutation-matrix-output / --permutation-matrix-min-weight; weight already x seq_count): align() writes
+    // a signed permutation for every set of LCBs the greedy breakpoint elimination passes through between this minimum
+    // weight and LCB_size -- the set at min_weight first, then one per lightest LCB removed, the set at LCB_size last.
+    void SetPermutationOutput(const std::string &filename, int64 min_weight) { perm_fn_ = filename; perm_weight_ = min_weight; }
     void SetScoring(const PairwiseScoringScheme &pss)
     {
         for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) p_.scoring.matrix[i][j] = pss.matrix[i][j];
@@ -145,6 +168,7 @@ public:
             len[i] = (int64_t)ml[i]->Length();
             for (uint g = 0; g < N && g < ml[i]->SeqCount(); g++) st[i * N + g] = ml[i]->Start(g);
         }
+        if (!perm_fn_.empty() && perm_weight_ >= 0 && LCB_size >= 0) write_permutations(len, st, LCB_size);
         const bool foreign = gapped && gal_ && dynamic_cast<HipGappedAligner *>(gal_) == nullptr;
         if (!foreign)
             hc.check(mauve_align_matches(hc.get(), &p, (int64_t)ml.size(), len.data(), st.data(), &il.sizes), "mauve_align_matches");
@@ -181,9 +205,39 @@ public:
         il.fetch(hc, seq_count_);
     }
 private:
+    // the LCB sets of the N-way matches between perm_weight_ and LCB_size (the chain align() runs, before recursion)
+    void write_permutations(const std::vector<int64_t> &len_in, const std::vector<int64_t> &st_in, int64 LCB_size)
+    {
+        const uint N = seq_count_;
+        std::vector<int64_t> len, st;
+        for (size_t i = 0; i < len_in.size(); i++) {
+            bool all = true;
+            for (uint g = 0; g < N; g++) all = all && st_in[i * N + g] != 0;
+            if (!all) continue;
+            len.push_back(len_in[i]); st.insert(st.end(), st_in.begin() + (std::ptrdiff_t)(i * N), st_in.begin() + (std::ptrdiff_t)((i + 1) * N));
+        }
+        int64_t n = (int64_t)len.size();
+        std::ofstream out(perm_fn_.c_str());
+        if (!out) throw genome::gnException("Aligner::align: cannot write the permutation file " + perm_fn_);
+        if (!n) return;
+        if (mauve_eliminate_overlaps((int)N, &n, len.data(), st.data()) != MAUVE_OK) throw genome::gnException("Aligner::align: permutation output: bad match list");
+        std::vector<int64_t> lcb((size_t)n), le((size_t)n * N), re((size_t)n * N), wt((size_t)n), la((size_t)n * N), ra((size_t)n * N);
+        for (int64_t w = std::min<int64_t>(perm_weight_, LCB_size);;) {
+            int64_t K = 0;
+            if (mauve_lcb_chain((int)N, n, len.data(), st.data(), w, 0, lcb.data(), &K, le.data(), re.data(), wt.data(), la.data(), ra.data()) != MAUVE_OK)
+                throw genome::gnException("Aligner::align: permutation output: chaining failed");
+            WritePermutation(out, N, K, le, la, ra);
+            if (w >= LCB_size || K <= 1) break;
+            int64_t lightest = wt[0];
+            for (int64_t l = 1; l < K; l++) lightest = std::min(lightest, wt[(size_t)l]);
+            w = std::min<int64_t>(std::max(w, lightest) + 1, LCB_size);
+        }
+    }
     uint seq_count_;
     mauve_params p_;
     GappedAligner *gal_;
+    std::string perm_fn_;
+    int64 perm_weight_ = -1;
 };
 
 }  // namespace mems

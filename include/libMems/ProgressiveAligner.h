@@ -4,6 +4,9 @@
 #define MAUVE_HIP_PROGRESSIVEALIGNER_H
 
 #include "Aligner.h"
+#include "GuideTree.h"
+#include <fstream>
+#include <sstream>
 
 namespace mems {
 
@@ -23,7 +26,8 @@ public:
     void setCollinear(boolean c) { p_.collinear = c; }                        // :594-597
     void setGappedAlignment(boolean g) { p_.gapped = g; }                     // --skip-gapped-alignment
     void setRefinement(boolean) {}                                            // :578-579 (no refinement stage)
-    void setRecursion(boolean r) { p_.recursive = r; }                        // :661-664
+    void setRecursion(boolean r) { p_.recursive = r; }
+    void SetRecursive(boolean r) { p_.recursive = r; }                        // :661-664
     void SetMaxGappedAlignmentLength(gnSeqI n) { p_.max_gapped_len = (int64_t)n; }
     void setPairwiseScoringScheme(const PairwiseScoringScheme &pss)           // :666-687
     {
@@ -36,7 +40,13 @@ public:
     enum LcbScoringScheme { AncestralScoring, AncestralSumOfPairsScoring, ExtantSumOfPairsScoring, LengthScoring };
     void setLcbScoringScheme(int s) { p_.lcb_scoring = s == LengthScoring ? MAUVE_LCB_SCORE_LENGTH : MAUVE_LCB_SCORE_SP; score_set_ = true; }
     void setUseLcbWeightScaling(boolean) {}                                   // :626-642
+    void setBreakpointDistanceScale(double) {}                                // :628-635: scales of libMems' penalty
+    void setConservationDistanceScale(double) {}                              // scaling, which S11 does not have
     void setBpDistEstimateMinScore(double) {}
+    // :689-692.  The input tree replaces the UPGMA one (mauve_progressive_align_tree); the output file receives the
+    // tree the alignment used, NEWICK both ways with leaves seq1..seqN (GuideTree.h).
+    void setInputGuideTreeFileName(const std::string &fn) { input_tree_fn_ = fn; }
+    void setOutputGuideTreeFileName(const std::string &fn) { output_tree_fn_ = fn; }
     void setUseSeedFamilies(boolean) {}
     void SetUseCacheDb(boolean) {}                                            // :643-646
     // progressiveMauve.cpp:652-655 hands the pairwise matches over; the device path finds them itself
@@ -51,7 +61,24 @@ public:
         HipContext &hc = HipContext::global();
         MatchList tmp; tmp.seq_table = seq_table;
         tmp.upload(hc);
-        hc.check(mauve_progressive_align(hc.get(), &p_, &il.sizes, tree_left_.data(), tree_right_.data(), nullptr), "mauve_progressive_align");
+        std::vector<int64_t> dist;
+        if (!input_tree_fn_.empty()) {
+            std::ifstream in(input_tree_fn_.c_str());
+            if (!in) throw genome::gnException("ProgressiveAligner::align: cannot read the input guide tree " + input_tree_fn_);
+            std::stringstream ss; ss << in.rdbuf();
+            std::string why;
+            if (!guideTreeFromNewick(ss.str(), (int)seq_count_, tree_left_, tree_right_, &why))
+                throw genome::gnException("ProgressiveAligner::align: input guide tree: " + why);
+            hc.check(mauve_progressive_align_tree(hc.get(), &p_, &il.sizes, tree_left_.data(), tree_right_.data()), "mauve_progressive_align_tree");
+        } else {
+            dist.assign((size_t)seq_count_ * seq_count_, 0);
+            hc.check(mauve_progressive_align(hc.get(), &p_, &il.sizes, tree_left_.data(), tree_right_.data(), dist.data()), "mauve_progressive_align");
+        }
+        if (!output_tree_fn_.empty()) {
+            std::ofstream out(output_tree_fn_.c_str());
+            if (!out) throw genome::gnException("ProgressiveAligner::align: cannot write the guide tree " + output_tree_fn_);
+            out << guideTreeToNewick((int)seq_count_, tree_left_, tree_right_, dist);
+        }
         il.seq_table = seq_table;
         il.fetch(hc, seq_count_);
     }
@@ -64,6 +91,7 @@ private:
     double bp_penalty_ = -1;
     bool score_set_ = false;
     std::vector<int32_t> tree_left_, tree_right_;
+    std::string input_tree_fn_, output_tree_fn_;
 };
 
 }  // namespace mems

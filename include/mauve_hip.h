@@ -236,6 +236,11 @@ int mauve_align_finish(mauve_ctx *ctx, const uint32_t *cols, const int64_t *col_
 int mauve_guide_tree(mauve_ctx *ctx, uint64_t pattern, int64_t *dist, int32_t *tree_left, int32_t *tree_right);
 int mauve_progressive_align(mauve_ctx *ctx, const mauve_params *p, mauve_align_sizes *sizes,
                             int32_t *tree_left, int32_t *tree_right, int64_t *dist);
+/* ProgressiveAligner::setInputGuideTreeFileName (progressiveMauve.cpp:689-690): the same alignment along the caller's
+   tree instead of the UPGMA one.  tree_left/right: [2*nseq-1] in the form mauve_guide_tree returns -- leaves 0..nseq-1
+   with -1, every internal node with two distinct children of smaller id, root last; anything else is MAUVE_ERR_ARG. */
+int mauve_progressive_align_tree(mauve_ctx *ctx, const mauve_params *p, mauve_align_sizes *sizes,
+                                 const int32_t *tree_left, const int32_t *tree_right);
 /* IntervalList::WriteStandardAlignment (mauveAligner.cpp:746-760; format mfa2xmfa.cpp:64-115).
    Two-phase: buf == NULL returns the needed size (including NUL) in *len. */
 int mauve_write_xmfa(mauve_ctx *ctx, const char *const *names, char *buf, int64_t *len);

@@ -25,7 +25,7 @@ EXPORTS = [
     "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_extend_hits", "mauve_seed_match_enumerate",
     "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_dp_batch_banded", "mauve_match_sp_scores", "mauve_align", "mauve_align_fetch",
     "mauve_align_matches", "mauve_align_begin", "mauve_align_begin_matches", "mauve_align_dp_anchors", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
-    "mauve_guide_tree", "mauve_progressive_align",
+    "mauve_guide_tree", "mauve_progressive_align", "mauve_progressive_align_tree",
     "mauve_write_xmfa", "mauve_profile_enable", "mauve_profile_reset", "mauve_profile_get", "mauve_last_stage_times",
 ]
 
@@ -417,15 +417,24 @@ class Context:
                                           _p(right, C.c_int32)), "mauve_guide_tree")
         return dist, left, right
 
-    def progressive_align(self, params=None, fetch=True, names=None, want_xmfa=False):
+    def progressive_align(self, params=None, fetch=True, names=None, want_xmfa=False, tree=None):
+        """tree=(left, right): align along the caller's guide tree (mauve_progressive_align_tree)."""
         p = params or default_params()
         N = self.nseq
         sz = AlignSizes()
         dist = np.zeros((N, N), np.int64)
-        left = np.zeros(2 * N - 1, np.int32)
-        right = np.zeros(2 * N - 1, np.int32)
-        self._chk(self.L.mauve_progressive_align(self.h, C.byref(p), C.byref(sz), _p(left, C.c_int32), _p(right, C.c_int32),
-                                                 _p(dist, C.c_int64)), "mauve_progressive_align")
+        if tree is None:
+            left = np.zeros(2 * N - 1, np.int32)
+            right = np.zeros(2 * N - 1, np.int32)
+            self._chk(self.L.mauve_progressive_align(self.h, C.byref(p), C.byref(sz), _p(left, C.c_int32), _p(right, C.c_int32),
+                                                     _p(dist, C.c_int64)), "mauve_progressive_align")
+        else:
+            left = np.ascontiguousarray(tree[0], np.int32)
+            right = np.ascontiguousarray(tree[1], np.int32)
+            if len(left) != 2 * N - 1 or len(right) != 2 * N - 1:
+                raise ValueError("guide tree must have 2*nseq-1 nodes")
+            self._chk(self.L.mauve_progressive_align_tree(self.h, C.byref(p), C.byref(sz), _p(left, C.c_int32),
+                                                          _p(right, C.c_int32)), "mauve_progressive_align_tree")
         out = self._fetch(sz, names, want_xmfa) if fetch else {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
         out["tree"] = (left, right)
         out["dist"] = dist

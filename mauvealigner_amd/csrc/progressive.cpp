@@ -322,8 +322,39 @@ int mauve_guide_tree(mauve_ctx *c, uint64_t pattern, int64_t *dist, int32_t *lef
     return MAUVE_OK;
 }
 
+static int progressive_core(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes, const int32_t *given_left,
+                            const int32_t *given_right, int32_t *tree_left, int32_t *tree_right, int64_t *dist);
+
 int mauve_progressive_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes, int32_t *tree_left,
                             int32_t *tree_right, int64_t *dist)
+{
+    return progressive_core(c, p, sizes, nullptr, nullptr, tree_left, tree_right, dist);
+}
+
+// the caller's guide tree instead of the UPGMA one: leaves 0..N-1 childless, every internal node N..2N-2 with two
+// distinct children of smaller id, every node but the root 2N-2 used exactly once
+int mauve_progressive_align_tree(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes, const int32_t *tree_left,
+                                 const int32_t *tree_right)
+{
+    if (!c || !tree_left || !tree_right) return MAUVE_ERR_ARG;
+    const int N = c->nseq, M = 2 * N - 1;
+    if (N < 2) { c->err = "progressive_align: at least two genomes required"; return MAUVE_ERR_STATE; }
+    std::vector<char> used((size_t)M, 0);
+    for (int k = 0; k < M; k++) {
+        const int a = tree_left[k], b = tree_right[k];
+        if (k < N) { if (a != -1 || b != -1) { c->err = "progressive_align_tree: a leaf has children"; return MAUVE_ERR_ARG; } continue; }
+        if (a < 0 || b < 0 || a >= k || b >= k || a == b || used[(size_t)a] || used[(size_t)b]) {
+            c->err = "progressive_align_tree: not a binary tree in merge order"; return MAUVE_ERR_ARG;
+        }
+        used[(size_t)a] = used[(size_t)b] = 1;
+    }
+    return progressive_core(c, p, sizes, tree_left, tree_right, nullptr, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+static int progressive_core(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes, const int32_t *given_left,
+                            const int32_t *given_right, int32_t *tree_left, int32_t *tree_right, int64_t *dist)
 {
     if (!c || !p || !sizes) return MAUVE_ERR_ARG;
     if (c->nseq < 2) { c->err = "progressive_align: at least two genomes required"; return MAUVE_ERR_STATE; }
@@ -337,7 +368,9 @@ int mauve_progressive_align(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     if (!pat) { c->err = "progressive_align: no seed pattern for this weight/rank"; return MAUVE_ERR_ARG; }
     Prog P; P.c = c; P.p = p; P.N = N;
     P.left.assign((size_t)(2 * N - 1), -1); P.right.assign((size_t)(2 * N - 1), -1);
-    int rc = mauve_guide_tree(c, pat, dist, P.left.data(), P.right.data());
+    int rc = 0;
+    if (given_left) { std::copy(given_left, given_left + (2 * N - 1), P.left.begin()); std::copy(given_right, given_right + (2 * N - 1), P.right.begin()); }
+    else rc = mauve_guide_tree(c, pat, dist, P.left.data(), P.right.data());
     if (rc) return rc;
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     const double tg1 = now_ms();
@@ -384,5 +417,3 @@ int mauve_progressive_align(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     c->stage.total_ms = now_ms() - t0;
     return MAUVE_OK;
 }
-
-}  // extern "C"

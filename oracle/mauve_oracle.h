@@ -158,6 +158,9 @@ int orc_guide_tree(int nseq, const uint8_t *const *codes, const int64_t *lens, u
                    int64_t *dist, int32_t *left, int32_t *right);
 int orc_progressive_align(int nseq, const uint8_t *const *codes, const int64_t *lens, const orc_params *p,
                           int32_t *tree_left, int32_t *tree_right, int64_t *dist, orc_alignment *aln);
+int orc_check_tree(int nseq, const int32_t *tree_left, const int32_t *tree_right);
+int orc_progressive_align_tree(int nseq, const uint8_t *const *codes, const int64_t *lens, const orc_params *p,
+                               const int32_t *tree_left, const int32_t *tree_right, orc_alignment *aln);
 /* XMFA text (format pinned by mfa2xmfa.cpp:64,89-91,104-115); returns malloc'd NUL-terminated text */
 char *orc_write_xmfa(int nseq, const uint8_t *const *codes, const int64_t *lens,
                      const char *const *names, const orc_alignment *a, int64_t *text_len);

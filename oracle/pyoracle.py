@@ -375,18 +375,35 @@ def guide_tree(codes, pattern):
     return dist, left, right
 
 
-def progressive_align(codes, params=None, names=None, want_xmfa=False):
-    """Guide-tree recursive anchoring.  -> dict(aln={...}, tree=(left,right), dist, xmfa)"""
+def check_tree(nseq, left, right):
+    left = np.ascontiguousarray(left, np.int32)
+    right = np.ascontiguousarray(right, np.int32)
+    if len(left) != 2 * nseq - 1 or len(right) != 2 * nseq - 1:
+        return False
+    return lib().orc_check_tree(nseq, left.ctypes.data_as(C.POINTER(C.c_int32)), right.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+
+
+def progressive_align(codes, params=None, names=None, want_xmfa=False, tree=None):
+    """Guide-tree recursive anchoring.  -> dict(aln={...}, tree=(left,right), dist, xmfa)
+    tree=(left, right): align along the caller's guide tree (--input-guide-tree) instead of the UPGMA one."""
     p = params or default_params()
     codes, arr, lens = _seq_args(codes)
     N = len(codes)
     al = Alignment()
     dist = np.zeros((N, N), np.int64)
-    left = np.zeros(2 * N - 1, np.int32)
-    right = np.zeros(2 * N - 1, np.int32)
-    rc = lib().orc_progressive_align(N, arr, lens, C.byref(p), left.ctypes.data_as(C.POINTER(C.c_int32)),
-                                     right.ctypes.data_as(C.POINTER(C.c_int32)), dist.ctypes.data_as(C.POINTER(C.c_int64)),
-                                     C.byref(al))
+    if tree is None:
+        left = np.zeros(2 * N - 1, np.int32)
+        right = np.zeros(2 * N - 1, np.int32)
+        rc = lib().orc_progressive_align(N, arr, lens, C.byref(p), left.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         right.ctypes.data_as(C.POINTER(C.c_int32)), dist.ctypes.data_as(C.POINTER(C.c_int64)),
+                                         C.byref(al))
+    else:
+        left = np.ascontiguousarray(tree[0], np.int32)
+        right = np.ascontiguousarray(tree[1], np.int32)
+        if len(left) != 2 * N - 1 or len(right) != 2 * N - 1:
+            raise ValueError("guide tree must have 2*nseq-1 nodes")
+        rc = lib().orc_progressive_align_tree(N, arr, lens, C.byref(p), left.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              right.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(al))
     if rc:
         raise RuntimeError("orc_progressive_align failed: %d" % rc)
     niv = int(al.n_iv)

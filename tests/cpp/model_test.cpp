@@ -100,5 +100,30 @@ int main()
         for (size_t i2 = 0; i2 < ml2.seq_table.size(); i2++) delete ml2.seq_table[i2];
         delete il2.seq_table[0];
     }
+    // ---- guide tree files (progressiveMauve.cpp:689-692) and signed permutations (mauveAligner.cpp:678-686) ----
+    {
+        // ((seq1,seq3),(seq2,seq4)) in merge order: 4 = (0,2), 5 = (1,3), 6 = (4,5)
+        std::vector<int32_t> L(7, -1), R(7, -1); L[4] = 0; R[4] = 2; L[5] = 1; R[5] = 3; L[6] = 4; R[6] = 5;
+        assert(guideTreeToNewick(4, L, R) == "((seq1,seq3),(seq2,seq4));\n");
+        std::vector<int64_t> D(16, 400000); for (int i = 0; i < 4; i++) D[(size_t)i * 5] = 0;
+        D[0 * 4 + 2] = D[2 * 4 + 0] = 100000; D[1 * 4 + 3] = D[3 * 4 + 1] = 200000;
+        const std::string nw = guideTreeToNewick(4, L, R, D);
+        assert(nw == "((seq1:0.050000,seq3:0.050000):0.150000,(seq2:0.100000,seq4:0.100000):0.100000);\n");
+        std::vector<int32_t> L2, R2; std::string why;
+        assert(guideTreeFromNewick(nw, 4, L2, R2, &why) && L2 == L && R2 == R);
+        // labels, comments, quoted names, bare numbers, an unrooted (trifurcating) root
+        assert(guideTreeFromNewick(" ( 'seq2':1e-3 , (3:0.1,seq1)x[c]:2 , SEQ4 ) root ;", 4, L2, R2, &why));
+        assert(L2[4] == 2 && R2[4] == 0 && L2[5] == 1 && R2[5] == 4 && L2[6] == 5 && R2[6] == 3);
+        assert(!guideTreeFromNewick("((seq1,seq2),seq3);", 4, L2, R2, &why) && why.find("missing") != std::string::npos);
+        assert(!guideTreeFromNewick("((seq1,seq2),(seq3,seq1));", 4, L2, R2, &why) && why.find("twice") != std::string::npos);
+        assert(!guideTreeFromNewick("((seq1,seq2),(seq3,seq4)", 4, L2, R2, &why));
+        assert(!guideTreeFromNewick("((seq1,genomeB),(seq3,seq4));", 4, L2, R2, &why));
+        assert(!guideTreeFromNewick("((seq1,seq2),(seq3,seq5));", 4, L2, R2, &why));
+        assert(!guideTreeFromNewick("(seq1,seq2));", 2, L2, R2, &why));
+        // three LCBs, the middle one inverted in sequence 1 and the order 3 -2 1 there
+        std::vector<int64_t> le = {10, 900, 400, -500, 800, 100}, la = {-1, 1, 0, 2, 1, -1}, ra = {1, -1, 2, 0, -1, 1};
+        std::ostringstream po; WritePermutation(po, 2, 3, le, la, ra);
+        assert(po.str() == "1\t2\t3\n3\t-2\t1\n\n");
+    }
     return 0;
 }

@@ -6,7 +6,10 @@
 //  3. a GappedAligner of the caller's own installed with Aligner::SetGappedAligner is called once per interval and,
 //     delegating to the built-in DP, reproduces the batched result;
 //  4. Aligner::align chains the match list it is given: with half the matches removed the anchors change.
+//  5. Aligner::SetPermutationOutput: a signed permutation per LCB set between the two weights, the last the aligned one;
+//  6. ProgressiveAligner with an output / input guide tree file: the written tree read back gives the same alignment.
 #include <cassert>
+#include <fstream>
 #include <iostream>
 #include <map>
 #include <set>
@@ -110,6 +113,42 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < nway.size(); i += 2) half.push_back(nway[i]);
         IntervalList il3; builtin.align(half, il3, 0, (int64)w * 3 * N, false, false, true, "");
         assert(il3.sizes.n_mums == (int64_t)half.size() && il3.sizes.n_anchor <= (int64_t)half.size() && il3.sizes.n_anchor > 0);
+        // 5. signed permutations of the LCB sets between two weights (mauveAligner.cpp:678-686)
+        {
+            const std::string pf = std::string(argv[1]) + ".perm";
+            Aligner pa(N); pa.SetGappedAligner(HipGappedAligner::getInterface()); pa.SetPermutationOutput(pf, (int64)w * N);
+            IntervalList il4; pa.align(nway, il4, 0, (int64)w * 3 * N, false, false, true, "");
+            std::ifstream in(pf.c_str()); std::string line; std::vector<std::vector<std::string>> sets(1);
+            while (std::getline(in, line)) { if (line.empty()) sets.emplace_back(); else sets.back().push_back(line); }
+            assert(sets.back().empty()); sets.pop_back();
+            assert(!sets.empty());
+            size_t prev = (size_t)-1;
+            for (const auto &set : sets) {
+                assert(set.size() == N);
+                std::vector<size_t> cnt;
+                for (const std::string &row : set) {                        // every row a signed permutation of 1..K
+                    std::istringstream is(row); long v; std::set<long> ids; while (is >> v) { assert(v != 0); ids.insert(std::labs(v)); }
+                    cnt.push_back(ids.size()); assert(!ids.empty() && *ids.begin() == 1 && *ids.rbegin() == (long)ids.size());
+                }
+                for (size_t g = 1; g < N; g++) assert(cnt[g] == cnt[0]);
+                { std::istringstream is(set[0]); long v, want = 1; while (is >> v) assert(v == want++); }    // sequence 0 is the identity
+                assert(cnt[0] <= prev); prev = cnt[0];                      // heavier minimum weight, fewer LCBs
+            }
+            assert(prev == (size_t)il4.sizes.n_lcb);                        // the last set is the one that was aligned
+        }
+        // 6. progressive alignment along the caller's guide tree (progressiveMauve.cpp:689-692)
+        if (N >= 3) {
+            const std::string tf = std::string(argv[1]) + ".tree";
+            ProgressiveAligner p1(N); p1.setOutputGuideTreeFileName(tf); IntervalList a1; p1.align(ml.seq_table, a1);
+            ProgressiveAligner p2(N); p2.setInputGuideTreeFileName(tf); IntervalList a2; p2.align(ml.seq_table, a2);
+            assert(a1.size() > 0 && xmfa(a1) == xmfa(a2) && p1.treeLeft() == p2.treeLeft() && p1.treeRight() == p2.treeRight());
+            { std::ofstream f(tf.c_str()); f << "(seq" << N << ",(seq1,seq2)"; for (uint g = 2; g + 1 < N; g++) f << ",seq" << g + 1; f << ");\n"; }
+            ProgressiveAligner p3(N); p3.setInputGuideTreeFileName(tf); IntervalList a3; p3.align(ml.seq_table, a3);
+            assert(a3.size() > 0 && p3.treeLeft()[N] == 0 && p3.treeRight()[N] == 1 && p3.treeLeft()[N + 1] == (int32_t)N - 1 && p3.treeRight()[N + 1] == (int32_t)N);
+            { std::ofstream f(tf.c_str()); f << "((seq1,seq2),seq1);\n"; }
+            bool threw = false; try { ProgressiveAligner p4(N); p4.setInputGuideTreeFileName(tf); IntervalList a4; p4.align(ml.seq_table, a4); } catch (genome::gnException &) { threw = true; }
+            assert(threw);
+        }
         std::cout << "callbacks " << oof.calls << ", matches " << dev.size() << ", repeats " << devrep.size() << ", plug calls " << ca.aligned << "\nOK" << std::endl;
         return 0;
     } catch (std::exception &e) {

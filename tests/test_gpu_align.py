@@ -645,13 +645,14 @@ def test_sharded_align_equals_whole(ctx):
         ctx.align_dp(np.array([0], np.int64), cap)
 
 
-def _same_progressive(ctx, gs, **kw):
+def _same_progressive(ctx, gs, tree=None, **kw):
     from mauvealigner_amd import _lib
     ctx.set_genomes(gs)
     names = ["g%d" % i for i in range(len(gs))]
-    r = ctx.progressive_align(_lib.default_params(**kw), names=names, want_xmfa=True)
-    e = O.progressive_align(gs, O.default_params(**kw), names=names, want_xmfa=True)
-    assert np.array_equal(r["dist"], e["dist"])
+    r = ctx.progressive_align(_lib.default_params(**kw), names=names, want_xmfa=True, tree=tree)
+    e = O.progressive_align(gs, O.default_params(**kw), names=names, want_xmfa=True, tree=tree)
+    if tree is None:
+        assert np.array_equal(r["dist"], e["dist"])
     assert np.array_equal(r["tree"][0], e["tree"][0]) and np.array_equal(r["tree"][1], e["tree"][1])
     a = e["aln"]
     assert r["n_iv"] == a["n_iv"]
@@ -660,6 +661,67 @@ def _same_progressive(ctx, gs, **kw):
     assert r["n_gap_dp"] == a["n_gap_dp"] and r["n_dp_cells"] == a["n_dp_cells"]
     assert r["xmfa"] == e["xmfa"]
     return r
+
+
+def _random_tree(N, rng):
+    """a random binary tree over N leaves in merge order (children before parents, root last)"""
+    left = np.full(2 * N - 1, -1, np.int32)
+    right = np.full(2 * N - 1, -1, np.int32)
+    roots = list(range(N))
+    for k in range(N, 2 * N - 1):
+        a, b = rng.choice(len(roots), 2, replace=False)
+        left[k], right[k] = roots[a], roots[b]
+        roots = [x for i, x in enumerate(roots) if i not in (a, b)] + [k]
+    return left, right
+
+
+def test_progressive_align_along_a_given_tree(ctx):
+    """--input-guide-tree (progressiveMauve.cpp:689-690; mauve_progressive_align_tree): the UPGMA tree handed back in
+    reproduces the default result; any other binary tree gives the oracle's result for that tree; what is not a
+    binary tree in merge order is refused."""
+    from mauvealigner_amd import _lib
+    gs = synth.make_config("C4", scale=0.02)
+    N = len(gs)
+    r0 = _same_progressive(ctx, gs)
+    r1 = _same_progressive(ctx, gs, tree=r0["tree"])
+    for k in ("left", "right", "reverse", "col_off", "cols", "dp_score"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert r0["xmfa"] == r1["xmfa"]
+    rng = np.random.default_rng(77)
+    differs = 0
+    for _ in range(3):
+        t = _random_tree(N, rng)
+        r = _same_progressive(ctx, gs, tree=t)
+        differs += r["xmfa"] != r0["xmfa"]
+        for g in range(N):                                   # still a partition of every genome
+            cover = np.zeros(len(gs[g]), np.int32)
+            for iv in range(r["n_iv"]):
+                if r["left"][iv, g]:
+                    cover[r["left"][iv, g] - 1:r["right"][iv, g]] += 1
+            assert np.all(cover == 1)
+    assert differs                                           # the tree does order the alignment
+    _same_progressive(ctx, gs, tree=_random_tree(N, rng), lcb_scoring=1)
+    gs3 = synth.make_config("C3", scale=0.01)
+    _same_progressive(ctx, gs3, tree=_random_tree(len(gs3), rng))
+    # refused: a leaf with children, a child used twice, a forward reference, a self pair, the wrong size
+    ctx.set_genomes(gs)
+    good = r0["tree"]
+    for mut in ("leaf", "twice", "forward", "self"):
+        left, right = good[0].copy(), good[1].copy()
+        if mut == "leaf":
+            left[0], right[0] = 1, 2
+        elif mut == "twice":
+            left[N + 1] = left[N]
+        elif mut == "forward":
+            left[N] = 2 * N - 2
+        else:
+            right[N] = left[N]
+        assert not O.check_tree(N, left, right)
+        with pytest.raises(RuntimeError):
+            ctx.progressive_align(_lib.default_params(), tree=(left, right))
+    with pytest.raises(ValueError):
+        ctx.progressive_align(_lib.default_params(), tree=(good[0][:-1], good[1][:-1]))
+    assert O.check_tree(N, good[0], good[1])
 
 
 def test_guide_tree_and_progressive_align(ctx):

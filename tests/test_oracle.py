@@ -199,6 +199,26 @@ def test_progressive_align_properties():
     assert rp["xmfa"] == ra["xmfa"]
 
 
+def test_progressive_align_given_tree():
+    """--input-guide-tree: the oracle's own UPGMA tree handed back in reproduces its result, another tree is a different
+    but complete alignment, and orc_check_tree refuses what is not a binary tree in merge order."""
+    gs = synth.make_config("C4", scale=0.01)[:4]
+    N = len(gs)
+    r0 = O.progressive_align(gs, want_xmfa=True)
+    r1 = O.progressive_align(gs, want_xmfa=True, tree=r0["tree"])
+    assert r0["xmfa"] == r1["xmfa"]
+    left = np.array([-1, -1, -1, -1, 0, 4, 5], np.int32)     # caterpillar ((0,3),1),2
+    right = np.array([-1, -1, -1, -1, 3, 1, 2], np.int32)
+    assert O.check_tree(N, left, right)
+    r2 = O.progressive_align(gs, want_xmfa=True, tree=(left, right))
+    _check_xmfa(r2["xmfa"], gs)
+    bad = left.copy(); bad[5] = 0                            # leaf 0 used twice
+    assert not O.check_tree(N, bad, right)
+    with pytest.raises(RuntimeError):
+        O.progressive_align(gs, tree=(bad, right))
+    assert not O.check_tree(N, left[:-1], right[:-1])
+
+
 def test_matches_canonical_order_and_content():
     gs = synth.make_config("C1", scale=0.05)
     pat = O.get_seed(11, 0)
