@@ -241,6 +241,24 @@ int mauve_progressive_align(mauve_ctx *ctx, const mauve_params *p, mauve_align_s
    with -1, every internal node with two distinct children of smaller id, root last; anything else is MAUVE_ERR_ARG. */
 int mauve_progressive_align_tree(mauve_ctx *ctx, const mauve_params *p, mauve_align_sizes *sizes,
                                  const int32_t *tree_left, const int32_t *tree_right);
+/* ---- backbone and islands: detectBackbone(iv_list, bb_list, &BigGapsDetector(island_gap_size)) of applyBackbone
+        (progressiveMauve.cpp:226-260, --island-gap-size :268) and simpleFindIslands / simpleFindBackbone
+        (mauveAligner.cpp:822,844-845).  libMems-internal; frozen form DESIGN.md S12: per genome pair, a run of more
+        than island_gap_size columns in which only one of the two has residues is an island; the pair is joined
+        outside the gap regions that hold an island or touch an end of the interval; a backbone segment is a connected
+        component (>= 2 genomes) of the joined pairs over a maximal run of columns.
+        mauve_backbone works on the alignment the context holds (after mauve_align* / mauve_progressive_align*, columns
+        still in HBM); mauve_backbone_alignment on the caller's (--apply-backbone, progressiveMauve.cpp:367-385).
+        Fetch: seg_iv/seg_col/seg_len[n_seg] (interval, first column in it, columns), seg_mask[n_seg] genomes,
+        seg_left/seg_right[n_seg*nseq] signed ends (negative = reverse strand, 0 = not in the segment);
+        islands[n_islands*8]: interval, a, b (a < b), the genome that has the residues, first column, last column,
+        its signed left and right end.  Order: interval, column, genome set / pair.  Any pointer may be NULL. ---- */
+int mauve_backbone(mauve_ctx *ctx, int64_t island_gap_size, int64_t *n_seg, int64_t *n_islands);
+int mauve_backbone_alignment(mauve_ctx *ctx, int nseq, int64_t n_iv, const int64_t *left, const int64_t *right,
+                             const int8_t *reverse, const int64_t *col_off, const uint32_t *cols,
+                             int64_t island_gap_size, int64_t *n_seg, int64_t *n_islands);
+int mauve_backbone_fetch(mauve_ctx *ctx, int64_t *seg_iv, int64_t *seg_col, int64_t *seg_len, uint32_t *seg_mask,
+                         int64_t *seg_left, int64_t *seg_right, int64_t *islands);
 /* IntervalList::WriteStandardAlignment (mauveAligner.cpp:746-760; format mfa2xmfa.cpp:64-115).
    Two-phase: buf == NULL returns the needed size (including NUL) in *len. */
 int mauve_write_xmfa(mauve_ctx *ctx, const char *const *names, char *buf, int64_t *len);

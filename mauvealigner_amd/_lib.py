@@ -26,6 +26,7 @@ EXPORTS = [
     "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_dp_batch_banded", "mauve_match_sp_scores", "mauve_align", "mauve_align_fetch",
     "mauve_align_matches", "mauve_align_begin", "mauve_align_begin_matches", "mauve_align_dp_anchors", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
     "mauve_guide_tree", "mauve_progressive_align", "mauve_progressive_align_tree",
+    "mauve_backbone", "mauve_backbone_alignment", "mauve_backbone_fetch",
     "mauve_write_xmfa", "mauve_profile_enable", "mauve_profile_reset", "mauve_profile_get", "mauve_last_stage_times",
 ]
 
@@ -439,6 +440,38 @@ class Context:
         out["tree"] = (left, right)
         out["dist"] = dist
         return out
+
+    def _backbone_fetch(self, n_seg, n_isl):
+        N = self._bb_nseq
+        out = {"seg_iv": np.zeros(n_seg, np.int64), "seg_col": np.zeros(n_seg, np.int64), "seg_len": np.zeros(n_seg, np.int64),
+               "seg_mask": np.zeros(n_seg, np.uint32), "seg_left": np.zeros((n_seg, N), np.int64),
+               "seg_right": np.zeros((n_seg, N), np.int64), "islands": np.zeros((n_isl, 8), np.int64)}
+        self._chk(self.L.mauve_backbone_fetch(self.h, _p(out["seg_iv"], C.c_int64), _p(out["seg_col"], C.c_int64), _p(out["seg_len"], C.c_int64),
+                                              _p(out["seg_mask"], C.c_uint32), _p(out["seg_left"], C.c_int64), _p(out["seg_right"], C.c_int64),
+                                              _p(out["islands"], C.c_int64)), "mauve_backbone_fetch")
+        return out
+
+    def backbone(self, island_gap=20, nseq=None):
+        """Backbone segments and islands of the alignment this context holds (mauve_backbone)."""
+        ns, ni = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.mauve_backbone(self.h, C.c_int64(island_gap), C.byref(ns), C.byref(ni)), "mauve_backbone")
+        self._bb_nseq = nseq or self.nseq
+        return self._backbone_fetch(ns.value, ni.value)
+
+    def backbone_alignment(self, left, right, reverse, col_off, cols, island_gap=20):
+        """... of the caller's alignment (mauve_backbone_alignment): left/right/reverse [n_iv, nseq], col_off [n_iv+1], cols."""
+        left = np.ascontiguousarray(left, np.int64)
+        right = np.ascontiguousarray(right, np.int64)
+        reverse = np.ascontiguousarray(reverse, np.int8)
+        col_off = np.ascontiguousarray(col_off, np.int64)
+        cols = np.ascontiguousarray(cols, np.uint32)
+        n_iv, N = left.shape
+        ns, ni = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.mauve_backbone_alignment(self.h, N, C.c_int64(n_iv), _p(left, C.c_int64), _p(right, C.c_int64), _p(reverse, C.c_int8),
+                                                  _p(col_off, C.c_int64), _p(cols if len(cols) else np.zeros(1, np.uint32), C.c_uint32),
+                                                  C.c_int64(island_gap), C.byref(ns), C.byref(ni)), "mauve_backbone_alignment")
+        self._bb_nseq = N
+        return self._backbone_fetch(ns.value, ni.value)
 
     def stage_times(self):
         t = StageTimes()

@@ -221,6 +221,14 @@ struct mauve_ctx {
     DevBuf as_work, as_isl, res_cols;    // device assembly (assemble_dev.hip): work area, islands, result columns
     PinnedBuf pin_asm, pin_cols;         // ... its per-LCB rows coming back; the columns and anchors on their way to a fetch
     PinnedBuf pin_chain;
+    // backbone / islands of the last alignment (backbone_dev.hip)
+    struct BackboneResult {
+        int N = 0; bool valid = false;
+        std::vector<int64_t> seg_iv, seg_col, seg_len, seg_left, seg_right, islands;
+        std::vector<uint32_t> seg_mask;
+    } bb;
+    DevBuf bb_cols, bb_work, bb_query;   // a caller's / a host-assembled column array; interval table + records; rank queries
+    size_t bb_rec_cap = 0;
     DevBuf run_sum;                      // pairwise finder: run list (start, length, exactly-once genome set)
     DevBuf rec_vinv, rec_vcm;            // ... and their ambiguity / contig bitmaps, when the resident genomes have them
     DevBuf rec_genomes, rec_seg;         // recursive anchoring: gap sub-sequences + segment table

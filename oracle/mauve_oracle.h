@@ -161,6 +161,20 @@ int orc_progressive_align(int nseq, const uint8_t *const *codes, const int64_t *
 int orc_check_tree(int nseq, const int32_t *tree_left, const int32_t *tree_right);
 int orc_progressive_align_tree(int nseq, const uint8_t *const *codes, const int64_t *lens, const orc_params *p,
                                const int32_t *tree_left, const int32_t *tree_right, orc_alignment *aln);
+/* backbone segments and pairwise islands of an alignment (stands in for libMems detectBackbone with
+   BigGapsDetector, progressiveMauve.cpp:242-243, and simpleFindIslands, mauveAligner.cpp:844) */
+typedef struct {
+    int32_t nseq;
+    int64_t n_seg;
+    int64_t *seg_iv, *seg_col, *seg_len;  /* [n_seg] interval, first column in it, columns */
+    uint32_t *seg_mask;                   /* [n_seg] genomes with residues in the segment (>= 2) */
+    int64_t *seg_left, *seg_right;        /* [n_seg*nseq] signed ends (negative = reverse), 0 = not in the segment */
+    int64_t n_isl;
+    int64_t *isl;                         /* [n_isl*8] interval, a, b (a < b), who has the residues, first col, last col, signed left, right */
+} orc_backbone;
+int orc_backbone_detect(int nseq, int64_t n_iv, const int64_t *left, const int64_t *right, const int8_t *reverse,
+                        const int64_t *col_off, const uint32_t *cols, int64_t island_gap, orc_backbone *out);
+void orc_free_backbone(orc_backbone *o);
 /* XMFA text (format pinned by mfa2xmfa.cpp:64,89-91,104-115); returns malloc'd NUL-terminated text */
 char *orc_write_xmfa(int nseq, const uint8_t *const *codes, const int64_t *lens,
                      const char *const *names, const orc_alignment *a, int64_t *text_len);

@@ -433,3 +433,39 @@ def progressive_align(codes, params=None, names=None, want_xmfa=False, tree=None
         lib().orc_free(C.c_void_p(ptr))
     lib().orc_free_alignment(C.byref(al))
     return {"aln": aln, "tree": (left, right), "dist": dist, "xmfa": xmfa}
+
+
+class Backbone(C.Structure):
+    _fields_ = [("nseq", C.c_int32), ("n_seg", C.c_int64), ("seg_iv", C.POINTER(C.c_int64)), ("seg_col", C.POINTER(C.c_int64)),
+                ("seg_len", C.POINTER(C.c_int64)), ("seg_mask", C.POINTER(C.c_uint32)), ("seg_left", C.POINTER(C.c_int64)),
+                ("seg_right", C.POINTER(C.c_int64)), ("n_isl", C.c_int64), ("isl", C.POINTER(C.c_int64))]
+
+
+def backbone(left, right, reverse, col_off, cols, island_gap=20):
+    """Backbone segments and pairwise islands of an alignment.  left/right/reverse: [n_iv, nseq].
+    -> dict(seg_iv, seg_col, seg_len, seg_mask, seg_left, seg_right, islands[n, 8])"""
+    left = np.ascontiguousarray(left, np.int64)
+    right = np.ascontiguousarray(right, np.int64)
+    reverse = np.ascontiguousarray(reverse, np.int8)
+    col_off = np.ascontiguousarray(col_off, np.int64)
+    cols = np.ascontiguousarray(cols, np.uint32)
+    niv, N = left.shape
+    if len(cols) == 0:
+        cols = np.zeros(1, np.uint32)
+    bb = Backbone()
+    rc = lib().orc_backbone_detect(N, C.c_int64(niv), left.ctypes.data_as(C.POINTER(C.c_int64)), right.ctypes.data_as(C.POINTER(C.c_int64)),
+                                   reverse.ctypes.data_as(C.POINTER(C.c_int8)), col_off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                   cols.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int64(island_gap), C.byref(bb))
+    if rc:
+        raise RuntimeError("orc_backbone_detect failed: %d" % rc)
+    n, ni = int(bb.n_seg), int(bb.n_isl)
+
+    def take(ptr, k, dt):
+        return np.ctypeslib.as_array(ptr, shape=(k,)).astype(dt).copy() if k else np.zeros(0, dt)
+    out = {
+        "seg_iv": take(bb.seg_iv, n, np.int64), "seg_col": take(bb.seg_col, n, np.int64), "seg_len": take(bb.seg_len, n, np.int64),
+        "seg_mask": take(bb.seg_mask, n, np.uint32), "seg_left": take(bb.seg_left, n * N, np.int64).reshape(n, N),
+        "seg_right": take(bb.seg_right, n * N, np.int64).reshape(n, N), "islands": take(bb.isl, ni * 8, np.int64).reshape(ni, 8),
+    }
+    lib().orc_free_backbone(C.byref(bb))
+    return out

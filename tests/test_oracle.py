@@ -219,6 +219,45 @@ def test_progressive_align_given_tree():
     assert not O.check_tree(N, left[:-1], right[:-1])
 
 
+def _cols_of(rows):
+    cols = np.zeros(len(rows[0]), np.uint32)
+    for g, r in enumerate(rows):
+        cols |= (np.frombuffer(r.encode(), np.uint8) != ord("-")).astype(np.uint32) << np.uint32(g)
+    return cols
+
+
+def test_backbone_oracle_known_answers():
+    """S12 on hand cases: islands, open regions at the ends, transitive components, reverse strands."""
+    # genome 1 lacks five columns: islands of 0 and of 2 against 1 when the gap limit is 3, none when it is 5
+    cols = _cols_of(["x" * 20, "x" * 10 + "-" * 5 + "x" * 5, "x" * 20])
+    left, right, rev = np.array([[1, 101, 201]]), np.array([[20, 115, 220]]), np.array([[0, 0, 1]], np.int8)
+    r = O.backbone(left, right, rev, [0, 20], cols, island_gap=3)
+    assert r["seg_mask"].tolist() == [7, 5, 7] and r["seg_col"].tolist() == [0, 10, 15] and r["seg_len"].tolist() == [10, 5, 5]
+    assert r["seg_left"].tolist() == [[1, 101, -211], [11, 0, -206], [16, 111, -201]]
+    assert r["seg_right"].tolist() == [[10, 110, -220], [15, 0, -210], [20, 115, -205]]
+    assert r["islands"].tolist() == [[0, 0, 1, 0, 10, 14, 11, 15], [0, 1, 2, 2, 10, 14, -206, -210]]
+    r = O.backbone(left, right, rev, [0, 20], cols, island_gap=5)
+    assert r["seg_mask"].tolist() == [7] and r["seg_len"].tolist() == [20] and len(r["islands"]) == 0
+    # ends: a pair is not joined before its first / after its last common column, however short the overhang
+    cols = _cols_of(["xxxxxxxx--", "--xxxxxxxx"])
+    r = O.backbone(np.array([[1, 1]]), np.array([[8, 8]]), np.zeros((1, 2), np.int8), [0, 10], cols, island_gap=20)
+    assert r["seg_col"].tolist() == [2] and r["seg_len"].tolist() == [6] and r["seg_left"].tolist() == [[3, 1]] and r["seg_right"].tolist() == [[8, 6]]
+    # two short one-sided runs of different genomes in a row are two runs, not one: no island at gap 3, both at gap 2
+    cols = _cols_of(["xx" + "xxx" + "---" + "xx", "xx" + "---" + "xxx" + "xx"])
+    lr = (np.array([[1, 1]]), np.array([[7, 7]]), np.zeros((1, 2), np.int8), [0, 10], cols)
+    assert O.backbone(*lr, island_gap=3)["seg_len"].tolist() == [10]
+    r = O.backbone(*lr, island_gap=2)
+    assert r["seg_col"].tolist() == [0, 8] and r["islands"][:, 3:6].tolist() == [[0, 2, 4], [1, 5, 7]]
+    # 0-1 share the first half, 1-2 the second, 0-2 never a column: two components, one after the other
+    cols = _cols_of(["xxxx----", "xxxxxxxx", "----xxxx"])
+    r = O.backbone(np.array([[1, 1, 1]]), np.array([[4, 8, 4]]), np.zeros((1, 3), np.int8), [0, 8], cols, island_gap=20)
+    assert r["seg_mask"].tolist() == [3, 6] and r["seg_col"].tolist() == [0, 4]
+    # columns neither genome of a pair has are skipped: the run of 0 against 1 is 4 + 4 columns around genome 2's insert
+    cols = _cols_of(["xx" + "xxxx" + "---" + "xxxx" + "xx", "xx" + "----" + "---" + "----" + "xx", "xx" + "----" + "xxx" + "----" + "xx"])
+    r = O.backbone(np.array([[1, 1, 1]]), np.array([[12, 4, 7]]), np.zeros((1, 3), np.int8), [0, 15], cols, island_gap=7)
+    assert [row[1:6] for row in r["islands"].tolist() if row[1:3] == [0, 1]] == [[0, 1, 0, 2, 12]]
+
+
 def test_matches_canonical_order_and_content():
     gs = synth.make_config("C1", scale=0.05)
     pat = O.get_seed(11, 0)
