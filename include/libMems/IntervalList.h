@@ -14,6 +14,7 @@ class IntervalList : public std::vector<Interval> {
 public:
     std::vector<genome::gnSequence *> seq_table;
     std::vector<std::string> seq_filename;
+    std::string backbone_filename;                       // progressiveMauve.cpp:259: the .bbcols file that goes with this list
     mauve_align_sizes sizes;
     IntervalList() { sizes = mauve_align_sizes(); }
 

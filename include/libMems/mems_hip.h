@@ -26,4 +26,6 @@
 #include "MuscleInterface.h"
 #include "Aligner.h"
 #include "ProgressiveAligner.h"
+#include "Backbone.h"
+#include "Islands.h"
 #endif

@@ -125,5 +125,47 @@ int main()
         std::ostringstream po; WritePermutation(po, 2, 3, le, la, ra);
         assert(po.str() == "1\t2\t3\n3\t-2\t1\n\n");
     }
+    // ---- .backbone / .bbcols files and the list helpers (progressiveMauve.cpp:245-258; bbFilter.cpp:75-90) ----
+    {
+        std::vector<bb_seqentry_t> rows;
+        auto row = [](int64 a, int64 b, int64 c, int64 d) { bb_seqentry_t r; r.push_back(std::make_pair(a, b)); r.push_back(std::make_pair(c, d)); return r; };
+        rows.push_back(row(101, 200, -900, -999));        // continues in both: forward 201.., reverse ..-899
+        rows.push_back(row(201, 260, -840, -899));
+        rows.push_back(row(300, 400, 0, 0));              // only sequence 0
+        rows.push_back(row(500, 600, 100, 200));
+        rows.push_back(row(601, 700, 250, 349));          // abuts in sequence 0 only: stays
+        std::ostringstream os; writeBackboneSeqFile(os, rows);
+        assert(os.str().find("seq0_leftend\tseq0_rightend\tseq1_leftend\tseq1_rightend\n101\t200\t-900\t-999\n") == 0);
+        std::istringstream is(os.str()); std::vector<bb_seqentry_t> back; readBackboneSeqFile(is, back);
+        assert(back == rows);
+        mergeAdjacentSegments(back);
+        assert(back.size() == 4 && back[0] == row(101, 260, -840, -999) && back[1] == row(300, 400, 0, 0));
+        addUniqueSegments(back, 20);
+        // sequence 0: 1-100, 261-299, 401-499; sequence 1: 1-99, 201-249, 350-839
+        size_t uniq0 = 0, uniq1 = 0;
+        for (const bb_seqentry_t &r : back) { if (r[0].first && !r[1].first && r != row(300, 400, 0, 0)) uniq0++; if (!r[0].first && r[1].first) uniq1++; }
+        assert(uniq0 == 3 && uniq1 == 3);
+        bool found = false; for (const bb_seqentry_t &r : back) found = found || r == row(0, 0, 350, 839);
+        assert(found);
+        std::istringstream bad("1\t2\t3\t4\n"); bool threw2 = false;
+        try { readBackboneSeqFile(bad, back); } catch (genome::gnException &) { threw2 = true; }
+        assert(threw2);
+        backbone_list_t bl(2);
+        BackboneSegment b; b.iv = 1; b.left_col = 7; b.length = 30; b.genomes = 5; b.ends.resize(3); b.ends[0] = std::make_pair(10, 39); b.ends[2] = std::make_pair(-61, -90);
+        bl[1].push_back(b);
+        assert(b.Multiplicity() == 2 && b.LeftEnd(2) == 61 && b.RightEnd(2) == 90 && b.Length(2) == 30 && b.Length(1) == 0);
+        std::ostringstream oc; writeBackboneColumns(oc, bl);
+        assert(oc.str() == "1\t7\t30\t0\t2\n");
+        std::istringstream ic(oc.str()); std::vector<bb_colentry_t> cl; readBackboneColsFile(ic, cl);
+        assert(cl.size() == 1 && cl[0].first == 1 && cl[0].second.size() == 4 && cl[0].second[1] == 30 && cl[0].second[3] == 2);
+        bb_entry_t e; e.bb_seq = b.ends; e.bb_cols = cl[0].second; e.iv = cl[0].first;       // bbAnalyze.cpp:1007-1012
+        assert(e.iv == 1 && e.bb_seq.size() == 3);
+        IntervalList il; std::ostringstream o2; writeBackboneSeqCoordinates(bl, il, o2);
+        assert(o2.str().find("10\t39\t0\t0\t-61\t-90\n") != std::string::npos);
+        genome::gnSequence sa("GGCCAT"), sb("ATATGC"); std::vector<genome::gnSequence *> st; st.push_back(&sa); st.push_back(&sb);
+        assert(computeGC(st) == 0.5);
+        Params hp = getAdaptedHoxdMatrixParameters(0.5); hp.iGoHomologous = 1e-5; hp.iGoUnrelated = 1e-9; adaptToPercentIdentity(hp, 0.7);
+        assert(hp.identity == 0.7);
+    }
     return 0;
 }

@@ -8,6 +8,8 @@
 //  4. Aligner::align chains the match list it is given: with half the matches removed the anchors change.
 //  5. Aligner::SetPermutationOutput: a signed permutation per LCB set between the two weights, the last the aligned one;
 //  6. ProgressiveAligner with an output / input guide tree file: the written tree read back gives the same alignment.
+//  7. the backbone stage as applyBackbone calls it (detectBackbone with a BigGapsDetector, the .backbone / .bbcols writers and
+//     readers) and simpleFindBackbone / simpleFindIslands / findIslandsBetweenLCBs: segment ends agree with the columns.
 #include <cassert>
 #include <fstream>
 #include <iostream>
@@ -149,6 +151,70 @@ int main(int argc, char **argv)
             bool threw = false; try { ProgressiveAligner p4(N); p4.setInputGuideTreeFileName(tf); IntervalList a4; p4.align(ml.seq_table, a4); } catch (genome::gnException &) { threw = true; }
             assert(threw);
         }
+        // 7. applyBackbone as progressiveMauve.cpp:226-260 writes it, and mauveAligner's backbone / island outputs (:807-847)
+        size_t n_bb = 0;
+        {
+            IntervalList &iv_list = il1;
+            backbone_list_t bb_list;
+            Params hmm_params = getAdaptedHoxdMatrixParameters(computeGC(iv_list.seq_table));
+            hmm_params.iGoHomologous = 0.00001; hmm_params.iGoUnrelated = 0.000000001;
+            adaptToPercentIdentity(hmm_params, 0.7);
+            detectAndApplyBackbone(iv_list, bb_list, hmm_params);
+            bb_list.clear();
+            BigGapsDetector bgd(20);
+            detectBackbone(iv_list, bb_list, &bgd);
+            assert(bb_list.size() == iv_list.size());
+            for (size_t i = 0; i < bb_list.size(); i++)
+                for (const BackboneSegment &b : bb_list[i]) {
+                    n_bb++;
+                    assert(b.iv == i && b.Multiplicity() >= 2 && b.left_col + b.length <= iv_list[i].AlignmentLength());
+                    const std::vector<uint32_t> &cols = iv_list[i].Columns();
+                    for (uint g = 0; g < N; g++) {                      // the ends are what the columns of the segment hold
+                        gnSeqI inside = 0, before = 0;
+                        for (gnSeqI cI = 0; cI < b.left_col + b.length; cI++) { const bool r = cols[(size_t)cI] >> g & 1; if (cI < b.left_col) before += r; else inside += r; }
+                        if (!(b.genomes >> g & 1)) { assert(b.Start(g) == 0); continue; }
+                        assert(inside == b.Length(g) && inside > 0);
+                        if (iv_list[i].Orientation(g) == AbstractMatch::forward) assert(b.Start(g) > 0 && b.LeftEnd(g) == iv_list[i].LeftEnd(g) + before);
+                        else assert(b.Start(g) < 0 && b.RightEnd(g) == iv_list[i].RightEnd(g) - before);
+                    }
+                }
+            assert(n_bb >= (size_t)iv_list.sizes.n_lcb && n_bb > 0);      // every LCB holds backbone
+            std::ostringstream bb_out; writeBackboneSeqCoordinates(bb_list, iv_list, bb_out);
+            std::vector<bb_seqentry_t> bb_seq_list; std::istringstream bbseq_input(bb_out.str()); readBackboneSeqFile(bbseq_input, bb_seq_list);
+            assert(bb_seq_list.size() == n_bb);
+            mergeAdjacentSegments(bb_seq_list); addUniqueSegments(bb_seq_list);
+            std::ostringstream bb_final; writeBackboneSeqFile(bb_final, bb_seq_list);
+            std::ostringstream bbcols; writeBackboneColumns(bbcols, bb_list);
+            std::istringstream bbcols_in(bbcols.str()); std::vector<bb_colentry_t> colrows; readBackboneColsFile(bbcols_in, colrows);
+            assert(colrows.size() == n_bb);
+            iv_list.backbone_filename = "x.bbcols";
+            // the other detector plug is refused, not ignored
+            HssDetector other; bool threw = false; try { detectBackbone(iv_list, bb_list, &other); } catch (genome::gnException &) { threw = true; }
+            assert(threw);
+            std::vector<GappedAlignment> backbone_data; simpleFindBackbone(iv_list, 50, 20, backbone_data);
+            assert(!backbone_data.empty());
+            for (const GappedAlignment &ga : backbone_data)
+                for (uint g = 0; g < N; g++) {
+                    size_t bases = 0; for (char ch : ga.GetAlignment()[g]) bases += ch != '-';
+                    assert(ga.Length(g) >= 50 && bases == ga.Length(g) && ga.Start(g) != 0);
+                }
+            std::ostringstream bbtxt; outputBackbone(backbone_data, bbtxt); assert(!bbtxt.str().empty());
+            std::ostringstream isl; simpleFindIslands(iv_list, 1, isl);
+            std::istringstream isl_in(isl.str()); std::string ln; size_t rows_isl = 0; while (std::getline(isl_in, ln)) rows_isl++;
+            size_t runs = 0;                                          // one-sided runs of every pair, counted column by column
+            for (const Interval &iv : iv_list)
+                for (uint x = 0; x < N; x++) for (uint y = x + 1; y < N; y++) {
+                    if (!iv.LeftEnd(x) || !iv.LeftEnd(y)) continue;
+                    int prev = 0;
+                    for (uint32_t m : iv.Columns()) { const int t = (int)(m >> x & 1) | (int)(m >> y & 1) << 1; if (!t) continue; if (t != 3 && t != prev) runs++; prev = t; }
+                }
+            assert(rows_isl == runs);
+            std::ostringstream between; findIslandsBetweenLCBs(iv_list, 1, between);
+            size_t singles = 0; for (const Interval &iv : iv_list) singles += iv.Multiplicity() == 1;
+            std::istringstream btw_in(between.str()); size_t rows_btw = 0; while (std::getline(btw_in, ln)) rows_btw++;
+            assert(rows_btw <= singles && (singles == 0) == (rows_btw == 0));   // leftovers between LCBs; adjacent ones print as one
+        }
+        std::cout << "backbone segments " << n_bb << "\n";
         std::cout << "callbacks " << oof.calls << ", matches " << dev.size() << ", repeats " << devrep.size() << ", plug calls " << ca.aligned << "\nOK" << std::endl;
         return 0;
     } catch (std::exception &e) {

@@ -59,6 +59,18 @@ def test_c3_full_size_equals_oracle(ctx):
     r2 = ctx.align(_lib.default_params(seed_weight=15))
     for k in KEYS:
         assert np.array_equal(r[k], r2[k]), k
+    # the backbone stage on the columns this alignment left in HBM, at full size against the oracle
+    import time
+    ctx.align(_lib.default_params(seed_weight=15), fetch=False)
+    ctx.backbone(island_gap=20)                               # first call sizes its buffers
+    t0 = time.perf_counter()
+    b = ctx.backbone(island_gap=20)
+    dt = time.perf_counter() - t0
+    eb = O.backbone(e["left"], e["right"], e["reverse"], e["col_off"], e["cols"], island_gap=20)
+    for k in ("seg_iv", "seg_col", "seg_len", "seg_mask", "seg_left", "seg_right", "islands"):
+        assert np.array_equal(b[k], eb[k]), k
+    assert len(b["seg_iv"]) >= r["n_lcb"] and len(b["islands"]) > 10
+    print("backbone at C3: %d segments, %d islands, %.2f ms" % (len(b["seg_iv"]), len(b["islands"]), dt * 1e3))
 
 
 def test_c4_full_size_progressive_equals_oracle(ctx):
