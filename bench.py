@@ -245,6 +245,26 @@ def main():
         acc = accuracy.score_alignment(gpu_result, origins)
         acc = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in acc.items()}
 
+    # ---- the same workload with the reference's default lcb_extension on (mauveAligner.cpp:95), and the
+    # backbone stage on the columns the pass left in HBM: reported beside `value`, never part of it ----
+    if rank == 0 and world == 1:
+        from mauvealigner_amd import accuracy
+        n2 = max(3, args.steps // 2)
+        pe = _lib.default_params(seed_weight=weight, extend_lcbs=1)
+        ctx.align(pe, fetch=False)
+        e4, _, _ = time_steps(ctx, pe, n2, barrier)
+        acc_e = accuracy.score_alignment(ctx.align(pe), origins)
+        extras["with_lcb_extension"] = {"ms_per_step": round(e4 / n2 * 1e3, 3), "Mbp_s": round(total_bp / 1e6 / (e4 / n2), 1),
+                                        "sensitivity": round(acc_e["sensitivity"], 5), "ppv": round(acc_e["ppv"], 5)}
+        ctx.align(params, fetch=False)
+        ctx.backbone(island_gap=20)
+        t0 = time.perf_counter()
+        for _ in range(n2):
+            bb = ctx.backbone(island_gap=20)
+        eb = time.perf_counter() - t0
+        extras["backbone"] = {"ms_per_call": round(eb / n2 * 1e3, 3), "segments": int(len(bb["seg_iv"])), "islands": int(len(bb["islands"])),
+                              "island_gap": 20}
+
     # ---- CPU baseline: the oracle on the same workload, host cores of this box ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

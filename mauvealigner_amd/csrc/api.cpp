@@ -63,7 +63,7 @@ void mauve_ctx_destroy(mauve_ctx *c)
                       &c->dp_prof_cnt, &c->dp_prof_mask, &c->dp_prof2_cnt, &c->dp_prof2_mask, &c->dp_tb, &c->dp_meta,
                       &c->dp_score, &c->dp_cols, &c->dp_rows};
     for (DevBuf *b : bufs) b->release();
-    c->pin_genomes.release(); c->pin_chain.release(); c->pin_asm.release(); c->pin_cols.release(); c->pin_anch.release(); c->pin_dcols.release(); c->pin_meta.release(); c->pin_seed.release(); c->pin_dp_in.release();
+    c->pin_genomes.release(); c->pin_chain.release(); c->pin_mask.release(); c->pin_asm.release(); c->pin_cols.release(); c->pin_anch.release(); c->pin_dcols.release(); c->pin_meta.release(); c->pin_seed.release(); c->pin_dp_in.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);

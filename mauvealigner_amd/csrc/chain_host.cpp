@@ -34,6 +34,22 @@ void sort_by_left(std::vector<uint64_t> &k, std::vector<uint64_t> &tmp)
 }
 }  // namespace
 
+// per-genome left-end order of an overlap-free list (what host_eliminate_overlaps would hand to host_lcb_chain)
+void host_left_orders(const MatchVec &m, ChainOrders &orders)
+{
+    const int N = m.N; const size_t n = m.size();
+    orders.ord.resize((size_t)N); orders.sparse = false;
+    static thread_local std::vector<uint64_t> key, tmp;
+    for (int g = 0; g < N; g++) {
+        key.resize(n);
+        for (size_t i = 0; i < n; i++) key[i] = ((uint64_t)std::llabs(m.st(i)[g]) << 32) | (uint64_t)i;
+        sort_by_left(key, tmp);
+        std::vector<uint32_t> &o = orders.ord[(size_t)g];
+        o.resize(n);
+        for (size_t r = 0; r < n; r++) o[r] = (uint32_t)key[r];
+    }
+}
+
 void MatchVec::sort_by_start0()
 {
     const size_t n = size();

@@ -221,6 +221,7 @@ struct mauve_ctx {
     DevBuf as_work, as_isl, res_cols;    // device assembly (assemble_dev.hip): work area, islands, result columns
     PinnedBuf pin_asm, pin_cols;         // ... its per-LCB rows coming back; the columns and anchors on their way to a fetch
     PinnedBuf pin_chain;
+    PinnedBuf pin_mask;                  // LCB extension: the valid-piece bitmap on its way to placed_mask
     // backbone / islands of the last alignment (backbone_dev.hip)
     struct BackboneResult {
         int N = 0; bool valid = false;
@@ -339,6 +340,7 @@ int chain_order_device(mauve_ctx *c, int N, int64_t nl, int64_t min_gap, int64_t
 struct ChainOrders { std::vector<std::vector<uint32_t>> ord; bool sparse = false; };   // per genome: match indices in left-end order;
                                                                                         // sparse: the list still holds dead records (not named here)
 void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders = nullptr, bool compact = true);
+void host_left_orders(const MatchVec &m, ChainOrders &orders);       // per-genome left-end order of an overlap-free list
 void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb,
                     const ChainOrders *orders = nullptr, const int64_t *match_weight = nullptr);
 // extant sum-of-pairs scores of the matches of m (n components; gmap: their genomes, nullptr = 0..n-1), assemble_dev.hip

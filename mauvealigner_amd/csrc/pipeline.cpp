@@ -40,12 +40,15 @@ static int extend_lcbs(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
     const int N = m.N;
     const uint32_t full = N >= 32 ? 0xffffffffu : ((1u << N) - 1);
     int w_e = w;
+    MatchVec base(N); ChainOrders base_ord; bool have_base = false;         // the surviving anchors and their per-genome orders
     for (int iter = 0; iter < p->max_extension_iters; iter++) {
         w_e -= 2;
         if (w_e < 5) break;
         const uint64_t pe = mauve_get_seed(w_e, 0);
         if (!pe) break;
         const int64_t span_e = mauve_seed_length(pe);
+        static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+        const double tr0 = now_ms();
         // LCB extents
         std::vector<int64_t> lo((size_t)nl * N, 0), hi((size_t)nl * N, 0);
         int64_t cols_before = 0;
@@ -64,13 +67,15 @@ static int extend_lcbs(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
         gs.mask_off.assign((size_t)N, 0);
         size_t words = 0;
         for (int g = 0; g < N; g++) { gs.mask_off[(size_t)g] = words; words += (size_t)((c->lens[g] + 63) / 64) + 2; }
-        std::vector<uint64_t> bits(words, ~0ULL);
+        HIPCHK(c, c->pin_mask.ensure(words * 8));
+        uint64_t *bits = c->pin_mask.as<uint64_t>();
+        memset(bits, 0xff, words * 8);
         bool starved = false;
         std::vector<std::pair<int64_t, int64_t>> sp((size_t)nl);
         for (int g = 0; g < N && !starved; g++) {
             for (int64_t l = 0; l < nl; l++) sp[(size_t)l] = {lo[(size_t)l * N + g], hi[(size_t)l * N + g]};
             std::sort(sp.begin(), sp.end());
-            uint64_t *M = bits.data() + gs.mask_off[(size_t)g];
+            uint64_t *M = bits + gs.mask_off[(size_t)g];
             int64_t cur = 1; bool any = false;
             for (int64_t l = 0; l <= nl; l++) {
                 const int64_t vlo = cur, vhi = l < nl ? sp[(size_t)l].first - 1 : c->lens[g];
@@ -90,13 +95,15 @@ static int extend_lcbs(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
         if (starved) break;
         if (c->has_invalid) for (size_t k = 0; k < words && k < c->h_invalid.size(); k++) bits[k] |= c->h_invalid[k];     // same word layout
         HIPCHK(c, c->placed_mask.ensure(words * 8));
-        HIPCHK(c, hipMemcpyAsync(c->placed_mask.p, bits.data(), words * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        gs.vmask = &c->placed_mask;
+        HIPCHK(c, hipMemcpyAsync(c->placed_mask.p, bits, words * 8, hipMemcpyHostToDevice, c->stream));
+        gs.vmask = &c->placed_mask;          // (the seed pass syncs the stream before the staging buffer is touched again)
         int64_t nx = 0;
+        const double tr1 = now_ms();
         int rc = seedpass_run(c, gs, pe, MAUVE_MODE_MEM, full, 1, nullptr, 0, &nx);
         if (rc) return rc;
+        if (trace) fprintf(stderr, "[trace] lcb extension round %d: mask %.3f ms, seed pass %.3f ms, %lld new matches\n", iter, tr1 - tr0, now_ms() - tr1, (long long)nx);
         if (nx == 0) continue;
+        const double tr2 = now_ms();
         // survivors + new matches, canonical order (both lists already are: merge)
         auto less = [N](const int64_t *a, const int64_t *b) {                // N-way records: |start0|, starts, length
             const int64_t sa = std::llabs(a[1]), sb = std::llabs(b[1]);
@@ -109,21 +116,80 @@ static int extend_lcbs(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
             ext.len((size_t)i) = c->match_len[(size_t)i];
             std::copy(&c->match_start[(size_t)i * N], &c->match_start[(size_t)i * N] + N, ext.st((size_t)i));
         }
-        MatchVec comb(N); comb.reserve(m.size() + ext.size());
-        size_t a = 0, b = 0;
-        while (a < m.size() && match_lcb[a] < 0) a++;
-        while (a < m.size() || b < ext.size()) {
-            const bool take_a = b >= ext.size() || (a < m.size() && !less(ext.rec(b), m.rec(a)));
-            if (take_a) { comb.push(m.rec(a)); a++; while (a < m.size() && match_lcb[a] < 0) a++; }
-            else { comb.push(ext.rec(b)); b++; }
+        // The new matches lie outside every LCB extent in every genome, the surviving anchors inside: a new match can
+        // only overlap another new one.  Overlap elimination of the merged list is therefore the elimination among the
+        // new matches alone (a handful) next to the untouched anchors, and the per-genome orders of the merged list
+        // are the anchors' orders with the new matches slipped in -- no sort of the whole list per round.
+        if (!have_base) {
+            base.d.clear();
+            for (size_t i = 0; i < m.size(); i++) if (match_lcb[i] >= 0) base.push(m.rec(i));
+            host_left_orders(base, base_ord);
+            have_base = true;
         }
-        ChainOrders orders;
-        host_eliminate_overlaps(comb, &orders);
+        host_eliminate_overlaps(ext);
+        const size_t nb = base.size(), ne = ext.size();
+        // merged list: the few new records go in at their places (binary search), the anchors move in blocks
+        const size_t R1 = (size_t)(1 + N);
+        std::vector<size_t> ins(ne);                                         // new record b goes before anchor ins[b]
+        for (size_t b = 0; b < ne; b++) {
+            size_t lo2 = b ? ins[b - 1] : 0, hi2 = nb;
+            while (lo2 < hi2) { const size_t mid = (lo2 + hi2) / 2; if (less(ext.rec(b), base.rec(mid))) hi2 = mid; else lo2 = mid + 1; }
+            ins[b] = lo2;
+        }
+        MatchVec comb(N); comb.d.resize((nb + ne) * R1);
+        std::vector<uint32_t> at_b(nb), at_e(ne);                            // where the records went
+        for (size_t b = 0, a = 0; b <= ne; b++) {
+            const size_t a_end = b < ne ? ins[b] : nb;
+            std::copy(base.d.begin() + (std::ptrdiff_t)(a * R1), base.d.begin() + (std::ptrdiff_t)(a_end * R1), comb.d.begin() + (std::ptrdiff_t)((a + b) * R1));
+            for (size_t x = a; x < a_end; x++) at_b[x] = (uint32_t)(x + b);
+            a = a_end;
+            if (b < ne) { at_e[b] = (uint32_t)(a + b); std::copy(ext.rec(b), ext.rec(b) + R1, comb.d.begin() + (std::ptrdiff_t)((a + b) * R1)); }
+        }
+        ChainOrders orders; orders.ord.resize((size_t)N);
+        std::vector<uint32_t> eo(ne);
+        for (int g = 0; g < N; g++) {
+            for (size_t k = 0; k < ne; k++) eo[k] = (uint32_t)k;
+            std::sort(eo.begin(), eo.end(), [&](uint32_t x, uint32_t y) { return std::llabs(ext.st(x)[g]) < std::llabs(ext.st(y)[g]); });
+            const std::vector<uint32_t> &bo = base_ord.ord[(size_t)g];
+            std::vector<uint32_t> &o = orders.ord[(size_t)g];
+            o.resize(nb + ne);
+            size_t a = 0;
+            for (size_t b = 0; b <= ne; b++) {
+                size_t a_end = nb;
+                if (b < ne) {                                                // first anchor (in this genome's order) right of the new match
+                    const int64_t key = std::llabs(ext.st(eo[b])[g]);
+                    size_t lo2 = a, hi2 = nb;
+                    while (lo2 < hi2) { const size_t mid = (lo2 + hi2) / 2; if (std::llabs(base.st(bo[mid])[g]) < key) lo2 = mid + 1; else hi2 = mid; }
+                    a_end = lo2;
+                }
+                for (size_t x = a; x < a_end; x++) o[x + b] = at_b[bo[x]];
+                a = a_end;
+                if (b < ne) o[a + b] = at_e[eo[b]];
+            }
+        }
         std::vector<int64_t> ml2; int64_t nl2 = 0;
+        const double tr3 = now_ms();
         host_lcb_chain(comb, lcbw, p->collinear != 0, ml2, nl2, &orders);
+        if (trace) fprintf(stderr, "[trace] lcb extension round %d: merge %.3f ms, lcb %.3f ms\n", iter, tr3 - tr2, now_ms() - tr3);
         int64_t cols_after = 0;
         for (size_t i = 0; i < comb.size(); i++) if (ml2[i] >= 0) cols_after += comb.len(i);
-        if (cols_after > cols_before) { m.d.swap(comb.d); match_lcb.swap(ml2); nl = nl2; }
+        if (cols_after > cols_before) {
+            // the anchors of the next round: what survived this one, orders thinned and renumbered accordingly
+            bool all_alive = true;
+            for (size_t i = 0; i < comb.size() && all_alive; i++) all_alive = ml2[i] >= 0;
+            if (all_alive) { base.d = comb.d; base_ord.ord.swap(orders.ord); }
+            else {
+                std::vector<uint32_t> renum(comb.size(), 0xffffffffu);
+                base.d.clear();
+                for (size_t i = 0; i < comb.size(); i++) if (ml2[i] >= 0) { renum[i] = (uint32_t)base.size(); base.push(comb.rec(i)); }
+                for (int g = 0; g < N; g++) {
+                    std::vector<uint32_t> &bo = base_ord.ord[(size_t)g];
+                    bo.clear();
+                    for (uint32_t x : orders.ord[(size_t)g]) if (renum[x] != 0xffffffffu) bo.push_back(renum[x]);
+                }
+            }
+            m.d.swap(comb.d); match_lcb.swap(ml2); nl = nl2;
+        }
     }
     return MAUVE_OK;
 }
