@@ -342,7 +342,8 @@ int mauve_backbone(mauve_ctx *c, int64_t island_gap_size, int64_t *n_seg, int64_
     if (!c || !n_seg || !n_islands) return MAUVE_ERR_ARG;
     AlignResult &R = c->res;
     const int64_t n_iv = R.sz.n_iv;
-    if ((int64_t)R.col_off.size() != n_iv + 1 || n_iv == 0) { c->err = "backbone: no alignment in this context"; return MAUVE_ERR_STATE; }
+    if ((int64_t)R.col_off.size() != n_iv + 1) { c->err = "backbone: no alignment in this context"; return MAUVE_ERR_STATE; }
+    if (n_iv == 0) { c->bb = mauve_ctx::BackboneResult(); c->bb.N = c->nseq; c->bb.valid = true; *n_seg = *n_islands = 0; return MAUVE_OK; }   // nothing was aligned
     const int N = (int)(R.iv_left.size() / (size_t)n_iv);
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t *d_cols;

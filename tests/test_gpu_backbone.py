@@ -167,6 +167,12 @@ def test_backbone_of_the_resident_alignment(ctx):
     _same(r, e)
     assert len(set(r["seg_mask"].tolist())) > 1              # clade-specific backbone next to the all-genome one
     _partition_checks(r, p, len(gs4))
+    # an alignment that kept nothing (no LCB reaches the weight, leftovers not listed) has an empty backbone
+    ctx.set_genomes(gs)
+    z = ctx.align(_lib.default_params(lcb_weight=10 ** 9, add_unaligned=0))
+    assert z["n_iv"] == 0
+    r = ctx.backbone()
+    assert len(r["seg_iv"]) == 0 and len(r["islands"]) == 0
     # error behaviour: nothing aligned yet in a fresh context, gap out of range
     c2 = _lib.Context(0)
     with pytest.raises(RuntimeError):
