@@ -57,5 +57,16 @@ private:
     uint seq_;
 };
 
+// the same order over match objects held by value (unalign.cpp:53-54 sorts an IntervalList with it)
+template <class MatchType>
+class AbstractMatchStartComparator {
+public:
+    explicit AbstractMatchStartComparator(uint seq = 0) : seq_(seq) {}
+    bool operator()(const MatchType &a, const MatchType &b) const { return std::llabs(a.Start(seq_)) < std::llabs(b.Start(seq_)); }
+    bool operator()(const MatchType *a, const MatchType *b) const { return (*this)(*a, *b); }
+private:
+    uint seq_;
+};
+
 }  // namespace mems
 #endif

@@ -104,6 +104,37 @@ inline void computeLCBAdjacencies_v2(std::vector<MatchList> &lcb_list, const std
     }
 }
 
+// the same table over the intervals of an alignment, each interval one LCB (toGrimmFormat.cpp:54, sortContigs.cpp:58)
+inline void computeLCBAdjacencies_v2(IntervalList &iv_list, const std::vector<int64> &weights, std::vector<LCB> &adjacencies)
+{
+    const size_t K = iv_list.size();
+    adjacencies.assign(K, LCB());
+    if (!K) return;
+    uint N = (uint)iv_list.seq_table.size();
+    for (const Interval &iv : iv_list) N = std::max(N, iv.SeqCount());
+    for (size_t l = 0; l < K; l++) {
+        LCB &b = adjacencies[l]; const Interval &iv = iv_list[l];
+        b.lcb_id = (int)l; b.weight = l < weights.size() ? (double)weights[l] : 0;
+        b.left_end.assign(N, 0); b.right_end.assign(N, 0);
+        b.left_adjacency.assign(N, ADJACENCY_UNSET); b.right_adjacency.assign(N, ADJACENCY_UNSET);
+        for (uint g = 0; g < iv.SeqCount(); g++) {
+            if (!iv.LeftEnd(g)) continue;
+            const bool rev = iv.Orientation(g) == AbstractMatch::reverse;
+            b.left_end[g] = rev ? -(int64)iv.LeftEnd(g) : (int64)iv.LeftEnd(g); b.right_end[g] = rev ? -(int64)iv.RightEnd(g) : (int64)iv.RightEnd(g);
+        }
+    }
+    std::vector<size_t> idx;
+    for (uint g = 0; g < N; g++) {
+        idx.clear();
+        for (size_t l = 0; l < K; l++) if (adjacencies[l].left_end[g]) idx.push_back(l);      // intervals without the sequence keep the -2 sentinel
+        std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return std::llabs(adjacencies[a].left_end[g]) < std::llabs(adjacencies[b].left_end[g]); });
+        for (size_t r = 0; r < idx.size(); r++) {
+            adjacencies[idx[r]].left_adjacency[g] = r > 0 ? (int64)idx[r - 1] : NO_ADJACENCY;
+            adjacencies[idx[r]].right_adjacency[g] = r + 1 < idx.size() ? (int64)idx[r + 1] : NO_ADJACENCY;
+        }
+    }
+}
+
 // mauveAligner.cpp:634: the starts of every match in sequence seqI, in list order
 inline void transposeMatches(MatchList &ml, uint seqI, std::vector<int64> &starts)
 {

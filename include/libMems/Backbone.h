@@ -12,6 +12,8 @@
 #define MAUVE_HIP_BACKBONE_H
 
 #include "IntervalList.h"
+#include "dynamic_bitset.h"
+#include <cmath>
 #include <algorithm>
 #include <cstdlib>
 #include <sstream>

@@ -1,16 +1,16 @@
 // libMems/CompactGappedAlignment.h -- the bit-matrix form of a gapped block (repeatoire.cpp:1316-1318,1347;
 // MatchRecord.h:341-343; scoreProcrastAlignment.cpp:292-298; bbBreakOnGenes.cpp:154-155): one bitset per sequence,
-// bit = residue present in the column; SeqPosToColumn, copyRange.  `bitset_t` stands in for boost::dynamic_bitset<>.
+// bit = residue present in the column; SeqPosToColumn, copyRange.  `bitset_t` (dynamic_bitset.h) stands in for boost::dynamic_bitset<>.
 #ifndef MAUVE_HIP_COMPACTGAPPEDALIGNMENT_H
 #define MAUVE_HIP_COMPACTGAPPEDALIGNMENT_H
 
 #include <algorithm>
 #include "GappedAlignment.h"
 #include "Interval.h"
+#include "dynamic_bitset.h"
 
 namespace mems {
 
-typedef std::vector<bool> bitset_t;
 
 template <class BaseType = AbstractMatch>
 class CompactGappedAlignment : public AbstractMatch {
@@ -58,7 +58,7 @@ public:
     virtual void CropEnd(gnSeqI cols) { crop_cols(aln_len_ - cols, aln_len_); }
     virtual void CropLeft(gnSeqI amount, uint seqI) { if (start_[seqI] > 0) CropStart(cols_for(seqI, amount, true)); else CropEnd(cols_for(seqI, amount, false)); }
     virtual void CropRight(gnSeqI amount, uint seqI) { if (start_[seqI] > 0) CropEnd(cols_for(seqI, amount, false)); else CropStart(cols_for(seqI, amount, true)); }
-    virtual void Invert() { for (size_t i = 0; i < bits_.size(); i++) { std::reverse(bits_[i].begin(), bits_[i].end()); start_[i] = -start_[i]; } }
+    virtual void Invert() { for (size_t i = 0; i < bits_.size(); i++) { bits_[i].reverse(); start_[i] = -start_[i]; } }
     virtual void GetColumn(gnSeqI col, std::vector<gnSeqI> &pos, std::vector<bool> &column) const
     {
         pos.assign(start_.size(), 0); column.assign(start_.size(), false);
@@ -96,7 +96,7 @@ private:
                 len_[i] -= gone;
                 if (len_[i] == 0) start_[i] = NO_MATCH;
             }
-            bits_[i].erase(bits_[i].begin() + (long)a, bits_[i].begin() + (long)b);
+            bits_[i].erase_range((size_t)a, (size_t)b);
         }
         aln_len_ -= b - a;
     }

@@ -8,6 +8,8 @@
 
 #include "GappedAlignment.h"
 #include "PairwiseScoringScheme.h"
+#include "GuideTree.h"
+#include <fstream>
 #include "SortedMerList.h"
 
 namespace mems {
@@ -70,6 +72,28 @@ public:
     void SetScoring(const PairwiseScoringScheme &p) { pss_ = p; }
     void SetExtraMuscleArguments(const std::string &) {}                     // mauveAligner.cpp:374-376: nothing to pass on
     void ParseMusclePath(const char *) {}
+    // mi.CreateTree(distance, tree_filename) (mauveAligner.cpp:619-622): UPGMA with the merge rule of mauve_guide_tree
+    // (closest pair, ties to the lowest ids, average linkage) over the caller's matrix, written as NEWICK (GuideTree.h)
+    template <class MatrixT> void CreateTree(const MatrixT &distance, const std::string &tree_filename)
+    {
+        const int N = (int)distance.rows(), M = 2 * N - 1;
+        if (N < 2) throw genome::gnException("CreateTree: at least two sequences required");
+        std::vector<double> D((size_t)M * M, 0.0); std::vector<int64_t> size((size_t)M, 1), ppm((size_t)N * N, 0);
+        std::vector<int32_t> left((size_t)M, -1), right((size_t)M, -1); std::vector<char> active((size_t)M, 0);
+        for (int i = 0; i < N; i++) { active[(size_t)i] = 1; for (int j = 0; j < N; j++) { D[(size_t)i * M + j] = distance(i, j); ppm[(size_t)i * N + j] = (int64_t)(distance(i, j) * 1e6 + 0.5); } }
+        for (int k = N; k < M; k++) {
+            int ba = -1, bb = -1; double bd = 0;
+            for (int a = 0; a < k; a++) if (active[(size_t)a]) for (int b = a + 1; b < k; b++) if (active[(size_t)b])
+                if (ba < 0 || D[(size_t)a * M + b] < bd) { ba = a; bb = b; bd = D[(size_t)a * M + b]; }
+            left[(size_t)k] = ba; right[(size_t)k] = bb; size[(size_t)k] = size[(size_t)ba] + size[(size_t)bb];
+            for (int x = 0; x < k; x++) if (active[(size_t)x] && x != ba && x != bb)
+                D[(size_t)k * M + x] = D[(size_t)x * M + k] = ((double)size[(size_t)ba] * D[(size_t)ba * M + x] + (double)size[(size_t)bb] * D[(size_t)bb * M + x]) / (double)size[(size_t)k];
+            active[(size_t)ba] = active[(size_t)bb] = 0; active[(size_t)k] = 1;
+        }
+        std::ofstream out(tree_filename.c_str());
+        if (!out) throw genome::gnException("CreateTree: cannot write " + tree_filename);
+        out << guideTreeToNewick(N, left, right, ppm);
+    }
     virtual bool CallMuscleFast(std::vector<std::string> &aln_out, const std::vector<std::string> &seqs_in, int gap_open, int gap_extend)
     {
         const int N = (int)seqs_in.size();

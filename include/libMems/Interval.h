@@ -7,27 +7,45 @@
 #define MAUVE_HIP_INTERVAL_H
 
 #include "AbstractMatch.h"
+#include <algorithm>
 
 namespace mems {
 
 // One Interval is one block of the alignment: for every genome its range and strand (absent: left = right = 0)
 // and, per alignment column, the set of genomes that have a base there.  The bases themselves stay in seq_table.
-class Interval {
+class Interval : public AbstractMatch {
 public:
     Interval() {}
     // Interval iv(begin, end) over AbstractMatch* (stripGapColumns.cpp:61-63): the matches are flattened into one block
     template <class It> Interval(It begin, It end) { std::vector<AbstractMatch *> v(begin, end); SetMatches(v); }
     Interval(const std::vector<int64> &left, const std::vector<int64> &right, const std::vector<char> &reverse,
              const std::vector<uint32_t> &cols) : left_(left), right_(right), rev_(reverse), cols_(cols) {}
-    uint SeqCount() const { return (uint)left_.size(); }
-    gnSeqI LeftEnd(uint seqI) const { return (gnSeqI)left_[seqI]; }                       // toGrimmFormat.cpp:62-77
-    gnSeqI RightEnd(uint seqI) const { return (gnSeqI)right_[seqI]; }
-    gnSeqI Length(uint seqI) const { return left_[seqI] ? (gnSeqI)(right_[seqI] - left_[seqI] + 1) : 0; }
-    int64 Start(uint seqI) const { return rev_[seqI] ? -left_[seqI] : left_[seqI]; }      // signed, NO_MATCH when absent
-    AbstractMatch::orientation Orientation(uint seqI) const
-    { return left_[seqI] == NO_MATCH ? AbstractMatch::undefined : (rev_[seqI] ? AbstractMatch::reverse : AbstractMatch::forward); }
-    uint Multiplicity() const { uint m = 0; for (int64 l : left_) m += l != NO_MATCH; return m; }
-    gnSeqI AlignmentLength() const { return (gnSeqI)cols_.size(); }
+    // An interval is a match like any other (libMems: Interval is an AbstractMatch -- extractBackbone.cpp:71-72 pushes
+    // them into a vector<AbstractMatch*>, stripSubsetLCBs.cpp:130-137 crops them, projectAndStrip.cpp:104 inverts them);
+    // LeftEnd / RightEnd / Orientation / Multiplicity / FirstStart come from the base (toGrimmFormat.cpp:62-77).
+    virtual AbstractMatch *Copy() const { return new Interval(*this); }
+    Interval *Clone() const { return new Interval(*this); }
+    virtual uint SeqCount() const { return (uint)left_.size(); }
+    virtual gnSeqI Length(uint seqI) const { return left_[seqI] ? (gnSeqI)(right_[seqI] - left_[seqI] + 1) : 0; }
+    virtual int64 Start(uint seqI) const { return rev_[seqI] ? -left_[seqI] : left_[seqI]; }      // signed, NO_MATCH when absent
+    virtual void SetStart(uint seqI, int64 start)
+    {
+        if (seqI >= left_.size()) { left_.resize(seqI + 1, 0); right_.resize(seqI + 1, 0); rev_.resize(seqI + 1, 0); }
+        const int64 len = (int64)Length(seqI);
+        left_[seqI] = std::llabs(start); rev_[seqI] = start < 0; right_[seqI] = start ? left_[seqI] + len - 1 : 0;
+    }
+    virtual void SetLength(gnSeqI len, uint seqI) { if (left_[seqI]) right_[seqI] = left_[seqI] + (int64)len - 1; }
+    virtual gnSeqI AlignmentLength() const { return (gnSeqI)cols_.size(); }
+    virtual void CropStart(gnSeqI n) { crop_cols(0, std::min<gnSeqI>(n, cols_.size())); }
+    virtual void CropEnd(gnSeqI n) { const gnSeqI k = std::min<gnSeqI>(n, cols_.size()); crop_cols(cols_.size() - k, cols_.size()); }
+    virtual void CropLeft(gnSeqI amount, uint seqI) { if (!rev_[seqI]) CropStart(cols_for(seqI, amount, true)); else CropEnd(cols_for(seqI, amount, false)); }
+    virtual void CropRight(gnSeqI amount, uint seqI) { if (!rev_[seqI]) CropEnd(cols_for(seqI, amount, false)); else CropStart(cols_for(seqI, amount, true)); }
+    virtual void Invert()
+    {
+        std::reverse(cols_.begin(), cols_.end());
+        for (size_t g = 0; g < rev_.size(); g++) if (left_[g]) rev_[g] = !rev_[g];
+        matches_.clear();
+    }
     const std::vector<uint32_t> &Columns() const { return cols_; }
     // SetMatches(vector&) STEALS the vector's contents (MatchRecord.h:338-339; getAlignmentWindows.cpp:64,71): the
     // matches, in order, become the block's columns -- the block keeps them (GetMatches / StealMatches give them back).
@@ -40,7 +58,7 @@ public:
     const std::vector<AbstractMatch *> &GetMatches() const { return matches_; }
     void StealMatches(std::vector<AbstractMatch *> &out) { out.swap(matches_); matches_.clear(); }
     // presence and 1-based position of every genome's residue in column col (coordinateTranslate.cpp:41)
-    void GetColumn(gnSeqI col, std::vector<gnSeqI> &pos, std::vector<bool> &column) const
+    virtual void GetColumn(gnSeqI col, std::vector<gnSeqI> &pos, std::vector<bool> &column) const
     {
         const uint N = SeqCount();
         pos.assign(N, 0); column.assign(N, false);
@@ -78,6 +96,28 @@ public:
         return "ACGT"[complement ? 3 - code : code];
     }
 private:
+    // columns [a, b) leave the block: every genome's range shrinks by the bases it had there, at the end they sat on
+    void crop_cols(gnSeqI a, gnSeqI b)
+    {
+        if (b <= a) return;
+        const bool at_start = a == 0;
+        for (size_t g = 0; g < left_.size(); g++) {
+            if (!left_[g]) continue;
+            int64 k = 0; for (gnSeqI c = a; c < b; c++) k += cols_[(size_t)c] >> g & 1;
+            if (at_start != (rev_[g] != 0)) left_[g] += k; else right_[g] -= k;
+            if (right_[g] < left_[g]) { left_[g] = right_[g] = 0; rev_[g] = 0; }
+        }
+        cols_.erase(cols_.begin() + (std::ptrdiff_t)a, cols_.begin() + (std::ptrdiff_t)b);
+        matches_.clear();                            // the flattened columns are the block now
+    }
+    // columns to drop so that `amount` bases of sequence seqI go: counted from the first column or from the last
+    gnSeqI cols_for(uint seqI, gnSeqI amount, bool from_start) const
+    {
+        gnSeqI seen = 0, n = 0;
+        const size_t L = cols_.size();
+        while (n < L && seen < amount) { const size_t c = from_start ? n : L - 1 - n; seen += cols_[c] >> seqI & 1; n++; }
+        return n;
+    }
     void rebuild()                                   // ranges, strands and column masks from the matches, in order
     {
         left_.clear(); right_.clear(); rev_.clear(); cols_.clear();
@@ -106,6 +146,9 @@ private:
     std::vector<AbstractMatch *> matches_;           // only when built by SetMatches
 };
 
+
+// GetAlignment(iv, seq_table, rows) (stripGapColumns.cpp:36): the gapped rows of an interval, bases from the sequences
+inline void GetAlignment(const Interval &iv, const std::vector<genome::gnSequence *> &seq_table, std::vector<std::string> &rows) { iv.GetAlignment(rows, seq_table); }
 
 }  // namespace mems
 #endif

@@ -7,6 +7,10 @@
 #include <sstream>
 #include "Interval.h"
 #include "SortedMerList.h"
+#include "MatchList.h"                  // LoadSequences(IntervalList&, ostream*) is reached through this header (backbone_global_to_local.cpp:21)
+#include <set>
+#include <map>
+#include <cmath>
 
 namespace mems {
 
@@ -14,6 +18,7 @@ class IntervalList : public std::vector<Interval> {
 public:
     std::vector<genome::gnSequence *> seq_table;
     std::vector<std::string> seq_filename;
+    std::vector<std::string> defline_name;               // per sequence: the name an XMFA that was read carried in its deflines (else the file name is written)
     std::string backbone_filename;                       // progressiveMauve.cpp:259: the .bbcols file that goes with this list
     mauve_align_sizes sizes;
     IntervalList() { sizes = mauve_align_sizes(); }
@@ -49,7 +54,7 @@ public:
             for (uint g = 0; g < N && g < iv.SeqCount(); g++) {
                 if (!iv.LeftEnd(g)) continue;
                 os << "> " << g + 1 << ':' << iv.LeftEnd(g) << '-' << iv.RightEnd(g) << ' ' << (iv.Orientation(g) == AbstractMatch::reverse ? '-' : '+')
-                   << ' ' << name(g) << '\n';
+                   << ' ' << defname(g) << '\n';
                 for (size_t pos = 0; pos < rows[g].size(); pos += 80) os << rows[g].substr(pos, 80) << '\n';
             }
             os << "=\n";
@@ -61,7 +66,7 @@ public:
     // as with libMems the caller loads the sequences named in seq_filename.
     void ReadStandardAlignment(std::istream &is)
     {
-        clear(); seq_filename.clear();
+        clear(); seq_filename.clear(); defline_name.clear();
         std::string line;
         struct Row { uint g; int64 lo, hi; bool rev; std::string txt; };
         std::vector<std::vector<Row>> blocks(1);
@@ -85,6 +90,11 @@ public:
                 if (sscanf(line.c_str(), "> %u:%lld-%lld %c", &g, &lo, &hi, &strand) < 3 || g < 1) throw genome::gnException("ReadStandardAlignment: bad defline: " + line);
                 if (g > MAUVE_MAX_SEQ) throw genome::gnException("ReadStandardAlignment: sequence index beyond the 32 this library aligns: " + line);
                 r.g = g - 1; r.lo = lo; r.hi = hi; r.rev = strand == '-';
+                {   // the name behind the strand sign: kept, so that what is read is written back as it was (mfa2xmfa.cpp:104-105 puts the record name there)
+                    size_t p = line.find(' ', 2); if (p != std::string::npos) p = line.find(' ', p + 1);
+                    if (defline_name.size() < g) defline_name.resize(g);
+                    if (p != std::string::npos && defline_name[g - 1].empty()) defline_name[g - 1] = line.substr(p + 1);
+                }
                 N = std::max(N, (uint)g);
                 blocks.back().push_back(r);
                 continue;
@@ -174,6 +184,7 @@ public:
     }
 private:
     std::string name(uint g) const { return g < seq_filename.size() ? seq_filename[g] : std::string(); }
+    std::string defname(uint g) const { return g < defline_name.size() && !defline_name[g].empty() ? defline_name[g] : name(g); }
 };
 
 

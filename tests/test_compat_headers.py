@@ -203,6 +203,63 @@ def test_reference_plugins_compile_unmodified():
         subprocess.check_call([exe])        # construction and Clone only: nothing here needs a GPU
 
 
+REFERENCE_TOOLS = [
+    "UniqueMatchFinder.cpp", "addUnalignedIntervals.cpp", "backbone_global_to_local.cpp", "bbFilter.cpp", "calculateBackboneCoverage.cpp",
+    "calculateCoverage.cpp", "coordinateTranslate.cpp", "countInPlaceInversions.cpp", "extractBackbone.cpp", "extractBackbone2.cpp",
+    "gappiness.cpp", "makeBadgerMatrix.cpp", "makeMc4Matrix.cpp", "mauveToXMFA.cpp", "mfa2xmfa.cpp", "sortContigs.cpp", "stripGapColumns.cpp",
+    "toEvoHighwayFormat.cpp", "toGrimmFormat.cpp", "toRawSequence.cpp", "transposeCoordinates.cpp", "uniqueMerCount.cpp",
+]
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree not present")
+@pytest.mark.parametrize("tool", REFERENCE_TOOLS)
+def test_reference_tools_compile_unmodified(tool):
+    """The in-tree programs that need nothing but libMems / libGenome (no boost, no tree or annotation classes) compile
+    unmodified, where they lie, against -I include: the data model, the LCB helpers, the stage-seam readers and writers,
+    the backbone files and the libGenome sequence / FastA surface they use are all there under the names they use."""
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-w", "-I" + os.path.join(ROOT, "include"), os.path.join(REFERENCE, tool)])
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree not present")
+def test_reference_mfa2xmfa_runs_on_the_mirror():
+    """src/mfa2xmfa.cpp -- the in-tree twin of the XMFA writer -- built from its own source against the mirror's
+    libGenome and RUN: the XMFA it writes is read by IntervalList::ReadStandardAlignment and written back byte for byte
+    by WriteStandardAlignment (80-column wrap, deflines, header, terminator), and the FastA it writes through
+    gnFASSource::Write is the ungapped input."""
+    rng = np.random.default_rng(3)
+    rows = []
+    L = 437                                                   # several wrapped lines and a ragged last one
+    for g in range(4):
+        r = rng.choice(list("ACGT"), L)
+        gaps = rng.random(L) < (0.05 + 0.1 * g)
+        r[gaps] = "-"
+        rows.append("".join(r)[:L - 7 * g])                   # shorter entries: the tool pads them with gaps
+    with tempfile.TemporaryDirectory() as td:
+        mfa = os.path.join(td, "in.mfa")
+        with open(mfa, "w") as f:
+            for g, r in enumerate(rows):
+                f.write(">seq_%d some words\n" % g)
+                for p in range(0, len(r), 61):
+                    f.write(r[p:p + 61] + "\n")
+        inc = os.path.join(ROOT, "include")
+        tool = os.path.join(td, "mfa2xmfa")
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-I" + inc, os.path.join(REFERENCE, "mfa2xmfa.cpp"), "-o", tool])
+        xmfa, fa = os.path.join(td, "out.xmfa"), os.path.join(td, "un.fa")
+        subprocess.check_call([tool, mfa, xmfa, fa])
+        text = open(xmfa).read()
+        assert text.startswith("#FormatVersion Mauve1\n#Sequence1File\t" + fa + "\n#Sequence1Entry\t1\n#Sequence1Format\tFastA\n")
+        for g, r in enumerate(rows):
+            assert "> %d:1-%d + seq_%d some words\n" % (g + 1, len(r.replace("-", "")), g) in text
+        assert text.endswith("=\n")
+        got = open(fa).read().split(">")[1:]
+        assert ["".join(x.split("\n")[1:]) for x in got] == [r.replace("-", "") for r in rows]
+        rt = os.path.join(td, "rt")
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + inc, os.path.join(ROOT, "tests", "cpp", "xmfa_roundtrip.cpp"), "-o", rt,
+                               "-L" + os.path.join(ROOT, "mauvealigner_amd"), "-lmauve_hip", "-Wl,-rpath," + os.path.join(ROOT, "mauvealigner_amd")])
+        r = subprocess.run([rt, xmfa], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout == text, r.stderr
+
+
 def test_data_model_host_classes():
     """GappedAlignment, CompactGappedAlignment, MatchProjectionAdapter, Interval::SetMatches / GetColumn, the LCB
     helpers (struct LCB, IdentifyBreakpoints, ComputeLCBs_v2, computeLCBAdjacencies_v2, EliminateOverlaps,
