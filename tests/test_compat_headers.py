@@ -260,6 +260,46 @@ def test_reference_mfa2xmfa_runs_on_the_mirror():
         assert r.returncode == 0 and r.stdout == text, r.stderr
 
 
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree not present")
+def test_oracle_xmfa_blocks_equal_what_mfa2xmfa_writes():
+    """The oracle's XMFA writer against the reference's own formatting code: every all-forward block of an oracle
+    alignment, handed to src/mfa2xmfa.cpp (built on the mirror's libGenome) as a multi-FastA of its gapped rows, comes
+    back as the same block text -- deflines, 80-column wrap, terminator -- up to the coordinates, which mfa2xmfa counts
+    from 1."""
+    import re
+    from oracle import pyoracle as O
+    from mauvealigner_amd import synth
+    gs = synth.make_config("C1", scale=0.05)
+    names = ["genomeA.fa", "genomeB.fa"]
+    text = O.align(gs, O.default_params(), names=names, want_xmfa=True)["xmfa"]
+    body = text[text.index("> "):]
+    blocks = [b for b in body.split("=\n") if b.strip()]
+    checked = 0
+    with tempfile.TemporaryDirectory() as td:
+        tool = os.path.join(td, "mfa2xmfa")
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-I" + os.path.join(ROOT, "include"), os.path.join(REFERENCE, "mfa2xmfa.cpp"), "-o", tool])
+        for b in blocks:
+            heads = re.findall(r"^> (\d+):(\d+)-(\d+) ([+-]) (.*)$", b, re.M)
+            if len(heads) < 2 or any(h[3] == "-" for h in heads):
+                continue
+            parts = re.split(r"^> .*$", b, flags=re.M)[1:]
+            rows = ["".join(p.split()) for p in parts]
+            mfa = os.path.join(td, "b.mfa")
+            with open(mfa, "w") as f:
+                for h, r in zip(heads, rows):
+                    f.write(">%s\n%s\n" % (h[4], r))
+            out = os.path.join(td, "b.xmfa")
+            subprocess.check_call([tool, mfa, out])
+            want = re.sub(r"^> (\d+):(\d+)-(\d+) ", lambda m: "> %s:1-%d " % (m.group(1), int(m.group(3)) - int(m.group(2)) + 1), b, flags=re.M) + "=\n"
+            # mfa2xmfa numbers the rows 1..k in file order; the oracle's block may skip absent genomes
+            got = open(out).read()
+            for k, h in enumerate(heads):
+                got = got.replace("> %d:1-" % (k + 1), "> %s:1-" % h[0], 1) if str(k + 1) != h[0] else got
+            assert got == want
+            checked += 1
+    assert checked >= 1
+
+
 def test_data_model_host_classes():
     """GappedAlignment, CompactGappedAlignment, MatchProjectionAdapter, Interval::SetMatches / GetColumn, the LCB
     helpers (struct LCB, IdentifyBreakpoints, ComputeLCBs_v2, computeLCBAdjacencies_v2, EliminateOverlaps,
