@@ -7,6 +7,7 @@
 #define MAUVE_HIP_INTERVAL_H
 
 #include "AbstractMatch.h"
+#include "gnAlignedSequences.h"
 #include <algorithm>
 
 namespace mems {
@@ -46,6 +47,7 @@ public:
         for (size_t g = 0; g < rev_.size(); g++) if (left_[g]) rev_[g] = !rev_[g];
         matches_.clear();
     }
+    void CalculateOffset() {}                                  // extractSubalignments.cpp:24: the ranges are always current here
     const std::vector<uint32_t> &Columns() const { return cols_; }
     // SetMatches(vector&) STEALS the vector's contents (MatchRecord.h:338-339; getAlignmentWindows.cpp:64,71): the
     // matches, in order, become the block's columns -- the block keeps them (GetMatches / StealMatches give them back).
@@ -86,6 +88,18 @@ public:
                 nxt += rev_[g] ? -1 : 1;
             }
         }
+    }
+    // GetAlignedSequences(gnas, seq_table) (scoreAlignment.cpp:191, mauveAligner.cpp:770): the same rows; a sequence the
+    // table does not cover (scoreAlignment hands in empty ones: it only asks where the gaps are) shows its bases as N
+    void GetAlignedSequences(gnAlignedSequences &gnas, const std::vector<genome::gnSequence *> &seq_table) const
+    {
+        const uint N = SeqCount();
+        gnas.sequences.assign(N, std::string(cols_.size(), '-')); gnas.names.assign(N, std::string());
+        std::vector<std::string> rows;
+        bool covered = true;
+        for (uint g = 0; g < N && covered; g++) covered = !left_[g] || (g < seq_table.size() && seq_table[g] && (gnSeqI)right_[g] <= seq_table[g]->length());
+        if (covered) { GetAlignment(rows, seq_table); gnas.sequences = rows; return; }
+        for (uint g = 0; g < N; g++) if (left_[g]) for (size_t k = 0; k < cols_.size(); k++) if (cols_[k] >> g & 1) gnas.sequences[g][k] = 'N';
     }
     // upper case A C G T (complemented on the reverse strand); every other letter of the input is written as N, as
     // mauve_write_xmfa does (the device path keeps a bitmap of the ambiguous bases, not their letters)
