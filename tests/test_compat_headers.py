@@ -205,9 +205,10 @@ def test_reference_plugins_compile_unmodified():
 
 REFERENCE_TOOLS = [
     "UniqueMatchFinder.cpp", "addUnalignedIntervals.cpp", "backbone_global_to_local.cpp", "bbFilter.cpp", "calculateBackboneCoverage.cpp",
-    "calculateCoverage.cpp", "coordinateTranslate.cpp", "countInPlaceInversions.cpp", "extractBackbone.cpp", "extractBackbone2.cpp",
-    "gappiness.cpp", "makeBadgerMatrix.cpp", "makeMc4Matrix.cpp", "mauveToXMFA.cpp", "mfa2xmfa.cpp", "sortContigs.cpp", "stripGapColumns.cpp",
-    "toEvoHighwayFormat.cpp", "toGrimmFormat.cpp", "toRawSequence.cpp", "transposeCoordinates.cpp", "uniqueMerCount.cpp",
+    "calculateCoverage.cpp", "coordinateTranslate.cpp", "countInPlaceInversions.cpp", "createBackboneMFA.cpp", "extractBackbone.cpp",
+    "extractBackbone2.cpp", "extractSubalignments.cpp", "gappiness.cpp", "makeBadgerMatrix.cpp", "makeMc4Matrix.cpp", "mauveToXMFA.cpp",
+    "mfa2xmfa.cpp", "scoreAlignment.cpp", "sortContigs.cpp", "stripGapColumns.cpp", "toEvoHighwayFormat.cpp", "toGrimmFormat.cpp",
+    "toMultiFastA.cpp", "toRawSequence.cpp", "transposeCoordinates.cpp", "uniqueMerCount.cpp",
 ]
 
 
