@@ -19,10 +19,11 @@ public:
     explicit ProgressiveAligner(uint seq_count) : seq_count_(seq_count), tree_left_(2 * seq_count - 1, -1), tree_right_(2 * seq_count - 1, -1)
     {
         mauve_default_params(&p_);
+        p_.weight_scaling = 1; p_.conservation_scale_ppm = 500000;       // the library's defaults: scaling on, scale 0.5 (progressiveMauve.cpp:285-287)
     }
     // --weight, :584-593: a length (x seq_count) under LengthScoring, a score under the sum-of-pairs scheme
     void setBreakpointPenalty(double w) { if (w >= 0) bp_penalty_ = w; }
-    void setMinimumBreakpointPenalty(double) {}
+    void setMinimumBreakpointPenalty(double w) { if (w >= 0) p_.min_scaled_penalty = (int64_t)w; }   // :649-652: floor of the scaled weight
     void setCollinear(boolean c) { p_.collinear = c; }                        // :594-597
     void setGappedAlignment(boolean g) { p_.gapped = g; }                     // --skip-gapped-alignment
     void setRefinement(boolean) {}                                            // :578-579 (no refinement stage)
@@ -39,9 +40,12 @@ public:
     // reconstruction and fall back to it as well.  LengthScoring (not in libMems) keeps the Aligner::align weights.
     enum LcbScoringScheme { AncestralScoring, AncestralSumOfPairsScoring, ExtantSumOfPairsScoring, LengthScoring };
     void setLcbScoringScheme(int s) { p_.lcb_scoring = s == LengthScoring ? MAUVE_LCB_SCORE_LENGTH : MAUVE_LCB_SCORE_SP; score_set_ = true; }
-    void setUseLcbWeightScaling(boolean) {}                                   // :626-642
-    void setBreakpointDistanceScale(double) {}                                // :628-635: scales of libMems' penalty
-    void setConservationDistanceScale(double) {}                              // scaling, which S11 does not have
+    // :626-637.  The conservation-distance factor is live (a node's minimum LCB weight shrinks with the
+    // mean pairwise distance between its two subtrees); the breakpoint-distance factor needs libMems' internal pairwise
+    // breakpoint estimate and is not reproduced (its two knobs are accepted).
+    void setUseLcbWeightScaling(boolean b) { p_.weight_scaling = b ? 1 : 0; }
+    void setBreakpointDistanceScale(double) {}                                // :628-632 (see above)
+    void setConservationDistanceScale(double d) { if (d >= 0 && d <= 1) p_.conservation_scale_ppm = (int32_t)(d * 1e6 + 0.5); }
     void setBpDistEstimateMinScore(double) {}
     // :689-692.  The input tree replaces the UPGMA one (mauve_progressive_align_tree); the output file receives the
     // tree the alignment used, NEWICK both ways with leaves seq1..seqN (GuideTree.h).

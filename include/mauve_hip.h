@@ -72,7 +72,11 @@ typedef struct {
     int32_t lcb_scoring;          /* ProgressiveAligner::setLcbScoringScheme (progressiveMauve.cpp:611-625): MAUVE_LCB_SCORE_LENGTH
                                      (0, default: weight = sum of length * n, the Aligner::align rule) or MAUVE_LCB_SCORE_SP (1: extant
                                      sum-of-pairs score of the anchors); lcb_weight is then a score */
-    int32_t reserved0;
+    int32_t weight_scaling;   /* progressive path: scale every node's minimum LCB weight by the conservation distance of its two
+                                 subtrees (ProgressiveAligner::setUseLcbWeightScaling, progressiveMauve.cpp:626-627); default 0 */
+    int32_t conservation_scale_ppm;   /* setConservationDistanceScale in parts per million (:633-637; call-site default 0.5 = 500000) */
+    int32_t reserved1;
+    int64_t min_scaled_penalty;       /* setMinimumBreakpointPenalty (:649-652): floor of the scaled weight; default 0 */
 } mauve_params;
 
 /* sizes of the result of mauve_align(), for the caller to allocate the fill buffers */

@@ -63,6 +63,7 @@ inline void gap_of(const int64_t *a, const int64_t *b, int g, int64_t &lo, int64
 struct Prog {
     mauve_ctx *c; const mauve_params *p; int N;
     std::vector<int32_t> left, right;
+    std::vector<int64_t> dist;         // [N*N] ppm, filled when the node weights are scaled
     std::vector<FreePool> rest;        // per genome: bases not placed in any block yet
     AlignResult *R;
     int64_t n_gap_dp = 0, n_cells = 0, n_anchor = 0, n_multi = 0;
@@ -151,15 +152,28 @@ int prog_node(Prog &P, int node)
     }
     ChainOrders orders;
     host_eliminate_overlaps(m, &orders);
-    const int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight * n / P.N : (int64_t)3 * w * n;
+    int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight * n / P.N : (int64_t)3 * w * n;
+    // the node's minimum weight shrinks with the conservation distance between its two subtrees
+    int64_t factor_ppm = 1000000;
+    const bool scaled = p->weight_scaling && !P.dist.empty();
+    if (scaled) {
+        std::vector<int> la, lb;
+        leaves_of(P, P.left[node], la); leaves_of(P, P.right[node], lb);
+        int64_t sum = 0;
+        for (int a : la) for (int b : lb) sum += P.dist[(size_t)a * P.N + b];
+        const int64_t c_ppm = sum / ((int64_t)la.size() * (int64_t)lb.size());
+        factor_ppm = std::max<int64_t>(0, 1000000 - (int64_t)p->conservation_scale_ppm * c_ppm / 1000000);
+        lcbw = std::max(lcbw * factor_ppm / 1000000, p->min_scaled_penalty);
+    }
     std::vector<int64_t> match_lcb; int64_t nl = 0;
     if (p->lcb_scoring == MAUVE_LCB_SCORE_SP) {
         std::vector<int64_t> mw;
         rc = match_sp_scores(c, m, gm.data(), &p->scoring, mw);
         if (rc) return rc;
         // a given score threshold is for all N genomes: scaled by the node's share of the pairs
-        const int64_t minw = p->lcb_weight >= 0 ? p->lcb_weight * ((int64_t)n * (n - 1) / 2) / ((int64_t)P.N * (P.N - 1) / 2)
-                                                : sp_default_min_weight(w, n, &p->scoring);
+        int64_t minw = p->lcb_weight >= 0 ? p->lcb_weight * ((int64_t)n * (n - 1) / 2) / ((int64_t)P.N * (P.N - 1) / 2)
+                                          : sp_default_min_weight(w, n, &p->scoring);
+        if (scaled) minw = std::max(minw * factor_ppm / 1000000, p->min_scaled_penalty);
         host_lcb_chain(m, minw, p->collinear != 0, match_lcb, nl, &orders, mw.data());
     } else
     host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl, &orders);
@@ -372,6 +386,14 @@ static int progressive_core(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     if (given_left) { std::copy(given_left, given_left + (2 * N - 1), P.left.begin()); std::copy(given_right, given_right + (2 * N - 1), P.right.begin()); }
     else rc = mauve_guide_tree(c, pat, dist, P.left.data(), P.right.data());
     if (rc) return rc;
+    if (p->weight_scaling) {                // the distances come from the pairwise matches even when the tree is the caller's
+        P.dist.assign((size_t)N * N, 0);
+        if (given_left || !dist) {
+            std::vector<int32_t> tl((size_t)(2 * N - 1)), tr((size_t)(2 * N - 1));
+            rc = mauve_guide_tree(c, pat, P.dist.data(), tl.data(), tr.data());
+            if (rc) return rc;
+        } else std::copy(dist, dist + (size_t)N * N, P.dist.begin());
+    }
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     const double tg1 = now_ms();
     if (trace) fprintf(stderr, "[trace] progressive: guide tree %.1f ms\n", tg1 - t0);

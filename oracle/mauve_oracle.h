@@ -86,7 +86,10 @@ typedef struct {
     orc_scoring scoring;
     int64_t max_banded_len;   /* banded DP for intervals in (max_gapped_len, max_banded_len]; default 0 = off */
     int32_t lcb_scoring;      /* 0 = length weights (Aligner::align), 1 = extant sum-of-pairs anchor scores */
-    int32_t reserved0;
+    int32_t weight_scaling;   /* node weight x (1 - conservation_scale x conservation distance of the node) */
+    int32_t conservation_scale_ppm;
+    int32_t reserved1;
+    int64_t min_scaled_penalty;
 } orc_params;
 
 /* ---- seeds ---------------------------------------------------------------------------------- */

@@ -51,7 +51,8 @@ class Params(C.Structure):
                 ("recursive", C.c_int32), ("gapped", C.c_int32), ("add_unaligned", C.c_int32),
                 ("extend_lcbs", C.c_int32), ("max_extension_iters", C.c_int32),
                 ("min_recursive_gap", C.c_int64), ("max_gapped_len", C.c_int64), ("scoring", Scoring),
-                ("max_banded_len", C.c_int64), ("lcb_scoring", C.c_int32), ("reserved0", C.c_int32)]
+                ("max_banded_len", C.c_int64), ("lcb_scoring", C.c_int32), ("weight_scaling", C.c_int32),
+                ("conservation_scale_ppm", C.c_int32), ("reserved1", C.c_int32), ("min_scaled_penalty", C.c_int64)]
 
 
 def build(force=False):

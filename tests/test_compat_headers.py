@@ -371,7 +371,8 @@ def test_example_matches_c_abi(flag):
         try:
             ctx.set_genomes(gs)
             if flag == "-p":
-                r = ctx.progressive_align(_lib.default_params(), names=paths, want_xmfa=True)
+                # ProgressiveAligner's own defaults: weight scaling on, conservation scale 0.5
+                r = ctx.progressive_align(_lib.default_params(weight_scaling=1, conservation_scale_ppm=500000), names=paths, want_xmfa=True)
             else:
                 r = ctx.align(_lib.default_params(extend_lcbs=1), names=paths, want_xmfa=True)    # the call site passes lcb_extension = true
         finally:

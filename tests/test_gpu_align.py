@@ -724,6 +724,31 @@ def test_progressive_align_along_a_given_tree(ctx):
     assert O.check_tree(N, good[0], good[1])
 
 
+def test_progressive_weight_scaling(ctx):
+    """DESIGN.md S11b (ProgressiveAligner::setUseLcbWeightScaling / setConservationDistanceScale /
+    setMinimumBreakpointPenalty, progressiveMauve.cpp:626-652): every node's minimum LCB weight scaled by the
+    conservation distance of its subtrees -- bit-exact against the oracle with length and sum-of-pairs weights, along
+    the UPGMA and along a given tree; scale 0 is the unscaled result; a floor above every weight empties the blocks."""
+    from mauvealigner_amd import _lib
+    gs = synth.make_config("C4", scale=0.02)
+    N = len(gs)
+    plain = _same_progressive(ctx, gs)
+    zero = _same_progressive(ctx, gs, weight_scaling=1, conservation_scale_ppm=0)
+    assert zero["xmfa"] == plain["xmfa"]
+    half = _same_progressive(ctx, gs, weight_scaling=1, conservation_scale_ppm=500000)
+    full = _same_progressive(ctx, gs, weight_scaling=1, conservation_scale_ppm=1000000, lcb_weight=400)
+    unscaled = _same_progressive(ctx, gs, lcb_weight=400)
+    assert full["n_lcb"] >= unscaled["n_lcb"]                  # lighter thresholds keep at least as many blocks
+    assert half["n_lcb"] >= plain["n_lcb"]
+    _same_progressive(ctx, gs, weight_scaling=1, conservation_scale_ppm=500000, lcb_scoring=1)
+    _same_progressive(ctx, gs, weight_scaling=1, conservation_scale_ppm=700000, min_scaled_penalty=300)
+    rng = np.random.default_rng(9)
+    _same_progressive(ctx, gs, tree=_random_tree(N, rng), weight_scaling=1, conservation_scale_ppm=500000)
+    none = _same_progressive(ctx, gs, weight_scaling=1, conservation_scale_ppm=500000, min_scaled_penalty=10 ** 9)
+    assert none["n_lcb"] == 0
+    _same_progressive(ctx, synth.make_config("C3", scale=0.02), weight_scaling=1, conservation_scale_ppm=500000)
+
+
 def test_guide_tree_and_progressive_align(ctx):
     """ProgressiveAligner stand-in: guide tree + guide-tree recursive anchoring, bit-exact vs oracle."""
     gs = synth.make_config("C4", scale=0.02)

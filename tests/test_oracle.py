@@ -219,6 +219,21 @@ def test_progressive_align_given_tree():
     assert not O.check_tree(N, left[:-1], right[:-1])
 
 
+def test_progressive_weight_scaling_oracle():
+    """S11b in the oracle: scale 0 changes nothing, a scaled threshold never exceeds the unscaled one (so it keeps at
+    least the blocks a heavier threshold keeps), and the floor is respected."""
+    gs = synth.make_config("C4", scale=0.01)[:4]
+    base = O.progressive_align(gs, O.default_params(lcb_weight=300), want_xmfa=True)
+    zero = O.progressive_align(gs, O.default_params(lcb_weight=300, weight_scaling=1, conservation_scale_ppm=0), want_xmfa=True)
+    assert zero["xmfa"] == base["xmfa"]
+    full = O.progressive_align(gs, O.default_params(lcb_weight=300, weight_scaling=1, conservation_scale_ppm=1000000), want_xmfa=True)
+    _check_xmfa(full["xmfa"], gs)
+    multi = lambda r: int(np.count_nonzero(np.count_nonzero(r["aln"]["left"], axis=1) >= 2))
+    assert multi(full) >= multi(base)
+    floor = O.progressive_align(gs, O.default_params(lcb_weight=300, weight_scaling=1, conservation_scale_ppm=1000000, min_scaled_penalty=10 ** 9))
+    assert multi(floor) == 0
+
+
 def _cols_of(rows):
     cols = np.zeros(len(rows[0]), np.uint32)
     for g, r in enumerate(rows):
