@@ -67,9 +67,16 @@ __global__ void __launch_bounds__(256) bb_pair_gaps(const uint32_t *__restrict__
         auto close_run = [&]() {
             if (run_n > (int64_t)island_gap) { has_island = true; emit(1u, (uint32_t)(run_t == 1 ? a : b), run_first, run_last); }
         };
-        for (int64_t w = cs; w < nc && !done && (w < ce || in_region); w += 64) {
-            const int64_t c = w + lane;
-            const uint32_t v = c < nc ? m[c] : 0u;
+        // four words (256 columns) are fetched at a time so that the loads overlap; the walk itself stays word by word
+        for (int64_t w0 = cs; w0 < nc && !done && (w0 < ce || in_region); w0 += 256) {
+          uint32_t vv[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) { const int64_t c = w0 + 64 * k + lane; vv[k] = c < nc ? m[c] : 0u; }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int64_t w = w0 + 64 * k;
+            if (!(w < nc && !done && (w < ce || in_region))) break;
+            const uint32_t v = vv[k];
             const bool ra = v >> a & 1, rb = v >> b & 1;
             const uint64_t mA = __ballot(ra && !rb), mB = __ballot(rb && !ra), mBoth = __ballot(ra && rb);
             int pos = 0;
@@ -110,6 +117,7 @@ __global__ void __launch_bounds__(256) bb_pair_gaps(const uint32_t *__restrict__
                     if (w + q >= ce) { done = true; break; }
                 } else break;
             }
+          }
         }
         if (in_region) { close_run(); emit(0u, 0u, first, last); }       // ran into the end of the interval
     }
@@ -134,18 +142,27 @@ __global__ void __launch_bounds__(256) bb_tile_count(const uint32_t *__restrict_
     if ((int)threadIdx.x < N) tile_cnt[(size_t)blockIdx.x * N + threadIdx.x] = acc[threadIdx.x];
 }
 
-// residues of every genome in [tile start of x, x) for every query column x
-__global__ void __launch_bounds__(64) bb_rank(const uint32_t *__restrict__ cols, const int64_t *__restrict__ query, int N, uint32_t *__restrict__ out)
+// residues of every genome in [tile start of x, x) for every query column x: the tile's 64 words are split over the four
+// waves of the workgroup, four words in flight per lane
+__global__ void __launch_bounds__(256) bb_rank(const uint32_t *__restrict__ cols, const int64_t *__restrict__ query, int N, uint32_t *__restrict__ out)
 {
-    const int lane = threadIdx.x;
-    const int64_t x = query[blockIdx.x], t0 = x & ~(int64_t)(BB_CHUNK - 1);
+    __shared__ uint32_t acc[32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 32) acc[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t x = query[blockIdx.x], t0 = (x & ~(int64_t)(BB_CHUNK - 1)) + (int64_t)wave * (BB_CHUNK / 4);
     uint32_t mine = 0;
-    for (int64_t w = t0; w < x; w += 64) {
-        const int64_t c = w + lane;
-        const uint32_t v = c < x ? cols[c] : 0u;
-        for (int g = 0; g < N; g++) { const uint32_t k = (uint32_t)__popcll(__ballot(v >> g & 1)); if (lane == g) mine += k; }
+    for (int64_t w = t0; w < x && w < t0 + BB_CHUNK / 4; w += 256) {
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int64_t c = w + 64 * k + lane; v[k] = c < x ? cols[c] : 0u; }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            for (int g = 0; g < N; g++) { const uint32_t n = (uint32_t)__popcll(__ballot(v[k] >> g & 1)); if (lane == g) mine += n; }
     }
-    if (lane < N) out[(size_t)blockIdx.x * N + lane] = mine;
+    if (lane < N && mine) atomicAdd(&acc[lane], mine);
+    __syncthreads();
+    if ((int)threadIdx.x < N) out[(size_t)blockIdx.x * N + threadIdx.x] = acc[threadIdx.x];
 }
 
 // connected components (>= 2 genomes) of the joined pairs: adj[g] = genomes joined to g (bit g included)
@@ -188,6 +205,7 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
         ivs.push_back(d);
     }
     if (ivs.empty()) { B.valid = true; return MAUVE_OK; }
+    const double tb0 = now_ms();
     HIPCHK(c, hipSetDevice(c->device));
     const size_t n_tiles = (size_t)((n_cols + BB_CHUNK - 1) / BB_CHUNK);
     // work area: interval table | counter | tile counts | records
@@ -216,6 +234,9 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
         if (n_rec) HIPCHK(c, hipMemcpy(recs.data(), wk + o_rec, (size_t)n_rec * sizeof(BbRec), hipMemcpyDeviceToHost));
         break;
     }
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    const double tb1 = now_ms();
+    if (trace) fprintf(stderr, "[trace] backbone: %u chunks, %zu records; kernels + copies %.3f ms\n", chunks, recs.size(), tb1 - tb0);
     // canonical order of the records: interval, kind, pair, first column (the append order is not deterministic)
     std::sort(recs.begin(), recs.end(), [](const BbRec &x, const BbRec &y) {
         if (x.iv != y.iv) return x.iv < y.iv;
@@ -265,6 +286,7 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
             }
         }
     }
+    const double tb2 = now_ms();
     // ---- residue counts at the segment and island ends: one query per distinct column
     std::vector<int64_t> qcol;
     for (const BbIv &d : ivs) qcol.push_back(d.col0);
@@ -272,34 +294,43 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
     std::map<uint32_t, const BbIv *> by_iv; for (const BbIv &d : ivs) by_iv[d.iv] = &d;
     for (const BbRec &q : isl) { const BbIv *d = by_iv[q.iv]; qcol.push_back(d->col0 + q.c_first); qcol.push_back(d->col0 + q.c_last + 1); }
     std::sort(qcol.begin(), qcol.end()); qcol.erase(std::unique(qcol.begin(), qcol.end()), qcol.end());
-    std::vector<uint32_t> qcnt(qcol.size() * (size_t)N);
+    const uint32_t *qcnt;
     {
-        const size_t o_q = 0, o_out = up(qcol.size() * 8);
-        HIPCHK(c, c->bb_query.ensure(o_out + qcnt.size() * 4 + 64));
-        char *qb = c->bb_query.as<char>();
-        HIPCHK(c, hipMemcpyAsync(qb + o_q, qcol.data(), qcol.size() * 8, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(bb_rank, dim3((uint32_t)qcol.size()), dim3(64), 0, c->stream, d_cols, reinterpret_cast<const int64_t *>(qb + o_q), N,
+        const size_t o_q = 0, o_out = up(qcol.size() * 8), n_out = qcol.size() * (size_t)N * 4;
+        HIPCHK(c, c->bb_query.ensure(o_out + n_out + 64));
+        HIPCHK(c, c->pin_bb.ensure(o_out + n_out + 64));                // page-locked staging, same layout
+        char *qb = c->bb_query.as<char>(), *hb = c->pin_bb.as<char>();
+        memcpy(hb + o_q, qcol.data(), qcol.size() * 8);
+        HIPCHK(c, hipMemcpyAsync(qb + o_q, hb + o_q, qcol.size() * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(bb_rank, dim3((uint32_t)qcol.size()), dim3(256), 0, c->stream, d_cols, reinterpret_cast<const int64_t *>(qb + o_q), N,
                            reinterpret_cast<uint32_t *>(qb + o_out));
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(qcnt.data(), qb + o_out, qcnt.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hb + o_out, qb + o_out, n_out, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        qcnt = reinterpret_cast<const uint32_t *>(hb + o_out);
     }
+    const double tb3 = now_ms();
+    if (trace) fprintf(stderr, "[trace] backbone: sort + sweep %.3f ms (%zu segments), %zu rank queries %.3f ms\n", tb2 - tb1, segs.size(), qcol.size(), tb3 - tb2);
     // exclusive prefix of the tile counts
     std::vector<int64_t> tile_pre((n_tiles + 1) * (size_t)N, 0);
     for (size_t t = 0; t < n_tiles; t++) for (int g = 0; g < N; g++) tile_pre[(t + 1) * N + g] = tile_pre[t * N + g] + tile_cnt[t * N + g];
-    auto count_at = [&](int64_t x, int g) {                            // residues of g in columns [0, x) of the whole array
-        const size_t k = (size_t)(std::lower_bound(qcol.begin(), qcol.end(), x) - qcol.begin());
+    auto qidx = [&](int64_t x) { return (size_t)(std::lower_bound(qcol.begin(), qcol.end(), x) - qcol.begin()); };
+    auto count_at = [&](int64_t x, size_t k, int g) {                  // residues of g in columns [0, x) of the whole array; k = qidx(x)
         return tile_pre[(size_t)(x / BB_CHUNK) * N + g] + (int64_t)qcnt[k * N + g];
     };
+    size_t kb = 0, ka = 0, kz = 0;                                     // query slots of the interval start and of the two ends in turn
     auto ends = [&](const BbIv &d, int g, int64_t c1, int64_t c2, int64_t *lo, int64_t *hi) {     // signed ends of g's residues in columns [c1, c2]
-        const int64_t base = count_at(d.col0, g), k1 = count_at(d.col0 + c1, g) - base, k2 = count_at(d.col0 + c2 + 1, g) - base - 1;
+        const int64_t base = count_at(d.col0, kb, g), k1 = count_at(d.col0 + c1, ka, g) - base, k2 = count_at(d.col0 + c2 + 1, kz, g) - base - 1;
         if (k2 < k1) return false;
         const int64_t L = left[(int64_t)d.iv * N + g], R = right[(int64_t)d.iv * N + g];
         if (!reverse[(int64_t)d.iv * N + g]) { *lo = L + k1; *hi = L + k2; } else { *lo = -(R - k2); *hi = -(R - k1); }
         return true;
     };
+    B.seg_iv.reserve(segs.size()); B.seg_col.reserve(segs.size()); B.seg_len.reserve(segs.size()); B.seg_mask.reserve(segs.size());
+    B.seg_left.reserve(segs.size() * (size_t)N); B.seg_right.reserve(segs.size() * (size_t)N);
     for (const Seg &s : segs) {
         const BbIv &d = ivs[s.ivx];
+        kb = qidx(d.col0); ka = qidx(d.col0 + s.c1); kz = qidx(d.col0 + s.c2 + 1);
         int64_t lo[32] = {0}, hi[32] = {0}; uint32_t got = 0;
         for (int g = 0; g < N; g++) if ((s.mask >> g & 1) && ends(d, g, s.c1, s.c2, &lo[g], &hi[g])) got |= 1u << g;
         if (__builtin_popcount(got) < 2) continue;
@@ -327,11 +358,13 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
         const BbIv &d = *by_iv[q.iv];
         const int who = (int)(q.packed >> 16 & 0xff);
         int64_t lo = 0, hi = 0;
+        kb = qidx(d.col0); ka = qidx(d.col0 + q.c_first); kz = qidx(d.col0 + (int64_t)q.c_last + 1);
         (void)ends(d, who, q.c_first, q.c_last, &lo, &hi);
         const int64_t row[8] = {(int64_t)q.iv, (int64_t)(q.packed & 0xff), (int64_t)(q.packed >> 8 & 0xff), who, (int64_t)q.c_first, (int64_t)q.c_last, lo, hi};
         B.islands.insert(B.islands.end(), row, row + 8);
     }
     B.valid = true;
+    if (trace) fprintf(stderr, "[trace] backbone: coordinates + tables %.3f ms\n", now_ms() - tb3);
     return MAUVE_OK;
 }
 
@@ -340,6 +373,7 @@ extern "C" {
 int mauve_backbone(mauve_ctx *c, int64_t island_gap_size, int64_t *n_seg, int64_t *n_islands)
 {
     if (!c || !n_seg || !n_islands) return MAUVE_ERR_ARG;
+    if (island_gap_size < 0 || island_gap_size > 0x7fffffff) { c->err = "backbone: island_gap_size out of range"; return MAUVE_ERR_ARG; }
     AlignResult &R = c->res;
     const int64_t n_iv = R.sz.n_iv;
     if ((int64_t)R.col_off.size() != n_iv + 1) { c->err = "backbone: no alignment in this context"; return MAUVE_ERR_STATE; }

@@ -228,6 +228,7 @@ struct mauve_ctx {
         std::vector<int64_t> seg_iv, seg_col, seg_len, seg_left, seg_right, islands;
         std::vector<uint32_t> seg_mask;
     } bb;
+    PinnedBuf pin_bb;                    // rank queries and their answers
     DevBuf bb_cols, bb_work, bb_query;   // a caller's / a host-assembled column array; interval table + records; rank queries
     size_t bb_rec_cap = 0;
     DevBuf run_sum;                      // pairwise finder: run list (start, length, exactly-once genome set)
