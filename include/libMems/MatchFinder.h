@@ -94,6 +94,7 @@ protected:
     uint64 mask_;
     std::ostream *log_;
     std::vector<int64_t> found_len_, found_start_;
+    uint found_seq_count_ = 0;                   // the sequence count the held matches were found with
 };
 
 }  // namespace mems

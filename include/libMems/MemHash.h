@@ -28,8 +28,20 @@ public:
             hc.check(mauve_extend_hits(hc.get(), pat, (int64_t)hit_mask_.size(), hit_mask_.data(), hit_pos_.data(), hit_strand_.data(),
                                        extendMatches() ? 1 : 0, &n), "mauve_extend_hits");
         }
-        found_len_.assign((size_t)n, 0); found_start_.assign((size_t)n * seq_count, 0);
-        hc.check(mauve_get_matches(hc.get(), found_len_.data(), found_start_.data()), "mauve_get_matches");
+        // A finder keeps what it found until Clear(): a second search -- the next seed of a family, progressiveMauve.cpp:523-546
+        // -- adds to it, and a match that an earlier one contains is not taken again (mauve_merge_matches).
+        std::vector<int64_t> len((size_t)n, 0), st((size_t)n * seq_count, 0);
+        hc.check(mauve_get_matches(hc.get(), len.data(), st.data()), "mauve_get_matches");
+        if (found_len_.empty() || found_seq_count_ != seq_count) { found_len_.swap(len); found_start_.swap(st); }
+        else {
+            int64_t total = (int64_t)found_len_.size() + n;
+            std::vector<int64_t> ml((size_t)total), ms((size_t)total * seq_count);
+            hc.check(mauve_merge_matches((int)seq_count, (int64_t)found_len_.size(), found_len_.data(), found_start_.data(), n, len.data(), st.data(),
+                                         &total, ml.data(), ms.data()), "mauve_merge_matches");
+            ml.resize((size_t)total); ms.resize((size_t)total * seq_count);
+            found_len_.swap(ml); found_start_.swap(ms);
+        }
+        found_seq_count_ = seq_count;
         if (log_) *log_ << "100%..done, " << n << " matches\n";
         return true;
     }

@@ -51,7 +51,7 @@ public:
     // tree the alignment used, NEWICK both ways with leaves seq1..seqN (GuideTree.h).
     void setInputGuideTreeFileName(const std::string &fn) { input_tree_fn_ = fn; }
     void setOutputGuideTreeFileName(const std::string &fn) { output_tree_fn_ = fn; }
-    void setUseSeedFamilies(boolean) {}
+    void setUseSeedFamilies(boolean b) { p_.seed_family = b ? 1 : 0; }        // :604-605: every node searches with the family of three seeds
     void SetUseCacheDb(boolean) {}                                            // :643-646
     // progressiveMauve.cpp:652-655 hands the pairwise matches over; the device path finds them itself
     // (PairwiseMatchFinder rule on the resident genomes), so only the seed pattern is taken from the list.
@@ -61,6 +61,10 @@ public:
     void align(std::vector<genome::gnSequence *> &seq_table, IntervalList &il)
     {
         if (seq_table.size() != seq_count_) throw genome::gnException("ProgressiveAligner::align: sequence count mismatch");
+        if (p_.seed_family) {                                 // the family comes from the weight; a pattern taken from the pairwise list only names it
+            if (!p_.seed_weight && p_.seed_pattern) p_.seed_weight = mauve_seed_weight(p_.seed_pattern);
+            p_.seed_pattern = 0;
+        }
         if (bp_penalty_ >= 0) p_.lcb_weight = p_.lcb_scoring == MAUVE_LCB_SCORE_SP ? (int64_t)bp_penalty_ : (int64_t)bp_penalty_ * (int64_t)seq_count_;
         HipContext &hc = HipContext::global();
         MatchList tmp; tmp.seq_table = seq_table;

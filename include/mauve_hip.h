@@ -75,7 +75,8 @@ typedef struct {
     int32_t weight_scaling;   /* progressive path: scale every node's minimum LCB weight by the conservation distance of its two
                                  subtrees (ProgressiveAligner::setUseLcbWeightScaling, progressiveMauve.cpp:626-627); default 0 */
     int32_t conservation_scale_ppm;   /* setConservationDistanceScale in parts per million (:633-637; call-site default 0.5 = 500000) */
-    int32_t reserved1;
+    int32_t seed_family;      /* search with the family of three seeds of the weight instead of one (progressiveMauve.cpp:502-546 --seed-family;
+                                 ProgressiveAligner::setUseSeedFamilies :604-605); default 0 */
     int64_t min_scaled_penalty;       /* setMinimumBreakpointPenalty (:649-652): floor of the scaled weight; default 0 */
 } mauve_params;
 
@@ -164,6 +165,12 @@ int mauve_seed_match_enumerate(mauve_ctx *ctx, int seq, uint64_t pattern, int64_
         computeLCBAdjacencies_v2; mauveAligner.cpp:596,600,698; toGrimmFormat.cpp:51-79).
         Host-side (sequential by nature); inputs/outputs are host arrays. ------ */
 int mauve_eliminate_overlaps(int nseq, int64_t *n_inout, int64_t *length, int64_t *start);
+/* one finder fed by the searches of several seeds (progressiveMauve.cpp:502-546: umf.FindMatches per seed of the family,
+   longest first, then umf.GetMatchList): list a, then the matches of b that no match of a contains (same components,
+   strands and diagonal), in canonical order.  Two-phase like the other list calls: with len_out == NULL
+   *n_out receives the size; with buffers, *n_out is their capacity on entry. */
+int mauve_merge_matches(int nseq, int64_t n_a, const int64_t *len_a, const int64_t *start_a, int64_t n_b, const int64_t *len_b,
+                        const int64_t *start_b, int64_t *n_out, int64_t *len_out, int64_t *start_out);
 int mauve_lcb_chain(int nseq, int64_t n, const int64_t *length, const int64_t *start,
                     int64_t min_weight, int collinear, int64_t *match_lcb, int64_t *n_lcb_out,
                     int64_t *left_end, int64_t *right_end, int64_t *weight, int64_t *left_adj,

@@ -26,7 +26,7 @@ EXPORTS = [
     "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_dp_batch_banded", "mauve_match_sp_scores", "mauve_align", "mauve_align_fetch",
     "mauve_align_matches", "mauve_align_begin", "mauve_align_begin_matches", "mauve_align_dp_anchors", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
     "mauve_guide_tree", "mauve_progressive_align", "mauve_progressive_align_tree",
-    "mauve_backbone", "mauve_backbone_alignment", "mauve_backbone_fetch",
+    "mauve_backbone", "mauve_backbone_alignment", "mauve_backbone_fetch", "mauve_merge_matches",
     "mauve_write_xmfa", "mauve_profile_enable", "mauve_profile_reset", "mauve_profile_get", "mauve_last_stage_times",
 ]
 
@@ -42,7 +42,7 @@ class Params(C.Structure):
                 ("extend_lcbs", C.c_int32), ("max_extension_iters", C.c_int32),
                 ("min_recursive_gap", C.c_int64), ("max_gapped_len", C.c_int64), ("scoring", Scoring),
                 ("max_banded_len", C.c_int64), ("lcb_scoring", C.c_int32), ("weight_scaling", C.c_int32),
-                ("conservation_scale_ppm", C.c_int32), ("reserved1", C.c_int32), ("min_scaled_penalty", C.c_int64)]
+                ("conservation_scale_ppm", C.c_int32), ("seed_family", C.c_int32), ("min_scaled_penalty", C.c_int64)]
 
 
 class AlignSizes(C.Structure):
@@ -108,6 +108,20 @@ def default_params(**kw):
     for k, v in kw.items():
         setattr(p, k, v)
     return p
+
+
+def merge_matches(len_a, st_a, len_b, st_b):
+    """mauve_merge_matches (host entry, no context): a, then the matches of b no match of a contains; canonical order."""
+    la = np.ascontiguousarray(len_a, np.int64); sa = np.ascontiguousarray(st_a, np.int64)
+    lb = np.ascontiguousarray(len_b, np.int64); sb = np.ascontiguousarray(st_b, np.int64)
+    N = sa.shape[1] if sa.ndim == 2 and sa.shape[0] else sb.shape[1]
+    cap = C.c_int64(len(la) + len(lb))
+    lo = np.zeros(max(cap.value, 1), np.int64); so = np.zeros((max(cap.value, 1), N), np.int64)
+    rc = load().mauve_merge_matches(N, C.c_int64(len(la)), _p(la, C.c_int64), _p(sa, C.c_int64), C.c_int64(len(lb)), _p(lb, C.c_int64),
+                                    _p(sb, C.c_int64), C.byref(cap), _p(lo, C.c_int64), _p(so, C.c_int64))
+    if rc:
+        raise RuntimeError("mauve_merge_matches failed (%d)" % rc)
+    return lo[:cap.value].copy(), so[:cap.value].copy()
 
 
 def default_scoring():

@@ -628,6 +628,19 @@ int chain_device_copy_back(mauve_ctx *c, int N, MatchVec &m, std::vector<int64_t
         }
         match_lcb[i] = hb[i];
     }
+    {   // the survivors in canonical order of their cropped records, as host_eliminate_overlaps leaves them; dead ones last
+        int64_t prev = 0; bool sorted = true;
+        for (uint32_t i = 0; i < n && sorted; i++) { if (hl[i] <= 0) continue; const int64_t s0 = std::llabs(m.st(i)[0]); sorted = s0 > prev; prev = s0; }
+        if (!sorted) {
+            std::vector<uint32_t> perm; perm.reserve(n);
+            for (uint32_t i = 0; i < n; i++) if (hl[i] > 0) perm.push_back(i);
+            std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return std::llabs(m.st(a)[0]) < std::llabs(m.st(b)[0]); });
+            for (uint32_t i = 0; i < n; i++) if (hl[i] <= 0) perm.push_back(i);
+            MatchVec t(N); t.d.resize(m.d.size()); std::vector<int64_t> tl((size_t)n);
+            for (uint32_t k = 0; k < n; k++) { std::copy(m.rec(perm[k]), m.rec(perm[k]) + 1 + N, t.d.begin() + (std::ptrdiff_t)((size_t)k * (1 + N))); tl[k] = match_lcb[perm[k]]; }
+            m.d.swap(t.d); match_lcb.swap(tl);
+        }
+    }
     if (trace) fprintf(stderr, "[trace] chain (device): copy back %.3f ms\n", now_ms() - t2);
     return MAUVE_OK;
 }

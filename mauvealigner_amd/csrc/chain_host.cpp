@@ -50,6 +50,92 @@ void host_left_orders(const MatchVec &m, ChainOrders &orders)
     }
 }
 
+// ---- seed families (progressiveMauve.cpp:502-546): the union of the searches of several seeds ----
+// canonical order of match records (length, starts): first component, its start, component set, starts, length
+static bool canon_less(int N, const int64_t *a, const int64_t *b)
+{
+    int fa = 0, fb = 0;
+    while (fa < N && a[1 + fa] == 0) fa++;
+    while (fb < N && b[1 + fb] == 0) fb++;
+    if (fa != fb) return fa < fb;
+    if (fa < N) { const int64_t sa = std::llabs(a[1 + fa]), sb = std::llabs(b[1 + fb]); if (sa != sb) return sa < sb; }
+    uint32_t ma = 0, mb = 0;
+    for (int g = 0; g < N; g++) { if (a[1 + g]) ma |= 1u << g; if (b[1 + g]) mb |= 1u << g; }
+    if (ma != mb) return ma < mb;
+    for (int g = 0; g < N; g++) if (a[1 + g] != b[1 + g]) return a[1 + g] < b[1 + g];
+    return a[0] < b[0];
+}
+// x lies inside y: every component of x in y, same strand relation, same diagonal (y read in x's direction)
+static bool match_contained(int N, const int64_t *x, const int64_t *y)
+{
+    const int64_t lx = x[0], ly = y[0];
+    int f = 0;
+    while (f < N && x[1 + f] == 0) f++;
+    if (f == N || lx > ly || y[1 + f] == 0) return false;
+    const bool flip = y[1 + f] < 0;
+    int64_t d = -1;
+    for (int g = f; g < N; g++) {
+        const int64_t xs = x[1 + g];
+        if (!xs) continue;
+        if (!y[1 + g]) return false;
+        const int64_t ys = flip ? -y[1 + g] : y[1 + g];
+        if ((xs < 0) != (ys < 0)) return false;
+        const int64_t ax = std::llabs(xs), ay = std::llabs(ys);
+        int64_t dg = xs > 0 ? ax - ay : (ay + ly) - (ax + lx);
+        if (flip) dg = (ly - lx) - dg;
+        if (d < 0) d = dg;
+        if (dg != d || dg < 0 || dg > ly - lx) return false;
+    }
+    return true;
+}
+
+// kept := kept, then the matches of add that no match of kept contains; canonical order.  For every genome g the kept
+// matches that have g are ordered by their left end there with a running maximum of their right ends: the candidates
+// that can hold a match x whose first component is g are the ones at or left of x's start, walked right to left until the
+// running maximum falls short of x's right end.
+void host_merge_matches(MatchVec &kept, const MatchVec &add)
+{
+    const int N = kept.N; const size_t R1 = (size_t)(1 + N);
+    const size_t nk = kept.size(), na = add.size();
+    if (!na) return;
+    std::vector<std::vector<uint64_t>> by((size_t)N);          // per genome: (left end << 32 | index), ascending
+    std::vector<std::vector<int64_t>> runmax((size_t)N);
+    std::vector<char> need((size_t)N, 0);
+    for (size_t j = 0; j < na; j++) { int f = 0; while (f < N && add.st(j)[f] == 0) f++; if (f < N) need[(size_t)f] = 1; }
+    for (int g = 0; g < N; g++) {
+        if (!need[(size_t)g]) continue;
+        std::vector<uint64_t> &k = by[(size_t)g];
+        for (size_t i = 0; i < nk; i++) if (kept.st(i)[g]) k.push_back((uint64_t)std::llabs(kept.st(i)[g]) << 32 | (uint64_t)i);
+        std::sort(k.begin(), k.end());
+        runmax[(size_t)g].resize(k.size());
+        int64_t mx = 0;
+        for (size_t r = 0; r < k.size(); r++) { const size_t i = (size_t)(uint32_t)k[r]; mx = std::max(mx, (int64_t)(k[r] >> 32) + kept.len(i) - 1); runmax[(size_t)g][r] = mx; }
+    }
+    std::vector<size_t> take;
+    for (size_t j = 0; j < na; j++) {
+        const int64_t *x = add.rec(j);
+        int f = 0; while (f < N && x[1 + f] == 0) f++;
+        bool dropped = false;
+        if (f < N) {
+            const std::vector<uint64_t> &k = by[(size_t)f];
+            const int64_t xs = std::llabs(x[1 + f]), xe = xs + x[0] - 1;
+            size_t r = (size_t)(std::upper_bound(k.begin(), k.end(), ((uint64_t)xs << 32) | 0xffffffffu) - k.begin());
+            while (r > 0 && runmax[(size_t)f][r - 1] >= xe && !dropped) { r--; dropped = match_contained(N, x, kept.rec((size_t)(uint32_t)k[r])); }
+        }
+        if (!dropped) take.push_back(j);
+    }
+    if (take.empty()) return;
+    // both lists are in canonical order: merge
+    MatchVec out(N); out.d.resize((nk + take.size()) * R1);
+    size_t a = 0, b = 0, o = 0;
+    while (a < nk || b < take.size()) {
+        const bool ta = b >= take.size() || (a < nk && !canon_less(N, add.rec(take[b]), kept.rec(a)));
+        const int64_t *src = ta ? kept.rec(a++) : add.rec(take[b++]);
+        std::copy(src, src + R1, out.d.begin() + (std::ptrdiff_t)(o++ * R1));
+    }
+    kept.d.swap(out.d);
+}
+
 void MatchVec::sort_by_start0()
 {
     const size_t n = size();
@@ -116,6 +202,31 @@ struct ElimScratch {
     std::vector<std::vector<uint32_t>> ordg;
 };
 }  // namespace
+
+// After the crops the survivors are put back in canonical order (with three or more matches overlapping, the
+// crops of one pass can carry a match past a neighbour; everything downstream reads the list as ordered along genome 0).
+// alive == nullptr: every record is a survivor.  Dead records (sparse lists) go to the end.  orders are renumbered.
+static void restore_canonical_order(MatchVec &m, const std::vector<uint8_t> *alive, ChainOrders *orders)
+{
+    const size_t n = m.size(); const int N = m.N;
+    int64_t prev = 0; bool sorted = true;
+    for (size_t i = 0; i < n && sorted; i++) {
+        if (alive && !(*alive)[i]) continue;
+        const int64_t s = std::llabs(m.st(i)[0]);
+        sorted = s > prev; prev = s;
+    }
+    if (sorted) return;
+    std::vector<uint32_t> perm; perm.reserve(n);
+    for (size_t i = 0; i < n; i++) if (!alive || (*alive)[i]) perm.push_back((uint32_t)i);
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return std::llabs(m.st(a)[0]) < std::llabs(m.st(b)[0]); });
+    if (alive) for (size_t i = 0; i < n; i++) if (!(*alive)[i]) perm.push_back((uint32_t)i);
+    std::vector<uint32_t> newidx(n);
+    MatchVec t(N); t.d.resize(m.d.size());
+    const size_t R1 = (size_t)(1 + N);
+    for (size_t k = 0; k < n; k++) { newidx[perm[k]] = (uint32_t)k; std::copy(m.rec(perm[k]), m.rec(perm[k]) + R1, t.d.begin() + (std::ptrdiff_t)(k * R1)); }
+    m.d.swap(t.d);
+    if (orders) for (auto &o : orders->ord) for (uint32_t &x : o) x = newidx[x];
+}
 
 // EliminateOverlaps.  Per genome: sweep the matches in left-end order; of two overlapping
 // neighbours the shorter one gives up the overlap (ties: the right one), crops are collected per pass and
@@ -219,6 +330,7 @@ void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders, bool compact)
             for (uint32_t i : S.ordg[(size_t)g]) if (S.alive[i]) o.push_back(i);
         }
         orders->sparse = true;
+        restore_canonical_order(m, &S.alive, orders);
         if (trace) fprintf(stderr, "[trace] eliminate (no compaction) order lists %.3f ms, total %.3f\n", now_ms() - te1, now_ms() - te0);
         return;
     }
@@ -234,6 +346,7 @@ void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders, bool compact)
             for (uint32_t i : S.ordg[(size_t)g]) if (S.alive[i]) o.push_back(S.newidx[i]);
         }
     }
+    restore_canonical_order(m, nullptr, orders);
     if (trace) fprintf(stderr, "[trace] eliminate compaction %.3f ms, total %.3f\n", now_ms() - te1, now_ms() - te0);
 }
 
@@ -407,6 +520,30 @@ void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::
 }
 
 extern "C" {
+
+int mauve_merge_matches(int nseq, int64_t n_a, const int64_t *len_a, const int64_t *start_a, int64_t n_b, const int64_t *len_b, const int64_t *start_b,
+                        int64_t *n_out, int64_t *len_out, int64_t *start_out)
+{
+    if (nseq < 1 || nseq > MAUVE_MAX_SEQ || n_a < 0 || n_b < 0 || !n_out) return MAUVE_ERR_ARG;
+    MatchVec a(nseq), b(nseq);
+    for (int64_t i = 0; i < n_a; i++) a.push(len_a[i], start_a + i * nseq);
+    for (int64_t i = 0; i < n_b; i++) b.push(len_b[i], start_b + i * nseq);
+    // the lists are taken in canonical order; a caller's list that is not gets sorted first
+    auto canon = [&](MatchVec &m) {
+        std::vector<size_t> idx(m.size()); std::iota(idx.begin(), idx.end(), 0);
+        if (std::is_sorted(idx.begin(), idx.end(), [&](size_t x, size_t y) { return canon_less(nseq, m.rec(x), m.rec(y)); })) return;
+        std::sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return canon_less(nseq, m.rec(x), m.rec(y)); });
+        MatchVec t(nseq); for (size_t i : idx) t.push(m.rec(i)); m.d.swap(t.d);
+    };
+    canon(a); canon(b);
+    host_merge_matches(a, b);
+    if (len_out && start_out) {
+        if (*n_out < (int64_t)a.size()) { *n_out = (int64_t)a.size(); return MAUVE_ERR_LIMIT; }
+        for (size_t i = 0; i < a.size(); i++) { len_out[i] = a.len(i); std::copy(a.st(i), a.st(i) + nseq, start_out + i * nseq); }
+    }
+    *n_out = (int64_t)a.size();
+    return MAUVE_OK;
+}
 
 int mauve_eliminate_overlaps(int nseq, int64_t *n_inout, int64_t *length, int64_t *start)
 {

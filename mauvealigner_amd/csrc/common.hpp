@@ -341,6 +341,8 @@ int chain_order_device(mauve_ctx *c, int N, int64_t nl, int64_t min_gap, int64_t
 struct ChainOrders { std::vector<std::vector<uint32_t>> ord; bool sparse = false; };   // per genome: match indices in left-end order;
                                                                                         // sparse: the list still holds dead records (not named here)
 void host_eliminate_overlaps(MatchVec &m, ChainOrders *orders = nullptr, bool compact = true);
+int seed_family_matches(mauve_ctx *c, const GenomeSet &gs, int w, int mode, uint64_t mask, MatchVec &out);    // pipeline.cpp
+void host_merge_matches(MatchVec &kept, const MatchVec &add);        // seed families: kept + what of add no kept match contains
 void host_left_orders(const MatchVec &m, ChainOrders &orders);       // per-genome left-end order of an overlap-free list
 void host_lcb_chain(const MatchVec &m, int64_t min_weight, bool collinear, std::vector<int64_t> &match_lcb, int64_t &n_lcb,
                     const ChainOrders *orders = nullptr, const int64_t *match_weight = nullptr);

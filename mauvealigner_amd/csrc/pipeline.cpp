@@ -123,6 +123,19 @@ static int extend_lcbs(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
         if (!have_base) {
             base.d.clear();
             for (size_t i = 0; i < m.size(); i++) if (match_lcb[i] >= 0) base.push(m.rec(i));
+            // Crops of the overlap elimination can carry a match past a neighbour (dense, overlapping lists: seed families):
+            // the merged list of a round is in canonical order of the CURRENT records, so the anchors are put in that order first
+            {
+                std::vector<size_t> idx(base.size());
+                for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+                auto by = [&](size_t x, size_t y) { return less(base.rec(x), base.rec(y)); };
+                if (!std::is_sorted(idx.begin(), idx.end(), by)) {
+                    std::stable_sort(idx.begin(), idx.end(), by);
+                    MatchVec t(N); t.reserve(base.size());
+                    for (size_t i : idx) t.push(base.rec(i));
+                    base.d.swap(t.d);
+                }
+            }
             host_left_orders(base, base_ord);
             have_base = true;
         }
@@ -194,6 +207,33 @@ static int extend_lcbs(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
     return MAUVE_OK;
 }
 
+// The searches of the seed family of weight w (ranks 0..2, longest seed first; ties: the higher rank, as the call site's
+// sort leaves them, progressiveMauve.cpp:515-521) merged into one list (host_merge_matches).
+int seed_family_matches(mauve_ctx *c, const GenomeSet &gs, int w, int mode, uint64_t mask, MatchVec &out)
+{
+    const int n = gs.nseq;
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + 3, [&](int a, int b) {
+        const int la = mauve_seed_length(mauve_get_seed(w, a)), lb = mauve_seed_length(mauve_get_seed(w, b));
+        return la != lb ? la > lb : a > b;
+    });
+    out = MatchVec(n);
+    for (int k = 0; k < 3; k++) {
+        const uint64_t pat = mauve_get_seed(w, order[k]);
+        if (!pat) continue;
+        int64_t nm = 0;
+        const int rc = seedpass_run(c, gs, pat, mode, mask, 1, nullptr, 0, &nm);
+        if (rc) return rc;
+        MatchVec cur(n); cur.resize((size_t)nm);
+        for (int64_t i = 0; i < nm; i++) {
+            cur.len((size_t)i) = c->match_len[(size_t)i];
+            std::copy(&c->match_start[(size_t)i * n], &c->match_start[(size_t)i * n] + n, cur.st((size_t)i));
+        }
+        if (k == 0) out.d.swap(cur.d); else host_merge_matches(out, cur);
+    }
+    return MAUVE_OK;
+}
+
 static const bool g_trace_pipeline = getenv("MAUVE_TRACE") != nullptr;     // read once, not in the timed path
 
 // ---- the whole path in three phases, so that the DP intervals of one alignment can be sharded over ranks ----
@@ -237,6 +277,15 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
         };
     int64_t nm = 0;
     int rc = MAUVE_OK;
+    MatchVec family(N);
+    if (!given && p->seed_family) {
+        // DESIGN.md S3b (progressiveMauve.cpp:502-546): one search per seed of the family, longest seed first, merged like the
+        // matches of one finder; the merged list then stands where a caller's list would
+        if (p->seed_pattern) { c->err = "align: seed_family takes its patterns from the weight, not from seed_pattern"; return MAUVE_ERR_ARG; }
+        rc = seed_family_matches(c, main_genome_set(c), w, p->mode, full, family);
+        if (rc) return rc;
+        given = &family;
+    }
     if (given) {
         // the caller's list: its N-way matches in canonical order (|start 0|, starts, length) stand where the seed pass's stood
         c->shadow = nullptr;

@@ -142,14 +142,22 @@ int prog_node(Prog &P, int node)
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     const double tn0 = now_ms();
     int64_t nm = 0;
-    int rc = seedpass_run(c, gs, pat, p->mode, full, 1, nullptr, 0, &nm);
-    if (rc) return rc;
-    const double tn1 = now_ms();
-    MatchVec m(n); m.resize((size_t)nm);
-    for (int64_t i = 0; i < nm; i++) {
-        m.len((size_t)i) = c->match_len[(size_t)i];
-        std::copy(&c->match_start[(size_t)i * n], &c->match_start[(size_t)i * n] + n, m.st((size_t)i));
+    MatchVec m(n);
+    int rc;
+    if (p->seed_family) {                                    // the node searches with the whole seed family
+        rc = seed_family_matches(c, gs, w, p->mode, full, m);
+        if (rc) return rc;
+        nm = (int64_t)m.size();
+    } else {
+        rc = seedpass_run(c, gs, pat, p->mode, full, 1, nullptr, 0, &nm);
+        if (rc) return rc;
+        m.resize((size_t)nm);
+        for (int64_t i = 0; i < nm; i++) {
+            m.len((size_t)i) = c->match_len[(size_t)i];
+            std::copy(&c->match_start[(size_t)i * n], &c->match_start[(size_t)i * n] + n, m.st((size_t)i));
+        }
     }
+    const double tn1 = now_ms();
     ChainOrders orders;
     host_eliminate_overlaps(m, &orders);
     int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight * n / P.N : (int64_t)3 * w * n;
@@ -373,6 +381,7 @@ static int progressive_core(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     if (!c || !p || !sizes) return MAUVE_ERR_ARG;
     if (c->nseq < 2) { c->err = "progressive_align: at least two genomes required"; return MAUVE_ERR_STATE; }
     if (p->lcb_scoring != MAUVE_LCB_SCORE_LENGTH && p->lcb_scoring != MAUVE_LCB_SCORE_SP) { c->err = "progressive_align: unknown lcb_scoring"; return MAUVE_ERR_ARG; }
+    if (p->seed_family && p->seed_pattern) { c->err = "progressive_align: seed_family takes its patterns from the weight, not from seed_pattern"; return MAUVE_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     const double t0 = now_ms();
     const int N = c->nseq;

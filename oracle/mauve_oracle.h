@@ -88,7 +88,7 @@ typedef struct {
     int32_t lcb_scoring;      /* 0 = length weights (Aligner::align), 1 = extant sum-of-pairs anchor scores */
     int32_t weight_scaling;   /* node weight x (1 - conservation_scale x conservation distance of the node) */
     int32_t conservation_scale_ppm;
-    int32_t reserved1;
+    int32_t seed_family;      /* search with the three seeds of the weight, longest first, contained matches dropped */
     int64_t min_scaled_penalty;
 } orc_params;
 
@@ -114,6 +114,8 @@ int64_t orc_sorted_mer_list(const uint8_t *codes, int64_t len, uint64_t pattern,
 /* ---- multi-MUM enumeration + ungapped extension ---------------------------------------------- */
 int orc_find_matches(int nseq, const uint8_t *const *codes, const int64_t *lens, uint64_t pattern,
                      int mode, uint64_t mask, int extend, orc_matches *out);
+/* union of two match lists for a seed family: a, then the matches of b no match of a contains; canonical order */
+int orc_merge_matches(int nseq, const orc_matches *a, const orc_matches *b, orc_matches *out);
 /* the same search restricted to the bases inside the given intervals (1-based inclusive, sorted, disjoint,
    CSR by genome: iv_off[nseq+1]); a window is valid only if it holds no base outside them */
 int orc_find_matches_masked(int nseq, const uint8_t *const *codes, const int64_t *lens, uint64_t pattern,

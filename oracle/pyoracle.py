@@ -52,7 +52,7 @@ class Params(C.Structure):
                 ("extend_lcbs", C.c_int32), ("max_extension_iters", C.c_int32),
                 ("min_recursive_gap", C.c_int64), ("max_gapped_len", C.c_int64), ("scoring", Scoring),
                 ("max_banded_len", C.c_int64), ("lcb_scoring", C.c_int32), ("weight_scaling", C.c_int32),
-                ("conservation_scale_ppm", C.c_int32), ("reserved1", C.c_int32), ("min_scaled_penalty", C.c_int64)]
+                ("conservation_scale_ppm", C.c_int32), ("seed_family", C.c_int32), ("min_scaled_penalty", C.c_int64)]
 
 
 def build(force=False):
@@ -470,3 +470,24 @@ def backbone(left, right, reverse, col_off, cols, island_gap=20):
     }
     lib().orc_free_backbone(C.byref(bb))
     return out
+
+
+def merge_matches(len_a, st_a, len_b, st_b):
+    """Seed-family union: a, then the matches of b that no match of a contains; canonical order."""
+    la = np.ascontiguousarray(len_a, np.int64); sa = np.ascontiguousarray(st_a, np.int64)
+    lb = np.ascontiguousarray(len_b, np.int64); sb = np.ascontiguousarray(st_b, np.int64)
+    N = sa.shape[1] if sa.ndim == 2 and sa.shape[0] else sb.shape[1]
+    A = Matches(); B = Matches(); out = Matches()
+    keep = [la, sa, lb, sb]
+    for M, l, s_ in ((A, la, sa), (B, lb, sb)):
+        M.n = len(l); M.nseq = N
+        M.length = l.ctypes.data_as(C.POINTER(C.c_int64)); M.start = s_.ctypes.data_as(C.POINTER(C.c_int64))
+    rc = lib().orc_merge_matches(N, C.byref(A), C.byref(B), C.byref(out))
+    if rc:
+        raise RuntimeError("orc_merge_matches failed")
+    n = int(out.n)
+    ln = np.ctypeslib.as_array(out.length, shape=(max(n, 1),))[:n].copy()
+    st = np.ctypeslib.as_array(out.start, shape=(max(n, 1) * N,))[:n * N].copy().reshape(n, N)
+    lib().orc_free_matches(C.byref(out))
+    del keep
+    return ln, st

@@ -8,6 +8,7 @@
 //  4. Aligner::align chains the match list it is given: with half the matches removed the anchors change.
 //  5. Aligner::SetPermutationOutput: a signed permutation per LCB set between the two weights, the last the aligned one;
 //  6. ProgressiveAligner with an output / input guide tree file: the written tree read back gives the same alignment.
+//  8. a seed family through one finder (progressiveMauve.cpp:510-546) and ProgressiveAligner::setUseSeedFamilies;
 //  7. the backbone stage as applyBackbone calls it (detectBackbone with a BigGapsDetector, the .backbone / .bbcols writers and
 //     readers) and simpleFindBackbone / simpleFindIslands / findIslandsBetweenLCBs: segment ends agree with the columns.
 #include <cassert>
@@ -213,6 +214,37 @@ int main(int argc, char **argv)
             size_t singles = 0; for (const Interval &iv : iv_list) singles += iv.Multiplicity() == 1;
             std::istringstream btw_in(between.str()); size_t rows_btw = 0; while (std::getline(btw_in, ln)) rows_btw++;
             assert(rows_btw <= singles && (singles == 0) == (rows_btw == 0));   // leftovers between LCBs; adjacent ones print as one
+        }
+        // 8. a seed family through ONE finder (progressiveMauve.cpp:510-546): three searches, longest seed first; the finder keeps
+        //    what it found, takes nothing an earlier match contains, and GetMatchList hands out the union
+        {
+            const uint wf = MatchList::GetDefaultMerSize(ml.seq_table);
+            std::vector<std::pair<int, int>> length_ranks(3);
+            for (int r = 0; r < 3; r++) length_ranks[(size_t)r] = std::make_pair((int)getSeedLength(getSeed((int)wf, r)), r);
+            std::sort(length_ranks.begin(), length_ranks.end());
+            HipUniqueMatchFinder umf; size_t first = 0, sum = 0;
+            for (int seedI = 2; seedI >= 0; seedI--) {
+                MatchList cur_list; cur_list.seq_filename = ml.seq_filename; cur_list.seq_table = ml.seq_table;
+                cur_list.CreateMemorySMLs(wf, nullptr, length_ranks[(size_t)seedI].second);
+                umf.FindMatches(cur_list);
+                umf.ClearSequences();
+                if (seedI == 2) first = cur_list.size();
+                for (size_t i = 0; i < cur_list.size(); i++) cur_list[i]->Free();
+                MatchList alone; alone.seq_filename = ml.seq_filename; alone.seq_table = ml.seq_table; alone.sml_table = cur_list.sml_table;
+                HipUniqueMatchFinder single; single.FindMatches(alone); sum += alone.size();
+                for (size_t i = 0; i < alone.size(); i++) alone[i]->Free();
+                for (size_t i = 0; i < cur_list.sml_table.size(); i++) delete cur_list.sml_table[i];
+            }
+            MatchList family; family.seq_table = ml.seq_table; umf.GetMatchList(family);
+            assert(first > 0 && family.size() >= first && family.size() < sum);      // the union, minus what was found twice
+            umf.Clear();
+            MatchList none; none.seq_table = ml.seq_table; umf.GetMatchList(none); assert(none.empty());
+            for (size_t i = 0; i < family.size(); i++) family[i]->Free();
+            if (N >= 3) {
+                ProgressiveAligner pf(N); pf.setUseSeedFamilies(true); IntervalList af; pf.align(ml.seq_table, af);
+                ProgressiveAligner ps(N); IntervalList as; ps.align(ml.seq_table, as);
+                assert(af.size() > 0 && as.size() > 0);
+            }
         }
         std::cout << "backbone segments " << n_bb << "\n";
         std::cout << "callbacks " << oof.calls << ", matches " << dev.size() << ", repeats " << devrep.size() << ", plug calls " << ca.aligned << "\nOK" << std::endl;

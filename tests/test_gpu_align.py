@@ -724,6 +724,33 @@ def test_progressive_align_along_a_given_tree(ctx):
     assert O.check_tree(N, good[0], good[1])
 
 
+def test_seed_family(ctx):
+    """DESIGN.md S3b (progressiveMauve.cpp:502-546 --seed-family; setUseSeedFamilies :604-605): the three seeds of the
+    weight searched longest first and merged -- bit-exact against the oracle through mauve_align and at every node of
+    the progressive path; the family finds at least the anchors of its first seed's search, and more on divergent input."""
+    from mauvealigner_amd import _lib, accuracy
+    for cfg, scale in (("C1", 0.1), ("C3", 0.02), ("C2", 0.01)):
+        _same_align(ctx, synth.make_config(cfg, scale=scale), seed_family=1)
+    gs = synth.make_config("C3", scale=0.02)
+    _same_align(ctx, gs, seed_family=1, seed_weight=11, recursive=0)
+    _same_align(ctx, gs, seed_family=1, extend_lcbs=1)
+    _same_align(ctx, gs, seed_family=1, lcb_scoring=1)
+    _same_progressive(ctx, synth.make_config("C4", scale=0.02), seed_family=1)
+    _same_progressive(ctx, synth.make_config("C4", scale=0.02), seed_family=1, weight_scaling=1, conservation_scale_ppm=500000, lcb_scoring=1)
+    # sensitivity on a divergent pair: the family anchors more
+    g2, org = synth.star_genomes(2, 60000, 0.16, 77, inversions=2, track=True)
+    ctx.set_genomes(g2)
+    one = ctx.align(_lib.default_params(recursive=0, gapped=0))
+    fam = ctx.align(_lib.default_params(recursive=0, gapped=0, seed_family=1))
+    assert fam["n_mums"] > one["n_mums"] and fam["anchor_length"].sum() > one["anchor_length"].sum()
+    assert accuracy.score_alignment(fam, org)["tp"] > accuracy.score_alignment(one, org)["tp"]
+    # an explicit pattern cannot name a family
+    with pytest.raises(RuntimeError):
+        ctx.align(_lib.default_params(seed_family=1, seed_pattern=O.get_seed(11, 0)))
+    with pytest.raises(RuntimeError):
+        ctx.progressive_align(_lib.default_params(seed_family=1, seed_pattern=O.get_seed(11, 0)))
+
+
 def test_progressive_weight_scaling(ctx):
     """DESIGN.md S11b (ProgressiveAligner::setUseLcbWeightScaling / setConservationDistanceScale /
     setMinimumBreakpointPenalty, progressiveMauve.cpp:626-652): every node's minimum LCB weight scaled by the

@@ -234,6 +234,76 @@ def test_progressive_weight_scaling_oracle():
     assert multi(floor) == 0
 
 
+def test_seed_family_merge_known_answers_and_host_entry():
+    """a later seed's match is dropped only when an earlier one contains it on the same diagonal (forward
+    and reverse components, subsets of the components); mauve_merge_matches (host code of the product) agrees with the
+    oracle on random lists."""
+    from mauvealigner_amd import _lib
+    # same diagonal inside -> dropped; off the diagonal, sticking out -> kept
+    ln, st = O.merge_matches([100], [[100, 500]], [30, 30, 50], [[120, 520], [120, 521], [180, 580]])
+    assert ln.tolist() == [100, 30, 50] and st.tolist() == [[100, 500], [120, 521], [180, 580]]
+    # reverse component: column k of the kept match sits at 500 + 99 - k, so x = (120, -550) is inside and (120, -549) is not
+    ln, st = O.merge_matches([100], [[100, -500]], [30, 30], [[120, -550], [120, -549]])
+    assert st.tolist() == [[100, -500], [120, -549]]
+    # a two-component match inside a three-component one is contained; the other way round never
+    ln, st = O.merge_matches([100], [[100, 500, 900]], [40, 40], [[0, 510, 910], [110, 510, 0]])
+    assert len(ln) == 1
+    ln, st = O.merge_matches([40], [[0, 510, 910]], [100], [[100, 500, 900]])
+    assert len(ln) == 2
+    # x found with its first component forward, inside a match that reads that component on the reverse strand
+    ln, st = O.merge_matches([100], [[100, -500, 900]], [30], [[0, 550, -920]])       # flipped view of columns 20..49
+    assert len(ln) == 1, st
+    ln, st = O.merge_matches([100], [[100, -500, 900]], [30], [[0, 550, -921]])
+    assert len(ln) == 2
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        N = int(rng.integers(2, 5))
+        na, nb = int(rng.integers(0, 60)), int(rng.integers(0, 60))
+
+        def rand_list(n, base=None):
+            ln_, st_ = [], []
+            for _ in range(n):
+                if base is not None and len(base[0]) and rng.random() < 0.5:      # cut out of a kept match: contained, or nearly
+                    k = int(rng.integers(0, len(base[0])))
+                    L, s = int(base[0][k]), base[1][k]
+                    l2 = int(rng.integers(1, L + 1)); d = int(rng.integers(0, L - l2 + 1))
+                    row = []
+                    for g in range(N):
+                        if s[g] == 0 or rng.random() < 0.15:
+                            row.append(0)
+                        elif s[g] > 0:
+                            row.append(int(s[g]) + d)
+                        else:
+                            row.append(-(abs(int(s[g])) + L - l2 - d))
+                    if rng.random() < 0.3 and any(row):
+                        g = int(rng.choice([g for g in range(N) if row[g]])); row[g] += 1 if row[g] > 0 else -1     # off the diagonal
+                    nz = [g for g in range(N) if row[g]]
+                    if len(nz) < 2:
+                        continue
+                    if row[nz[0]] < 0:                                            # canonical form: first component forward
+                        row = [(-(abs(v)) if v > 0 else abs(v)) if v else 0 for v in row]
+                        # (flipping the view turns forward into reverse and keeps the left ends)
+                    ln_.append(l2); st_.append(row)
+                else:
+                    L = int(rng.integers(5, 300))
+                    row = [int(rng.integers(1, 5000)) * int(rng.choice([1, 1, -1])) if rng.random() < 0.8 else 0 for _ in range(N)]
+                    nz = [g for g in range(N) if row[g]]
+                    if len(nz) < 2:
+                        continue
+                    row[nz[0]] = abs(row[nz[0]])
+                    ln_.append(L); st_.append(row)
+            return np.array(ln_, np.int64), np.array(st_, np.int64).reshape(len(ln_), N)
+        a = rand_list(na)
+        b = rand_list(nb, a)
+        if len(a[0]) + len(b[0]) == 0:
+            continue
+        # canonical order of the inputs (the oracle's merge of a list with the empty list sorts it)
+        a = O.merge_matches(np.zeros(0, np.int64), np.zeros((0, N), np.int64), a[0], a[1]) if len(a[0]) else a
+        want = O.merge_matches(a[0], a[1], b[0], b[1])
+        got = _lib.merge_matches(a[0], a[1], b[0], b[1])
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), trial
+
+
 def _cols_of(rows):
     cols = np.zeros(len(rows[0]), np.uint32)
     for g, r in enumerate(rows):
