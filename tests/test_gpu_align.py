@@ -403,6 +403,29 @@ def test_golden_progressive(ctx):
         assert f.read() == r["xmfa"]
 
 
+def test_golden_round2(ctx):
+    """The round-2 fixture through the C-ABI: seed-family alignment, its backbone and islands, progressive alignment
+    along the given tree with scaled node weights."""
+    from mauvealigner_amd import _lib
+    z = np.load(os.path.join(GOLDEN, "g3x6k_round2.npz"))
+    gs = [z["genome%d" % g] for g in range(3)]
+    names = ["g%d" % g for g in range(3)]
+    ctx.set_genomes(gs)
+    r = ctx.align(_lib.default_params(seed_weight=int(z["seed_weight"]), seed_family=1), names=names, want_xmfa=True)
+    for k in ("anchor_start", "anchor_length", "left", "right", "reverse", "col_off", "cols"):
+        assert np.array_equal(r[k], z["fam_" + k]), k
+    with open(os.path.join(GOLDEN, "g3x6k_round2.xmfa")) as f:
+        assert f.read() == r["xmfa"]
+    bb = ctx.backbone(island_gap=int(z["bb_island_gap"]))
+    for k in ("seg_iv", "seg_col", "seg_len", "seg_mask", "seg_left", "seg_right", "islands"):
+        assert np.array_equal(bb[k], z["bb_" + k]), k
+    assert len(bb["islands"]) >= 1 and len(bb["seg_iv"]) >= 1
+    pr = ctx.progressive_align(_lib.default_params(seed_weight=int(z["seed_weight"]), weight_scaling=1, conservation_scale_ppm=500000),
+                               tree=(z["tree_left"], z["tree_right"]))
+    for k in ("left", "right", "reverse", "col_off", "cols"):
+        assert np.array_equal(pr[k], z["prog_" + k]), k
+
+
 def _same_align(ctx, gs, **kw):
     from mauvealigner_amd import _lib
     ctx.set_genomes(gs)

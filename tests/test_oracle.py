@@ -616,6 +616,29 @@ def test_golden_fixtures_reproduce(name):
         assert f.read() == r["xmfa"]
 
 
+def test_golden_round2_fixture_reproduces():
+    """seed-family alignment + its backbone / islands, and a progressive alignment along a given tree with scaled node
+    weights: the committed fixture is what the oracle computes."""
+    z = np.load(os.path.join(GOLDEN, "g3x6k_round2.npz"))
+    gs = [z["genome%d" % g] for g in range(3)]
+    names = ["g%d" % g for g in range(3)]
+    fam = O.align(gs, O.default_params(seed_weight=int(z["seed_weight"]), seed_family=1), names=names, want_xmfa=True)
+    assert np.array_equal(fam["mums"][0], z["fam_mum_length"]) and np.array_equal(fam["mums"][1], z["fam_mum_start"])
+    assert len(z["fam_mum_length"]) > int(z["one_seed_mums"])
+    a = fam["aln"]
+    for k in ("anchor_start", "anchor_length", "left", "right", "reverse", "col_off", "cols"):
+        assert np.array_equal(a[k], z["fam_" + k]), k
+    with open(os.path.join(GOLDEN, "g3x6k_round2.xmfa")) as f:
+        assert f.read() == fam["xmfa"]
+    bb = O.backbone(a["left"], a["right"], a["reverse"], a["col_off"], a["cols"], island_gap=int(z["bb_island_gap"]))
+    for k in ("seg_iv", "seg_col", "seg_len", "seg_mask", "seg_left", "seg_right", "islands"):
+        assert np.array_equal(bb[k], z["bb_" + k]), k
+    pr = O.progressive_align(gs, O.default_params(seed_weight=int(z["seed_weight"]), weight_scaling=1, conservation_scale_ppm=500000),
+                             tree=(z["tree_left"], z["tree_right"]))["aln"]
+    for k in ("left", "right", "reverse", "col_off", "cols"):
+        assert np.array_equal(pr[k], z["prog_" + k]), k
+
+
 def test_golden_progressive_fixture_reproduces():
     z = np.load(os.path.join(GOLDEN, "g4x3k_tree.npz"))
     N = int(z["nseq"])
