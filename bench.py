@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--shard", default="replicas", choices=["replicas", "lcb"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the genomes (debug only; 1.0 = BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the C2 side measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the side measurements (C2, the pass with LCB extension, the backbone call)")
     args = ap.parse_args()
 
     import torch
@@ -247,7 +247,7 @@ def main():
 
     # ---- the same workload with the reference's default lcb_extension on (mauveAligner.cpp:95), and the
     # backbone stage on the columns the pass left in HBM: reported beside `value`, never part of it ----
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_secondary:
         from mauvealigner_amd import accuracy
         n2 = max(3, args.steps // 2)
         pe = _lib.default_params(seed_weight=weight, extend_lcbs=1)
