@@ -105,8 +105,9 @@ void host_merge_matches(MatchVec &kept, const MatchVec &add)
     for (int g = 0; g < N; g++) {
         if (!need[(size_t)g]) continue;
         std::vector<uint64_t> &k = by[(size_t)g];
+        k.reserve(nk);
         for (size_t i = 0; i < nk; i++) if (kept.st(i)[g]) k.push_back((uint64_t)std::llabs(kept.st(i)[g]) << 32 | (uint64_t)i);
-        std::sort(k.begin(), k.end());
+        if (!std::is_sorted(k.begin(), k.end())) std::sort(k.begin(), k.end());       // canonical order is this order for the first component
         runmax[(size_t)g].resize(k.size());
         int64_t mx = 0;
         for (size_t r = 0; r < k.size(); r++) { const size_t i = (size_t)(uint32_t)k[r]; mx = std::max(mx, (int64_t)(k[r] >> 32) + kept.len(i) - 1); runmax[(size_t)g][r] = mx; }

@@ -229,7 +229,10 @@ int seed_family_matches(mauve_ctx *c, const GenomeSet &gs, int w, int mode, uint
             cur.len((size_t)i) = c->match_len[(size_t)i];
             std::copy(&c->match_start[(size_t)i * n], &c->match_start[(size_t)i * n] + n, cur.st((size_t)i));
         }
+        const double tm0 = now_ms();
         if (k == 0) out.d.swap(cur.d); else host_merge_matches(out, cur);
+        static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[trace] seed family: seed %d gave %lld matches, merge %.3f ms\n", order[k], (long long)nm, now_ms() - tm0);
     }
     return MAUVE_OK;
 }
@@ -282,8 +285,10 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
         // DESIGN.md S3b (progressiveMauve.cpp:502-546): one search per seed of the family, longest seed first, merged like the
         // matches of one finder; the merged list then stands where a caller's list would
         if (p->seed_pattern) { c->err = "align: seed_family takes its patterns from the weight, not from seed_pattern"; return MAUVE_ERR_ARG; }
+        const double tf0 = now_ms();
         rc = seed_family_matches(c, main_genome_set(c), w, p->mode, full, family);
         if (rc) return rc;
+        if (g_trace_pipeline) fprintf(stderr, "[trace] seed family: three searches + merges %.3f ms, %zu matches\n", now_ms() - tf0, family.size());
         given = &family;
     }
     if (given) {
@@ -299,14 +304,15 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
             for (int g = 0; g < N && nway; g++) nway = given->st(i)[g] != 0;
             if (nway) keep.push_back(i);
         }
-        std::sort(keep.begin(), keep.end(), [&](size_t a, size_t b) {
+        auto canon = [&](size_t a, size_t b) {
             const int64_t *x = given->rec(a), *y = given->rec(b);
             const int64_t sa = std::llabs(x[1]), sb = std::llabs(y[1]);
             if (sa != sb) return sa < sb;
             for (int g = 0; g < N; g++) if (x[1 + g] != y[1 + g]) return x[1 + g] < y[1 + g];
             if (x[0] != y[0]) return x[0] < y[0];
             return a < b;
-        });
+        };
+        if (!std::is_sorted(keep.begin(), keep.end(), canon)) std::sort(keep.begin(), keep.end(), canon);     // a merged family list comes in order
         nm = (int64_t)keep.size();
         c->match_len.resize((size_t)nm); c->match_start.resize((size_t)nm * N);
         for (int64_t i = 0; i < nm; i++) {
