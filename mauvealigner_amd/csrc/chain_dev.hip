@@ -24,11 +24,15 @@ using namespace devscan;
 constexpr int CH_TILE = devscan::TILE;
 
 // records as the seed pass left them (int64 length[n], start[n*N]) -> working arrays (int32)
+// (both init kernels also clear what the stage accumulates into -- the counter block and the node weights -- instead of two memsets)
 __global__ void __launch_bounds__(256) ch_init(const int64_t *__restrict__ rlen, const int64_t *__restrict__ rst, uint32_t n, int N,
-                                               int32_t *__restrict__ len, int32_t *__restrict__ st, uint32_t *__restrict__ crop)
+                                               int32_t *__restrict__ len, int32_t *__restrict__ st, uint32_t *__restrict__ crop,
+                                               uint32_t *__restrict__ cnt, unsigned long long *__restrict__ weight)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < 64) cnt[i] = 0;
     if (i >= n) return;
+    weight[i] = 0;
     len[i] = (int32_t)rlen[i];
     for (int g = 0; g < N; g++) st[(size_t)i * N + g] = (int32_t)rst[(size_t)i * N + g];
     crop[2 * (size_t)i] = 0; crop[2 * (size_t)i + 1] = 0;
@@ -39,10 +43,13 @@ __global__ void __launch_bounds__(256) ch_init(const int64_t *__restrict__ rlen,
 // start lies in (seg0: K + 1 segment starts)
 __global__ void __launch_bounds__(256) ch_init_seg(const int64_t *__restrict__ rlen, const int64_t *__restrict__ rst, uint32_t n, int N,
                                                    const uint32_t *__restrict__ seg0, uint32_t K, int32_t *__restrict__ len, int32_t *__restrict__ st,
-                                                   uint32_t *__restrict__ crop, uint32_t *__restrict__ gapid)
+                                                   uint32_t *__restrict__ crop, uint32_t *__restrict__ gapid,
+                                                   uint32_t *__restrict__ cnt, unsigned long long *__restrict__ weight)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < 64) cnt[i] = 0;
     if (i >= n) return;
+    weight[i] = 0;
     bool fwd = true;
     for (int g = 0; g < N; g++) { const int64_t s = rst[(size_t)i * N + g]; st[(size_t)i * N + g] = (int32_t)s; fwd &= s > 0; }
     len[i] = fwd ? (int32_t)rlen[i] : 0;
@@ -330,9 +337,11 @@ __global__ void __launch_bounds__(256) ch_label(const int32_t *__restrict__ len,
 // ---- the chains on the device (align_device_tail, pipeline.cpp) ---------------------------------------------------
 // chain order = LCB by LCB, canonical (genome-0) order inside: a stable sort of the labelled matches by LCB id
 __global__ void __launch_bounds__(256) co_keys(const int32_t *__restrict__ lcb, uint32_t n, uint32_t nl, uint32_t *__restrict__ key,
-                                               uint32_t *__restrict__ val)
+                                               uint32_t *__restrict__ val, unsigned long long *__restrict__ lw, uint32_t *__restrict__ out)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < nl) lw[i] = 0;                                    // what co_gather accumulates into (nl <= n)
+    if (i < 2) out[i] = 0;
     if (i >= n) return;
     const int32_t l = lcb[i];
     key[i] = l >= 0 ? (uint32_t)l : nl;                      // dead / eliminated: behind every LCB
@@ -390,9 +399,7 @@ int chain_order_device(mauve_ctx *c, int N, int64_t nl, int64_t min_gap, int64_t
     uint32_t *cnt = c->ch_cnt.as<uint32_t>();
     const uint32_t blocks = (n + 255) / 256;
     int bits = 1; while ((1LL << bits) <= nl) bits++;
-    HIPCHK(c, hipMemsetAsync(lw, 0, (size_t)nl * 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(cnt + 16, 0, 8, c->stream));
-    hipLaunchKernelGGL(co_keys, dim3(blocks), dim3(256), 0, c->stream, lcb, n, (uint32_t)nl, k1, v1);
+    hipLaunchKernelGGL(co_keys, dim3(blocks), dim3(256), 0, c->stream, lcb, n, (uint32_t)nl, k1, v1, lw, cnt + 16);
     uint32_t *kk = k1, *vv = v1;
     int rc = sort_pairs_u32(c, n, bits, &kk, &vv, k2, v2, MAUVE_K_MISC);
     if (rc) return rc;
@@ -442,9 +449,11 @@ int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *s
     const int64_t *rlen = c->sorted_rec.as<int64_t>(), *rst = rlen + n;
     const uint32_t blocks = (n + 255) / 256;
     static const int cl_max = []() { const char *e = getenv("MAUVE_CH_CL_MAX"); const int v = e ? atoi(e) : CH_CL_MAX; return v < 1 ? 1 : (v > CH_CL_MAX ? CH_CL_MAX : v); }();   // (tests lower it)
-    HIPCHK(c, hipMemsetAsync(cnt, 0, 256, c->stream));
-    if (seg0) hipLaunchKernelGGL(ch_init_seg, dim3(blocks), dim3(256), 0, c->stream, rlen, rst, n, N, seg0, nseg, len, st, crop, gapid);
-    else hipLaunchKernelGGL(ch_init, dim3(blocks), dim3(256), 0, c->stream, rlen, rst, n, N, len, st, crop);
+    // the graph arrays are sized for the worst case K = n
+    HIPCHK(c, c->ch_graph.ensure((size_t)n * (8 + 4 + (size_t)N * 4 * 3 + 4) + 8 + (size_t)n * (8 + 4 + (size_t)N * 8) + 64));     // the arrays + their packed copy
+    unsigned long long *weight = c->ch_graph.as<unsigned long long>();
+    if (seg0) hipLaunchKernelGGL(ch_init_seg, dim3(blocks), dim3(256), 0, c->stream, rlen, rst, n, N, seg0, nseg, len, st, crop, gapid, cnt, weight);
+    else hipLaunchKernelGGL(ch_init, dim3(blocks), dim3(256), 0, c->stream, rlen, rst, n, N, len, st, crop, cnt, weight);
     for (int g = 0; g < N; g++) {
         hipLaunchKernelGGL(ch_keys, dim3(blocks), dim3(256), 0, c->stream, len, st, n, N, g, dead_key, k1, v1);
         uint32_t *kk = k1, *vv = v1;
@@ -466,13 +475,9 @@ int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *s
     const FinalRanks fr{len, n, ord, ordc, rank, cnt};
     hipLaunchKernelGGL((cmp_count<FinalRanks>), dim3(nb, N), dim3(256), 0, c->stream, fr, bcnt);
     hipLaunchKernelGGL((cmp_write<FinalRanks>), dim3(nb, N), dim3(256), 0, c->stream, fr, bcnt);
-    // the graph arrays are sized for the worst case K = n
-    HIPCHK(c, c->ch_graph.ensure((size_t)n * (8 + 4 + (size_t)N * 4 * 3 + 4) + 8 + (size_t)n * (8 + 4 + (size_t)N * 8) + 64));     // the arrays + their packed copy
-    unsigned long long *weight = c->ch_graph.as<unsigned long long>();
     uint32_t *orient = reinterpret_cast<uint32_t *>(weight + n);
     int32_t *prevv = reinterpret_cast<int32_t *>(orient + n), *nextv = prevv + (size_t)n * N, *seq = nextv + (size_t)n * N;
     int32_t *final_dev = seq + (size_t)n * N;
-    HIPCHK(c, hipMemsetAsync(weight, 0, (size_t)n * 8, c->stream));
     const LcbNodes ln{len, st, n, N, ordc, rank, cnt, node_of, weight, orient, gapid};
     hipLaunchKernelGGL((cmp_count<LcbNodes>), dim3(nb), dim3(256), 0, c->stream, ln, bcnt);
     hipLaunchKernelGGL((cmp_write<LcbNodes>), dim3(nb), dim3(256), 0, c->stream, ln, bcnt);

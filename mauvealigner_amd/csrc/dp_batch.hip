@@ -1036,9 +1036,10 @@ __device__ __forceinline__ void dpf_gap(const int32_t *__restrict__ alen, const 
 // gap code of anchor k: -1 no gap behind it, -2 a gap that is emitted unaligned, 0 a gap for the DP (slot follows)
 __global__ void __launch_bounds__(256) dpf_gap_flags(const int32_t *__restrict__ alen, const int32_t *__restrict__ ast,
                                                      const int32_t *__restrict__ alcb, uint32_t na, int N, int gapped, int64_t max_gapped,
-                                                     int32_t *__restrict__ gapcode)
+                                                     int32_t *__restrict__ gapcode, uint32_t *__restrict__ totals_words)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k < 64) totals_words[k] = 0;                          // the front end's totals block (256 B), cleared here instead of by a memset
     if (k >= na) return;
     int32_t code = -1;
     if (k + 1 < na && alcb[k] == alcb[k + 1]) {
@@ -1191,13 +1192,12 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     DpFrontTotals *tot = ctx->dpf_tot.as<DpFrontTotals>();
     int64_t *d_seq_off = ctx->dp_off.as<int64_t>();
     int64_t *d_tb_off = d_seq_off + ((size_t)na * N + 1), *d_rows_off = d_tb_off + (na + 1), *d_col_off = d_rows_off + (na + 1);
-    HIPCHK(ctx, hipMemsetAsync(tot, 0, 256, ctx->stream));
     if (!anchors_in_place) {
         HIPCHK(ctx, hipMemcpyAsync(alen, h_len, (size_t)na * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(ast, h_st, (size_t)na * N * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(alcb, h_lcb, (size_t)na * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    hipLaunchKernelGGL(dpf_gap_flags, dim3(blocks), dim3(256), 0, ctx->stream, alen, ast, alcb, na, N, gapped, max_gapped_len, d_gapcode);
+    hipLaunchKernelGGL(dpf_gap_flags, dim3(blocks), dim3(256), 0, ctx->stream, alen, ast, alcb, na, N, gapped, max_gapped_len, d_gapcode, reinterpret_cast<uint32_t *>(tot));
     const DpSlots sl{d_gapcode, na, anchor_of, tot};
     hipLaunchKernelGGL((cmp_count<DpSlots>), dim3(nb), dim3(256), 0, ctx->stream, sl, bcnt);
     hipLaunchKernelGGL((cmp_write<DpSlots>), dim3(nb), dim3(256), 0, ctx->stream, sl, bcnt);
