@@ -4,7 +4,8 @@
 // on stdout.  Optional first argument "-u" uses UniqueMatchFinder as progressiveMauve.cpp:490-495 does; "-p" runs
 // the progressiveMauve alignment stage instead (ProgressiveAligner, progressiveMauve.cpp:575-722).  With
 // MAUVE_MUMS_OUT / MAUVE_MLN_OUT set, the match list and the interval list are also written at the stage seams
-// (--mums / --output of the original, mauveAligner.cpp:603,702).
+// (--mums / --output of the original, mauveAligner.cpp:603,702); with MAUVE_BACKBONE_OUT set, "-p" also runs applyBackbone
+// as progressiveMauve.cpp:226-260 writes it and leaves <name> (.backbone rows) and <name>.bbcols behind.
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -16,6 +17,7 @@
 #include "libMems/MaskedMemHash.h"
 #include "libMems/MatchList.h"
 #include "libMems/ProgressiveAligner.h"
+#include "libMems/Backbone.h"
 
 using namespace mems;
 using namespace genome;
@@ -43,6 +45,26 @@ int main(int argc, char **argv)
             IntervalList interval_list;
             interval_list.seq_filename = match_list.seq_filename;
             aligner.align(match_list.seq_table, interval_list);          // :710
+            if (const char *bp = getenv("MAUVE_BACKBONE_OUT")) {         // applyBackbone, :226-260 (:712-719)
+                backbone_list_t bb_list;
+                BigGapsDetector bgd(20);                                 // island_gap_size, :322
+                detectBackbone(interval_list, bb_list, &bgd);            // :242-243
+                std::ofstream bb_out(bp);
+                writeBackboneSeqCoordinates(bb_list, interval_list, bb_out);                      // :245
+                bb_out.close();
+                std::vector<bb_seqentry_t> bb_seq_list;
+                std::ifstream bbseq_input(bp);
+                readBackboneSeqFile(bbseq_input, bb_seq_list);           // :249
+                mergeAdjacentSegments(bb_seq_list);                      // :251
+                addUniqueSegments(bb_seq_list);                          // :252
+                bbseq_input.close();
+                bb_out.open(bp);
+                writeBackboneSeqFile(bb_out, bb_seq_list);               // :255
+                const std::string bbcols_fname = std::string(bp) + ".bbcols";
+                std::ofstream bbcols_out(bbcols_fname.c_str());
+                writeBackboneColumns(bbcols_out, bb_list);               // :257-258
+                interval_list.backbone_filename = bbcols_fname;          // :259
+            }
             interval_list.WriteStandardAlignment(std::cout);             // :722
             for (auto *s : match_list.seq_table) delete s;
             return 0;

@@ -359,7 +359,8 @@ def test_example_matches_c_abi(flag):
                     f.write(a[k:k + 70] + "\n")
             paths.append(p)
         cmd = [os.path.join(ROOT, "examples", "mauve_hip_align")] + ([flag] if flag else []) + paths
-        env = dict(os.environ, MAUVE_MUMS_OUT=os.path.join(td, "o.mums"), MAUVE_MLN_OUT=os.path.join(td, "o.mln"))
+        env = dict(os.environ, MAUVE_MUMS_OUT=os.path.join(td, "o.mums"), MAUVE_MLN_OUT=os.path.join(td, "o.mln"),
+                   MAUVE_BACKBONE_OUT=os.path.join(td, "o.backbone"))
         out = subprocess.run(cmd, check=True, capture_output=True, text=True, env=env).stdout
         if flag != "-p":        # the seam files of the mauveAligner path: match list and interval list
             mums = open(env["MAUVE_MUMS_OUT"]).read().splitlines()
@@ -375,6 +376,15 @@ def test_example_matches_c_abi(flag):
                 r = ctx.progressive_align(_lib.default_params(weight_scaling=1, conservation_scale_ppm=500000), names=paths, want_xmfa=True)
             else:
                 r = ctx.align(_lib.default_params(extend_lcbs=1), names=paths, want_xmfa=True)    # the call site passes lcb_extension = true
+            if flag == "-p":        # applyBackbone in the example: the .bbcols rows are the segments of mauve_backbone on the same alignment
+                bb = ctx.backbone(island_gap=20)
+                rows = [ln.split("\t") for ln in open(env["MAUVE_BACKBONE_OUT"] + ".bbcols").read().splitlines()]
+                assert len(rows) == len(bb["seg_iv"]) > 0
+                for row, iv, col, ln_, mask in zip(rows, bb["seg_iv"], bb["seg_col"], bb["seg_len"], bb["seg_mask"]):
+                    assert [int(x) for x in row[:3]] == [int(iv), int(col), int(ln_)]
+                    assert [int(x) for x in row[3:]] == [g for g in range(len(gs)) if int(mask) >> g & 1]
+                head = open(env["MAUVE_BACKBONE_OUT"]).readline().rstrip("\n").split("\t")
+                assert head == sum((["seq%d_leftend" % g, "seq%d_rightend" % g] for g in range(len(gs))), [])
         finally:
             ctx.close()
         assert out == r["xmfa"]
