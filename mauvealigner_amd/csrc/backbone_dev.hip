@@ -11,7 +11,6 @@
 #include "common.hpp"
 #include <algorithm>
 #include <cstring>
-#include <map>
 
 namespace {
 
@@ -287,13 +286,26 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
         }
     }
     const double tb2 = now_ms();
-    // ---- residue counts at the segment and island ends: one query per distinct column
+    // ---- residue counts at the segment and island ends.  The query slots are laid out by construction -- interval starts,
+    // then two per segment, then two per island -- so nothing has to be sorted or looked up (a column asked twice costs a wave)
     std::vector<int64_t> qcol;
+    qcol.reserve(ivs.size() + 2 * (segs.size() + isl.size()));
     for (const BbIv &d : ivs) qcol.push_back(d.col0);
+    const size_t q_seg = qcol.size();
     for (const Seg &s : segs) { qcol.push_back(ivs[s.ivx].col0 + s.c1); qcol.push_back(ivs[s.ivx].col0 + s.c2 + 1); }
-    std::map<uint32_t, const BbIv *> by_iv; for (const BbIv &d : ivs) by_iv[d.iv] = &d;
-    for (const BbRec &q : isl) { const BbIv *d = by_iv[q.iv]; qcol.push_back(d->col0 + q.c_first); qcol.push_back(d->col0 + q.c_last + 1); }
-    std::sort(qcol.begin(), qcol.end()); qcol.erase(std::unique(qcol.begin(), qcol.end()), qcol.end());
+    const size_t q_isl = qcol.size();
+    std::vector<uint32_t> isl_ivx(isl.size());                          // the islands' intervals (records and ivs are both ordered by interval)
+    { size_t x = 0; for (size_t k = 0; k < isl.size(); k++) { while (ivs[x].iv != isl[k].iv) x++; isl_ivx[k] = (uint32_t)x; } }
+    for (size_t k = 0; k < isl.size(); k++) { const BbIv &d = ivs[isl_ivx[k]]; qcol.push_back(d.col0 + isl[k].c_first); qcol.push_back(d.col0 + (int64_t)isl[k].c_last + 1); }
+    // many genomes with many islands ask for the same columns pair after pair: beyond a million queries they are made unique
+    // first (one sort) and every slot is looked up once
+    std::vector<uint32_t> slot;
+    if (qcol.size() > (1u << 20)) {
+        std::vector<int64_t> all(qcol);
+        std::sort(qcol.begin(), qcol.end()); qcol.erase(std::unique(qcol.begin(), qcol.end()), qcol.end());
+        slot.resize(all.size());
+        for (size_t k = 0; k < all.size(); k++) slot[k] = (uint32_t)(std::lower_bound(qcol.begin(), qcol.end(), all[k]) - qcol.begin());
+    }
     const uint32_t *qcnt;
     {
         const size_t o_q = 0, o_out = up(qcol.size() * 8), n_out = qcol.size() * (size_t)N * 4;
@@ -302,8 +314,11 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
         char *qb = c->bb_query.as<char>(), *hb = c->pin_bb.as<char>();
         memcpy(hb + o_q, qcol.data(), qcol.size() * 8);
         HIPCHK(c, hipMemcpyAsync(qb + o_q, hb + o_q, qcol.size() * 8, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(bb_rank, dim3((uint32_t)qcol.size()), dim3(256), 0, c->stream, d_cols, reinterpret_cast<const int64_t *>(qb + o_q), N,
-                           reinterpret_cast<uint32_t *>(qb + o_out));
+        for (size_t q0 = 0; q0 < qcol.size(); q0 += (size_t)1 << 22) {      // grid x block stays below 2^32 threads per launch
+            const size_t nq = std::min<size_t>((size_t)1 << 22, qcol.size() - q0);
+            hipLaunchKernelGGL(bb_rank, dim3((uint32_t)nq), dim3(256), 0, c->stream, d_cols, reinterpret_cast<const int64_t *>(qb + o_q) + q0, N,
+                               reinterpret_cast<uint32_t *>(qb + o_out) + q0 * (size_t)N);
+        }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(hb + o_out, qb + o_out, n_out, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -314,8 +329,8 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
     // exclusive prefix of the tile counts
     std::vector<int64_t> tile_pre((n_tiles + 1) * (size_t)N, 0);
     for (size_t t = 0; t < n_tiles; t++) for (int g = 0; g < N; g++) tile_pre[(t + 1) * N + g] = tile_pre[t * N + g] + tile_cnt[t * N + g];
-    auto qidx = [&](int64_t x) { return (size_t)(std::lower_bound(qcol.begin(), qcol.end(), x) - qcol.begin()); };
-    auto count_at = [&](int64_t x, size_t k, int g) {                  // residues of g in columns [0, x) of the whole array; k = qidx(x)
+    auto count_at = [&](int64_t x, size_t k, int g) {                  // residues of g in columns [0, x) of the whole array; k = the query's slot
+        if (!slot.empty()) k = slot[k];
         return tile_pre[(size_t)(x / BB_CHUNK) * N + g] + (int64_t)qcnt[k * N + g];
     };
     size_t kb = 0, ka = 0, kz = 0;                                     // query slots of the interval start and of the two ends in turn
@@ -328,9 +343,10 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
     };
     B.seg_iv.reserve(segs.size()); B.seg_col.reserve(segs.size()); B.seg_len.reserve(segs.size()); B.seg_mask.reserve(segs.size());
     B.seg_left.reserve(segs.size() * (size_t)N); B.seg_right.reserve(segs.size() * (size_t)N);
-    for (const Seg &s : segs) {
+    for (size_t si = 0; si < segs.size(); si++) {
+        const Seg &s = segs[si];
         const BbIv &d = ivs[s.ivx];
-        kb = qidx(d.col0); ka = qidx(d.col0 + s.c1); kz = qidx(d.col0 + s.c2 + 1);
+        kb = s.ivx; ka = q_seg + 2 * si; kz = ka + 1;
         int64_t lo[32] = {0}, hi[32] = {0}; uint32_t got = 0;
         for (int g = 0; g < N; g++) if ((s.mask >> g & 1) && ends(d, g, s.c1, s.c2, &lo[g], &hi[g])) got |= 1u << g;
         if (__builtin_popcount(got) < 2) continue;
@@ -341,24 +357,29 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
     {
         std::vector<size_t> idx(B.seg_iv.size());
         for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
-        std::sort(idx.begin(), idx.end(), [&](size_t x, size_t y) {
+        auto before = [&](size_t x, size_t y) {
             if (B.seg_iv[x] != B.seg_iv[y]) return B.seg_iv[x] < B.seg_iv[y];
             if (B.seg_col[x] != B.seg_col[y]) return B.seg_col[x] < B.seg_col[y];
             return B.seg_mask[x] < B.seg_mask[y];
-        });
-        mauve_ctx::BackboneResult S; S.N = N;
-        for (size_t i : idx) {
-            S.seg_iv.push_back(B.seg_iv[i]); S.seg_col.push_back(B.seg_col[i]); S.seg_len.push_back(B.seg_len[i]); S.seg_mask.push_back(B.seg_mask[i]);
-            S.seg_left.insert(S.seg_left.end(), B.seg_left.begin() + (std::ptrdiff_t)(i * N), B.seg_left.begin() + (std::ptrdiff_t)((i + 1) * N));
-            S.seg_right.insert(S.seg_right.end(), B.seg_right.begin() + (std::ptrdiff_t)(i * N), B.seg_right.begin() + (std::ptrdiff_t)((i + 1) * N));
+        };
+        if (!std::is_sorted(idx.begin(), idx.end(), before)) {             // (the sweep hands them out nearly in this order already)
+            std::sort(idx.begin(), idx.end(), before);
+            mauve_ctx::BackboneResult S; S.N = N;
+            for (size_t i : idx) {
+                S.seg_iv.push_back(B.seg_iv[i]); S.seg_col.push_back(B.seg_col[i]); S.seg_len.push_back(B.seg_len[i]); S.seg_mask.push_back(B.seg_mask[i]);
+                S.seg_left.insert(S.seg_left.end(), B.seg_left.begin() + (std::ptrdiff_t)(i * N), B.seg_left.begin() + (std::ptrdiff_t)((i + 1) * N));
+                S.seg_right.insert(S.seg_right.end(), B.seg_right.begin() + (std::ptrdiff_t)(i * N), B.seg_right.begin() + (std::ptrdiff_t)((i + 1) * N));
+            }
+            B = std::move(S);
         }
-        B = std::move(S);
     }
-    for (const BbRec &q : isl) {
-        const BbIv &d = *by_iv[q.iv];
+    B.islands.reserve(isl.size() * 8);
+    for (size_t k = 0; k < isl.size(); k++) {
+        const BbRec &q = isl[k];
+        const BbIv &d = ivs[isl_ivx[k]];
         const int who = (int)(q.packed >> 16 & 0xff);
         int64_t lo = 0, hi = 0;
-        kb = qidx(d.col0); ka = qidx(d.col0 + q.c_first); kz = qidx(d.col0 + (int64_t)q.c_last + 1);
+        kb = isl_ivx[k]; ka = q_isl + 2 * k; kz = ka + 1;
         (void)ends(d, who, q.c_first, q.c_last, &lo, &hi);
         const int64_t row[8] = {(int64_t)q.iv, (int64_t)(q.packed & 0xff), (int64_t)(q.packed >> 8 & 0xff), who, (int64_t)q.c_first, (int64_t)q.c_last, lo, hi};
         B.islands.insert(B.islands.end(), row, row + 8);
