@@ -32,6 +32,10 @@ int mauve_ctx_create(int device, mauve_ctx **out)
     mauve_ctx *c = new (std::nothrow) mauve_ctx();
     if (!c) { g_create_err = "out of host memory"; return MAUVE_ERR_ARG; }
     c->device = device;
+    if (const char *sp = getenv("MAUVE_SCHEDULE")) {            // A/B hook: how the host waits in hipStreamSynchronize (spin | yield | block)
+        const unsigned f = !strcmp(sp, "spin") ? hipDeviceScheduleSpin : !strcmp(sp, "yield") ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync;
+        (void)hipSetDevice(device); (void)hipSetDeviceFlags(f); (void)hipGetLastError();
+    }
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
