@@ -283,12 +283,27 @@ __global__ void __launch_bounds__(256) ch_cluster_pass(int32_t *__restrict__ len
                                                        const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ cnt_in,
                                                        uint32_t *__restrict__ fail, int leave_big, int cl_max)
 {
+    // Nearly every thread has a cluster of one and leaves at once; the few that work keep their arrays in LDS (a slot each,
+    // handed out by a counter; sized by the cluster: 8 words per entry) instead of in scratch, whose latency was the kernel's
+    // whole run time.  A block that runs out of LDS falls back to scratch for the rest.
+    constexpr int POOL_WORDS = 12 * 1024;                      // 48 KB
+    __shared__ uint32_t pool[POOL_WORDS];
+    __shared__ uint32_t pool_used;
+    if (threadIdx.x == 0) pool_used = 0;
+    __syncthreads();
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= cnt_in[0]) return;
     const uint32_t a = cstart[j];
     const int s = (int)(cstart[j + 1] - a);
     if (s < 2) return;
     if (s > cl_max) { if (!leave_big) *fail = 1; return; }
+    const uint32_t want = 8u * (uint32_t)s, at = atomicAdd(&pool_used, want);
+    if (at + want <= (uint32_t)POOL_WORDS) {
+        uint32_t *w = pool + at;
+        ch_cluster_run(len, st, N, g, dead_key, eleft, eidx, a, s, w, w + s, w + 2 * s, w + 3 * s, w + 4 * s, w + 5 * s, w + 6 * s,
+                       reinterpret_cast<uint8_t *>(w + 7 * s));
+        return;
+    }
     uint32_t L[CH_CL_MAX], Ln[CH_CL_MAX], I[CH_CL_MAX], CF[CH_CL_MAX], CL[CH_CL_MAX], pf[CH_CL_MAX], pl[CH_CL_MAX];
     uint8_t F[CH_CL_MAX];
     ch_cluster_run(len, st, N, g, dead_key, eleft, eidx, a, s, L, Ln, I, CF, CL, pf, pl, F);
