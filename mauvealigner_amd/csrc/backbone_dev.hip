@@ -2,7 +2,7 @@
 // for libMems' detectBackbone(iv_list, bb_list, &BigGapsDetector(island_gap_size)) (progressiveMauve.cpp:242-243) and
 // for simpleFindIslands (mauveAligner.cpp:844).  The alignment is the column array the assembly stage left in HBM
 // (one uint32 presence mask per column); everything that touches columns runs on the device:
-//   bb_pair_gaps  one wave per (4096-column chunk, genome pair): the pair's gap regions that start in the chunk are
+//   bb_pair_gaps  one wave (= one workgroup) per (4096-column chunk, genome pair): the pair's gap regions that start in the chunk are
 //                 walked 64 columns at a time on wave ballots (all bookkeeping is wave-uniform, i.e. scalar), and the
 //                 open regions and the islands are appended to a record list;
 //   bb_tile_count per-genome residue counts of every 4096-column tile;  bb_rank  residue counts at query columns
@@ -31,17 +31,17 @@ __device__ __forceinline__ void bb_pair_of(uint32_t gmask, uint32_t p, int *a, i
     *a = g[x]; *b = g[x + 1 + (int)p];
 }
 
-__global__ void __launch_bounds__(256) bb_pair_gaps(const uint32_t *__restrict__ cols, const BbIv *__restrict__ ivs, uint32_t n_ivs, uint32_t island_gap,
+__global__ void __launch_bounds__(64) bb_pair_gaps(const uint32_t *__restrict__ cols, const BbIv *__restrict__ ivs, uint32_t n_ivs, uint32_t island_gap,
                                                     BbRec *__restrict__ rec, uint32_t cap, uint32_t *__restrict__ count)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     // which interval this chunk belongs to
     uint32_t lo = 0, hi = n_ivs;
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (ivs[mid].chunk0 <= blockIdx.x) lo = mid; else hi = mid; }
     const BbIv d = ivs[lo];
     const int64_t nc = d.ncols, cs = (int64_t)(blockIdx.x - d.chunk0) * BB_CHUNK, ce = cs + BB_CHUNK < nc ? cs + BB_CHUNK : nc;
     const uint32_t *m = cols + d.col0;
-    for (uint32_t p = blockIdx.y * 4u + (uint32_t)wave; p < d.npairs; p += gridDim.y * 4u) {
+    for (uint32_t p = blockIdx.y; p < d.npairs; p += gridDim.y) {
         int a, b;
         bb_pair_of(d.gmask, p, &a, &b);
         // the nearest column before the chunk that holds a residue of the pair: a both-column (or none) means a region that
@@ -66,18 +66,32 @@ __global__ void __launch_bounds__(256) bb_pair_gaps(const uint32_t *__restrict__
         auto close_run = [&]() {
             if (run_n > (int64_t)island_gap) { has_island = true; emit(1u, (uint32_t)(run_t == 1 ? a : b), run_first, run_last); }
         };
-        // four words (256 columns) are fetched at a time so that the loads overlap; the walk itself stays word by word
+        // four words (256 columns) are fetched at a time, one batch ahead; the walk itself stays word by word
+        uint32_t nx[4];                                          // the next four words are on their way while these four are walked
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int64_t c = cs + 64 * k + lane; nx[k] = c < nc ? m[c] : 0u; }
         for (int64_t w0 = cs; w0 < nc && !done && (w0 < ce || in_region); w0 += 256) {
           uint32_t vv[4];
 #pragma unroll
-          for (int k = 0; k < 4; k++) { const int64_t c = w0 + 64 * k + lane; vv[k] = c < nc ? m[c] : 0u; }
+          for (int k = 0; k < 4; k++) { vv[k] = nx[k]; const int64_t c = w0 + 256 + 64 * k + lane; nx[k] = c < nc ? m[c] : 0u; }
+          if (!in_region && !skipping) {                         // the common batch: 256 columns without a one-sided one, no region open
+              bool one = false, both = false;
+#pragma unroll
+              for (int k = 0; k < 4; k++) { const bool ra = vv[k] >> a & 1, rb = vv[k] >> b & 1; one |= ra != rb; both |= ra && rb; }
+              if (!__ballot(one)) { if (__ballot(both)) seen_both = true; continue; }
+          }
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const int64_t w = w0 + 64 * k;
             if (!(w < nc && !done && (w < ce || in_region))) break;
             const uint32_t v = vv[k];
             const bool ra = v >> a & 1, rb = v >> b & 1;
-            const uint64_t mA = __ballot(ra && !rb), mB = __ballot(rb && !ra), mBoth = __ballot(ra && rb);
+            const uint64_t mOne = __ballot(ra != rb);
+            if (!mOne && !in_region && !skipping) {              // the common word: nothing one-sided in it and no region open
+                if (__ballot(ra && rb)) seen_both = true;
+                continue;
+            }
+            const uint64_t mA = __ballot(ra && !rb), mB = mOne & ~mA, mBoth = __ballot(ra && rb);
             int pos = 0;
             while (pos < 64) {
                 if (skipping) {
@@ -218,8 +232,8 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
         char *wk = c->bb_work.as<char>();
         HIPCHK(c, hipMemcpyAsync(wk, ivs.data(), ivs.size() * sizeof(BbIv), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(wk + o_cnt, 0, 64, c->stream));
-        const uint32_t gy = std::min<uint32_t>((max_pairs + 3) / 4, 16);
-        hipLaunchKernelGGL(bb_pair_gaps, dim3(chunks, gy), dim3(256), 0, c->stream, d_cols, reinterpret_cast<const BbIv *>(wk), (uint32_t)ivs.size(),
+        const uint32_t gy = std::min<uint32_t>(max_pairs, 64);        // one wave per (chunk, pair): with few pairs, too, every resident wave works
+        hipLaunchKernelGGL(bb_pair_gaps, dim3(chunks, gy), dim3(64), 0, c->stream, d_cols, reinterpret_cast<const BbIv *>(wk), (uint32_t)ivs.size(),
                            (uint32_t)island_gap, reinterpret_cast<BbRec *>(wk + o_rec), (uint32_t)cap, reinterpret_cast<uint32_t *>(wk + o_cnt));
         if (attempt == 0)
             hipLaunchKernelGGL(bb_tile_count, dim3((uint32_t)n_tiles), dim3(256), 0, c->stream, d_cols, n_cols, N, reinterpret_cast<uint32_t *>(wk + o_tile));
