@@ -21,6 +21,15 @@ struct BbRec { uint32_t iv, packed, c_first, c_last; };       // packed: a | b <
 
 __device__ __forceinline__ uint64_t below(int p) { return p >= 64 ? ~0ull : (1ull << p) - 1; }
 
+// does m hold a run of at least `need` consecutive ones?  (AND with itself shifted, doubling the length known so far)
+__device__ __forceinline__ bool has_run(uint64_t m, int need)
+{
+    if (need > 64) return false;
+    int have = 1;
+    while (have < need && m) { const int sh = have < need - have ? have : need - have; m &= m >> sh; have += sh; }
+    return m != 0;
+}
+
 // the k-th genome pair (a < b) among the genomes of gmask, in the order (g0,g1), (g0,g2), .., (g1,g2), ..
 __device__ __forceinline__ void bb_pair_of(uint32_t gmask, uint32_t p, int *a, int *b)
 {
@@ -92,6 +101,14 @@ __global__ void __launch_bounds__(64) bb_pair_gaps(const uint32_t *__restrict__ 
                 continue;
             }
             const uint64_t mA = __ballot(ra && !rb), mB = mOne & ~mA, mBoth = __ballot(ra && rb);
+            if (!in_region && !skipping) {
+                // the usual gapped word: every column holds a base of the pair, the gaps open after a both-column and close
+                // before the word's last column, and none of them is an island -- nothing to report, nothing carried over
+                const uint64_t valid = __ballot(w + lane < nc);
+                const int top = 63 - __clzll((long long)valid);
+                if ((mA | mB | mBoth) == valid && (mBoth >> top & 1) && (seen_both || (mBoth & 1)) &&
+                    !has_run(mA, (int)island_gap + 1) && !has_run(mB, (int)island_gap + 1)) { seen_both = true; continue; }
+            }
             int pos = 0;
             while (pos < 64) {
                 if (skipping) {
