@@ -1065,13 +1065,13 @@ __global__ void __launch_bounds__(256) pair_length_sums(const int32_t *__restric
 }
 
 __global__ void __launch_bounds__(256) canon_keys(const int32_t *__restrict__ mlen, const int32_t *__restrict__ mstart, uint32_t ncand,
-                                                  int nseq, int pos_bits, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                  int nseq, int pos_bits, int inval, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                   uint32_t *__restrict__ n_valid)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = false;
     if (i < ncand) {
-        uint64_t key = (uint64_t)nseq << pos_bits;
+        uint64_t key = (uint64_t)inval << pos_bits;                 // dropped candidates: behind every match
         if (mlen[i] != 0) {
             const int32_t *s = mstart + (size_t)i * nseq;
             int f = 0; while (f < nseq && s[f] == 0) f++;
@@ -1493,10 +1493,14 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
         int64_t maxlen = 1; for (int g = 0; g < N; g++) maxlen = std::max<int64_t>(maxlen, gs.lens[(size_t)g]);
         int pos_bits = 1; while (pos_bits < 32 && (1LL << pos_bits) <= maxlen) pos_bits++;
-        int fbits = 1; while ((1 << fbits) <= N) fbits++;
+        // the bits above the position hold the first component (0 .. N-1; N = dropped).  An N-way search (mask = every genome) only
+        // has matches that start in genome 0: one bit tells them from the dropped ones, which at bacterial sizes saves a sort pass
+        const uint32_t full_mask = N >= 32 ? 0xffffffffu : ((1u << N) - 1);
+        const bool nway_only = mask != 0 && (uint32_t)mask == full_mask && mode != MAUVE_MODE_PAIRWISE;
+        int fbits = 1; if (!nway_only) while ((1 << fbits) <= N) fbits++;
         { KernelTimer t(ctx, MAUVE_K_CANON, ncand);
           hipLaunchKernelGGL(canon_keys, dim3((ncand + 255) / 256), dim3(256), 0, ctx->stream, ctx->mlen.as<int32_t>(),
-                             ctx->mstart.as<int32_t>(), ncand, N, pos_bits, ck, cv, ctx->counters.as<uint32_t>() + 3); }
+                             ctx->mstart.as<int32_t>(), ncand, N, pos_bits, nway_only ? 1 : N, ck, cv, ctx->counters.as<uint32_t>() + 3); }
         HIPCHK(ctx, hipGetLastError());
         int rc2 = sort_pairs<uint64_t>(ctx, ncand, pos_bits + fbits, &ck, &cv, ck2, cv2, false, MAUVE_K_CANON);
         if (rc2) return rc2;
