@@ -1,29 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native mauveAligner hot path.
 
-Metric (BASELINE.json): aligned Mbp/s (seed + extend + chain + recursive anchoring + gapped DP) on N x 5 Mbp
-genomes.  A "step" is one pass of the whole hot path (mauve_align) over one synthetic genome set whose packed
-genomes are already resident in HBM; the timed region ends with the SoA results in host RAM.
+Metric (BASELINE.json): aligned Mbp/s = total bases / t(seed + extend + chain + recursive anchoring + gapped
+DP), "t measured from packed genomes resident in host RAM to final SoA results in host RAM (includes H2D/D2H, excludes
+FASTA parse and XMFA text formatting)".  A "step" is therefore: upload of the packed genomes (mauve_set_genomes), one
+pass of the whole hot path (mauve_align / mauve_progressive_align) and the copy of every result array into the caller's
+buffers (mauve_align_fetch).  The caller's buffers are page-locked (mauve_host_alloc), as a production caller's would be.
+`value` is that figure; the same pass with the genomes already resident in HBM and the results left there is reported
+beside it as `device_resident` (never as `value`).
 
 Workload at N = 1: BASELINE config C3 -- 5 x 5 Mbp genomes, ~3 % divergence, ~50 inversions, seed weight 15: the
-configuration the >= 50 Mbp/s target of `north_star` is quoted on.  C2 (3 x 5 Mbp, configs[1]) is measured beside
-it and reported in the "c2" object.  --config picks another primary workload.
+configuration the >= 50 Mbp/s target of `north_star` is quoted on.  The other BASELINE configs are measured in the same
+run and reported as objects of their own ("c2", "c4", "c5"), each with its stage times, roofline and CPU baseline:
+C2 (3 x 5 Mbp), C4 (8 x 2 Mbp, progressive path), C5 (2 x 100 Mbp, default seed weight 19, 64-bit keys).
+--config picks another primary workload; --only-primary skips the others.
 
 --gpus N, two forms (--shard):
   replicas (default): every rank aligns its own genome set of the workload's shape (different PRNG stream), no
              data-path collective: weak scaling, value = total Mbp of all ranks / max-over-ranks time.
-  lcb      : ONE alignment (the same genomes on every rank); every rank runs the deterministic front (seed pass,
-             chaining, recursion), the gapped-DP intervals are LPT-sharded over the ranks and the packed columns
-             exchanged with one RCCL all_gather (mauvealigner_amd/parallel.py): strong scaling.
+  lcb      : ONE alignment (the same genomes on every rank); the independent units of the path -- the pairwise finder
+             passes of the guide tree, the recursion's gaps, the gapped-DP intervals -- are LPT-sharded over the ranks and
+             their results exchanged with RCCL all_gathers (mauvealigner_amd/parallel.py): strong scaling.
 
 Extra objects on the JSON line:
   roofline     -- dominant HBM kernel (by HIP-event time on the library's stream): algorithmic bytes per launch
                    / average launch duration, against the 8 TB/s HBM peak; the seed-pass
                   aggregate (SURVEY.md 8d's B_seed per position) and the DP kernel's GCUPS beside it.
   cpu_baseline -- the CPU oracle (oracle/, a restatement: kind "port") timed on this box's host cores on the
-                  same workload (rank 0, N = 1 only).
+                  same workload or a bounded sample of it (rank 0, N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -39,10 +46,14 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s s
 DP_PEAK_GCUPS = 256 * 64 * 2.4 / 12.0
 
 WORKLOADS = {
-    "C2": dict(n=3, L=5_000_000, inversions=0, weight=15,
+    "C2": dict(n=3, L=5_000_000, weight=15, path="align", key=2,
                text="C2: 3 x %d bp synthetic genomes, ~3%% divergence, seed weight 15"),
-    "C3": dict(n=5, L=5_000_000, inversions=50, weight=15,
+    "C3": dict(n=5, L=5_000_000, weight=15, path="align", key=3,
                text="C3: 5 x %d bp synthetic genomes, ~3%% divergence, ~50 inversions, seed weight 15"),
+    "C4": dict(n=8, L=2_000_000, weight=0, path="progressive", key=4,
+               text="C4: 8 x %d bp synthetic genomes on a balanced tree (branch divergence 0.01, 2 inversions + 1 clade insertion per branch), progressive path, default seed weight"),
+    "C5": dict(n=2, L=100_000_000, weight=0, path="align", key=5,
+               text="C5: 2 x %d bp synthetic genomes, ~3%% divergence, 2000 lineage-specific insertions + 200 hyper-divergent segments per genome, default seed weight (19)"),
 }
 
 
@@ -61,33 +72,123 @@ def algorithmic_bytes_per_position(weight):
     return total, per_kernel, K, R
 
 
-def make_workload(name, scale, rank):
+def make_workload(name, scale, rank, track=False):
+    """-> (genomes, origins or None, nominal genome length)"""
     from mauvealigner_amd import synth
     w = WORKLOADS[name]
     L = int(w["L"] * scale)
-    key = {"C2": 2, "C3": 3}[name] + 1000 * rank
-    return synth.star_genomes(w["n"], L, 0.03, key, inversions=w["inversions"], track=True), L
+    if name in ("C2", "C3"):
+        inv = 0 if name == "C2" else (50 if scale >= 0.25 else max(1, int(round(50 * min(1.0, scale * 4)))))
+        out = synth.star_genomes(w["n"], L, 0.03, w["key"] + 1000 * rank, inversions=inv, track=track)
+        return (out[0], out[1], L) if track else (out, None, L)
+    if rank:
+        raise SystemExit("bench.py: %s is a single-alignment workload (use --shard lcb with --gpus N)" % name)
+    return synth.make_config(name, scale), None, L
 
 
-def time_steps(ctx, params, steps, barrier, fetch=False):
-    barrier()
-    t0 = time.perf_counter()
-    acc = {}
-    sizes = None
-    for _ in range(steps):
-        sizes = ctx.align(params, fetch=fetch)
-        for k, v in ctx.stage_times().items():
-            acc[k] = acc.get(k, 0.0) + v
-    barrier()
-    return time.perf_counter() - t0, acc, sizes
+def pack_pinned(genomes):
+    """the packed genomes in host RAM, in page-locked caller buffers (where the timed region starts)"""
+    from mauvealigner_amd import _lib
+    out = []
+    for g in genomes:
+        w = _lib.pack_codes(g)
+        p = _lib.pinned_empty(len(w), np.uint64)
+        p[:] = w
+        out.append(p)
+    return out, [len(g) for g in genomes]
 
 
-def kernel_profile(ctx, params, weight, nprof=3):
-    """per-kernel HIP-event timing (separate, untimed passes; events serialize the launches)"""
+def seed_weight_of(cfg, genomes):
+    from mauvealigner_amd import _lib
+    return cfg["weight"] or _lib.default_seed_weight(sum(len(g) for g in genomes) // len(genomes))
+
+
+class Runner:
+    """one workload on one context: the host-to-host step and the device-resident pass"""
+
+    def __init__(self, ctx, name, genomes, params, barrier):
+        from mauvealigner_amd import _lib
+        self.ctx, self.name, self.cfg, self.params, self.barrier = ctx, name, WORKLOADS[name], params, barrier
+        self.genomes = genomes
+        self.packed, self.lens = pack_pinned(genomes)
+        self.bufs = _lib.ResultBuffers()
+        self.total_bp = sum(self.lens)
+        self.progressive = self.cfg["path"] == "progressive"
+
+    def upload(self):
+        self.ctx.set_genomes_packed(self.packed, self.lens)
+
+    def run(self, params=None, fetch=False, out=None):
+        p = params or self.params
+        if self.progressive:
+            return self.ctx.progressive_align(p, fetch=fetch, out=out)
+        return self.ctx.align(p, fetch=fetch, out=out)
+
+    def step_host(self, params=None):                     # SURVEY 8(d): host RAM -> host RAM
+        self.upload()
+        return self.run(params, fetch=True, out=self.bufs)
+
+    def time_host(self, steps, warmup, params=None):
+        for _ in range(warmup):
+            self.step_host(params)
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = self.step_host(params)
+        self.barrier()
+        return time.perf_counter() - t0, r
+
+    def time_resident(self, steps, warmup, params=None):
+        self.upload()
+        for _ in range(warmup):
+            self.run(params)
+        acc = {}
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sizes = self.run(params)
+            for k, v in self.ctx.stage_times().items():
+                acc[k] = acc.get(k, 0.0) + v
+        self.barrier()
+        sizes = {k: v for k, v in sizes.items() if isinstance(v, int)}
+        return time.perf_counter() - t0, {k: round(v / steps, 3) for k, v in acc.items()}, sizes
+
+
+def kernel_source_digest():
+    h = hashlib.sha256()
+    for f in ("seed_pass.hip", "dp_batch.hip", "common.hpp", "dev_scan.hpp"):
+        with open(os.path.join(ROOT, "mauvealigner_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kernel):
+    """roofline.traffic: HBM bytes per launch from the committed PMC passes (profiles/roofline_traffic.json, made by
+    tools/summarize_profile.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command).  The file carries the
+    digest of the kernel sources it was measured on; when the sources have changed since, the figure is dropped (null)
+    rather than quoted stale."""
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    try:
+        with open(tpath) as f:
+            t = json.load(f)
+    except Exception:
+        return None, "no committed PMC profile"
+    meta = t.get("_meta", {})
+    if meta.get("kernel_source_digest") != kernel_source_digest():
+        return None, "committed PMC profile (%s) predates the current kernel sources" % meta.get("round", "?")
+    v = t.get(kernel, {}).get("hbm_bytes_per_launch")
+    return v, "profiles/roofline_traffic.json (%s, commit %s)" % (meta.get("round", "?"), meta.get("commit", "?"))
+
+
+def kernel_profile(rn, weight, nprof=3, params=None):
+    """per-kernel HIP-event timing on the library's stream (separate, untimed passes; events serialize the launches)"""
+    ctx = rn.ctx
+    rn.upload()
+    rn.run(params)
     ctx.profile(True)
     ctx.profile_reset()
     for _ in range(nprof):
-        sizes = ctx.align(params, fetch=False)
+        sizes = rn.run(params)
     ctx.profile(False)
     kernels = ctx.profile_get()
     tot_b, per_kernel, K, R = algorithmic_bytes_per_position(weight)
@@ -100,28 +201,25 @@ def kernel_profile(ctx, params, weight, nprof=3):
     units = d["units"] / d["launches"]
     bpp = per_kernel[dom]
     achieved = bpp * units / (avg_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            with open(tpath) as f:
-                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, tnote = committed_traffic(dom) if rn.name == "C3" else (None, "PMC passes are collected on the C3 command only")
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tnote,
                 "algorithmic_bytes_per_launch": bpp * units, "avg_launch_ms": round(avg_ms, 4),
                 "launches_timed": d["launches"],
                 "dominant_overall": {"kernel": overall, "ms_per_pass": round(kernels[overall]["ms"] / nprof, 4),
                                      "bound": "hbm" if per_kernel.get(overall) else "valu/shuffle (no HBM or MFMA roofline applies)"}}
     seed_k = ["seed_extract", "rs_hist", "rs_rowscan", "rs_scatter", "mum_join"]
     seed_ms = sum(kernels[k]["ms"] for k in seed_k) / nprof
-    P = kernels["seed_extract"]["units"] / max(1, kernels["seed_extract"]["launches"])
+    P = kernels["seed_extract"]["units"] / nprof                     # positions of all seed passes of one step
+    ext_ms = (kernels["mum_runs"]["ms"] + kernels["mum_extend"]["ms"]) / nprof
     roofline["seed_pass"] = {"bytes_per_position": tot_b, "positions": P, "kernel_ms": round(seed_ms, 4),
                              "achieved_GBs": round(tot_b * P / (seed_ms * 1e-3) / 1e9, 1) if seed_ms else None,
                              "frac": round(tot_b * P / (seed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if seed_ms else None,
+                             "with_runs_and_extend": {"kernel_ms": round(seed_ms + ext_ms, 4),
+                                                      "frac": round(tot_b * P / ((seed_ms + ext_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if seed_ms else None},
+                             "seed_passes_per_step": kernels["seed_extract"]["launches"] // nprof,
                              "sort_passes_run": kernels["rs_scatter"]["launches"] // nprof,
-                             "note": "B_seed is SURVEY 8(d)'s figure for a full LSD sort of ceil(2w/8) passes; the seed pass "
+                             "note": "B_seed is SURVEY 8(d)'s figure for a full LSD sort of ceil(2w/8) passes; the N-way seed pass "
                                      "sorts the high mer bits only and joins through an LDS hash table (DESIGN.md section 4)"}
     dp_ms = kernels["dp_step"]["ms"] / nprof
     cells = sizes["n_dp_cells"]
@@ -133,6 +231,98 @@ def kernel_profile(ctx, params, weight, nprof=3):
     return roofline, kern_ms
 
 
+KEYS_ALIGN = ("anchor_start", "anchor_length", "left", "right", "reverse", "col_off", "cols", "dp_score")
+KEYS_PROG = ("left", "right", "reverse", "col_off", "cols", "dp_score")
+
+
+def cpu_baseline(name, scale, weight, gpu_result, genomes, sample_scale):
+    """the oracle on the workload (sample_scale = 1.0: the very genomes, doubling as the full-size parity check of the GPU
+    result) or on a bounded sample of the same shape (a smaller scale of the same generator)"""
+    from oracle import pyoracle as O
+    from mauvealigner_amd import synth
+    cfg = WORKLOADS[name]
+    if sample_scale >= 1.0:
+        gs = genomes
+    else:
+        gs = synth.make_config(name, scale * sample_scale)
+    kw = dict(seed_weight=weight) if cfg["weight"] else {}
+    tc0 = time.perf_counter()
+    if cfg["path"] == "progressive":
+        ref = O.progressive_align(gs, O.default_params(**kw))
+    else:
+        ref = O.align(gs, O.default_params(**kw))
+    tc = time.perf_counter() - tc0
+    bp = sum(len(g) for g in gs)
+    cpu = {"value": round(bp / 1e6 / tc, 3), "unit": "Mbp/s", "cores": 1, "kind": "port",
+           "sample": ("full workload" if sample_scale >= 1.0 else "the same generator at %.3g of the size" % sample_scale) +
+                     " (%d x ~%d bp), single thread, one pass, %.1f s" % (len(gs), bp // len(gs), tc),
+           "host_cpus": os.cpu_count()}
+    if sample_scale >= 1.0 and gpu_result is not None:
+        keys = KEYS_PROG if cfg["path"] == "progressive" else KEYS_ALIGN
+        cpu["gpu_result_identical"] = bool(all(np.array_equal(gpu_result[k], ref["aln"][k]) for k in keys))
+    return cpu
+
+
+def all_cores_baseline(config, scale, weight):
+    """the same baseline on every core this process may use: independent copies of the workload (the path has no intra-job CPU
+    parallelism to offer; throughput adds up), at 1/5 size so that the memory of all copies fits"""
+    import subprocess
+    try:
+        ncore = max(1, len(os.sched_getaffinity(0)))
+        wscale = 0.2 * scale
+        ws = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", config, str(wscale), str(weight)], cwd=ROOT,
+                               stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for _ in range(ncore)]
+        for w in ws:
+            assert w.stdout.readline().strip() == "ready"
+        tw0 = time.perf_counter()
+        for w in ws:
+            w.stdin.write("go\n"); w.stdin.flush()
+        bases = 0
+        for w in ws:
+            bases += int(w.stdout.readline().split()[1])
+        tw = time.perf_counter() - tw0
+        for w in ws:
+            w.wait(timeout=60)
+        return {"value": round(bases / 1e6 / tw, 2), "unit": "Mbp/s", "cores": ncore,
+                "sample": "%d concurrent copies of the workload at scale %.2f, %.1f s" % (ncore, wscale, tw)}
+    except Exception as ex:                      # the single-core figure stands on its own
+        return {"error": repr(ex)}
+
+
+def params_for(name, **kw):
+    from mauvealigner_amd import _lib
+    cfg = WORKLOADS[name]
+    if cfg["weight"]:
+        kw.setdefault("seed_weight", cfg["weight"])
+    return _lib.default_params(**kw)
+
+
+def secondary_leg(ctx, name, scale, steps, warmup, barrier, cpu_sample):
+    """one of the other BASELINE configs, measured like the primary: host-to-host value, resident pass, stages, roofline, CPU"""
+    cfg = WORKLOADS[name]
+    tg0 = time.perf_counter()
+    genomes, _, L = make_workload(name, scale, 0)
+    tgen = time.perf_counter() - tg0
+    params = params_for(name)
+    rn = Runner(ctx, name, genomes, params, barrier)
+    weight = seed_weight_of(cfg, genomes)
+    e_h, res = rn.time_host(steps, warmup)
+    gpu_result = {k: np.array(v, copy=True) for k, v in res.items() if isinstance(v, np.ndarray)} if cpu_sample >= 1.0 else None
+    e_r, stages, sizes = rn.time_resident(steps, 1)
+    roof, kern = kernel_profile(rn, weight, nprof=2)
+    out = {"workload": cfg["text"] % L, "metric": "aligned Mbp/s (seed+extend+DP)", "value": round(rn.total_bp / 1e6 / (e_h / steps), 2), "unit": "Mbp/s",
+           "ms_per_step": round(e_h / steps * 1e3, 3), "steps": steps,
+           "timed_region": "packed genomes in page-locked host RAM -> upload -> %s -> every result array in page-locked host RAM" %
+                           ("mauve_progressive_align" if rn.progressive else "mauve_align"),
+           "total_bp": rn.total_bp, "seed_weight": weight, "extend_lcbs": int(params.extend_lcbs),
+           "device_resident": {"ms_per_step": round(e_r / steps * 1e3, 3), "Mbp_s": round(rn.total_bp / 1e6 / (e_r / steps), 2),
+                               "note": "genomes resident in HBM, results left there"},
+           "stages_ms": stages, "kernels_ms": kern, "roofline": roof, "result_sizes": sizes, "generate_s": round(tgen, 1)}
+    if cpu_sample:
+        out["cpu_baseline"] = cpu_baseline(name, scale, weight, gpu_result, genomes, cpu_sample)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,7 +332,8 @@ def main():
     ap.add_argument("--shard", default="replicas", choices=["replicas", "lcb"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the genomes (debug only; 1.0 = BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the side measurements (C2, the pass with LCB extension, the backbone call)")
+    ap.add_argument("--no-secondary", "--only-primary", dest="no_secondary", action="store_true",
+                    help="skip the side measurements (the other configs, the pass with the other lcb_extension setting, the backbone call)")
     args = ap.parse_args()
 
     import torch
@@ -166,15 +357,16 @@ def main():
     from mauvealigner_amd import _lib
 
     cfg = WORKLOADS[args.config]
-    weight = cfg["weight"]
     shard_lcb = args.shard == "lcb" and dist is not None
-    (genomes, origins), L = make_workload(args.config, args.scale, 0 if shard_lcb else rank)
+    if cfg["path"] == "progressive" or args.config == "C5":
+        if dist is not None and not shard_lcb and world > 1:
+            print("bench.py: %s with --gpus N needs --shard lcb" % args.config, file=sys.stderr)
+            sys.exit(2)
+    genomes, origins, L = make_workload(args.config, args.scale, 0 if shard_lcb else rank, track=args.config in ("C2", "C3"))
     total_bp = sum(len(g) for g in genomes)
     ctx = _lib.Context(local_rank)
-    t_up0 = time.perf_counter()
-    ctx.set_genomes(genomes)            # H2D upload: outside the timed region (inputs resident in HBM)
-    t_upload = time.perf_counter() - t_up0
-    params = _lib.default_params(seed_weight=weight)
+    weight = seed_weight_of(cfg, genomes)
+    params = params_for(args.config)
 
     def barrier():
         if dist is not None:
@@ -182,23 +374,30 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
+    rn = Runner(ctx, args.config, genomes, params, barrier)
+    t_up0 = time.perf_counter()
+    rn.upload()                                   # first upload: allocates the device buffers
+    t_upload = time.perf_counter() - t_up0
+
     if shard_lcb:
         from mauvealigner_amd import parallel
 
         def step():
-            return parallel.align_sharded(ctx, params, dist, fetch=False)
+            rn.upload()
+            if rn.progressive:
+                return parallel.progressive_align_sharded(ctx, params, dist, fetch=True, out=rn.bufs)
+            return parallel.align_sharded(ctx, params, dist, fetch=True, out=rn.bufs)
         for _ in range(args.warmup):
-            sizes = step()
+            res = step()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            sizes = step()
+            res = step()
         barrier()
-        elapsed, stage_acc = time.perf_counter() - t0, {}
+        elapsed = time.perf_counter() - t0
     else:
-        for _ in range(args.warmup):
-            sizes = ctx.align(params, fetch=False)
-        elapsed, stage_acc, sizes = time_steps(ctx, params, args.steps, barrier)
+        elapsed, res = rn.time_host(args.steps, args.warmup)
+    sizes = {k: v for k, v in res.items() if isinstance(v, int)}
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -210,53 +409,44 @@ def main():
         total_all = float(total_bp)
     ms_per_step = elapsed / args.steps * 1e3
     value = total_all / 1e6 / (elapsed / args.steps)
+    side = rank == 0 and world == 1                          # the side measurements: one GPU, rank 0
+    gpu_result = {k: np.array(v, copy=True) for k, v in res.items() if isinstance(v, np.ndarray)} if side else None
 
-    roofline, kern_ms, extras = None, {}, {}
-    if rank == 0:
-        roofline, kern_ms = kernel_profile(ctx, params, weight)
-        ksum = sum(kern_ms.values())
-        extras["kernel_share_of_step"] = round(ksum / ms_per_step, 3) if not shard_lcb else None
+    roofline, kern_ms, extras, stages = None, {}, {}, {}
+    if rank == 0 and not shard_lcb:
+        # ---- the same pass with the genomes resident in HBM and the results left there (a named extra, never `value`) ----
+        e_r, stages, _ = rn.time_resident(args.steps, 1)
+        extras["device_resident"] = {"ms_per_step": round(e_r / args.steps * 1e3, 3), "Mbp_s": round(total_bp / 1e6 / (e_r / args.steps), 2),
+                                     "note": "genomes resident in HBM, results left there (mauve_align only)"}
+        roofline, kern_ms = kernel_profile(rn, weight)
+        extras["kernel_share_of_resident_pass"] = round(sum(kern_ms.values()) / (e_r / args.steps * 1e3), 3)
 
-    # ---- SURVEY 8(d) variants of the figure (not `value`): results fetched into caller buffers; genomes uploaded
-    # inside the timed region (host buffers at the boundary, PCIe-inclusive) ----
-    if rank == 0 and world == 1:
+    # ---- the other setting of lcb_extension (mauveAligner.cpp:95: the reference's default is on) ----
+    if side and not args.no_secondary and not rn.progressive:
         n2 = max(3, args.steps // 2)
-        e2, _, _ = time_steps(ctx, params, n2, barrier, fetch=True)
-        extras["with_fetch"] = {"ms_per_step": round(e2 / n2 * 1e3, 3), "Mbp_s": round(total_bp / 1e6 / (e2 / n2), 1)}
-        packed = [_lib.pack_codes(g) for g in genomes]           # the packed genomes start in host RAM
-        glens = [len(g) for g in genomes]
-        ctx.set_genomes_packed(packed, glens)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(n2):
-            ctx.set_genomes_packed(packed, glens)
-            ctx.align(params, fetch=True)
-        barrier()
-        e3 = time.perf_counter() - t0
-        extras["h2d_inclusive"] = {"ms_per_step": round(e3 / n2 * 1e3, 3), "Mbp_s": round(total_bp / 1e6 / (e3 / n2), 1),
-                                   "note": "upload of the packed genomes (host RAM -> HBM), the pass, and the copy of all results into caller buffers"}
+        other = 0 if params.extend_lcbs else 1
+        pe = params_for(args.config, extend_lcbs=other)
+        e4, r4 = rn.time_host(n2, 1, pe)
+        extras["lcb_extension_%s" % ("on" if other else "off")] = {
+            "ms_per_step": round(e4 / n2 * 1e3, 3), "Mbp_s": round(total_bp / 1e6 / (e4 / n2), 1), "timed_region": "host RAM -> host RAM, as `value`",
+            "n_anchor": r4["n_anchor"], "n_lcb": r4["n_lcb"]}
+        if origins is not None:
+            from mauvealigner_amd import accuracy
+            acc_e = accuracy.score_alignment(r4, origins)
+            extras["lcb_extension_%s" % ("on" if other else "off")].update(sensitivity=round(acc_e["sensitivity"], 5), ppv=round(acc_e["ppv"], 5))
 
     # ---- accuracy of the bench workload's alignment against the generator's truth (not timed) ----
     acc = None
-    gpu_result = None
-    if rank == 0 and world == 1:
+    if side and origins is not None:
         from mauvealigner_amd import accuracy
-        gpu_result = ctx.align(params)
         acc = accuracy.score_alignment(gpu_result, origins)
         acc = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in acc.items()}
 
-    # ---- the same workload with the reference's default lcb_extension on (mauveAligner.cpp:95), and the
-    # backbone stage on the columns the pass left in HBM: reported beside `value`, never part of it ----
-    if rank == 0 and world == 1 and not args.no_secondary:
-        from mauvealigner_amd import accuracy
+    # ---- the backbone stage on the columns the pass left in HBM: reported beside `value`, never part of it ----
+    if side and not args.no_secondary and not rn.progressive:
         n2 = max(3, args.steps // 2)
-        pe = _lib.default_params(seed_weight=weight, extend_lcbs=1)
-        ctx.align(pe, fetch=False)
-        e4, _, _ = time_steps(ctx, pe, n2, barrier)
-        acc_e = accuracy.score_alignment(ctx.align(pe), origins)
-        extras["with_lcb_extension"] = {"ms_per_step": round(e4 / n2 * 1e3, 3), "Mbp_s": round(total_bp / 1e6 / (e4 / n2), 1),
-                                        "sensitivity": round(acc_e["sensitivity"], 5), "ppv": round(acc_e["ppv"], 5)}
-        ctx.align(params, fetch=False)
+        rn.upload()
+        rn.run()
         ctx.backbone(island_gap=20)
         t0 = time.perf_counter()
         for _ in range(n2):
@@ -267,58 +457,27 @@ def main():
 
     # ---- CPU baseline: the oracle on the same workload, host cores of this box ----
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import pyoracle as O
-        tc0 = time.perf_counter()
-        ref = O.align(genomes, O.default_params(seed_weight=weight))
-        tc = time.perf_counter() - tc0
-        # the same pass doubles as the full-size parity check of the GPU result (the oracle as the checker)
-        parity = all(np.array_equal(gpu_result[k], ref["aln"][k]) for k in
-                     ("anchor_start", "anchor_length", "left", "right", "reverse", "col_off", "cols", "dp_score"))
-        cpu = {"value": round(total_bp / 1e6 / tc, 3), "unit": "Mbp/s", "cores": 1, "kind": "port",
-               "sample": "full workload (%d x %d bp), single thread, one pass, %.1f s" % (cfg["n"], L, tc),
-               "host_cpus": os.cpu_count(), "gpu_result_identical": bool(parity)}
-        # the same baseline on every core this process may use: independent copies of the workload (the path has no
-        # intra-job CPU parallelism to offer; throughput adds up), at 1/5 size so that the memory of all copies fits
-        try:
-            import subprocess
-            ncore = max(1, len(os.sched_getaffinity(0)))
-            wscale = 0.2 * args.scale
-            ws = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", args.config, str(wscale), str(weight)], cwd=ROOT,
-                                   stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for _ in range(ncore)]
-            for w in ws:
-                assert w.stdout.readline().strip() == "ready"
-            tw0 = time.perf_counter()
-            for w in ws:
-                w.stdin.write("go\n"); w.stdin.flush()
-            bases = 0
-            for w in ws:
-                bases += int(w.stdout.readline().split()[1])
-            tw = time.perf_counter() - tw0
-            for w in ws:
-                w.wait(timeout=60)
-            cpu["all_cores"] = {"value": round(bases / 1e6 / tw, 2), "unit": "Mbp/s", "cores": ncore,
-                                "sample": "%d concurrent copies of the workload at scale %.2f, %.1f s" % (ncore, wscale, tw)}
-        except Exception as ex:                      # the single-core figure above stands on its own
-            cpu["all_cores"] = {"error": repr(ex)}
+    if side and not args.no_cpu_baseline:
+        sample = 1.0 if args.config in ("C2", "C3", "C4") else 0.1
+        cpu = cpu_baseline(args.config, args.scale, weight, gpu_result, genomes, sample)
+        if cfg["path"] == "align" and args.config != "C5":
+            cpu["all_cores"] = all_cores_baseline(args.config, args.scale, weight)
 
-    # ---- C2 (configs[1]) beside the primary workload ----
-    c2 = None
-    if rank == 0 and world == 1 and args.config != "C2" and not args.no_secondary:
-        (g2, _), L2 = make_workload("C2", args.scale, 0)
-        ctx.set_genomes(g2)
-        p2 = _lib.default_params(seed_weight=WORKLOADS["C2"]["weight"])
-        for _ in range(max(1, args.warmup)):
-            ctx.align(p2, fetch=False)
-        e, st, sz = time_steps(ctx, p2, args.steps, barrier)
-        r2, k2 = kernel_profile(ctx, p2, WORKLOADS["C2"]["weight"])
-        bp2 = sum(len(g) for g in g2)
-        c2 = {"workload": WORKLOADS["C2"]["text"] % L2, "value": round(bp2 / 1e6 / (e / args.steps), 2), "unit": "Mbp/s",
-              "ms_per_step": round(e / args.steps * 1e3, 3), "stages_ms": {k: round(v / args.steps, 3) for k, v in st.items()},
-              "kernels_ms": k2, "roofline": r2, "result_sizes": sz}
+    # ---- the other BASELINE configs ----
+    legs = {}
+    if side and not args.no_secondary:
+        del rn
+        plan = [("C2", max(3, args.steps // 2), 0), ("C4", max(3, args.steps // 4), 1.0), ("C5", max(3, args.steps // 4), 0.1)]
+        for name, st, cpu_sample in plan:
+            if name == args.config:
+                continue
+            try:
+                legs[name.lower()] = secondary_leg(ctx, name, args.scale, st, 1, barrier, 0 if args.no_cpu_baseline else cpu_sample)
+            except Exception as ex:                # a side leg never takes the headline down with it
+                legs[name.lower()] = {"error": repr(ex)}
 
     if rank == 0:
-        par = ("one alignment, DP intervals LPT-sharded over the ranks, columns exchanged with one RCCL all_gather" if shard_lcb
+        par = ("one alignment: pairwise finder passes, recursion gaps and DP intervals LPT-sharded over the ranks, results exchanged with RCCL all_gathers" if shard_lcb
                else "independent genome sets per GPU (no data-path collective)")
         out = {
             "metric": "aligned Mbp/s (seed+extend+DP)", "value": round(value, 2), "unit": "Mbp/s",
@@ -326,16 +485,17 @@ def main():
             "higher_is_better": True, "scaling": "strong" if shard_lcb else "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": (cfg["text"] % L) + ", recursive anchoring + gapped DP on",
-                       "genomes_per_gpu": cfg["n"], "genome_length": L, "seed_weight": weight, "parallelism": par},
+                       "genomes_per_gpu": cfg["n"], "genome_length": L, "seed_weight": weight, "parallelism": par,
+                       "extend_lcbs": int(params.extend_lcbs), "max_extension_iters": int(params.max_extension_iters),
+                       "timed_region": "packed genomes in page-locked host RAM -> upload -> %s -> every result array in page-locked host RAM (SURVEY.md 8d)" %
+                                       ("mauve_progressive_align" if cfg["path"] == "progressive" else "mauve_align")},
             "roofline": roofline, "cpu_baseline": cpu, "accuracy_vs_truth": acc,
-            "stages_ms": {k: round(v / args.steps, 3) for k, v in stage_acc.items()},
-            "kernels_ms": kern_ms, "result_sizes": sizes, "upload_ms": round(t_upload * 1e3, 2), "device": ctx.device_name(),
-            "prng": "numpy PCG64 (SURVEY 8d names xoshiro256**; the workloads are defined by mauvealigner_amd/synth.py)",
+            "stages_ms": stages, "kernels_ms": kern_ms, "result_sizes": sizes, "upload_ms": round(t_upload * 1e3, 2), "device": ctx.device_name(),
+            "prng": "numpy PCG64 (SURVEY 8d names xoshiro256**; the workloads are defined by mauvealigner_amd/synth.py, BASELINE.md section 4)",
         }
         out.update(extras)
-        if c2:
-            out["c2"] = c2
-        print(json.dumps(out))
+        out.update(legs)
+        print(json.dumps(out, default=lambda o: o.tolist() if hasattr(o, 'tolist') else repr(o)))
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -97,6 +97,12 @@ void mauve_ctx_destroy(mauve_ctx *ctx);
 const char *mauve_last_error(const mauve_ctx *ctx);       /* ctx may be NULL: last create error */
 int mauve_device_name(const mauve_ctx *ctx, char *buf, size_t buflen);
 int mauve_synchronize(mauve_ctx *ctx);
+/* Page-locked host memory for the caller's bulk buffers (no reference counterpart: libMems keeps everything in pageable
+   std::vectors).  Optional: every entry point takes any host pointer.  mauve_set_genomes uploads packed genomes that
+   live in such a buffer straight from it, and mauve_align_fetch copies the column array straight into one (one DMA,
+   no staging copy); pageable buffers go through the context's page-locked staging as before. */
+int mauve_host_alloc(size_t bytes, void **out);
+void mauve_host_free(void *p);
 
 /* ---- seeds (host-side helpers; libMems free functions getSeed/getSeedLength/getDefaultSeedWeight,
         progressiveMauve.cpp:217,511-517; MatchList::GetDefaultMerSize, mauveAligner.cpp:651) ------ */
@@ -290,9 +296,10 @@ int mauve_write_xmfa(mauve_ctx *ctx, const char *const *names, char *buf, int64_
 int mauve_profile_enable(mauve_ctx *ctx, int on);
 int mauve_profile_reset(mauve_ctx *ctx);
 int mauve_profile_get(mauve_ctx *ctx, int kernel, double *total_ms, int64_t *launches, int64_t *units);
-/* wall-clock of the stages of the last mauve_align call, milliseconds */
+/* wall-clock of the stages of the last mauve_align / mauve_progressive_align call, milliseconds (progressive: summed over the
+   nodes of the guide tree; tree_ms = the pairwise passes and the guide tree in front of them) */
 typedef struct {
-    double seed_ms, chain_ms, recurse_ms, dp_ms, assemble_ms, total_ms;
+    double seed_ms, chain_ms, recurse_ms, dp_ms, assemble_ms, total_ms, tree_ms;
 } mauve_stage_times;
 int mauve_last_stage_times(mauve_ctx *ctx, mauve_stage_times *t);
 

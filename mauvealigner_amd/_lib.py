@@ -19,6 +19,7 @@ KERNEL_NAMES = ["seed_extract", "rs_hist", "rs_rowscan", "rs_scatter", "mum_join
 # every symbol include/mauve_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = [
     "mauve_ctx_create", "mauve_ctx_destroy", "mauve_last_error", "mauve_device_name", "mauve_synchronize",
+    "mauve_host_alloc", "mauve_host_free",
     "mauve_get_seed", "mauve_seed_length", "mauve_seed_weight", "mauve_default_seed_weight", "mauve_default_scoring",
     "mauve_default_params", "mauve_packed_words", "mauve_pack_ascii", "mauve_pack_codes", "mauve_set_genomes", "mauve_set_genomes_contigs",
     "mauve_ambiguity_bitmap",
@@ -52,7 +53,7 @@ class AlignSizes(C.Structure):
 
 class StageTimes(C.Structure):
     _fields_ = [("seed_ms", C.c_double), ("chain_ms", C.c_double), ("recurse_ms", C.c_double),
-                ("dp_ms", C.c_double), ("assemble_ms", C.c_double), ("total_ms", C.c_double)]
+                ("dp_ms", C.c_double), ("assemble_ms", C.c_double), ("total_ms", C.c_double), ("tree_ms", C.c_double)]
 
 
 _lib = None
@@ -78,12 +79,64 @@ def load():
     L.mauve_packed_words.argtypes = [C.c_int64]
     L.mauve_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.mauve_ctx_destroy.argtypes = [C.c_void_p]
+    L.mauve_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.mauve_host_free.argtypes = [C.c_void_p]
+    L.mauve_host_free.restype = None
     _lib = L
     return L
 
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+class _PinnedBlock:
+    """one mauve_host_alloc allocation, released when the last numpy view of it goes away"""
+
+    def __init__(self, nbytes):
+        self.L = load()
+        p = C.c_void_p()
+        rc = self.L.mauve_host_alloc(C.c_size_t(max(int(nbytes), 64)), C.byref(p))
+        if rc or not p.value:
+            raise MemoryError("mauve_host_alloc(%d) failed (%d)" % (nbytes, rc))
+        self.p = p
+        self.buf = (C.c_uint8 * max(int(nbytes), 64)).from_address(p.value)
+
+    def __del__(self):
+        try:
+            if self.p:
+                self.L.mauve_host_free(self.p)
+                self.p = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in page-locked host memory (mauve_host_alloc): what a caller hands to set_genomes / fetch for one-DMA transfers"""
+    dt = np.dtype(dtype)
+    shape = (shape,) if np.isscalar(shape) else tuple(shape)
+    n = int(np.prod(shape)) if shape else 1
+    blk = _PinnedBlock(n * dt.itemsize)
+    a = np.frombuffer(blk.buf, dtype=dt, count=n).reshape(shape)
+    blk.buf._mauve_block = blk          # the ctypes buffer is the base of every view: it keeps the allocation alive
+    return a
+
+
+class ResultBuffers:
+    """Caller-owned, reusable result arrays for Context.align(..., out=...): page-locked, grown on demand, so that a fetch is
+    one DMA per bulk array and no allocation.  The arrays returned by a fetch are views that the next fetch overwrites."""
+
+    def __init__(self):
+        self._a = {}
+
+    def get(self, name, shape, dtype):
+        shape = (shape,) if np.isscalar(shape) else tuple(shape)
+        n = int(np.prod(shape)) if shape else 1
+        cur = self._a.get(name)
+        if cur is None or cur.size < n or cur.dtype != np.dtype(dtype):
+            cur = pinned_empty(max(n + n // 8, 16), dtype)
+            self._a[name] = cur
+        return cur[:n].reshape(shape)
 
 
 def get_seed(weight, rank=0):
@@ -242,7 +295,8 @@ class Context:
         self.lens = [len(c) for c in codes_list]
 
     def set_genomes_packed(self, packed, lens):
-        """genomes already in the boundary's 2-bit packing (pack_codes): the upload alone"""
+        """genomes already in the boundary's 2-bit packing (pack_codes): the upload alone (arrays from pinned_empty go up
+        in one DMA each, without a staging copy)"""
         n = len(packed)
         arr = (C.POINTER(C.c_uint64) * n)(*[_p(w, C.c_uint64) for w in packed])
         self._chk(self.L.mauve_set_genomes(self.h, n, arr, (C.c_int64 * n)(*[int(x) for x in lens])), "mauve_set_genomes")
@@ -350,28 +404,33 @@ class Context:
                                                C.byref(sc), _p(out, C.c_int64)), "mauve_match_sp_scores")
         return out[:len(length)].copy()
 
-    def align(self, params=None, fetch=True, names=None, want_xmfa=False):
+    def align(self, params=None, fetch=True, names=None, want_xmfa=False, out=None):
+        """out: a ResultBuffers the result arrays are fetched into (reused from call to call; views)"""
         p = params or default_params()
         sz = AlignSizes()
         self._chk(self.L.mauve_align(self.h, C.byref(p), C.byref(sz)), "mauve_align")
-        out = {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
+        res = {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
         if not fetch:
-            return out
-        return self._fetch(sz, names, want_xmfa)
+            return res
+        return self._fetch(sz, names, want_xmfa, out)
 
-    def _fetch(self, sz, names=None, want_xmfa=False):
+    def _fetch(self, sz, names=None, want_xmfa=False, bufs=None):
         N = self.nseq
         out = {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
-        a = {
-            "mum_length": np.zeros(sz.n_mums, np.int64), "mum_start": np.zeros((sz.n_mums, N), np.int64),
-            "lcb_left": np.zeros((sz.n_lcb, N), np.int64), "lcb_right": np.zeros((sz.n_lcb, N), np.int64),
-            "lcb_weight": np.zeros(sz.n_lcb, np.int64),
-            "anchor_length": np.zeros(sz.n_anchor, np.int64), "anchor_start": np.zeros((sz.n_anchor, N), np.int64),
-            "anchor_lcb": np.zeros(sz.n_anchor, np.int64),
-            "left": np.zeros((sz.n_iv, N), np.int64), "right": np.zeros((sz.n_iv, N), np.int64),
-            "reverse": np.zeros((sz.n_iv, N), np.int8), "col_off": np.zeros(sz.n_iv + 1, np.int64),
-            "cols": np.zeros(sz.n_cols, np.uint32), "dp_score": np.zeros(sz.n_iv, np.int64),
+        shapes = {
+            "mum_length": (sz.n_mums, np.int64), "mum_start": ((sz.n_mums, N), np.int64),
+            "lcb_left": ((sz.n_lcb, N), np.int64), "lcb_right": ((sz.n_lcb, N), np.int64),
+            "lcb_weight": (sz.n_lcb, np.int64),
+            "anchor_length": (sz.n_anchor, np.int64), "anchor_start": ((sz.n_anchor, N), np.int64),
+            "anchor_lcb": (sz.n_anchor, np.int64),
+            "left": ((sz.n_iv, N), np.int64), "right": ((sz.n_iv, N), np.int64),
+            "reverse": ((sz.n_iv, N), np.int8), "col_off": (sz.n_iv + 1, np.int64),
+            "cols": (sz.n_cols, np.uint32), "dp_score": (sz.n_iv, np.int64),
         }
+        if bufs is None:
+            a = {k: np.zeros(sh, dt) for k, (sh, dt) in shapes.items()}
+        else:
+            a = {k: bufs.get(k, sh, dt) for k, (sh, dt) in shapes.items()}
         self._chk(self.L.mauve_align_fetch(
             self.h, _p(a["mum_length"], C.c_int64), _p(a["mum_start"], C.c_int64), _p(a["lcb_left"], C.c_int64),
             _p(a["lcb_right"], C.c_int64), _p(a["lcb_weight"], C.c_int64), _p(a["anchor_length"], C.c_int64),
@@ -410,7 +469,7 @@ class Context:
                                         _p(score, C.c_int64), C.byref(cells)), "mauve_align_dp")
         return [cols[col_off[i]:col_off[i + 1]] for i in range(n)], score[:n], cells.value
 
-    def align_finish(self, cols_list, scores, cells, fetch=True, names=None, want_xmfa=False):
+    def align_finish(self, cols_list, scores, cells, fetch=True, names=None, want_xmfa=False, out=None):
         n = len(cols_list)
         col_off = np.zeros(n + 1, np.int64)
         for i, c in enumerate(cols_list):
@@ -422,7 +481,7 @@ class Context:
                                             C.c_int64(cells), C.byref(sz)), "mauve_align_finish")
         if not fetch:
             return {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
-        return self._fetch(sz, names, want_xmfa)
+        return self._fetch(sz, names, want_xmfa, out)
 
     def guide_tree(self, pattern):
         N = self.nseq
@@ -433,8 +492,8 @@ class Context:
                                           _p(right, C.c_int32)), "mauve_guide_tree")
         return dist, left, right
 
-    def progressive_align(self, params=None, fetch=True, names=None, want_xmfa=False, tree=None):
-        """tree=(left, right): align along the caller's guide tree (mauve_progressive_align_tree)."""
+    def progressive_align(self, params=None, fetch=True, names=None, want_xmfa=False, tree=None, out=None):
+        """tree=(left, right): align along the caller's guide tree (mauve_progressive_align_tree).  out: ResultBuffers."""
         p = params or default_params()
         N = self.nseq
         sz = AlignSizes()
@@ -451,10 +510,10 @@ class Context:
                 raise ValueError("guide tree must have 2*nseq-1 nodes")
             self._chk(self.L.mauve_progressive_align_tree(self.h, C.byref(p), C.byref(sz), _p(left, C.c_int32),
                                                           _p(right, C.c_int32)), "mauve_progressive_align_tree")
-        out = self._fetch(sz, names, want_xmfa) if fetch else {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
-        out["tree"] = (left, right)
-        out["dist"] = dist
-        return out
+        res = self._fetch(sz, names, want_xmfa, out) if fetch else {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
+        res["tree"] = (left, right)
+        res["dist"] = dist
+        return res
 
     def _backbone_fetch(self, n_seg, n_isl):
         N = self._bb_nseq

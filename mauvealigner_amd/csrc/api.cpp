@@ -15,6 +15,30 @@ GenomeSet main_genome_set(mauve_ctx *c)
     return gs;
 }
 
+// is p inside a page-locked (hipHostMalloc / hipHostRegister) allocation?  Plain pointers make the query fail: that error is swallowed.
+bool host_pointer_is_pinned(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+// the host copy of the packed genomes (the XMFA writer reads bases from it): made by the staged upload, or fetched back here
+int host_genomes(mauve_ctx *c)
+{
+    if (c->host_copy_valid) return MAUVE_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->pin_genomes.ensure((c->total_words + 4) * sizeof(uint64_t)));
+    HIPCHK(c, hipMemcpyAsync(c->pin_genomes.p, c->genomes.p, (c->total_words + 4) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t *stage = c->pin_genomes.as<uint64_t>();
+    c->host_packed.assign((size_t)c->nseq, nullptr);
+    for (int g = 0; g < c->nseq; g++) c->host_packed[(size_t)g] = stage + c->word_off[(size_t)g];
+    c->host_copy_valid = true;
+    return MAUVE_OK;
+}
+
 extern "C" {
 
 int mauve_ctx_create(int device, mauve_ctx **out)
@@ -67,7 +91,7 @@ void mauve_ctx_destroy(mauve_ctx *c)
                       &c->dp_prof_cnt, &c->dp_prof_mask, &c->dp_prof2_cnt, &c->dp_prof2_mask, &c->dp_tb, &c->dp_meta,
                       &c->dp_score, &c->dp_cols, &c->dp_rows};
     for (DevBuf *b : bufs) b->release();
-    c->pin_genomes.release(); c->pin_chain.release(); c->pin_mask.release(); c->pin_bb.release(); c->pin_asm.release(); c->pin_cols.release(); c->pin_anch.release(); c->pin_dcols.release(); c->pin_meta.release(); c->pin_seed.release(); c->pin_dp_in.release();
+    c->pin_genomes.release(); c->pin_tail.release(); c->pin_chain.release(); c->pin_mask.release(); c->pin_bb.release(); c->pin_asm.release(); c->pin_tab.release(); c->pin_cols.release(); c->pin_anch.release(); c->pin_dcols.release(); c->pin_meta.release(); c->pin_seed.release(); c->pin_dp_in.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -93,11 +117,22 @@ int mauve_synchronize(mauve_ctx *c)
     return MAUVE_OK;
 }
 
+int mauve_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return MAUVE_ERR_ARG;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return MAUVE_ERR_HIP; }
+    return MAUVE_OK;
+}
+
+void mauve_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 int mauve_set_genomes(mauve_ctx *c, int nseq, const uint64_t *const *packed, const int64_t *lens)
 {
     if (!c) return MAUVE_ERR_ARG;
     if (nseq < 1 || nseq > MAUVE_MAX_SEQ || !packed || !lens) { c->err = "set_genomes: 1..32 sequences required"; return MAUVE_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
+    { int rcm = materialize_tables(c); if (rcm) return rcm; }           // a result still in HBM refers to the genomes it was made from
     size_t total_words = 0;
     std::vector<uint64_t> off(nseq);
     int64_t total_len = 0;
@@ -109,23 +144,49 @@ int mauve_set_genomes(mauve_ctx *c, int nseq, const uint64_t *const *packed, con
     }
     if (total_len >= (1LL << 31)) { c->err = "set_genomes: total length must stay below 2^31 bases"; return MAUVE_ERR_LIMIT; }
     HIPCHK(c, c->genomes.ensure((total_words + 4) * sizeof(uint64_t)));
-    // The host copy (XMFA text) lives in page-locked memory and doubles as the staging buffer of ONE upload: a
-    // pageable source would go through the runtime's bounce buffers, and fresh vectors per call cost page faults.
-    HIPCHK(c, c->pin_genomes.ensure((total_words + 4) * sizeof(uint64_t)));
-    uint64_t *stage = c->pin_genomes.as<uint64_t>();
+    // Genomes in page-locked caller memory (mauve_host_alloc) go up straight from there: one DMA per genome, plus the few
+    // words of its tail (the last data word with the bits past the last base cleared, the zero padding) from a small staging
+    // block; the host copy that the XMFA writer reads is then fetched back from the device when it is first needed
+    // (host_genomes).  Anything else is staged: the host copy lives in page-locked memory and doubles as the staging buffer
+    // of ONE upload (a pageable source would go through the runtime's bounce buffers, fresh vectors per call cost page faults).
+    bool all_pinned = true;
+    for (int g = 0; g < nseq && all_pinned; g++) all_pinned = lens[g] == 0 || host_pointer_is_pinned(packed[g]);
     c->host_packed.assign((size_t)nseq, nullptr);
-    for (int g = 0; g < nseq; g++) {
-        const size_t nw = mauve_packed_words(lens[g]), data = (size_t)((lens[g] + 31) / 32);
-        uint64_t *dst = stage + off[g];
-        if (data) memcpy(dst, packed[g], data * sizeof(uint64_t));
-        for (size_t k = data; k < nw; k++) dst[k] = 0;
-        // clear any bits past the last base so window reads beyond the end are deterministic
-        if (lens[g] & 31) dst[data - 1] &= (1ULL << (2 * (lens[g] & 31))) - 1ULL;
-        c->host_packed[(size_t)g] = dst;
+    uint64_t *dev = c->genomes.as<uint64_t>();
+    if (all_pinned) {
+        HIPCHK(c, c->pin_tail.ensure((size_t)nseq * 8 * sizeof(uint64_t) + 64));
+        uint64_t *tails = c->pin_tail.as<uint64_t>();
+        for (int g = 0; g < nseq; g++) {
+            const size_t nw = mauve_packed_words(lens[g]), data = (size_t)((lens[g] + 31) / 32);
+            const size_t body = data ? data - 1 : 0;                     // whole words that need no fix-up
+            uint64_t *t = tails + (size_t)g * 8;
+            size_t nt = 0;
+            if (data) { t[nt] = packed[g][data - 1]; if (lens[g] & 31) t[nt] &= (1ULL << (2 * (lens[g] & 31))) - 1ULL; nt++; }
+            for (size_t k = data; k < nw; k++) t[nt++] = 0;              // nw - data <= 4
+            if (body) HIPCHK(c, hipMemcpyAsync(dev + off[g], packed[g], body * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+            if (nt) HIPCHK(c, hipMemcpyAsync(dev + off[g] + body, t, nt * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        }
+        HIPCHK(c, hipMemsetAsync(dev + total_words, 0, 4 * sizeof(uint64_t), c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->host_copy_valid = false;
+    } else {
+        HIPCHK(c, c->pin_genomes.ensure((total_words + 4) * sizeof(uint64_t)));
+        uint64_t *stage = c->pin_genomes.as<uint64_t>();
+        for (int g = 0; g < nseq; g++) {
+            const size_t nw = mauve_packed_words(lens[g]), data = (size_t)((lens[g] + 31) / 32);
+            uint64_t *dst = stage + off[g];
+            if (data) memcpy(dst, packed[g], data * sizeof(uint64_t));
+            for (size_t k = data; k < nw; k++) dst[k] = 0;
+            // clear any bits past the last base so window reads beyond the end are deterministic
+            if (lens[g] & 31) dst[data - 1] &= (1ULL << (2 * (lens[g] & 31))) - 1ULL;
+            c->host_packed[(size_t)g] = dst;
+        }
+        for (size_t k = total_words; k < total_words + 4; k++) stage[k] = 0;
+        HIPCHK(c, hipMemcpyAsync(dev, stage, (total_words + 4) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->host_copy_valid = true;
     }
-    for (size_t k = total_words; k < total_words + 4; k++) stage[k] = 0;
-    HIPCHK(c, hipMemcpyAsync(c->genomes.p, stage, (total_words + 4) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->total_words = total_words;
     c->nseq = nseq;
     c->lens.assign(lens, lens + nseq);
     c->word_off = off;
@@ -198,6 +259,7 @@ int mauve_seed_mums(mauve_ctx *c, uint64_t pattern, int mode, uint64_t mask, int
     if (!c) return MAUVE_ERR_ARG;
     if (mode != MAUVE_MODE_MEM && mode != MAUVE_MODE_UNIQUE && mode != MAUVE_MODE_PAIRWISE) { c->err = "seed_mums: unknown mode"; return MAUVE_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
+    { int rcm = materialize_tables(c); if (rcm) return rcm; }           // the pass reuses the buffers a resident result lives in
     return seedpass_run(c, main_genome_set(c), pattern, mode, mask, extend, nullptr, 0, n_matches);
 }
 
@@ -208,6 +270,7 @@ int mauve_extend_hits(mauve_ctx *c, uint64_t pattern, int64_t n_hits, const uint
     if (n_hits < 0 || n_hits >= (1LL << 31) || (n_hits && (!mask || !pos || !strand))) { c->err = "extend_hits: bad argument"; return MAUVE_ERR_ARG; }
     if (c->nseq < 1) { c->err = "extend_hits: no genomes set"; return MAUVE_ERR_STATE; }
     HIPCHK(c, hipSetDevice(c->device));
+    { int rcm = materialize_tables(c); if (rcm) return rcm; }
     const int N = c->nseq;
     const int span = mauve_seed_length(pattern);
     if (span < 1) { c->err = "extend_hits: bad seed pattern"; return MAUVE_ERR_ARG; }
@@ -246,6 +309,7 @@ int mauve_sorted_mer_list(mauve_ctx *c, int seq, uint64_t pattern, uint64_t *mer
 {
     if (!c || !n_out) return MAUVE_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rcm = materialize_tables(c); if (rcm) return rcm; }
     std::vector<uint64_t> keys; std::vector<uint32_t> vals; int w = 0;
     int rc = seedpass_sorted_list(c, main_genome_set(c), seq, pattern, &keys, &vals, &w);
     if (rc) return rc;
@@ -267,6 +331,7 @@ int mauve_seed_match_enumerate(mauve_ctx *c, int seq, uint64_t pattern, int64_t 
     if (!c || !n_out || !n_starts) return MAUVE_ERR_ARG;
     if ((mult || start_off || starts) && !(mult && start_off && starts)) { c->err = "seed_match_enumerate: mult, start_off and starts go together"; return MAUVE_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
+    { int rcm = materialize_tables(c); if (rcm) return rcm; }
     EnumRequest q; q.min_multi = min_multi; q.max_multi = max_multi; q.direct_only = direct_only != 0; q.n = q.ns = 0;
     q.mult = mult; q.start_off = start_off; q.starts = starts;
     int rc = seedpass_enumerate(c, main_genome_set(c), seq, pattern, q);

@@ -302,7 +302,7 @@ int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes
             }
         }
     }
-    R.dev_pending = true; R.dev_na = host_chains ? 0 : na; R.cols_ext = nullptr;
+    R.dev_pending = true; R.cols_pending = true; R.dev_na = host_chains ? 0 : na; R.cols_ext = nullptr;
     R.cols_fill = 0; R.cols_dirty.clear();                       // the host column buffer no longer holds the "all anchors" state
     R.sz.n_mums = S.nm; R.sz.n_lcb = nl; R.sz.n_anchor = na; R.sz.n_iv = niv; R.sz.n_cols = ncols;
     R.sz.n_gap_dp = fo.n_dp; R.sz.n_dp_cells = cells;
@@ -315,37 +315,73 @@ int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes
     return MAUVE_OK;
 }
 
-// columns and anchor table of a device-assembled result -> host (page-locked staging); idempotent
-int materialize_result(mauve_ctx *c)
+// The anchor table and (if the seed pass left it there) the match list of a device-assembled result -> host.  These two
+// live in buffers the next seed pass / chain / DP front end reuses (sorted_rec, ch_anch), so every entry point that runs
+// such work calls this first; the columns have a buffer of their own (res_cols) that only the next assembly writes.
+// Idempotent.
+int materialize_tables(mauve_ctx *c)
 {
     AlignResult &R = c->res;
     if (!R.dev_pending) return MAUVE_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->ast.N; const size_t na = R.dev_na;
-    const size_t cb = (R.n_cols * 4 + 63) & ~(size_t)63, ab = (na * (2 + (size_t)N) * 4 + 63) & ~(size_t)63, mb = R.dev_nm * (1 + (size_t)N) * 8;
-    HIPCHK(c, c->pin_cols.ensure(cb + ab + mb + 64));
-    char *pc = c->pin_cols.as<char>();
-    if (cb) HIPCHK(c, hipMemcpyAsync(pc, c->res_cols.p, R.n_cols * 4, hipMemcpyDeviceToHost, c->stream));
+    const size_t ab = (na * (2 + (size_t)N) * 4 + 63) & ~(size_t)63, mb = R.dev_nm * (1 + (size_t)N) * 8;
+    HIPCHK(c, c->pin_tab.ensure(ab + mb + 64));
+    char *pa = c->pin_tab.as<char>();
     if (ab) {
-        char *pa = pc + cb;
         HIPCHK(c, hipMemcpyAsync(pa, R.dev_alen, na * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(pa + na * 4, R.dev_ast, na * N * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(pa + na * 4 * (1 + (size_t)N), R.dev_alcb, na * 4, hipMemcpyDeviceToHost, c->stream));
     }
-    if (mb) HIPCHK(c, hipMemcpyAsync(pc + cb + ab, c->sorted_rec.p, mb, hipMemcpyDeviceToHost, c->stream));
+    if (mb) HIPCHK(c, hipMemcpyAsync(pa + ab, c->sorted_rec.p, mb, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (mb) {
-        const int64_t *hm = reinterpret_cast<const int64_t *>(pc + cb + ab);
+        const int64_t *hm = reinterpret_cast<const int64_t *>(pa + ab);
         R.mum_length.assign(hm, hm + R.dev_nm); R.mum_start.assign(hm + R.dev_nm, hm + R.dev_nm * (1 + (size_t)N));
         R.dev_nm = 0;
     }
-    R.cols_ext = reinterpret_cast<const uint32_t *>(pc);
-    const int32_t *hl = reinterpret_cast<const int32_t *>(pc + cb), *hs = hl + na, *hb = hs + na * N;
+    const int32_t *hl = reinterpret_cast<const int32_t *>(pa), *hs = hl + na, *hb = hs + na * N;
     if (na) {                                                    // (0: the anchor table came from host chains and is filled)
         R.anchor_length.resize(na); R.anchor_start.resize(na * N); R.anchor_lcb.resize(na);
         for (size_t a = 0; a < na; a++) { R.anchor_length[a] = hl[a]; R.anchor_lcb[a] = hb[a]; }
         for (size_t i = 0; i < na * N; i++) R.anchor_start[i] = hs[i];
     }
     R.dev_pending = false;
+    return MAUVE_OK;
+}
+
+// ... and the columns into page-locked staging (the XMFA writer, a fetch into pageable memory); idempotent
+int materialize_result(mauve_ctx *c)
+{
+    int rc = materialize_tables(c);
+    if (rc) return rc;
+    AlignResult &R = c->res;
+    if (!R.cols_pending) return MAUVE_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->pin_cols.ensure(R.n_cols * 4 + 64));
+    if (R.n_cols) {
+        HIPCHK(c, hipMemcpyAsync(c->pin_cols.p, c->res_cols.p, R.n_cols * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    R.cols_ext = c->pin_cols.as<uint32_t>();
+    R.cols_pending = false;
+    return MAUVE_OK;
+}
+
+// the columns of the result into the caller's buffer: one DMA straight from HBM when the buffer is page-locked
+// (mauve_host_alloc) and the columns are still there; otherwise through the staging copy
+int fetch_columns(mauve_ctx *c, uint32_t *dst)
+{
+    AlignResult &R = c->res;
+    if (!R.n_cols) return MAUVE_OK;
+    if (R.cols_pending && host_pointer_is_pinned(dst)) {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipMemcpyAsync(dst, c->res_cols.p, R.n_cols * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return MAUVE_OK;
+    }
+    int rc = materialize_result(c);
+    if (rc) return rc;
+    memcpy(dst, R.cols_data(), R.n_cols * sizeof(uint32_t));
     return MAUVE_OK;
 }

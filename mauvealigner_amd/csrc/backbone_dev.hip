@@ -433,7 +433,7 @@ int mauve_backbone(mauve_ctx *c, int64_t island_gap_size, int64_t *n_seg, int64_
     const int N = (int)(R.iv_left.size() / (size_t)n_iv);
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t *d_cols;
-    if (R.dev_pending) d_cols = c->res_cols.as<uint32_t>();                // still where the assembly stage wrote them
+    if (R.cols_pending) d_cols = c->res_cols.as<uint32_t>();                // still where the assembly stage wrote them
     else {
         const size_t nb = (size_t)R.col_off[(size_t)n_iv] * 4;
         HIPCHK(c, c->bb_cols.ensure(nb + 64));

@@ -128,7 +128,8 @@ struct AlignResult {
     std::vector<std::pair<size_t, size_t>> cols_dirty;   // (offset, length) ranges holding gap columns
     std::vector<int64_t> dp_score;
     // device-assembled result (assemble_dev.hip): the columns (res_cols), the anchor table and maybe the match list are still in HBM
-    bool dev_pending = false;
+    bool dev_pending = false;               // anchor table / match list still on the device
+    bool cols_pending = false;              // columns only in res_cols (cols_ext not set)
     size_t dev_na = 0, dev_nm = 0;          // anchors; matches still on the device (0: mum_* are filled)
     const int32_t *dev_alen = nullptr, *dev_ast = nullptr, *dev_alcb = nullptr;     // ... where the anchors are (chain_order_device's arrays)
     const uint32_t *cols_ext = nullptr;      // the columns in page-locked staging after materialize_result (else: cols)
@@ -201,6 +202,9 @@ struct mauve_ctx {
     std::vector<uint64_t> word_off;      // per genome, in 64-bit words
     std::vector<const uint64_t *> host_packed;   // host copy of every genome's packed words (XMFA text), inside pin_genomes
     PinnedBuf pin_genomes;
+    PinnedBuf pin_tail;                  // direct upload from page-locked caller memory: the fixed-up tail words of every genome
+    bool host_copy_valid = false;         // host_packed / pin_genomes hold the genomes (else: fetched back on demand, host_genomes)
+    size_t total_words = 0;
     DevBuf genomes;
     // ambiguous bases and contig starts of the resident genomes (mauve_set_genomes_contigs): device bitmaps in the
     // layout of GenomeSet::vmask / cmask, their host copies (masks of the guide-tree nodes and of the LCB extension
@@ -219,6 +223,7 @@ struct mauve_ctx {
     DevBuf ch_big;                       // working arrays of overlap clusters beyond the per-thread limit (recursion batches)
     DevBuf ch_anch, ch_lw;               // the chains in chain order and the LCB weights (chain_order_device)
     DevBuf as_work, as_isl, res_cols;    // device assembly (assemble_dev.hip): work area, islands, result columns
+    PinnedBuf pin_tab;                   // anchor table and match list of a device-assembled result on their way to the host
     PinnedBuf pin_asm, pin_cols;         // ... its per-LCB rows coming back; the columns and anchors on their way to a fetch
     PinnedBuf pin_chain;
     PinnedBuf pin_mask;                  // LCB extension: the valid-piece bitmap on its way to placed_mask
@@ -365,6 +370,10 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na, const int32_t *h_len,
                         PinnedBuf *dcols, std::vector<int64_t> &dcol_off, std::vector<int64_t> &dscore, int64_t *cells, int stay = 0);
 int assemble_device(mauve_ctx *c, int64_t na, int64_t cells, mauve_align_sizes *sizes, bool host_chains = false);
 int materialize_result(mauve_ctx *c);
+int materialize_tables(mauve_ctx *c);
+int fetch_columns(mauve_ctx *c, uint32_t *dst);
+bool host_pointer_is_pinned(const void *p);
+int host_genomes(mauve_ctx *c);
 int seed_matches_to_host(mauve_ctx *ctx);
 int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,
                  const mauve_scoring *sc, uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells);

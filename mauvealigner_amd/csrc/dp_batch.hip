@@ -94,7 +94,7 @@ __device__ __forceinline__ int64_t dp_step_cells(int32_t m, int32_t n, bool band
 // the kernels check the real lengths and fall back (dp_groups).  3: four per wave (rows <= 16), 2: two per wave
 // (rows <= 32), 1: a wave of its own.
 struct DpClassEst {
-    int64_t mbound = 0, longest = 0, rows = 0, steps = 0; bool first = true;
+    int64_t mbound = 0, longest = 0, rows = 0, steps = 0, nmax = 0; bool first = true;
     int mode = 0;                     // 0: the estimate; 1: the safe bound (MAUVE_DP_CLASS=bound); 2: half the longest (=wild: tests the fallback)
     __host__ __device__ void add(int64_t n)
     {
@@ -104,9 +104,20 @@ struct DpClassEst {
         if (e > mbound) e = mbound;
         if (e > rows) rows = e;
         if (e + n > steps) steps = e + n;
+        if (n > nmax) nmax = n;
         mbound += n; if (n > longest) longest = n;
     }
-    __host__ __device__ int klass(int tmax) const { return steps <= tmax ? (rows <= 16 ? 3 : (rows <= 32 ? 2 : 1)) : 1; }
+    // systolic kernels (MAUVE_DP_OLD): 4: four per wave (rows <= 16), 3: two per wave (rows <= 32), 1: a wave of its own
+    __host__ __device__ int klass(int tmax) const { return steps <= tmax ? (rows <= 16 ? 4 : (rows <= 32 ? 3 : 1)) : 1; }
+    // register-blocked kernels: G lanes x 4 rows per interval, n + G steps in the LDS slice.  4: G = 4 (sixteen per wave),
+    // 3: G = 8, 2: G = 16, 1: a wave of its own
+    __host__ __device__ int klass2(int rows_per_lane, int tcap) const
+    {
+        if (rows <= 4 * rows_per_lane && nmax + 4 <= tcap) return 4;
+        if (rows <= 8 * rows_per_lane && nmax + 8 <= tcap) return 3;
+        if (rows <= 16 * rows_per_lane && nmax + 16 <= tcap) return 2;
+        return 1;
+    }
 };
 
 // lane l receives lane l-1's value; wave_shr1z: lane 0 receives 0 (its caller puts the real input there), wave_shr1: lane 0
@@ -553,6 +564,375 @@ __device__ void dp_groups(int nseq, const int64_t *__restrict__ list, int64_t fi
     }
 }
 
+
+// ================================================================================================================
+// Register-blocked sweep.  The systolic kernels above give every lane ONE profile row: a step costs ~75 instructions
+// whatever the lane does with it, a profile of m rows against n bases takes m + n steps, and most inter-anchor
+// intervals are a handful of bases (most lanes of the wave idle in the skew).  Here a lane owns R consecutive rows: it
+// takes (i0-1, j) and (i0-1, j-1) from the lane above once per step (three DPP shifts, not three per row) and runs
+// down its R cells in registers -- (i-1, j) of row r+1 is what it has just computed for row r, (i-1, j-1) what row r
+// held before.  A step is ~25 + 31 R instructions for R cells, the sweep takes n + ceil(m / R) steps, and a problem of
+// m <= 16 rows needs 4 lanes instead of 16: sixteen intervals share a wave (G = 4), eight with m <= 32 (G = 8), four
+// with m <= 64 (G = 16); anything larger gets the wave to itself in stripes of 64 R rows (dp2_interval).  The
+// traceback byte of the lane's R cells of a step is one 32-bit store.  Same recurrence, same tie rules (the first of
+// M, X, Y that attains the maximum), same traceback walk and profile rebuild as above: the result is bit-identical.
+// ================================================================================================================
+constexpr int DP2_R = 4;                         // rows per lane
+constexpr int DP2_T = 64;                        // systolic steps a sub-wave group keeps in LDS: n + G <= DP2_T
+constexpr int DP2_TB_DW = DP2_T * 64;            // per wave: DP2_T steps x 64 lanes x one dword (R bytes)
+constexpr int DP2_REC = 16 * (16 + DP2_T);       // per wave: reversed op records of all groups (G = 4: 16 groups x (16 rows + 64))
+constexpr int DP2_SEQ = 16 * (DP2_T + 4);        // per wave: the groups' sequences, each behind G bytes of padding
+constexpr int DP2_WAVES = 2;                     // waves per workgroup (40 KB of LDS: four workgroups per CU)
+
+template <int R>
+struct Dp2Rows {
+    int32_t M[R], X[R], Y[R];                    // column j-1 before a step, column j after it
+    int32_t s0[R], s1[R], s2[R], s3[R], gxo[R], gxe[R];
+    __device__ __forceinline__ void constants(const uint32_t *Pc, int32_t i0, int32_t m, const DpScoring &sc)
+    {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t cn = i0 + r < m ? Pc[i0 + r] : 0u;         // rows beyond the profile: zeros (their cells feed nothing)
+            const int32_t c0 = cn & 255, c1 = (cn >> 8) & 255, c2 = (cn >> 16) & 255, c3 = cn >> 24;
+            const int32_t rr = c0 + c1 + c2 + c3;
+            s0[r] = c0 * sc.s[0][0] + c1 * sc.s[1][0] + c2 * sc.s[2][0] + c3 * sc.s[3][0];
+            s1[r] = c0 * sc.s[0][1] + c1 * sc.s[1][1] + c2 * sc.s[2][1] + c3 * sc.s[3][1];
+            s2[r] = c0 * sc.s[0][2] + c1 * sc.s[1][2] + c2 * sc.s[2][2] + c3 * sc.s[3][2];
+            s3[r] = c0 * sc.s[0][3] + c1 * sc.s[1][3] + c2 * sc.s[2][3] + c3 * sc.s[3][3];
+            gxo[r] = sc.go * rr; gxe[r] = sc.ge * rr;
+            M[r] = X[r] = Y[r] = DP_NEG_INF;
+        }
+    }
+    // one step: the lane's R cells of column j.  (Mu, Xu, Yu) = (i0-1, j), (Md, Xd, Yd) = (i0-1, j-1), b = base j.
+    // Returns the R traceback bytes (row r in byte r).
+    __device__ __forceinline__ uint32_t step(int32_t Mu, int32_t Xu, int32_t Yu, int32_t Md, int32_t Xd, int32_t Yd, uint32_t b,
+                                             int32_t gyo, int32_t gye, bool j1)
+    {
+        const bool lo = (b & 1u) != 0, hi = (b & 2u) != 0;
+        uint32_t tb = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int32_t Ml = M[r], Xl = X[r], Yl = Y[r];            // (i, j-1): the diagonal input of row r + 1
+            const int32_t bd = max(max(Md, Xd), Yd);
+            const uint32_t pm = Md == bd ? 0u : (Xd == bd ? 1u : 2u);
+            const int32_t sa = lo ? s1[r] : s0[r], sb = lo ? s3[r] : s2[r];
+            int32_t Mn = max(bd + (hi ? sb : sa), DP_NEG_INF);
+            const int32_t xa = Mu + gxo[r], xb = Xu + gxe[r], xc = Yu + gxo[r];
+            const int32_t bx = max(max(xa, xb), xc);
+            const uint32_t px = xa == bx ? 0u : (xb == bx ? 4u : 8u);
+            const int32_t Xn = max(bx, DP_NEG_INF);
+            const int32_t ya = Ml + gyo, yb = Xl + gyo, yc = Yl + gye;
+            const int32_t by = max(max(ya, yb), yc);
+            const uint32_t py = ya == by ? 0u : (yb == by ? 16u : 32u);
+            int32_t Yn = max(by, DP_NEG_INF);
+            Mn = j1 ? Mn : DP_NEG_INF; Yn = j1 ? Yn : DP_NEG_INF;     // column 0: only X exists
+            tb |= (pm | px | py) << (8 * r);
+            M[r] = Mn; X[r] = Xn; Y[r] = Yn;
+            Md = Ml; Xd = Xl; Yd = Yl; Mu = Mn; Xu = Xn; Yu = Yn;
+        }
+        return tb;
+    }
+    __device__ __forceinline__ void row(int ro, int32_t &m_, int32_t &x_, int32_t &y_) const
+    {
+        m_ = M[0]; x_ = X[0]; y_ = Y[0];
+#pragma unroll
+        for (int r = 1; r < R; r++) if (ro == r) { m_ = M[r]; x_ = X[r]; y_ = Y[r]; }
+    }
+};
+
+// ---- sub-wave groups: 64 / G intervals per wave, G lanes x R rows each, everything of a step in LDS ----
+template <int G>
+__device__ void dp2_groups(int nseq, const int64_t *__restrict__ list, int64_t first, int64_t count, int64_t wave_index, int64_t nwaves,
+                           const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
+                           uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA, uint32_t *__restrict__ cntB,
+                           uint32_t *__restrict__ maskB, uint32_t *s_tb_wave, uint16_t *s_rec_wave, uint8_t *s_seq_wave, const DpScoring &sc)
+{
+    constexpr int R = DP2_R, GROUPS = 64 / G, ROWS = G * R;
+    const int lane = threadIdx.x & 63, ql = lane & (G - 1), q = lane / G, gbase = lane & ~(G - 1);
+    const bool leader = ql == 0;
+    uint32_t *tbq = s_tb_wave + q * (DP2_T * G);                       // one dword per (step, lane of the group)
+    const uint8_t *tbq8 = reinterpret_cast<const uint8_t *>(tbq);
+    uint16_t *recq = s_rec_wave + q * (ROWS + DP2_T);
+    uint8_t *seqq = s_seq_wave + q * (DP2_T + G);
+    for (int64_t li0 = wave_index * GROUPS; li0 < count; li0 += nwaves * GROUPS) {
+        const bool have = li0 + q < count;
+        const int64_t iv = have ? list[first + li0 + q] : 0;
+        DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
+        const int64_t base = have ? seq_off[iv * nseq] : 0;
+        // The class comes from an ESTIMATE of the profile lengths (DpClassEst): a group whose profile outgrows its rows, or
+        // whose step outgrows the LDS slice, gives the interval up (mt.m = -1); the wave runs it alone afterwards.
+        bool dead = false;
+        for (int g = 0; g < nseq; g++) {
+            int64_t so = 0; int32_t n = 0;
+            if (have && !dead) { so = seq_off[iv * nseq + g]; n = (int32_t)(seq_off[iv * nseq + g + 1] - so); }
+            if (n > 0 && mt.krows > 0 && (mt.m > ROWS || n + G > DP2_T)) { dead = true; n = 0; }
+            const uint8_t *seq = codes + so;
+            uint32_t *Pc = (mt.cur ? cntB : cntA) + base, *Pm = (mt.cur ? maskB : maskA) + base;
+            uint32_t *Qc = (mt.cur ? cntA : cntB) + base, *Qm = (mt.cur ? maskA : maskB) + base;
+            const bool init = n > 0 && mt.krows == 0, step = n > 0 && mt.krows > 0;
+            if (init) for (int32_t c = ql; c < n; c += G) { Pc[c] = 1u << (8 * seq[c]); Pm[c] = 1u << g; }
+            if (__ballot(step)) {
+                const int32_t m = step ? mt.m : 0, nn = step ? n : 0;
+                for (int32_t c = ql; c < nn; c += G) seqq[G + c] = seq[c];       // base j at seqq[G + j - 1]
+                Dp2Rows<R> L;
+                L.constants(Pc, ql * R, m, sc);
+                const int32_t gyo = sc.go * mt.krows, gye = sc.ge * mt.krows;
+                const int32_t La = (m + R - 1) / R;                               // lanes of the group that hold rows
+                const bool has = ql < La;
+                const int32_t steps = step ? nn + La : 0;                          // t = 0 .. n + La - 1
+                int32_t tmax = 0;
+#pragma unroll
+                for (int k = 0; k < GROUPS; k++) tmax = max(tmax, __builtin_amdgcn_readlane(steps, k * G));
+                int32_t Md = DP_NEG_INF, Xd = DP_NEG_INF, Yd = DP_NEG_INF;
+                __threadfence_block();                                             // the staged sequence: written by some lanes, read by others
+                const uint8_t *sp = seqq + (G - 1 - ql);                           // sp[t] = base of column j = t - ql
+                uint32_t *tw = tbq + ql;
+                for (int32_t t = 0; t < tmax; t++, tw += G) {
+                    const int32_t j = t - ql;
+                    int32_t Mu = wave_shr1z(L.M[R - 1]), Xu = wave_shr1z(L.X[R - 1]), Yu = wave_shr1z(L.Y[R - 1]);
+                    // row 0 of the matrix, for the lane that holds row 1 (its j is t)
+                    const int32_t M0 = t == 0 ? 0 : DP_NEG_INF, Y0 = t == 0 ? DP_NEG_INF : gyo + (t - 1) * gye;
+                    Mu = leader ? M0 : Mu; Xu = leader ? DP_NEG_INF : Xu; Yu = leader ? Y0 : Yu;
+                    if (has && (uint32_t)j <= (uint32_t)nn) {
+                        const uint32_t b = sp[t];
+                        *tw = L.step(Mu, Xu, Yu, Md, Xd, Yd, b, gyo, gye, j >= 1);
+                    }
+                    Md = Mu; Xd = Xu; Yd = Yu;
+                }
+                __threadfence_block();                       // traceback dwords: written by the lanes, read by the leader
+                const int owner = gbase + (max(m, 1) - 1) / R;
+                int32_t fM, fX, fY;
+                L.row((max(m, 1) - 1) % R, fM, fX, fY);       // the lane of row m holds (m, n) in that row: its state stopped at column n
+                fM = lane_read(fM, owner); fX = lane_read(fX, owner); fY = lane_read(fY, owner);
+                int32_t best = fM; int state = 0;
+                if (fX > best) { best = fX; state = 1; }
+                if (fY > best) { best = fY; state = 2; }
+                // ---- traceback: the group leaders walk side by side; an op is recorded with the profile column / base it consumes ----
+                int32_t len = 0;
+                if (leader && step) {
+                    int32_t ti = m, tj = nn;
+                    while (ti > 0 || tj > 0) {
+                        uint32_t op, nstate;
+                        if (ti == 0) { op = 2; nstate = (tj == 1) ? 0 : 2; }
+                        else {
+                            const int32_t l = (ti - 1) / R, r = (ti - 1) % R;
+                            const uint8_t bt = tbq8[((tj + l) * G + l) * R + r];
+                            if (state == 0) { op = 3; nstate = bt & 3; }
+                            else if (state == 1) { op = 1; nstate = (bt >> 2) & 3; }
+                            else { op = 2; nstate = (bt >> 4) & 3; }
+                        }
+                        recq[len] = (uint16_t)(op | ((uint32_t)(ti - 1) & 127u) << 2 | ((uint32_t)(tj - 1) & 127u) << 9);
+                        len++;
+                        if (op & 1) ti--;
+                        if (op & 2) tj--;
+                        state = (int)nstate;
+                    }
+                }
+                __threadfence_block();
+                len = lane_read(len, gbase);
+                int32_t maxlen = 0;
+#pragma unroll
+                for (int k = 0; k < GROUPS; k++) maxlen = max(maxlen, __builtin_amdgcn_readlane(len, k * G));
+                // ---- new profile in forward order, per group: column c comes from record len - 1 - c ----
+                for (int32_t c = ql; c < maxlen; c += G) {
+                    if (step && c < len) {
+                        const uint32_t rec = recq[len - 1 - c];
+                        uint32_t cv = 0, mv = 0;
+                        if (rec & 1u) { const uint32_t pi = (rec >> 2) & 127u; cv = Pc[pi]; mv = Pm[pi]; }
+                        if (rec & 2u) { cv += 1u << (8 * seqq[G + ((rec >> 9) & 127u)]); mv |= 1u << g; }
+                        Qc[c] = cv; Qm[c] = mv;
+                    }
+                }
+                if (step) { mt.cells += (int64_t)m * nn; mt.score += best; mt.m = len; mt.krows += 1; mt.cur ^= 1; }
+            }
+            if (init) { mt.m = n; mt.krows = 1; }
+            __threadfence_block();       // profiles written by some lanes are read by others in the next step
+        }
+        if (dead) mt.m = -1;
+        if (have && leader) meta[iv] = mt;
+    }
+}
+
+// ---- one interval per wave: stripes of 64 R rows, traceback in HBM (walked through an LDS window) ----
+// lanes a step uses: all 64 when the profile has several stripes, else the lanes that hold rows, rounded up to 4 (so that a
+// step's traceback bytes are a multiple of 16); the traceback stride of a stripe is n + that many steps
+__host__ __device__ __forceinline__ int64_t dp2_lanes(int64_t m) { return m > 64 * DP2_R ? 64 : (((m + DP2_R - 1) / DP2_R + 3) & ~(int64_t)3); }
+__host__ __device__ __forceinline__ int64_t dp2_tb_need(int64_t m, int64_t n)
+{
+    const int64_t W = dp2_lanes(m), stripes = (m + 64 * DP2_R - 1) / (64 * DP2_R);
+    return stripes * (n + W) * W * DP2_R;
+}
+
+template <int R>
+struct Dp2Stripe {
+    Dp2Rows<R> L;
+    int32_t s, n, steps, gyo, gye, La;
+    bool has, park;
+    const uint8_t *seq; const int32_t *rin; int32_t *rout; uint8_t *tbs; int32_t rowbytes;
+    int32_t Md, Xd, Yd;
+    uint32_t bcur, sq_cur, sq_nxt;
+    int32_t bM_cur, bX_cur, bY_cur, bM_nxt, bX_nxt, bY_nxt;
+};
+
+template <int R>
+__device__ __forceinline__ void dp2_stripe_begin(Dp2Stripe<R> &S, int32_t s, int lane, int32_t m, int32_t n, int32_t nstripes, int32_t W,
+                                                 const uint32_t *Pc, const uint8_t *seq, const DpScoring &sc, int32_t krows, int32_t *rowbuf,
+                                                 uint8_t *tbp)
+{
+    S.s = s; S.n = n; S.seq = seq;
+    const int32_t rows_here = min(64 * R, m - s * 64 * R);
+    S.La = (rows_here + R - 1) / R;
+    S.has = lane < S.La;
+    S.L.constants(Pc, s * 64 * R + lane * R, m, sc);
+    S.gyo = sc.go * krows; S.gye = sc.ge * krows;
+    S.rin = rowbuf + (size_t)((s & 1) ^ 1) * 3 * (n + 1);      // written by stripe s-1
+    S.rout = rowbuf + (size_t)(s & 1) * 3 * (n + 1);
+    S.park = s + 1 < nstripes;
+    S.steps = n + S.La;                                         // t = 0 .. n + La - 1
+    S.rowbytes = W * R;
+    S.tbs = tbp + (size_t)s * (n + W) * S.rowbytes + lane * R;
+    S.Md = S.Xd = S.Yd = DP_NEG_INF;
+    S.bcur = 0;
+}
+
+// chunk k of lane 0's inputs: base t-1 and the row above the stripe at column t, for t = 64k + lane
+template <int R>
+__device__ __forceinline__ void dp2_stripe_chunk(const Dp2Stripe<R> &S, int32_t k, int lane, uint32_t &sq, int32_t &bM, int32_t &bX, int32_t &bY)
+{
+    const int32_t col = 64 * k + lane;
+    sq = (uint32_t)S.seq[min(max(col - 1, 0), S.n - 1)];
+    if (S.s == 0) {
+        bM = col == 0 ? 0 : DP_NEG_INF; bX = DP_NEG_INF;
+        bY = col == 0 ? DP_NEG_INF : S.gyo + (col - 1) * S.gye;
+    } else {
+        const int32_t cc = min(col, S.n);
+        bM = S.rin[cc]; bX = S.rin[(S.n + 1) + cc]; bY = S.rin[2 * (S.n + 1) + cc];
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void dp2_stripe_round(Dp2Stripe<R> &S, int32_t c, int lane)
+{
+    if (c == 0) dp2_stripe_chunk<R>(S, 0, lane, S.sq_cur, S.bM_cur, S.bX_cur, S.bY_cur);
+    else { S.sq_cur = S.sq_nxt; S.bM_cur = S.bM_nxt; S.bX_cur = S.bX_nxt; S.bY_cur = S.bY_nxt; }
+    dp2_stripe_chunk<R>(S, c + 1, lane, S.sq_nxt, S.bM_nxt, S.bX_nxt, S.bY_nxt);
+    const int32_t t0 = __builtin_amdgcn_readfirstlane(64 * c), t_end = __builtin_amdgcn_readfirstlane(min(64 * c + 64, S.steps));
+    const bool park = __builtin_amdgcn_readfirstlane((int)S.park) != 0;
+    uint8_t *tbw = S.tbs + (size_t)t0 * S.rowbytes;
+    for (int32_t t = t0; t < t_end; t++, tbw += S.rowbytes) {
+        const int32_t j = t - lane;
+        int32_t Mu = wave_shr1z(S.L.M[R - 1]), Xu = wave_shr1z(S.L.X[R - 1]), Yu = wave_shr1z(S.L.Y[R - 1]);
+        int32_t bn = wave_shr1z((int32_t)S.bcur);
+        const int sel = t & 63;
+        Mu = lane0_set(Mu, __builtin_amdgcn_readlane(S.bM_cur, sel));
+        Xu = lane0_set(Xu, __builtin_amdgcn_readlane(S.bX_cur, sel));
+        Yu = lane0_set(Yu, __builtin_amdgcn_readlane(S.bY_cur, sel));
+        bn = lane0_set(bn, __builtin_amdgcn_readlane((int32_t)S.sq_cur, sel));
+        S.bcur = (uint32_t)bn;
+        if (S.has && (uint32_t)j <= (uint32_t)S.n) {
+            const uint32_t tb = S.L.step(Mu, Xu, Yu, S.Md, S.Xd, S.Yd, (uint32_t)bn, S.gyo, S.gye, j >= 1);
+            *reinterpret_cast<uint32_t *>(tbw) = tb;
+            if (park && lane == 63) { S.rout[j] = S.L.M[R - 1]; S.rout[(S.n + 1) + j] = S.L.X[R - 1]; S.rout[2 * (S.n + 1) + j] = S.L.Y[R - 1]; }
+        }
+        S.Md = Mu; S.Xd = Xu; S.Yd = Yu;
+    }
+}
+
+// all progressive steps of interval iv, by one wave; win: the wave's LDS slice (DP2_TB_DW dwords) for the traceback walk
+__device__ void dp2_interval(int nseq, int64_t iv, const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
+                             uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA, uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
+                             uint8_t *__restrict__ tb, const int64_t *__restrict__ tb_off, int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
+                             uint8_t *__restrict__ ops, uint8_t *win, const DpScoring &sc)
+{
+    constexpr int R = DP2_R;
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
+    const int64_t base = seq_off[iv * nseq];
+    for (int g = 0; g < nseq; g++) {
+        const int64_t so = seq_off[iv * nseq + g];
+        const int32_t n = (int32_t)(seq_off[iv * nseq + g + 1] - so);
+        if (n == 0) continue;
+        const uint8_t *seq = codes + so;
+        uint32_t *Pc = (mt.cur ? cntB : cntA) + base, *Pm = (mt.cur ? maskB : maskA) + base;
+        uint32_t *Qc = (mt.cur ? cntA : cntB) + base, *Qm = (mt.cur ? maskA : maskB) + base;
+        if (mt.krows == 0) {           // first non-empty sequence becomes the profile
+            for (int32_t c = lane; c < n; c += 64) { Pc[c] = 1u << (8 * seq[c]); Pm[c] = 1u << g; }
+            mt.m = n; mt.krows = 1;
+            __threadfence_block();      // the next step's lanes read what other lanes just wrote
+            continue;
+        }
+        const int32_t m = mt.m;
+        const int32_t W = (int32_t)dp2_lanes(m), T = n + W, rowbytes = W * R;
+        uint8_t *tbp = tb + tb_off[iv];
+        int32_t *rowbuf = rows + rows_off[iv];             // 2 x 3 x (n+1)
+        const int32_t nstripes = (m + 64 * R - 1) / (64 * R);
+        int32_t fM = DP_NEG_INF, fX = DP_NEG_INF, fY = DP_NEG_INF;   // values at (m, n)
+        for (int32_t s = 0; s < nstripes; s++) {
+            Dp2Stripe<R> S;
+            dp2_stripe_begin<R>(S, s, lane, m, n, nstripes, W, Pc, seq, sc, mt.krows, rowbuf, tbp);
+            const int32_t nrounds = (S.steps + 63) / 64;
+            for (int32_t c = 0; c < nrounds; c++) dp2_stripe_round<R>(S, c, lane);
+            __threadfence_block();   // the parked row / traceback bytes are read back by this wave
+            if (s == nstripes - 1) S.L.row((m - 1) % R, fM, fX, fY);     // the lane of row m holds (m, n) in that row
+        }
+        const int owner = ((m - 1) % (64 * R)) / R;
+        fM = __shfl(fM, owner); fX = __shfl(fX, owner); fY = __shfl(fY, owner);
+        int32_t best = fM; int state = 0;
+        if (fX > best) { best = fX; state = 1; }
+        if (fY > best) { best = fY; state = 2; }
+        // ---- traceback (wave-uniform walk) through a window of the last DP2_TB_DW * 4 / rowbytes steps in LDS ----
+        uint8_t *opr = ops + base;                         // reversed ops, capacity m + n
+        const int32_t wsteps = (DP2_TB_DW * 4) / rowbytes;
+        int32_t ti = m, tj = n, len = 0, ws = -1, wlo = 0;
+        while (ti > 0 || tj > 0) {
+            uint32_t op, nstate;
+            if (ti == 0) { op = 2; nstate = (tj == 1) ? 0 : 2; }
+            else {
+                const int32_t i0 = ti - 1, s = i0 / (64 * R), l = (i0 % (64 * R)) / R, r = i0 % R;
+                const int32_t t = tj + l;
+                if (s != ws || t < wlo) {
+                    ws = s; wlo = max(0, t - (wsteps - 1));
+                    const uint8_t *src = tbp + ((size_t)s * T + wlo) * rowbytes;
+                    const int32_t nbytes = (t - wlo + 1) * rowbytes;
+                    for (int32_t o = lane * 16; o < nbytes; o += 1024)
+                        *reinterpret_cast<uint4 *>(win + o) = *reinterpret_cast<const uint4 *>(src + o);
+                    __threadfence_block();             // the window is read by every lane
+                }
+                const uint8_t bt = win[(size_t)(t - wlo) * rowbytes + l * R + r];
+                if (state == 0) { op = 3; nstate = bt & 3; }
+                else if (state == 1) { op = 1; nstate = (bt >> 2) & 3; }
+                else { op = 2; nstate = (bt >> 4) & 3; }
+            }
+            if (lane == 0) opr[len] = (uint8_t)op;
+            len++;
+            if (op & 1) ti--;
+            if (op & 2) tj--;
+            state = (int)nstate;
+        }
+        __threadfence_block();
+        // ---- new profile in forward order: ballot prefix counts give each column its sources ----
+        int32_t carry_p = 0, carry_s = 0;
+        for (int32_t c0i = 0; c0i < len; c0i += 64) {
+            const int32_t c = c0i + lane;
+            const bool ok = c < len;
+            const uint32_t op = ok ? opr[len - 1 - c] : 0u;
+            const uint64_t bp = __ballot(ok && (op & 1)), bs = __ballot(ok && (op & 2));
+            if (ok) {
+                const int32_t pi = carry_p + (int32_t)__popcll(bp & lt), sj = carry_s + (int32_t)__popcll(bs & lt);
+                uint32_t cv = 0, mv = 0;
+                if (op & 1) { cv = Pc[pi]; mv = Pm[pi]; }
+                if (op & 2) { cv += 1u << (8 * seq[sj]); mv |= 1u << g; }
+                Qc[c] = cv; Qm[c] = mv;
+            }
+            carry_p += (int32_t)__popcll(bp); carry_s += (int32_t)__popcll(bs);
+        }
+        mt.cells += (int64_t)m * n; mt.score += best; mt.m = len; mt.krows += 1; mt.cur ^= 1;
+        __threadfence_block();
+    }
+    if (lane == 0) meta[iv] = mt;
+}
+
 __global__ void __launch_bounds__(64 * DP_MW_WAVES) dp_step_big(int nseq, const int64_t *__restrict__ list, const uint8_t *__restrict__ codes,
                                                const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
                                                uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
@@ -564,7 +944,7 @@ __global__ void __launch_bounds__(64 * DP_MW_WAVES) dp_step_big(int nseq, const 
     dp_interval_mw(nseq, list[blockIdx.x], codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, sc, band_from);
 }
 
-struct DpClasses { int64_t first_med, n_med, first_s32, n_s32, first_s16, n_s16; uint32_t blocks_med, blocks_s32; };
+struct DpClasses { int64_t first_med, n_med, first_c, n_c, first_s32, n_s32, first_s16, n_s16; uint32_t blocks_med, blocks_c, blocks_s32; };   // list = [big | one wave | G = 16 | s32 (G = 8) | s16 (G = 4)]
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) dp_step(int nseq, const int64_t *__restrict__ list, DpClasses cl, const uint8_t *__restrict__ codes,
                                                const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
@@ -704,6 +1084,47 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
 }
 
+
+// The register-blocked launch: block ranges [one wave per interval | G = 16 | G = 8 | G = 4], the long ones first.
+__global__ void __launch_bounds__(64 * DP2_WAVES) dp_step2(int nseq, const int64_t *__restrict__ list, DpClasses cl, const uint8_t *__restrict__ codes,
+                                               const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
+                                               uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
+                                               uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
+                                               uint8_t *__restrict__ tb, const int64_t *__restrict__ tb_off,
+                                               int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
+                                               uint8_t *__restrict__ ops, DpScoring sc)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_tb[DP2_WAVES][DP2_TB_DW];
+    __shared__ uint16_t s_rec[DP2_WAVES][DP2_REC];
+    __shared__ uint8_t s_seq[DP2_WAVES][DP2_SEQ];
+    const int wv = threadIdx.x >> 6;
+    int per = 1; bool only_failed = false;
+    int64_t pos0, pstep, pend;
+    if (blockIdx.x >= cl.blocks_med) {
+        uint32_t b = blockIdx.x - cl.blocks_med, nb; int k = 0; int64_t first, count;
+        if (b < cl.blocks_c) { nb = cl.blocks_c; first = cl.first_c; count = cl.n_c; }
+        else if (b < cl.blocks_c + cl.blocks_s32) { k = 1; b -= cl.blocks_c; nb = cl.blocks_s32; first = cl.first_s32; count = cl.n_s32; }
+        else { k = 2; b -= cl.blocks_c + cl.blocks_s32; nb = gridDim.x - cl.blocks_med - cl.blocks_c - cl.blocks_s32; first = cl.first_s16; count = cl.n_s16; }
+        const int64_t widx = (int64_t)b * DP2_WAVES + wv, nw = (int64_t)nb * DP2_WAVES;
+        if (k == 0) dp2_groups<16>(nseq, list, first, count, widx, nw, codes, seq_off, meta, cntA, maskA, cntB, maskB, s_tb[wv], s_rec[wv], s_seq[wv], sc);
+        else if (k == 1) dp2_groups<8>(nseq, list, first, count, widx, nw, codes, seq_off, meta, cntA, maskA, cntB, maskB, s_tb[wv], s_rec[wv], s_seq[wv], sc);
+        else dp2_groups<4>(nseq, list, first, count, widx, nw, codes, seq_off, meta, cntA, maskA, cntB, maskB, s_tb[wv], s_rec[wv], s_seq[wv], sc);
+        // second look at this wave's own list positions: what a group gave up is aligned below, one interval per wave
+        per = k == 0 ? 4 : (k == 1 ? 8 : 16); only_failed = true;
+        pos0 = first + widx * per; pstep = nw * per; pend = first + count;
+        __threadfence_block();
+    } else {
+        pos0 = cl.first_med + (int64_t)blockIdx.x * DP2_WAVES + wv; pstep = (int64_t)cl.blocks_med * DP2_WAVES;
+        pend = cl.first_med + cl.n_med;
+    }
+    for (int64_t lb = pos0; lb < pend; lb += pstep)
+        for (int q = 0; q < per && lb + q < pend; q++) {
+            const int64_t iv = list[lb + q];
+            if (only_failed && meta[iv].m != -1) continue;
+            dp2_interval(nseq, iv, codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, reinterpret_cast<uint8_t *>(s_tb[wv]), sc);
+        }
+}
+
 // masks of the final profiles, compacted: cols[col_off[iv] + c]
 __global__ void __launch_bounds__(256) dp_gather(int nseq, int64_t n_iv, const int64_t *__restrict__ seq_off,
                                                  const DpMeta *__restrict__ meta, const uint32_t *__restrict__ maskA,
@@ -751,6 +1172,7 @@ static int dp_class_mode()
     static const int m = []() { const char *e = getenv("MAUVE_DP_CLASS"); return !e ? 0 : (!strcmp(e, "bound") ? 1 : (!strcmp(e, "wild") ? 2 : 0)); }();
     return m;
 }
+static bool dp_old_kernels() { static const bool o = getenv("MAUVE_DP_OLD") != nullptr; return o; }   // A/B switch: the systolic one-row-per-lane kernels
 static int64_t dp_big_factor4() { static const int64_t f = getenv("MAUVE_DP_BIG_FACTOR4") ? atoll(getenv("MAUVE_DP_BIG_FACTOR4")) : 16; return f; }
 static int64_t dp_big_max() { static const int64_t m = getenv("MAUVE_DP_BIG_MAX") ? atoll(getenv("MAUVE_DP_BIG_MAX")) : 128; return m; }
 
@@ -765,11 +1187,16 @@ static int dp_launch_steps(mauve_ctx *ctx, int nseq, int64_t a, int64_t b, int64
     clip(0, n_big, bf, bn);
     DpClasses cl; memset(&cl, 0, sizeof cl);
     clip(full.first_med, full.n_med, cl.first_med, cl.n_med);
+    clip(full.first_c, full.n_c, cl.first_c, cl.n_c);
     clip(full.first_s32, full.n_s32, cl.first_s32, cl.n_s32);
     clip(full.first_s16, full.n_s16, cl.first_s16, cl.n_s16);
-    cl.blocks_med = (uint32_t)std::min<int64_t>((cl.n_med + 3) / 4, 256 * 8);
-    cl.blocks_s32 = (uint32_t)std::min<int64_t>((cl.n_s32 + 7) / 8, 256 * 8);
-    const uint32_t blocks = cl.blocks_med + cl.blocks_s32 + (uint32_t)std::min<int64_t>((cl.n_s16 + 15) / 16, 256 * 8);
+    const bool oldk = dp_old_kernels();
+    // intervals per workgroup: systolic kernels 4 waves x {1, 2, 4}; register-blocked kernels 2 waves x {1, 4, 8, 16}
+    const int64_t wpb = oldk ? 4 : DP2_WAVES, cap = oldk ? 256 * 8 : 256 * 16;
+    cl.blocks_med = (uint32_t)std::min<int64_t>((cl.n_med + wpb - 1) / wpb, cap);
+    cl.blocks_c = (uint32_t)std::min<int64_t>((cl.n_c + 4 * wpb - 1) / (4 * wpb), cap);
+    cl.blocks_s32 = (uint32_t)std::min<int64_t>(oldk ? (cl.n_s32 + 7) / 8 : (cl.n_s32 + 8 * wpb - 1) / (8 * wpb), cap);
+    const uint32_t blocks = cl.blocks_med + cl.blocks_c + cl.blocks_s32 + (uint32_t)std::min<int64_t>(oldk ? (cl.n_s16 + 15) / 16 : (cl.n_s16 + 16 * wpb - 1) / (16 * wpb), cap);
     uint8_t *tb = ctx->dp_tb.as<uint8_t>() - tb_base;                   // only offsets >= tb_base are used in this round
     KernelTimer t(ctx, MAUVE_K_DP, b - a);
     if (bn) {   // the workgroup-per-interval launch runs beside the one-wave launch on a second stream
@@ -782,8 +1209,14 @@ static int dp_launch_steps(mauve_ctx *ctx, int nseq, int64_t a, int64_t b, int64
                            d_rows_off, ctx->dp_score.as<uint8_t>(), sc, band_from);
         HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
     }
-    if (blocks)
+    if (blocks && oldk)
         hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, nseq, ctx->dp_list.as<int64_t>(), cl,
+                           ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
+                           ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
+                           ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(),
+                           d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
+    else if (blocks)
+        hipLaunchKernelGGL(dp_step2, dim3(blocks), dim3(64 * DP2_WAVES), 0, ctx->stream, nseq, ctx->dp_list.as<int64_t>(), cl,
                            ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
                            ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
                            ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(),
@@ -859,19 +1292,20 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
                 ce.add(n);
                 if (n == 0) continue;
                 if (first) { first = false; mmax = mmin = n; continue; }
-                const int64_t tbn = dp_tb_need(mmin, mmax, n, banded);  // the profile is at least as long as its longest member
+                const int64_t tbo = dp_tb_need(mmin, mmax, n, banded);  // the profile is at least as long as its longest member
+                const int64_t tbn = banded ? tbo : std::max(tbo, dp2_tb_need(mmax, n));     // (either kernel family may run the interval)
                 need = std::max(need, tbn);
                 nmax = std::max(nmax, n);
                 // a step with >= 3 stripes against >= 256 columns pipelines over several waves
                 if (mmax > 128 && n >= 256 && !no_mw) big = 1;
-                es += tbn / 64;                                        // systolic steps of a single wave
+                es += tbo / 64;                                        // systolic steps of a single wave
                 mmax += n; mmin = std::max(mmin, n);
             }
             if (banded && nmax) big = 2;                               // banded steps exist only in the workgroup kernel
             need_v[(size_t)iv] = need; nmax_v[(size_t)iv] = nmax; est[(size_t)iv] = es; is_big[(size_t)iv] = big;
             // sub-wave classes: every profile the interval will see fits G rows, every step fits the LDS slice
             uint8_t k = 1;
-            if (!no_groups && !banded) k = (uint8_t)ce.klass(DP_GRP_TMAX);
+            if (!no_groups && !banded) k = (uint8_t)(dp_old_kernels() ? ce.klass(DP_GRP_TMAX) : ce.klass2(DP2_R, DP2_T));
             cls[(size_t)iv] = k;
         }
     });
@@ -908,11 +1342,11 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     DpClasses cl; memset(&cl, 0, sizeof cl);
     {
         std::vector<int64_t> &tmp = H.lst2; tmp.resize((size_t)n_iv);
-        int64_t cnt4[4] = {0, 0, 0, 0};
+        int64_t cnt4[5] = {0, 0, 0, 0, 0};
         auto klass = [&](int64_t iv) { return is_big[(size_t)iv] ? 0 : (int)cls[(size_t)iv]; };
         for (int64_t k = 0; k < n_iv; k++) cnt4[klass(lst[(size_t)k])]++;
-        int64_t pos[4] = {0, cnt4[0], cnt4[0] + cnt4[1], cnt4[0] + cnt4[1] + cnt4[2]};
-        cl.first_med = pos[1]; cl.n_med = cnt4[1]; cl.first_s32 = pos[2]; cl.n_s32 = cnt4[2]; cl.first_s16 = pos[3]; cl.n_s16 = cnt4[3];
+        int64_t pos[5] = {0, cnt4[0], cnt4[0] + cnt4[1], cnt4[0] + cnt4[1] + cnt4[2], cnt4[0] + cnt4[1] + cnt4[2] + cnt4[3]};
+        cl.first_med = pos[1]; cl.n_med = cnt4[1]; cl.first_c = pos[2]; cl.n_c = cnt4[2]; cl.first_s32 = pos[3]; cl.n_s32 = cnt4[3]; cl.first_s16 = pos[4]; cl.n_s16 = cnt4[4];
         for (int64_t k = 0; k < n_iv; k++) { const int64_t iv = lst[(size_t)k]; tmp[(size_t)pos[klass(iv)]++] = iv; }
         lst.swap(tmp);
     }
@@ -1020,7 +1454,7 @@ namespace {
 using namespace devscan;
 
 struct DpFrontTotals {                       // device block read back once
-    int64_t codes, tb, rows, est, n_dp, first_med, first_s32, first_s16, cols, cells;
+    int64_t codes, tb, rows, est, n_dp, first_med, first_s32, first_s16, cols, cells, first_c;
 };
 
 __device__ __forceinline__ void dpf_gap(const int32_t *__restrict__ alen, const int32_t *__restrict__ ast, int N, uint32_t k, int g,
@@ -1074,7 +1508,7 @@ __global__ void __launch_bounds__(256) dpf_desc(const int32_t *__restrict__ alen
     if (s >= (uint32_t)tot->n_dp) return;
     const uint32_t k = anchor_of[s];
     int64_t mmax = 0, mmin = 0, nd = 0, nmax = 0, es = 0, longest = 0; bool first = true; uint8_t big = 0;
-    DpClassEst ce; ce.mode = class_mode;
+    DpClassEst ce; ce.mode = class_mode & 7;                 // bit 3: the systolic kernels' classes (MAUVE_DP_OLD)
     for (int g = 0; g < N; g++) {
         int64_t lo, n; bool rv;
         dpf_gap(alen, ast, N, k, g, lo, n, rv);
@@ -1089,17 +1523,18 @@ __global__ void __launch_bounds__(256) dpf_desc(const int32_t *__restrict__ alen
         ce.add(n);
         if (n == 0) continue;
         if (first) { first = false; mmax = mmin = n; continue; }
-        const int64_t tbn = dp_tb_need(mmin, mmax, n, banded);
+        const int64_t tbo = dp_tb_need(mmin, mmax, n, banded);
+        const int64_t tbn = banded ? tbo : max(tbo, dp2_tb_need(mmax, n));
         nd = max(nd, tbn);
         nmax = max(nmax, n);
         if (mmax > 128 && n >= 256 && !no_mw) big = 1;       // a step with >= 3 stripes against >= 256 columns pipelines over several waves
-        es += tbn / 64;
+        es += tbo / 64;
         mmax += n; mmin = max(mmin, n);
     }
     if (banded && nmax) big = 2;                             // banded steps exist only in the workgroup kernel
     need[s] = nd; rowsn[s] = 6 * (nmax + 1); est[s] = es; cand[s] = big;
     uint8_t kc = 1;
-    if (!no_groups && !banded) kc = (uint8_t)ce.klass(DP_GRP_TMAX);
+    if (!no_groups && !banded) kc = (uint8_t)(class_mode & 8 ? ce.klass(DP_GRP_TMAX) : ce.klass2(DP2_R, DP2_T));
     cls[s] = kc;
     int c = 0; for (int64_t f = nd; f > 1; f >>= 1) c++;
     sizekey[s] = (uint32_t)(63 - c);                         // largest traceback footprint first
@@ -1130,10 +1565,10 @@ __global__ void __launch_bounds__(256) dpf_list(const uint32_t *__restrict__ key
 {
     const uint32_t n = (uint32_t)tot->n_dp, j = blockIdx.x * 256u + threadIdx.x;
     if (j < n) list[j] = order[j];
-    if (j < 3) {                                              // first index with key >= j + 1
+    if (j < 4) {                                              // first index with key >= j + 1
         uint32_t lo = 0, hi = n;
         while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (key2[mid] >= j + 1) hi = mid; else lo = mid + 1; }
-        if (j == 0) tot->first_med = lo; else if (j == 1) tot->first_s32 = lo; else tot->first_s16 = lo;
+        if (j == 0) tot->first_med = lo; else if (j == 1) tot->first_c = lo; else if (j == 2) tot->first_s32 = lo; else tot->first_s16 = lo;
     }
 }
 struct MetaCols { const DpMeta *m; __device__ int64_t value(uint32_t i) const { return m[i].m; } };
@@ -1202,7 +1637,7 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     hipLaunchKernelGGL((cmp_count<DpSlots>), dim3(nb), dim3(256), 0, ctx->stream, sl, bcnt);
     hipLaunchKernelGGL((cmp_write<DpSlots>), dim3(nb), dim3(256), 0, ctx->stream, sl, bcnt);
     hipLaunchKernelGGL(dpf_desc, dim3(blocks), dim3(256), 0, ctx->stream, alen, ast, N, anchor_of, tot, desc, need, rowsn, est, cand, cls, k1, v1,
-                       (int)no_mw, (int)no_groups, ctx->dp_band_from, dp_class_mode());
+                       (int)no_mw, (int)no_groups, ctx->dp_band_from, dp_class_mode() | (dp_old_kernels() ? 8 : 0));
     // the counts below are device values; the launches cover na (>= n_dp) entries and the kernels stop at n_dp.
     // Offsets: the value functors return 0 beyond n_dp because the arrays there are never read -- so clear them first.
     // (need / rows / est / desc of slots >= n_dp are not written: scan over exactly n_dp needs the count -> two-phase:
@@ -1237,7 +1672,7 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     hipLaunchKernelGGL((cmp_count<DpBigPick>), dim3(nbd), dim3(256), 0, ctx->stream, bp, bcnt);
     hipLaunchKernelGGL((cmp_write<DpBigPick>), dim3(nbd), dim3(256), 0, ctx->stream, bp, bcnt);
     uint32_t *ck = fk, *cv = ov;
-    rc = sort_pairs_u32(ctx, n_dp, 2, &ck, &cv, k3, fv, MAUVE_K_MISC);
+    rc = sort_pairs_u32(ctx, n_dp, 3, &ck, &cv, k3, fv, MAUVE_K_MISC);
     if (rc) return rc;
     hipLaunchKernelGGL(dpf_list, dim3(blk_d), dim3(256), 0, ctx->stream, ck, cv, tot, ctx->dp_list.as<int64_t>());
     // traceback offsets in list order (a round of the list then uses one contiguous piece of the buffer)
@@ -1252,11 +1687,10 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     *code_total_out = total;
     DpClasses cl; memset(&cl, 0, sizeof cl);
     const int64_t n_big = ht->first_med;
-    cl.first_med = ht->first_med; cl.n_med = ht->first_s32 - ht->first_med;
+    cl.first_med = ht->first_med; cl.n_med = ht->first_c - ht->first_med;
+    cl.first_c = ht->first_c; cl.n_c = ht->first_s32 - ht->first_c;
     cl.first_s32 = ht->first_s32; cl.n_s32 = ht->first_s16 - ht->first_s32;
-    cl.first_s16 = ht->first_s16; cl.n_s16 = (int64_t)n_dp - ht->first_s16;
-    cl.blocks_med = (uint32_t)std::min<int64_t>((cl.n_med + 3) / 4, 256 * 8);
-    cl.blocks_s32 = (uint32_t)std::min<int64_t>((cl.n_s32 + 7) / 8, 256 * 8);
+    cl.first_s16 = ht->first_s16; cl.n_s16 = (int64_t)n_dp - ht->first_s16;          // (block counts: dp_launch_steps)
     const double t2 = now_ms();
     HIPCHK(ctx, ctx->dp_codes.ensure((size_t)total + 16));
     HIPCHK(ctx, ctx->dp_prof_cnt.ensure((size_t)(total + 1) * 4));

@@ -67,6 +67,7 @@ struct Prog {
     std::vector<FreePool> rest;        // per genome: bases not placed in any block yet
     AlignResult *R;
     int64_t n_gap_dp = 0, n_cells = 0, n_anchor = 0, n_multi = 0;
+    double t_seed = 0, t_chain = 0, t_rec = 0, t_dp = 0, t_blocks = 0;      // stage times summed over the nodes (mauve_last_stage_times)
 };
 
 int leaves_of(const Prog &P, int node, std::vector<int> &out)
@@ -253,6 +254,7 @@ int prog_node(Prog &P, int node)
     rc = dp_batch_run_desc(c, n, n_dp, desc.data(), &p->scoring, dcols, dcol_off.data(), dscore.data(), &cells);
     if (rc) return rc;
     P.n_gap_dp += n_dp; P.n_cells += cells;
+    { const double tn4 = now_ms(); P.t_seed += tn1 - tn0; P.t_chain += tn2 - tn1; P.t_rec += tn3 - tn2; P.t_dp += tn4 - tn3; }
     if (trace) {
         int64_t big = 0; for (int64_t k = 0; k < n_dp; k++) { int64_t mx = 0; for (int j = 0; j < n; j++) mx = std::max(mx, desc[(size_t)(k * n + j)].len); big = std::max(big, mx); }
         fprintf(stderr, "[trace] node %d (n=%d, pool %lld): seed %.1f ms (%lld mums), chain %.1f, recursion %.1f, dp %.1f ms (%lld intervals, %lld cells, longest side %lld)\n",
@@ -297,6 +299,7 @@ int prog_node(Prog &P, int node)
         }
     }
     for (int j = 0; j < n; j++) for (const auto &pl : placed[(size_t)j]) P.rest[gm[j]].carve(pl.first, pl.second);
+    P.t_blocks += now_ms() - tb0;
     if (trace) fprintf(stderr, "[trace] node %d: blocks %.1f ms\n", node, now_ms() - tb0);
     rc = prog_node(P, P.left[node]);
     if (rc) return rc;
@@ -313,6 +316,7 @@ int mauve_guide_tree(mauve_ctx *c, uint64_t pattern, int64_t *dist, int32_t *lef
     if (!c || !left || !right) return MAUVE_ERR_ARG;
     if (c->nseq < 2) { c->err = "guide_tree: at least two genomes required"; return MAUVE_ERR_STATE; }
     HIPCHK(c, hipSetDevice(c->device));
+    { int rcm = materialize_tables(c); if (rcm) return rcm; }           // a resident result keeps its tables in buffers the passes below reuse
     const int N = c->nseq, M = 2 * N - 1;
     int64_t nm = 0;
     // similarity = sum of the pairwise match lengths per genome pair: summed on the device, the matches themselves stay there
@@ -413,7 +417,7 @@ static int progressive_core(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     R.mum_length.clear(); R.mum_start.clear(); R.lcb_left.clear(); R.lcb_right.clear(); R.lcb_weight.clear();
     R.anchor_length.clear(); R.anchor_start.clear(); R.anchor_lcb.clear(); R.iv_left.clear(); R.iv_right.clear();
     R.iv_reverse.clear(); R.col_off.clear(); R.cols.clear(); R.dp_score.clear();
-    R.dev_pending = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr; R.cols_fill = 0; R.cols_dirty.clear();
+    R.dev_pending = false; R.cols_pending = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr; R.cols_fill = 0; R.cols_dirty.clear();
     R.cols_fill = 0; R.cols_dirty.clear();           // mauve_align's prefilled-buffer invariant no longer holds
     P.R = &R;
     P.rest.assign((size_t)N, FreePool());
@@ -445,6 +449,8 @@ static int progressive_core(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     R.sz.n_cols = (int64_t)R.cols.size(); R.sz.n_gap_dp = P.n_gap_dp; R.sz.n_dp_cells = P.n_cells;
     *sizes = R.sz;
     memset(&c->stage, 0, sizeof c->stage);
+    c->stage.tree_ms = tg1 - t0; c->stage.seed_ms = P.t_seed; c->stage.chain_ms = P.t_chain; c->stage.recurse_ms = P.t_rec; c->stage.dp_ms = P.t_dp;
+    c->stage.assemble_ms = P.t_blocks + (now_ms() - tg2);
     c->stage.total_ms = now_ms() - t0;
     return MAUVE_OK;
 }

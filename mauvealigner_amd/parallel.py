@@ -106,7 +106,7 @@ def reduce_throughput(elapsed_s, base_pairs, dist=None, group=None):
     return float(t.item()), float(b.item())
 
 
-def align_sharded(ctx, params=None, dist=None, group=None, names=None, want_xmfa=False, fetch=True):
+def align_sharded(ctx, params=None, dist=None, group=None, names=None, want_xmfa=False, fetch=True, out=None):
     """One alignment, its gapped-alignment intervals sharded over the ranks (LCB sharding).
 
     Every rank holds the same genomes (ctx.set_genomes) and runs the deterministic front of the path
@@ -141,4 +141,4 @@ def align_sharded(ctx, params=None, dist=None, group=None, names=None, want_xmfa
                 all_score[i] = g_score[r][k]
                 off += ln
         all_cells = int(sum(int(x[0]) for x in g_cells))
-    return ctx.align_finish(all_cols, all_score, all_cells, fetch=fetch, names=names, want_xmfa=want_xmfa)
+    return ctx.align_finish(all_cols, all_score, all_cells, fetch=fetch, names=names, want_xmfa=want_xmfa, out=out)

@@ -822,3 +822,58 @@ def test_guide_tree_and_progressive_align(ctx):
     _same_progressive(ctx, gs, recursive=0)
     _same_progressive(ctx, synth.make_config("C3", scale=0.02))
     _same_progressive(ctx, synth.make_config("C1", scale=0.1))
+
+
+def test_resident_result_survives_other_device_work(ctx):
+    """A result left in HBM (align(fetch=False)) keeps its anchor table and match list in buffers later seed passes
+    reuse: every entry point that runs such work first brings them to the host, so a fetch after it is still the result."""
+    from mauvealigner_amd import _lib
+    gs = synth.make_config("C3", scale=0.4)             # > 16 k matches: the chains, the DP front and the assembly stay on the device
+    ctx.set_genomes(gs)
+    p = _lib.default_params(seed_weight=15)
+    ref = ctx.align(p)
+    if True:
+        for other in ("seed_mums", "sorted_mer_list", "enumerate", "dp_batch", "guide_tree"):
+            sz = ctx.align(p, fetch=False)
+            assert sz["n_anchor"] == ref["n_anchor"]
+            if other == "seed_mums":
+                ctx.seed_mums(_lib.get_seed(9, 0), mask=0)
+            elif other == "sorted_mer_list":
+                ctx.sorted_mer_list(1, _lib.get_seed(9, 0))
+            elif other == "enumerate":
+                ctx.seed_match_enumerate(0, _lib.get_seed(7, 0))
+            elif other == "dp_batch":
+                ctx.dp_batch([[gs[0][:50], gs[1][:60]] + [np.zeros(0, np.uint8)] * (len(gs) - 2)])
+            else:
+                ctx.guide_tree(_lib.get_seed(11, 0))
+            sz_t = _lib.AlignSizes(**{k: sz[k] for k, _ in _lib.AlignSizes._fields_})
+            r = ctx._fetch(sz_t)
+            for k in ("mum_length", "mum_start", "anchor_start", "anchor_length", "anchor_lcb", "left", "right", "reverse", "col_off", "cols", "dp_score"):
+                assert np.array_equal(r[k], ref[k]), (other, k)
+
+
+def test_page_locked_caller_buffers(ctx):
+    """mauve_host_alloc buffers on both sides of the pass: genomes uploaded straight from them, results fetched straight into
+    them; same result as through pageable buffers, and the XMFA text (which needs the host copy of the genomes) as well."""
+    from mauvealigner_amd import _lib
+    gs = synth.make_config("C3", scale=0.4)
+    ctx.set_genomes(gs)
+    p = _lib.default_params(seed_weight=15)
+    ref = ctx.align(p, want_xmfa=True)
+    packed = []
+    for g in gs:
+        w = _lib.pack_codes(g)
+        pw = _lib.pinned_empty(len(w), np.uint64)
+        pw[:] = w
+        packed.append(pw)
+    bufs = _lib.ResultBuffers()
+    for _ in range(2):
+        ctx.set_genomes_packed(packed, [len(g) for g in gs])
+        r = ctx.align(p, out=bufs, want_xmfa=True)
+        for k in ("mum_length", "mum_start", "anchor_start", "anchor_length", "anchor_lcb", "left", "right", "reverse", "col_off", "cols", "dp_score"):
+            assert np.array_equal(r[k], ref[k]), k
+        assert r["xmfa"] == ref["xmfa"]
+    # a second fetch of the same result into pageable memory still works (the columns are still in HBM)
+    sz_t = _lib.AlignSizes(**{k: r[k] for k, _ in _lib.AlignSizes._fields_})
+    again = ctx._fetch(sz_t)
+    assert np.array_equal(again["cols"], ref["cols"])
