@@ -128,6 +128,8 @@ __device__ __forceinline__ int32_t wave_shr1(int32_t v) { return __builtin_amdgc
 // v with lane 0 replaced by the wave-uniform value x (v_writelane_b32; this compiler has no builtin for it)
 __device__ __forceinline__ int32_t lane0_set(int32_t v, int32_t x)
 {
+    x = __builtin_amdgcn_readfirstlane(x);               // (wave-uniform by contract; this pins it to a scalar register)
+    asm("" : "+s"(x));                                   // a compile-time constant would be folded into the operand: v_writelane takes no literal
     asm("v_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(x));
     return v;
 }
@@ -944,7 +946,7 @@ __global__ void __launch_bounds__(64 * DP_MW_WAVES) dp_step_big(int nseq, const 
     dp_interval_mw(nseq, list[blockIdx.x], codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, sc, band_from);
 }
 
-struct DpClasses { int64_t first_med, n_med, first_c, n_c, first_s32, n_s32, first_s16, n_s16; uint32_t blocks_med, blocks_c, blocks_s32; };   // list = [big | one wave | G = 16 | s32 (G = 8) | s16 (G = 4)]
+struct DpClasses { int64_t first_med, n_med, first_c, n_c, first_s32, n_s32, first_s16, n_s16; uint32_t blocks_med, blocks_c, blocks_s32; int32_t scan; };   // list = [big | one wave | G = 16 | s32 (G = 8) | s16 (G = 4)]
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) dp_step(int nseq, const int64_t *__restrict__ list, DpClasses cl, const uint8_t *__restrict__ codes,
                                                const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
@@ -1085,6 +1087,466 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 }
 
 
+
+// ================================================================================================================
+// Scan-formulated sweep (one wave per interval).  An anti-diagonal schedule needs m + n dependent steps whatever the
+// lanes do; the recurrence itself does not: only ONE of the two gap states depends on the cell computed just before
+// it in the sweep direction.  Going column by column with the profile rows on the lanes (orientation A), M(i, j) and
+// Y(i, j) read column j - 1 only -- element-wise -- and X(i, j) = max(-inf, t_i, X(i-1, j) + gxe_i) with
+// t_i = max(M, Y)(i-1, j) + gxo_i is a max-plus linear recurrence along the rows: with E_i the prefix sums of gxe it is
+// X(i, j) = E_i + max_{k <= i} (max(-inf, t_k) - E_k), i.e. R local steps per lane and ONE wave-wide prefix maximum (six
+// DPP steps).  A step of the sweep is a whole column (64 R rows per band), the sweep takes n + 1 steps instead of
+// n + 64, and a tall thin problem (a 6.7 kb insertion against 20 bases) takes 21 steps per band of 256 rows instead of
+// 105 stripes of 84 anti-diagonals.  Orientation B is the mirror image for a short profile against a long sequence:
+// columns on the lanes, row by row, Y the scanned state.  The orientation is chosen per progressive step by cost.
+// Values, tie rules (the first of M, X, Y that attains the maximum, found by comparing the unclamped candidates) and
+// the clamp at -2^29 are those of the systolic kernels: max is associative, the sums are exact in 32 bits for every
+// interval the host admits here (dp3_admissible), so the traceback bytes of every reachable cell are identical.
+// ================================================================================================================
+template <int CTRL, int RM> __device__ __forceinline__ int32_t dpp_keep(int32_t v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xf, false); }
+template <int CTRL, int RM> __device__ __forceinline__ int32_t dpp_zero(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, RM, 0xf, false); }
+// inclusive prefix maximum / sum over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 and :31
+__device__ __forceinline__ int32_t wave_prefix_max(int32_t v)
+{
+    v = max(v, dpp_keep<0x111, 0xf>(v)); v = max(v, dpp_keep<0x112, 0xf>(v));
+    v = max(v, dpp_keep<0x114, 0xf>(v)); v = max(v, dpp_keep<0x118, 0xf>(v));
+    v = max(v, dpp_keep<0x142, 0xa>(v)); v = max(v, dpp_keep<0x143, 0xc>(v));
+    return v;
+}
+__device__ __forceinline__ int32_t wave_prefix_sum(int32_t v)
+{
+    v += dpp_zero<0x111, 0xf>(v); v += dpp_zero<0x112, 0xf>(v);
+    v += dpp_zero<0x114, 0xf>(v); v += dpp_zero<0x118, 0xf>(v);
+    v += dpp_zero<0x142, 0xa>(v); v += dpp_zero<0x143, 0xc>(v);
+    return v;
+}
+
+constexpr int DP3_R = 4, DP3_BAND = 64 * DP3_R;           // rows (A) / columns (B) of one band
+// rows (A) / columns (B) a lane holds: as few as cover the dimension with 64 lanes (a tiny problem keeps 4: fewer bytes)
+__host__ __device__ __forceinline__ int32_t dp3_rows_per_lane(int64_t x) { return x <= 32 ? 4 : (x <= 64 ? 1 : (x <= 128 ? 2 : 4)); }
+// stride of a traceback line: four bytes per lane that holds something, in 16-byte units; whole bands beyond one
+__host__ __device__ __forceinline__ int64_t dp3_pad(int64_t x)
+{
+    if (x > DP3_BAND) return (x + DP3_BAND - 1) / DP3_BAND * DP3_BAND;
+    const int64_t R = dp3_rows_per_lane(x);
+    return (4 * ((x + R - 1) / R) + 15) & ~(int64_t)15;
+}
+// ... and its largest value over all dimensions up to x (the host sizes for a bound of the profile length)
+__host__ __device__ __forceinline__ int64_t dp3_pad_bound(int64_t x) { return x <= 32 ? ((x + 15) & ~(int64_t)15) : (x <= DP3_BAND ? DP3_BAND : (x + DP3_BAND - 1) / DP3_BAND * DP3_BAND); }
+__host__ __device__ __forceinline__ bool dp3_orient_b(int64_t m, int64_t n)    // cost: steps x bands
+{
+    return m * ((n + DP3_BAND - 1) / DP3_BAND) < (n + 1) * ((m + DP3_BAND - 1) / DP3_BAND);
+}
+// traceback bytes of a step whose profile has at most m rows (either orientation), and parked boundary entries
+__host__ __device__ __forceinline__ int64_t dp3_tb_need(int64_t m, int64_t n)
+{
+    const int64_t a = (n + 1) * dp3_pad_bound(m), b = m * dp3_pad_bound(n);
+    return a > b ? a : b;
+}
+// parked boundary entries: A keeps the last row of a band for every column, B (more than one band of columns) the last column for every row
+__host__ __device__ __forceinline__ int64_t dp3_rows_need(int64_t m, int64_t n) { return 6 * ((n > DP3_BAND && m > n ? m : n) + 1); }
+
+template <int R>
+struct Dp3A {
+    int32_t M[R], X[R], Y[R];
+    int32_t s0[R], s1[R], s2[R], s3[R], gxo[R], gxe[R], E;
+    __device__ __forceinline__ void constants(const uint32_t *Pc, int32_t i0, int32_t m, const DpScoring &sc)
+    {
+        int32_t bsum = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t cn = i0 + r < m ? Pc[i0 + r] : 0u;
+            const int32_t c0 = cn & 255, c1 = (cn >> 8) & 255, c2 = (cn >> 16) & 255, c3 = cn >> 24;
+            const int32_t rr = c0 + c1 + c2 + c3;
+            s0[r] = c0 * sc.s[0][0] + c1 * sc.s[1][0] + c2 * sc.s[2][0] + c3 * sc.s[3][0];
+            s1[r] = c0 * sc.s[0][1] + c1 * sc.s[1][1] + c2 * sc.s[2][1] + c3 * sc.s[3][1];
+            s2[r] = c0 * sc.s[0][2] + c1 * sc.s[1][2] + c2 * sc.s[2][2] + c3 * sc.s[3][2];
+            s3[r] = c0 * sc.s[0][3] + c1 * sc.s[1][3] + c2 * sc.s[2][3] + c3 * sc.s[3][3];
+            gxo[r] = sc.go * rr; gxe[r] = sc.ge * rr; bsum += gxe[r];
+            M[r] = X[r] = Y[r] = DP_NEG_INF;
+        }
+        E = wave_prefix_sum(bsum);
+    }
+    // column j from column j - 1.  b: base of column j (wave-uniform); t?o / t?n: the row above the band at columns j - 1 / j.
+    __device__ __forceinline__ uint32_t step(uint32_t b, bool j1, int32_t gyo, int32_t gye, int32_t tMo, int32_t tXo, int32_t tYo,
+                                             int32_t tMn, int32_t tXn, int32_t tYn)
+    {
+        int32_t Md = lane0_set(wave_shr1z(M[R - 1]), tMo), Xd = lane0_set(wave_shr1z(X[R - 1]), tXo), Yd = lane0_set(wave_shr1z(Y[R - 1]), tYo);
+        const bool lo = (b & 1u) != 0, hi = (b & 2u) != 0;
+        int32_t Mn[R], Yn[R];
+        uint32_t tb = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int32_t bd = max(max(Md, Xd), Yd);
+            const uint32_t pm = Md == bd ? 0u : (Xd == bd ? 1u : 2u);
+            const int32_t sa = lo ? s1[r] : s0[r], sb = lo ? s3[r] : s2[r];
+            const int32_t mv = max(bd + (hi ? sb : sa), DP_NEG_INF);
+            const int32_t ya = M[r] + gyo, yb = X[r] + gyo, yc = Y[r] + gye;
+            const int32_t by = max(max(ya, yb), yc);
+            const uint32_t py = ya == by ? 0u : (yb == by ? 16u : 32u);
+            Mn[r] = j1 ? mv : DP_NEG_INF; Yn[r] = j1 ? max(by, DP_NEG_INF) : DP_NEG_INF;
+            tb |= (pm | py) << (8 * r);
+            Md = M[r]; Xd = X[r]; Yd = Y[r];
+        }
+        // the scanned state: local chains, one prefix maximum over the lanes, then the cells with their real carry-in
+        const int32_t Mu0 = lane0_set(wave_shr1z(Mn[R - 1]), tMn), Yu0 = lane0_set(wave_shr1z(Yn[R - 1]), tYn);
+        int32_t a = DP_NEG_INF, Mu = Mu0, Yu = Yu0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int32_t t = max(Mu, Yu) + gxo[r];
+            a = r == 0 ? max(t, DP_NEG_INF) : max(max(t, a + gxe[r]), DP_NEG_INF);
+            Mu = Mn[r]; Yu = Yn[r];
+        }
+        const int32_t pv = wave_prefix_max(a - E);
+        const int32_t xout = max(E + pv, tXn + E);
+        int32_t Xu = lane0_set(wave_shr1z(xout), tXn);
+        Mu = Mu0; Yu = Yu0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int32_t xa = Mu + gxo[r], xb = Xu + gxe[r], xc = Yu + gxo[r];
+            const int32_t bx = max(max(xa, xb), xc);
+            const uint32_t px = xa == bx ? 0u : (xb == bx ? 4u : 8u);
+            tb |= px << (8 * r);
+            Xu = max(bx, DP_NEG_INF);
+            X[r] = Xu; Mu = Mn[r]; Yu = Yn[r]; M[r] = Mn[r]; Y[r] = Yn[r];
+        }
+        return tb;
+    }
+};
+
+template <int R>
+struct Dp3B {
+    int32_t M[R], X[R], Y[R];
+    uint32_t bases;                                        // 2 bits per column of the lane
+    int32_t E;
+    // row i from row i - 1.  s0..s3, gxo, gxe: the profile row (wave-uniform); l?o / l?n: the column left of the band at rows i - 1 / i.
+    __device__ __forceinline__ uint32_t step(int32_t s0, int32_t s1, int32_t s2, int32_t s3, int32_t gxo, int32_t gxe, int32_t gyo, int32_t gye,
+                                             int32_t lMo, int32_t lXo, int32_t lYo, int32_t lMn, int32_t lXn, int32_t lYn)
+    {
+        int32_t Md = lane0_set(wave_shr1z(M[R - 1]), lMo), Xd = lane0_set(wave_shr1z(X[R - 1]), lXo), Yd = lane0_set(wave_shr1z(Y[R - 1]), lYo);
+        int32_t Mn[R], Xn[R];
+        uint32_t tb = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int32_t bd = max(max(Md, Xd), Yd);
+            const uint32_t pm = Md == bd ? 0u : (Xd == bd ? 1u : 2u);
+            const uint32_t b = (bases >> (2 * r)) & 3u;
+            const int32_t sa = (b & 1u) ? s1 : s0, sb = (b & 1u) ? s3 : s2;
+            Mn[r] = max(bd + ((b & 2u) ? sb : sa), DP_NEG_INF);
+            const int32_t xa = M[r] + gxo, xb = X[r] + gxe, xc = Y[r] + gxo;
+            const int32_t bx = max(max(xa, xb), xc);
+            const uint32_t px = xa == bx ? 0u : (xb == bx ? 4u : 8u);
+            Xn[r] = max(bx, DP_NEG_INF);
+            tb |= (pm | px) << (8 * r);
+            Md = M[r]; Xd = X[r]; Yd = Y[r];
+        }
+        const int32_t Ml0 = lane0_set(wave_shr1z(Mn[R - 1]), lMn), Xl0 = lane0_set(wave_shr1z(Xn[R - 1]), lXn);
+        int32_t a = DP_NEG_INF, Ml = Ml0, Xl = Xl0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int32_t t = max(Ml, Xl) + gyo;
+            a = r == 0 ? max(t, DP_NEG_INF) : max(max(t, a + gye), DP_NEG_INF);
+            Ml = Mn[r]; Xl = Xn[r];
+        }
+        const int32_t pv = wave_prefix_max(a - E);
+        const int32_t yout = max(E + pv, lYn + E);
+        int32_t Yl = lane0_set(wave_shr1z(yout), lYn);
+        Ml = Ml0; Xl = Xl0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int32_t ya = Ml + gyo, yb = Xl + gyo, yc = Yl + gye;
+            const int32_t by = max(max(ya, yb), yc);
+            const uint32_t py = ya == by ? 0u : (yb == by ? 16u : 32u);
+            tb |= py << (8 * r);
+            Yl = max(by, DP_NEG_INF);
+            Y[r] = Yl; Ml = Mn[r]; Xl = Xn[r]; M[r] = Mn[r]; X[r] = Xn[r];
+        }
+        return tb;
+    }
+};
+
+// Traceback of one step, all lanes together: from (ti, tj) in `state` the wave looks 64 cells ahead along the state's own
+// direction (M: the diagonal, X: up, Y: left) -- lane l reads the byte of cell l -- and a ballot tells how long the run of
+// "the predecessor is the same state again" is: a gap of 6.7 kb is a hundred ballots, not 6.7 k dependent loads.  The bytes
+// come from a rectangle of the matrix kept in LDS (the whole step when it fits).  ops: reversed op bytes (global).
+// Layout of a step's traceback: the dimension on the lanes (A: rows, B: columns) is stored lane by lane, four bytes per lane
+// of which the first R are used: index x (0-based) sits at byte P(x) = (x / R) * 4 + x % R of its line; a line per step of the
+// sweep (A: per column j, B: per row i).
+struct Dp3Walk {
+    const uint8_t *tb; int64_t stride; bool orient_b; int32_t R;
+    uint8_t *win; int32_t cap;                                   // LDS window
+    int32_t p_lo, p_hi, s_lo, s_hi, PW;                           // lane-dimension bytes [p_lo, p_hi] x lines [s_lo, s_hi] are in the window (p_hi < p_lo: empty)
+    __device__ __forceinline__ int32_t P(int32_t x) const { return R == 4 ? x : (R == 2 ? ((x >> 1) << 2) + (x & 1) : (R == 1 ? x << 2 : (x / 3) * 4 + x % 3)); }
+    // rectangle with the cell (lane-dimension index x, line t) at its lower right corner
+    __device__ __forceinline__ void load(int32_t x, int32_t t, int32_t tmin, int lane)
+    {
+        const int32_t pend = (P(x) + 16) & ~15;                  // exclusive end, multiple of 16
+        int32_t pw = min(pend, 256);
+        int32_t nl = min(t - tmin + 1, cap / pw);
+        if (nl < 64 && t - tmin + 1 > nl) { pw = min(pend, 128); nl = min(t - tmin + 1, cap / pw); }     // square-ish: look further back along the lines
+        PW = pw; p_lo = pend - pw; p_hi = pend - 1; s_hi = t; s_lo = t - nl + 1;
+        const int32_t per = pw / 16, total = per * nl;
+        for (int32_t u0 = lane; u0 < total; u0 += 256) {         // four 16-byte loads in flight per lane
+            uint4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int32_t u = min(u0 + 64 * q, total - 1), cl = u / per, seg = u % per;
+                v[q] = *reinterpret_cast<const uint4 *>(tb + (size_t)(s_lo + cl) * stride + p_lo + seg * 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int32_t u = u0 + 64 * q, cl = u / per, seg = u % per;
+                if (u < total) *reinterpret_cast<uint4 *>(win + (size_t)cl * pw + seg * 16) = v[q];
+            }
+        }
+        __threadfence_block();
+    }
+    __device__ __forceinline__ bool inside(int32_t x, int32_t t) const { const int32_t p = P(x); return p >= p_lo && p <= p_hi && t >= s_lo && t <= s_hi; }
+    __device__ __forceinline__ uint8_t at(int32_t x, int32_t t) const { return win[(size_t)(t - s_lo) * PW + (P(x) - p_lo)]; }
+};
+
+// walks from (m, n) in `state` to (0, 0); returns the number of ops written (reversed) to opr
+__device__ __forceinline__ int32_t dp3_walk(Dp3Walk &W, int32_t m, int32_t n, int state, uint8_t *opr, int lane)
+{
+    int32_t ti = m, tj = n, len = 0;
+    W.p_lo = 1; W.p_hi = 0; W.s_lo = 1; W.s_hi = 0;
+    const bool ob = W.orient_b;
+    while (ti > 0 || tj > 0) {
+        if (ti == 0) {                                   // row 0: only Y exists
+            for (int32_t o = lane; o < tj; o += 64) opr[len + o] = 2;
+            len += tj; tj = 0;
+            break;
+        }
+        if (tj == 0) {                                   // column 0: only X exists (the predecessor is X again, or M at row 1: the op is the same)
+            for (int32_t o = lane; o < ti; o += 64) opr[len + o] = 1;
+            len += ti; ti = 0;
+            break;
+        }
+        // A: cell (i, j) = (lane-dimension index i - 1, line j); B: (j - 1, line i - 1)
+        if (!(ob ? W.inside(tj - 1, ti - 1) : W.inside(ti - 1, tj))) { if (ob) W.load(tj - 1, ti - 1, 0, lane); else W.load(ti - 1, tj, 0, lane); }
+        const int32_t di = state == 2 ? 0 : 1, dj = state == 1 ? 0 : 1;
+        const int32_t ci = ti - lane * di, cj = tj - lane * dj;
+        const bool valid = ci >= 1 && cj >= 1 && (ob ? W.inside(cj - 1, ci - 1) : W.inside(ci - 1, cj));    // (row 0 / column 0 end the look-ahead: handled on arrival)
+        uint32_t ns = 3;
+        if (valid) { const uint32_t bt = ob ? W.at(cj - 1, ci - 1) : W.at(ci - 1, cj); ns = (bt >> (2 * state)) & 3u; }
+        const uint64_t cont = __ballot(valid && ns == (uint32_t)state);
+        const int32_t k = cont == ~0ULL ? 64 : (int32_t)__builtin_ctzll(~cont);     // lanes 0 .. k-1 continue in the same state
+        // lane k (if it looked at a real cell) is the cell where the state changes: its op still belongs to the run
+        const uint64_t vmask = __ballot(valid);
+        const bool turn = k < 64 && ((vmask >> k) & 1ULL);
+        const int32_t cnt = turn ? k + 1 : k;            // >= 1: lane 0 is always valid here
+        const uint8_t op = state == 0 ? 3 : (state == 1 ? 1 : 2);
+        if (lane < cnt) opr[len + lane] = op;
+        len += cnt;
+        if (turn) state = (int)__builtin_amdgcn_readlane((int32_t)ns, k);
+        ti -= cnt * di; tj -= cnt * dj;
+    }
+    return len;
+}
+
+// 32-bit exactness of the scan: the prefix sums of the gap-extension terms (|E| <= len * rows * |extend|) must stay far from
+// the clamp; otherwise the interval keeps the anti-diagonal kernel
+__host__ __device__ __forceinline__ bool dp3_admissible(int64_t total_len, int64_t krows_max, int64_t ge, int64_t go)
+{
+    const int64_t a = ge < 0 ? -ge : ge, b = go < 0 ? -go : go;
+    return total_len * krows_max * (a > b ? a : b) < (1LL << 28) && ge <= 0 && go <= 0;
+}
+
+// orientation A, all bands: rows on the lanes (R per lane, bands of 64 R), column by column.  Leaves (m, n) in fM / fX / fY.
+template <int R>
+__device__ __forceinline__ void dp3_sweep_a(int lane, int32_t m, int32_t n, const uint32_t *Pc, const uint8_t *seq, const DpScoring &sc, int32_t krows,
+                                            int32_t *rowbuf, uint8_t *tbp, int32_t mpad, int32_t &fM, int32_t &fX, int32_t &fY)
+{
+    constexpr int BAND = 64 * R;
+    const int32_t nbands = (m + BAND - 1) / BAND;
+    const int32_t gyo = sc.go * krows, gye = sc.ge * krows;
+    for (int32_t s = 0; s < nbands; s++) {
+        Dp3A<R> L;
+        const int32_t i0 = s * BAND + lane * R;                      // 0-based first row of the lane
+        L.constants(Pc, i0, m, sc);
+        const int32_t *rin = rowbuf + (size_t)((s & 1) ^ 1) * 3 * (n + 1);
+        int32_t *rout = rowbuf + (size_t)(s & 1) * 3 * (n + 1);
+        const bool park = s + 1 < nbands, writes = (s * 64 + lane) * 4 < mpad;
+        // What a column needs from outside the band -- its base, and (bands below the first) the parked row of the band above --
+        // is fetched by the whole wave 64 columns at a time, one chunk ahead, and handed out with v_readlane: a load per
+        // column would put a memory round trip into every step.  Chunk k: lane l holds column 64 k + l.
+        auto chunk = [&](int32_t k, uint32_t &sq, int32_t &cM, int32_t &cX, int32_t &cY) {
+            const int32_t col = 64 * k + lane;
+            sq = (uint32_t)seq[min(max(col - 1, 0), n - 1)];
+            if (s == 0) { cM = col == 0 ? 0 : DP_NEG_INF; cX = DP_NEG_INF; cY = col == 0 ? DP_NEG_INF : gyo + (col - 1) * gye; }
+            else { const int32_t cc = min(col, n); cM = rin[cc]; cX = rin[(n + 1) + cc]; cY = rin[2 * (n + 1) + cc]; }
+        };
+        uint32_t sq_cur, sq_nxt; int32_t cM_cur, cX_cur, cY_cur, cM_nxt, cX_nxt, cY_nxt;
+        chunk(0, sq_nxt, cM_nxt, cX_nxt, cY_nxt);
+        int32_t tMo = DP_NEG_INF, tXo = DP_NEG_INF, tYo = DP_NEG_INF;
+        uint8_t *tw = tbp + (size_t)(s * 64 + lane) * 4;
+        for (int32_t k = 0; 64 * k <= n; k++) {
+            sq_cur = sq_nxt; cM_cur = cM_nxt; cX_cur = cX_nxt; cY_cur = cY_nxt;
+            chunk(k + 1, sq_nxt, cM_nxt, cX_nxt, cY_nxt);
+            const int32_t jend = min(64 * k + 63, n);
+            for (int32_t j = 64 * k; j <= jend; j++, tw += mpad) {
+                const int sel = j & 63;
+                const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int32_t)sq_cur, sel);
+                const int32_t tMn = __builtin_amdgcn_readlane(cM_cur, sel), tXn = __builtin_amdgcn_readlane(cX_cur, sel),
+                              tYn = __builtin_amdgcn_readlane(cY_cur, sel);
+                const uint32_t tbw = L.step(b, j >= 1, gyo, gye, tMo, tXo, tYo, tMn, tXn, tYn);
+                if (writes) *reinterpret_cast<uint32_t *>(tw) = tbw;
+                if (park && lane == 63) { rout[j] = L.M[R - 1]; rout[(n + 1) + j] = L.X[R - 1]; rout[2 * (n + 1) + j] = L.Y[R - 1]; }
+                tMo = tMn; tXo = tXn; tYo = tYn;
+            }
+        }
+        __threadfence_block();
+        if (s == nbands - 1) {
+            int32_t a = L.M[0], b2 = L.X[0], c2 = L.Y[0];
+#pragma unroll
+            for (int r = 1; r < R; r++) if (((m - 1) % R) == r) { a = L.M[r]; b2 = L.X[r]; c2 = L.Y[r]; }
+            const int owner = ((m - 1) % BAND) / R;
+            fM = __shfl(a, owner); fX = __shfl(b2, owner); fY = __shfl(c2, owner);
+        }
+    }
+}
+
+// orientation B, all bands: columns on the lanes, row by row
+template <int R>
+__device__ __forceinline__ void dp3_sweep_b(int lane, int32_t m, int32_t n, const uint32_t *Pc, const uint8_t *seq, const DpScoring &sc, int32_t krows,
+                                            int32_t *rowbuf, uint8_t *tbp, int32_t npad, int32_t &fM, int32_t &fX, int32_t &fY)
+{
+    constexpr int BAND = 64 * R;
+    const int32_t nbands = (n + BAND - 1) / BAND;
+    const int32_t gyo = sc.go * krows, gye = sc.ge * krows;
+    for (int32_t s = 0; s < nbands; s++) {
+        Dp3B<R> L;
+        const int32_t j0 = s * BAND + lane * R;                      // 0-based first column index (j - 1) of the lane
+        L.bases = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            L.bases |= (uint32_t)(j0 + r < n ? seq[j0 + r] : 0) << (2 * r);
+            // row 0: only Y exists (analytic, not clamped: the systolic kernels' boundary row)
+            L.M[r] = DP_NEG_INF; L.X[r] = DP_NEG_INF; L.Y[r] = gyo + (j0 + r) * gye;
+        }
+        L.E = (lane + 1) * R * gye;
+        const int32_t *cin = rowbuf + (size_t)((s & 1) ^ 1) * 3 * (m + 1);
+        int32_t *cout = rowbuf + (size_t)(s & 1) * 3 * (m + 1);
+        const bool park = s + 1 < nbands, writes = (s * 64 + lane) * 4 < npad;
+        // per row from outside the band: the profile column's counts and (bands right of the first) the parked column of the
+        // band to the left -- fetched 64 rows at a time, one chunk ahead (see orientation A).  Chunk k: lane l holds row 64 k + l + 1.
+        auto chunk = [&](int32_t k, uint32_t &pc, int32_t &cM, int32_t &cX, int32_t &cY) {
+            const int32_t row = min(64 * k + lane + 1, m);
+            pc = Pc[row - 1];
+            if (s == 0) { cM = cX = cY = DP_NEG_INF; }
+            else { cM = cin[row]; cX = cin[(m + 1) + row]; cY = cin[2 * (m + 1) + row]; }
+        };
+        // column 0 (band 0): M and Y do not exist there, X is the chain down from (0, 0)
+        int32_t lMo, lXo, lYo;
+        if (s == 0) { lMo = 0; lXo = DP_NEG_INF; lYo = DP_NEG_INF; }
+        else { lMo = __builtin_amdgcn_readfirstlane(cin[0]); lXo = __builtin_amdgcn_readfirstlane(cin[(m + 1)]); lYo = __builtin_amdgcn_readfirstlane(cin[2 * (m + 1)]); }
+        if (park && lane == 63) { cout[0] = L.M[R - 1]; cout[(m + 1)] = L.X[R - 1]; cout[2 * (m + 1)] = L.Y[R - 1]; }    // row 0 of the band's last column
+        uint32_t pc_cur, pc_nxt; int32_t cM_cur, cX_cur, cY_cur, cM_nxt, cX_nxt, cY_nxt;
+        chunk(0, pc_nxt, cM_nxt, cX_nxt, cY_nxt);
+        uint8_t *tw = tbp + (size_t)(s * 64 + lane) * 4;
+        for (int32_t k = 0; 64 * k < m; k++) {
+            pc_cur = pc_nxt; cM_cur = cM_nxt; cX_cur = cX_nxt; cY_cur = cY_nxt;
+            chunk(k + 1, pc_nxt, cM_nxt, cX_nxt, cY_nxt);
+            const int32_t iend = min(64 * k + 64, m);
+            for (int32_t i = 64 * k + 1; i <= iend; i++, tw += npad) {
+                const int sel = (i - 1) & 63;
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int32_t)pc_cur, sel);
+                const int32_t c0 = c & 255, c1 = (c >> 8) & 255, c2 = (c >> 16) & 255, c3 = c >> 24, rr = c0 + c1 + c2 + c3;
+                const int32_t s0 = c0 * sc.s[0][0] + c1 * sc.s[1][0] + c2 * sc.s[2][0] + c3 * sc.s[3][0];
+                const int32_t s1 = c0 * sc.s[0][1] + c1 * sc.s[1][1] + c2 * sc.s[2][1] + c3 * sc.s[3][1];
+                const int32_t s2 = c0 * sc.s[0][2] + c1 * sc.s[1][2] + c2 * sc.s[2][2] + c3 * sc.s[3][2];
+                const int32_t s3 = c0 * sc.s[0][3] + c1 * sc.s[1][3] + c2 * sc.s[2][3] + c3 * sc.s[3][3];
+                const int32_t gxo = sc.go * rr, gxe = sc.ge * rr;
+                int32_t lMn, lXn, lYn;
+                if (s == 0) {
+                    const int32_t xa = lMo + gxo, xb = lXo + gxe, xc = lYo + gxo, bx = max(max(xa, xb), xc);
+                    lMn = DP_NEG_INF; lYn = DP_NEG_INF; lXn = max(bx, DP_NEG_INF);
+                } else { lMn = __builtin_amdgcn_readlane(cM_cur, sel); lXn = __builtin_amdgcn_readlane(cX_cur, sel); lYn = __builtin_amdgcn_readlane(cY_cur, sel); }
+                const uint32_t tbw = L.step(s0, s1, s2, s3, gxo, gxe, gyo, gye, lMo, lXo, lYo, lMn, lXn, lYn);
+                if (writes) *reinterpret_cast<uint32_t *>(tw) = tbw;
+                if (park && lane == 63) { cout[i] = L.M[R - 1]; cout[(m + 1) + i] = L.X[R - 1]; cout[2 * (m + 1) + i] = L.Y[R - 1]; }
+                lMo = lMn; lXo = lXn; lYo = lYn;
+            }
+        }
+        __threadfence_block();
+        if (s == nbands - 1) {
+            int32_t a = L.M[0], b2 = L.X[0], c2 = L.Y[0];
+#pragma unroll
+            for (int r = 1; r < R; r++) if (((n - 1) % R) == r) { a = L.M[r]; b2 = L.X[r]; c2 = L.Y[r]; }
+            const int owner = ((n - 1) % BAND) / R;
+            fM = __shfl(a, owner); fX = __shfl(b2, owner); fY = __shfl(c2, owner);
+        }
+    }
+}
+
+__device__ void dp3_interval(int nseq, int64_t iv, const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
+                             uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA, uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
+                             uint8_t *__restrict__ tb, const int64_t *__restrict__ tb_off, int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
+                             uint8_t *__restrict__ ops, uint8_t *win, const DpScoring &sc)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
+    const int64_t base = seq_off[iv * nseq];
+    for (int g = 0; g < nseq; g++) {
+        const int64_t so = seq_off[iv * nseq + g];
+        const int32_t n = (int32_t)(seq_off[iv * nseq + g + 1] - so);
+        if (n == 0) continue;
+        const uint8_t *seq = codes + so;
+        uint32_t *Pc = (mt.cur ? cntB : cntA) + base, *Pm = (mt.cur ? maskB : maskA) + base;
+        uint32_t *Qc = (mt.cur ? cntA : cntB) + base, *Qm = (mt.cur ? maskA : maskB) + base;
+        if (mt.krows == 0) {           // first non-empty sequence becomes the profile
+            for (int32_t c = lane; c < n; c += 64) { Pc[c] = 1u << (8 * seq[c]); Pm[c] = 1u << g; }
+            mt.m = n; mt.krows = 1;
+            __threadfence_block();
+            continue;
+        }
+        const int32_t m = mt.m;
+        uint8_t *tbp = tb + tb_off[iv];
+        int32_t *rowbuf = rows + rows_off[iv];
+        const bool ob = dp3_orient_b(m, n);
+        int32_t fM = DP_NEG_INF, fX = DP_NEG_INF, fY = DP_NEG_INF;   // values at (m, n)
+        // rows (A) / columns (B) per lane: as few as cover the dimension with the 64 lanes, at most 4 (then bands)
+        const int32_t ldim = ob ? n : m, R = dp3_rows_per_lane(ldim), pad = (int32_t)dp3_pad(ldim);
+        Dp3Walk W; W.win = win; W.cap = DP2_TB_DW * 4; W.orient_b = ob; W.R = R; W.stride = pad;
+        W.tb = ob ? tbp : tbp;                             // A: line j at tbp + j * pad; B: line i - 1 at tbp + (i - 1) * pad
+        if (!ob) {
+            if (R == 1) dp3_sweep_a<1>(lane, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, fM, fX, fY);
+            else if (R == 2) dp3_sweep_a<2>(lane, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, fM, fX, fY);
+            else dp3_sweep_a<4>(lane, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, fM, fX, fY);
+        } else {
+            if (R == 1) dp3_sweep_b<1>(lane, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, fM, fX, fY);
+            else if (R == 2) dp3_sweep_b<2>(lane, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, fM, fX, fY);
+            else dp3_sweep_b<4>(lane, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, fM, fX, fY);
+        }
+        int32_t best = fM; int state = 0;
+        if (fX > best) { best = fX; state = 1; }
+        if (fY > best) { best = fY; state = 2; }
+        uint8_t *opr = ops + base;                         // reversed ops, capacity m + n
+        const int32_t len = dp3_walk(W, m, n, state, opr, lane);
+        __threadfence_block();
+        // ---- new profile in forward order: ballot prefix counts give each column its sources ----
+        int32_t carry_p = 0, carry_s = 0;
+        for (int32_t c0i = 0; c0i < len; c0i += 64) {
+            const int32_t c = c0i + lane;
+            const bool ok = c < len;
+            const uint32_t op = ok ? opr[len - 1 - c] : 0u;
+            const uint64_t bp = __ballot(ok && (op & 1)), bs = __ballot(ok && (op & 2));
+            if (ok) {
+                const int32_t pi = carry_p + (int32_t)__popcll(bp & lt), sj = carry_s + (int32_t)__popcll(bs & lt);
+                uint32_t cv = 0, mv = 0;
+                if (op & 1) { cv = Pc[pi]; mv = Pm[pi]; }
+                if (op & 2) { cv += 1u << (8 * seq[sj]); mv |= 1u << g; }
+                Qc[c] = cv; Qm[c] = mv;
+            }
+            carry_p += (int32_t)__popcll(bp); carry_s += (int32_t)__popcll(bs);
+        }
+        mt.cells += (int64_t)m * n; mt.score += best; mt.m = len; mt.krows += 1; mt.cur ^= 1;
+        __threadfence_block();
+    }
+    if (lane == 0) meta[iv] = mt;
+}
+
 // The register-blocked launch: block ranges [one wave per interval | G = 16 | G = 8 | G = 4], the long ones first.
 __global__ void __launch_bounds__(64 * DP2_WAVES) dp_step2(int nseq, const int64_t *__restrict__ list, DpClasses cl, const uint8_t *__restrict__ codes,
                                                const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
@@ -1121,7 +1583,10 @@ __global__ void __launch_bounds__(64 * DP2_WAVES) dp_step2(int nseq, const int64
         for (int q = 0; q < per && lb + q < pend; q++) {
             const int64_t iv = list[lb + q];
             if (only_failed && meta[iv].m != -1) continue;
-            dp2_interval(nseq, iv, codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, reinterpret_cast<uint8_t *>(s_tb[wv]), sc);
+            // column / row scans where 32-bit prefix sums are exact (always, for real scoring schemes); else the anti-diagonal sweep
+            const bool scan = cl.scan && dp3_admissible(seq_off[(iv + 1) * nseq] - seq_off[iv * nseq], nseq, sc.ge, sc.go);
+            if (scan) dp3_interval(nseq, iv, codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, reinterpret_cast<uint8_t *>(s_tb[wv]), sc);
+            else dp2_interval(nseq, iv, codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, reinterpret_cast<uint8_t *>(s_tb[wv]), sc);
         }
 }
 
@@ -1191,6 +1656,8 @@ static int dp_launch_steps(mauve_ctx *ctx, int nseq, int64_t a, int64_t b, int64
     clip(full.first_s32, full.n_s32, cl.first_s32, cl.n_s32);
     clip(full.first_s16, full.n_s16, cl.first_s16, cl.n_s16);
     const bool oldk = dp_old_kernels();
+    static const bool no_scan = getenv("MAUVE_DP_NOSCAN") != nullptr;     // A/B switch: anti-diagonal sweep for the one-wave class too
+    cl.scan = no_scan ? 0 : 1;
     // intervals per workgroup: systolic kernels 4 waves x {1, 2, 4}; register-blocked kernels 2 waves x {1, 4, 8, 16}
     const int64_t wpb = oldk ? 4 : DP2_WAVES, cap = oldk ? 256 * 8 : 256 * 16;
     cl.blocks_med = (uint32_t)std::min<int64_t>((cl.n_med + wpb - 1) / wpb, cap);
@@ -1283,7 +1750,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     need_v.resize((size_t)n_iv); nmax_v.resize((size_t)n_iv);
     ctx->pool->parallel_for(n_iv, 2048, [&](int64_t b, int64_t e) {
         for (int64_t iv = b; iv < e; iv++) {
-            int64_t mmax = 0, mmin = 0, need = 0, nmax = 0, es = 0, longest = 0; bool first = true; uint8_t big = 0;
+            int64_t mmax = 0, mmin = 0, need = 0, nmax = 0, es = 0, longest = 0, rneed = 0; bool first = true; uint8_t big = 0;
             DpClassEst ce; ce.mode = dp_class_mode();
             for (int g = 0; g < nseq; g++) longest = std::max(longest, seq_off[iv * nseq + g + 1] - seq_off[iv * nseq + g]);
             const bool banded = longest > band_from;
@@ -1293,7 +1760,8 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
                 if (n == 0) continue;
                 if (first) { first = false; mmax = mmin = n; continue; }
                 const int64_t tbo = dp_tb_need(mmin, mmax, n, banded);  // the profile is at least as long as its longest member
-                const int64_t tbn = banded ? tbo : std::max(tbo, dp2_tb_need(mmax, n));     // (either kernel family may run the interval)
+                const int64_t tbn = banded ? tbo : std::max(tbo, std::max(dp2_tb_need(mmax, n), dp3_tb_need(mmax, n)));     // (any of the kernel families may run the interval)
+                rneed = std::max(rneed, dp3_rows_need(mmax, n));
                 need = std::max(need, tbn);
                 nmax = std::max(nmax, n);
                 // a step with >= 3 stripes against >= 256 columns pipelines over several waves
@@ -1302,7 +1770,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
                 mmax += n; mmin = std::max(mmin, n);
             }
             if (banded && nmax) big = 2;                               // banded steps exist only in the workgroup kernel
-            need_v[(size_t)iv] = need; nmax_v[(size_t)iv] = nmax; est[(size_t)iv] = es; is_big[(size_t)iv] = big;
+            need_v[(size_t)iv] = need; nmax_v[(size_t)iv] = std::max(6 * (nmax + 1), rneed); est[(size_t)iv] = es; is_big[(size_t)iv] = big;
             // sub-wave classes: every profile the interval will see fits G rows, every step fits the LDS slice
             uint8_t k = 1;
             if (!no_groups && !banded) k = (uint8_t)(dp_old_kernels() ? ce.klass(DP_GRP_TMAX) : ce.klass2(DP2_R, DP2_T));
@@ -1311,7 +1779,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     });
     for (int64_t iv = 0; iv < n_iv; iv++) {
         tb_off[iv] = tbt; rows_off[iv] = rwt;
-        tbt += need_v[(size_t)iv]; rwt += 6 * (nmax_v[(size_t)iv] + 1);
+        tbt += need_v[(size_t)iv]; rwt += nmax_v[(size_t)iv];                        // (nmax_v: parked-row entries)
         est_total += est[(size_t)iv];
     }
     tb_off[n_iv] = tbt; rows_off[n_iv] = rwt;
@@ -1507,7 +1975,7 @@ __global__ void __launch_bounds__(256) dpf_desc(const int32_t *__restrict__ alen
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
     if (s >= (uint32_t)tot->n_dp) return;
     const uint32_t k = anchor_of[s];
-    int64_t mmax = 0, mmin = 0, nd = 0, nmax = 0, es = 0, longest = 0; bool first = true; uint8_t big = 0;
+    int64_t mmax = 0, mmin = 0, nd = 0, nmax = 0, es = 0, longest = 0, rneed = 0; bool first = true; uint8_t big = 0;
     DpClassEst ce; ce.mode = class_mode & 7;                 // bit 3: the systolic kernels' classes (MAUVE_DP_OLD)
     for (int g = 0; g < N; g++) {
         int64_t lo, n; bool rv;
@@ -1524,7 +1992,8 @@ __global__ void __launch_bounds__(256) dpf_desc(const int32_t *__restrict__ alen
         if (n == 0) continue;
         if (first) { first = false; mmax = mmin = n; continue; }
         const int64_t tbo = dp_tb_need(mmin, mmax, n, banded);
-        const int64_t tbn = banded ? tbo : max(tbo, dp2_tb_need(mmax, n));
+        const int64_t tbn = banded ? tbo : max(tbo, max(dp2_tb_need(mmax, n), dp3_tb_need(mmax, n)));
+        rneed = max(rneed, dp3_rows_need(mmax, n));
         nd = max(nd, tbn);
         nmax = max(nmax, n);
         if (mmax > 128 && n >= 256 && !no_mw) big = 1;       // a step with >= 3 stripes against >= 256 columns pipelines over several waves
@@ -1532,7 +2001,7 @@ __global__ void __launch_bounds__(256) dpf_desc(const int32_t *__restrict__ alen
         mmax += n; mmin = max(mmin, n);
     }
     if (banded && nmax) big = 2;                             // banded steps exist only in the workgroup kernel
-    need[s] = nd; rowsn[s] = 6 * (nmax + 1); est[s] = es; cand[s] = big;
+    need[s] = nd; rowsn[s] = max(6 * (nmax + 1), rneed); est[s] = es; cand[s] = big;
     uint8_t kc = 1;
     if (!no_groups && !banded) kc = (uint8_t)(class_mode & 8 ? ce.klass(DP_GRP_TMAX) : ce.klass2(DP2_R, DP2_T));
     cls[s] = kc;

@@ -877,3 +877,54 @@ def test_page_locked_caller_buffers(ctx):
     sz_t = _lib.AlignSizes(**{k: r[k] for k, _ in _lib.AlignSizes._fields_})
     again = ctx._fetch(sz_t)
     assert np.array_equal(again["cols"], ref["cols"])
+
+
+SCAN_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from mauvealigner_amd import _lib, synth
+from oracle import pyoracle as O
+rng = np.random.default_rng(21)
+ctx = _lib.Context(0)
+def seqs(lens, div=0.15):
+    base = rng.integers(0, 4, max(max(lens), 1), dtype=np.uint8)
+    out = []
+    for L in lens:
+        if L == 0:
+            out.append(np.zeros(0, np.uint8)); continue
+        x = synth.mutate(base, div, rng, indel_frac=0.3)[:L]
+        if len(x) < L:
+            x = np.concatenate([x, rng.integers(0, 4, L - len(x), dtype=np.uint8)])
+        out.append(x)
+    return out
+def check(ivs):
+    cols, score = ctx.dp_batch(ivs)
+    for iv, c, s in zip(ivs, cols, score):
+        ec, es = O.align_interval(iv)
+        assert len(c) == len(ec) and np.array_equal(c, ec) and int(s) == es, [len(x) for x in iv]
+# two sequences: every combination of one band / several bands of rows and of columns, band edges, tall and flat
+shapes2 = [(700, 20), (20, 700), (256, 256), (257, 255), (255, 257), (513, 64), (64, 513), (600, 512), (512, 600), (1030, 300), (300, 1030),
+           (120, 117), (117, 120), (65, 64), (1, 900), (900, 1), (2, 2), (300, 299), (1500, 7), (7, 1500), (260, 3), (3, 260)]
+check([seqs(list(s)) for s in shapes2])
+# unrelated sequences (long gap runs in the traceback) and identical ones (one long diagonal run)
+a = rng.integers(0, 4, 800, dtype=np.uint8)
+check([[a, rng.integers(0, 4, 30, dtype=np.uint8)], [rng.integers(0, 4, 30, dtype=np.uint8), a], [a, a.copy()], [a[:300], a[:300].copy()],
+       [rng.integers(0, 4, 400, dtype=np.uint8), rng.integers(0, 4, 380, dtype=np.uint8)]])
+# more sequences: the long one first, in the middle, last; empty members; profiles that grow across the band edge
+check([seqs(l) for l in ([1200, 20, 18, 22, 19], [20, 18, 1200, 22, 19], [20, 18, 22, 19, 1200], [250, 260, 255, 0, 258], [0, 130, 0, 140, 135],
+                         [90, 95, 100, 105, 110], [300, 10, 0, 310, 12], [5, 5, 600, 600, 5])])
+check([seqs([int(rng.integers(0, 140)) for _ in range(4)], div=0.1) for _ in range(150)])
+print("OK")
+"""
+
+
+def test_dp_scan_kernels():
+    """The one-wave class runs the scan-formulated sweeps (rows on the lanes column by column, or columns on the lanes row by
+    row, chosen per step) and the run-length traceback; with the workgroup pipeline switched off every shape goes through them.
+    The anti-diagonal sweep of the same class (MAUVE_DP_NOSCAN) must agree as well."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({"MAUVE_DP_ONE_WAVE": "1"}, {"MAUVE_DP_ONE_WAVE": "1", "MAUVE_DP_NOSCAN": "1"}, {"MAUVE_DP_ONE_WAVE": "1", "MAUVE_DP_NO_GROUPS": "1"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", SCAN_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), str(extra) + "\n" + r.stdout + r.stderr[-3000:]
