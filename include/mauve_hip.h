@@ -61,7 +61,7 @@ typedef struct {
     int32_t recursive;            /* mauveAligner.cpp:94 */
     int32_t gapped;               /* mauveAligner.cpp:96 */
     int32_t add_unaligned;        /* mauveAligner.cpp:748 addUnalignedIntervals */
-    int32_t extend_lcbs;          /* lcb_extension, mauveAligner.cpp:95 (there: default on; here: 0) */
+    int32_t extend_lcbs;          /* lcb_extension, mauveAligner.cpp:95: default 1, as there (frozen form DESIGN.md S10; not applied to score-weighted LCBs) */
     int32_t max_extension_iters;  /* Aligner::SetMaxExtensionIterations, default 4 (mauveAligner.cpp:687-690) */
     int64_t min_recursive_gap;    /* Aligner::SetMinRecursionGapLength, default 200 (:670-672,899) */
     int64_t max_gapped_len;       /* Aligner::SetMaxGappedAlignmentLength (:674-676), default 10000 */

@@ -245,7 +245,7 @@ int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes
     R.col_off.assign(h_col, h_col + nl);
     R.lcb_left.assign(h_left, h_left + nl * N); R.lcb_right.assign(h_right, h_right + nl * N);
     R.dp_score.assign(h_score, h_score + nl);
-    if (!host_chains) R.lcb_weight.assign(h_lw, h_lw + nl);              // (host chains: filled by align_begin)
+    if (!host_chains && !S.lw_from_host) R.lcb_weight.assign(h_lw, h_lw + nl);      // (host chains, device extension: filled by align_begin)
     R.iv_left.assign((size_t)nl * N, 0); R.iv_right.assign((size_t)nl * N, 0); R.iv_reverse.assign((size_t)nl * N, 0);
     for (int64_t i = 0; i < nl * N; i++) {
         R.iv_left[(size_t)i] = std::llabs(R.lcb_left[(size_t)i]);

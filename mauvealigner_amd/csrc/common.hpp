@@ -164,6 +164,8 @@ struct AlignState {
     bool open = false;
     bool anchor_table_done = false;     // anchor_length/start/lcb already filled (in the DP kernel's shadow)
     bool dev_tail = false;              // the chains stayed on the device: DP front end and assembly run there (mauve_align)
+    const int32_t *dv_len = nullptr, *dv_st = nullptr, *dv_lcb = nullptr;   // ... where: anchors in chain order (chain_order_device, or the extended list)
+    bool lw_from_host = false;          // the LCB weights of the result are those align_begin left in R.lcb_weight (device extension)
     mauve_params p{};
     int N = 0; uint32_t full = 0;
     int64_t sum = 0, nm = 0, nl = 0, n_dp = 0, code_total = 0, n_anchor = 0, anchor_cols = 0;
@@ -181,7 +183,7 @@ struct AlignState {
     // start a new alignment: scalars to zero, vectors emptied but not released
     void reset()
     {
-        open = false; anchor_table_done = false; dev_tail = false; p = mauve_params(); N = 0; full = 0;
+        open = false; anchor_table_done = false; dev_tail = false; dv_len = dv_st = dv_lcb = nullptr; lw_from_host = false; p = mauve_params(); N = 0; full = 0;
         sum = nm = nl = n_dp = code_total = n_anchor = anchor_cols = 0; t0 = t_dp0 = 0;
         gaps.clear(); desc.clear(); dcol_off.clear(); dscore.clear();
         match_lcb.clear(); match_weight.clear(); items.clear();
@@ -222,6 +224,8 @@ struct mauve_ctx {
     DevBuf ch_len, ch_st, ch_crop, ch_ent, ch_ord, ch_rank, ch_node, ch_graph, ch_cnt;   // device chain (chain_dev.hip)
     DevBuf ch_big;                       // working arrays of overlap clusters beyond the per-thread limit (recursion batches)
     DevBuf ch_anch, ch_lw;               // the chains in chain order and the LCB weights (chain_order_device)
+    DevBuf ch_anch2, ext_work, sorted_rec_keep;   // device-resident LCB extension (extend_dev.hip): the extended anchor list, its work area, the main pass's match list set aside
+    PinnedBuf pin_ext;
     DevBuf as_work, as_isl, res_cols;    // device assembly (assemble_dev.hip): work area, islands, result columns
     PinnedBuf pin_tab;                   // anchor table and match list of a device-assembled result on their way to the host
     PinnedBuf pin_asm, pin_cols;         // ... its per-LCB rows coming back; the columns and anchors on their way to a fetch
@@ -341,6 +345,8 @@ int chain_device_gaps(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0_
                       std::vector<uint8_t> &survive);
 int chain_device_copy_back(mauve_ctx *c, int N, MatchVec &m, std::vector<int64_t> &match_lcb);
 int chain_order_device(mauve_ctx *c, int N, int64_t nl, int64_t min_gap, int64_t *na_out, int64_t *n_rec_out);
+int extend_lcbs_device(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw, int N, const int32_t **alen_io, const int32_t **ast_io,
+                       const int32_t **alcb_io, int64_t *na_io, int64_t *nl_io, int64_t *n_rec_io, std::vector<int64_t> &lcb_weight);
 
 // host chaining (chain_host.cpp)
 struct ChainOrders { std::vector<std::vector<uint32_t>> ord; bool sparse = false; };   // per genome: match indices in left-end order;

@@ -280,6 +280,11 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
         };
     int64_t nm = 0;
     int rc = MAUVE_OK;
+    // LCB extension without taking the chains off the device (extend_dev.hip): plain genomes, length-weighted LCBs.  MAUVE_HOST_EXTEND: A/B switch
+    static const bool host_extend = getenv("MAUVE_HOST_EXTEND") != nullptr;
+    const bool do_extend = p->extend_lcbs && p->lcb_scoring == MAUVE_LCB_SCORE_LENGTH;      // (score-weighted LCBs are not extended: the rule counts columns)
+    const bool ext_on_device = do_extend && !host_extend && !c->has_invalid && !c->has_contigs;
+    bool chains_ready = false;                       // S.chains filled from the device anchors (extension done there, recursion to follow on the host)
     MatchVec family(N);
     if (!given && p->seed_family) {
         // DESIGN.md S3b (progressiveMauve.cpp:502-546): one search per seed of the family, longest seed first, merged like the
@@ -322,7 +327,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
         c->n_matches = nm; c->dev_rec_n = -1;
     } else {
         static const bool host_tail_env = getenv("MAUVE_HOST_TAIL") != nullptr;
-        c->lazy_matches_ok = want_tail && !host_tail_env && !p->extend_lcbs;     // the list may stay in HBM (device tail below)
+        c->lazy_matches_ok = want_tail && !host_tail_env && (!do_extend || ext_on_device);     // the list may stay in HBM (device tail below)
         rc = seedpass_run(c, main_genome_set(c), pat, p->mode, full, 1, nullptr, 0, &nm);
         c->lazy_matches_ok = false;
         c->shadow = nullptr;
@@ -341,7 +346,6 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
     std::vector<int64_t> &match_lcb = S.match_lcb; int64_t nl = 0;
     static const bool host_chain = getenv("MAUVE_HOST_CHAIN") != nullptr;
     if (p->lcb_scoring != MAUVE_LCB_SCORE_LENGTH && p->lcb_scoring != MAUVE_LCB_SCORE_SP) { c->err = "align: unknown lcb_scoring"; return MAUVE_ERR_ARG; }
-    if (p->lcb_scoring == MAUVE_LCB_SCORE_SP && p->extend_lcbs) { c->err = "align: lcb_scoring and extend_lcbs cannot be combined"; return MAUVE_ERR_ARG; }
     bool on_device = !host_chain && nm > 0 && c->dev_rec_n == nm && p->lcb_scoring == MAUVE_LCB_SCORE_LENGTH;   // score weights: host chain
     double t1b = t1;
     if (on_device) {
@@ -353,10 +357,18 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
             // inter-anchor gap long enough for the recursion (counted on the device).  The DP front end and the assembly
             // then run there too (mauve_align), and the host sees only the per-LCB rows.
             static const bool host_tail = getenv("MAUVE_HOST_TAIL") != nullptr;      // A/B switch
-            if (want_tail && !host_tail && !p->extend_lcbs && nl > 0) {
+            if (want_tail && !host_tail && (!do_extend || ext_on_device) && nl > 0) {
                 int64_t na = 0, nrec = 0;
                 rc = chain_order_device(c, N, nl, p->min_recursive_gap, &na, &nrec);
                 if (rc) return rc;
+                const uint32_t cap = (uint32_t)c->dev_rec_n;
+                S.dv_len = c->ch_anch.as<int32_t>(); S.dv_st = S.dv_len + cap; S.dv_lcb = S.dv_st + (size_t)cap * N;
+                if (do_extend && na >= 1) {
+                    std::vector<int64_t> lw;
+                    rc = extend_lcbs_device(c, p, w, lcbw, N, &S.dv_len, &S.dv_st, &S.dv_lcb, &na, &nl, &nrec, lw);
+                    if (rc) return rc;
+                    R.lcb_weight.swap(lw); S.lw_from_host = true;
+                }
                 if (na >= 2 && (!p->recursive || nrec == 0)) {
                     S.nl = nl; S.n_anchor = na; S.dev_tail = true;
                     const double t2 = now_ms();
@@ -366,14 +378,38 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
                     S.open = true;
                     return MAUVE_OK;
                 }
+                if (do_extend) {
+                    // the extension is done; what follows (recursion) wants the chains on the host: the anchors come over as they are
+                    const size_t rb = (size_t)na * (2 + (size_t)N) * 4;
+                    HIPCHK(c, c->pin_chain.ensure(256 + rb));
+                    int32_t *hl = reinterpret_cast<int32_t *>(c->pin_chain.as<char>() + 256), *hs = hl + na, *hb = hs + (size_t)na * N;
+                    HIPCHK(c, hipMemcpyAsync(hl, S.dv_len, (size_t)na * 4, hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(c, hipMemcpyAsync(hs, S.dv_st, (size_t)na * N * 4, hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(c, hipMemcpyAsync(hb, S.dv_lcb, (size_t)na * 4, hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    std::vector<MatchVec> &chs = S.chains;
+                    chs.resize((size_t)nl);
+                    for (auto &ch : chs) { ch.N = N; ch.d.clear(); }
+                    int64_t rec[1 + MAUVE_MAX_SEQ];
+                    for (int64_t a = 0; a < na; a++) {
+                        rec[0] = hl[a];
+                        for (int g = 0; g < N; g++) rec[1 + g] = hs[(size_t)a * N + g];
+                        chs[(size_t)hb[a]].push(rec);
+                    }
+                    chains_ready = true;
+                    if (g_trace_pipeline) fprintf(stderr, "[trace] chain (device): %lld extended anchors to the host (recursion to follow)\n", (long long)na);
+                    S.dv_len = S.dv_st = S.dv_lcb = nullptr; S.lw_from_host = false;
+                }
             }
             if (c->matches_pending) {                    // the host goes on: it needs its copy of the list after all
                 rc = seed_matches_to_host(c);
                 if (rc) return rc;
                 R.mum_length = c->match_len; R.mum_start = c->match_start;
             }
-            rc = chain_device_copy_back(c, N, m, match_lcb);
-            if (rc) return rc;
+            if (!chains_ready) {
+                rc = chain_device_copy_back(c, N, m, match_lcb);
+                if (rc) return rc;
+            }
         }
         t1b = now_ms();
     }
@@ -402,19 +438,21 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
         } else
         host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl, &orders);
     }
-    if (p->extend_lcbs) {
+    if (do_extend && !chains_ready) {
         rc = extend_lcbs(c, p, w, lcbw, m, match_lcb, nl);
         if (rc) return rc;
     }
     S.nl = nl;
     std::vector<MatchVec> &chains = S.chains;
-    chains.resize((size_t)nl);                        // element buffers keep their capacity
-    for (auto &ch : chains) { ch.N = N; ch.d.clear(); }
-    R.lcb_weight.assign((size_t)nl, 0);
-    for (size_t i = 0; i < m.size(); i++) {
-        int64_t l = match_lcb[i]; if (l < 0) continue;
-        chains[(size_t)l].push(m.rec(i));              // m is sorted by genome-0 start (canonical order)
-        R.lcb_weight[(size_t)l] += S.match_weight.empty() ? m.len(i) * N : S.match_weight[i];
+    if (!chains_ready) {
+        chains.resize((size_t)nl);                        // element buffers keep their capacity
+        for (auto &ch : chains) { ch.N = N; ch.d.clear(); }
+        R.lcb_weight.assign((size_t)nl, 0);
+        for (size_t i = 0; i < m.size(); i++) {
+            int64_t l = match_lcb[i]; if (l < 0) continue;
+            chains[(size_t)l].push(m.rec(i));              // m is sorted by genome-0 start (canonical order)
+            R.lcb_weight[(size_t)l] += S.match_weight.empty() ? m.len(i) * N : S.match_weight[i];
+        }
     }
     const double t2 = now_ms();
     c->stage.chain_ms = t2 - t1;
@@ -655,8 +693,7 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     int64_t cells = 0;
     if (S.dev_tail) {
         // chains, DP and assembly on the device: anchors from chain_order_device, results left in HBM until they are fetched
-        const uint32_t cap = (uint32_t)c->dev_rec_n;
-        const int32_t *d_len = c->ch_anch.as<int32_t>(), *d_st = d_len + cap, *d_lcb = d_st + (size_t)cap * S.N;
+        const int32_t *d_len = S.dv_len, *d_st = S.dv_st, *d_lcb = S.dv_lcb;
         c->dp_band_from = dp_band_from_of(&S.p);
         rc = dp_run_from_anchors(c, S.N, S.n_anchor, d_len, d_st, d_lcb, S.p.gapped, dp_len_limit(&S.p), &S.p.scoring, nullptr, &S.n_dp, &S.code_total,
                                  nullptr, S.dcol_off, S.dscore, &cells, 1);

@@ -141,4 +141,5 @@ def align_sharded(ctx, params=None, dist=None, group=None, names=None, want_xmfa
                 all_score[i] = g_score[r][k]
                 off += ln
         all_cells = int(sum(int(x[0]) for x in g_cells))
-    return ctx.align_finish(all_cols, all_score, all_cells, fetch=fetch, names=names, want_xmfa=want_xmfa, out=out)
+    kw = {} if out is None else {"out": out}
+    return ctx.align_finish(all_cols, all_score, all_cells, fetch=fetch, names=names, want_xmfa=want_xmfa, **kw)

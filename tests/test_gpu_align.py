@@ -223,7 +223,7 @@ def test_device_tail_equals_host_tail_and_oracle():
     r = subprocess.run([sys.executable, "-c", TAIL_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr[-3000:]
     stay = [l for l in r.stderr.splitlines() if "stay there" in l]
-    back = [l for l in r.stderr.splitlines() if "copy back" in l]
+    back = [l for l in r.stderr.splitlines() if "copy back" in l or "anchors to the host" in l]
     assert len(stay) >= 8 and back, r.stderr[-2000:]          # recursion-free cases stay; the one with long gaps goes back
     env["MAUVE_HOST_TAIL"] = "1"
     r = subprocess.run([sys.executable, "-c", TAIL_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
@@ -363,8 +363,9 @@ def test_sp_lcb_scoring(ctx):
     _same_align(ctx, gs, lcb_scoring=1, lcb_weight=200000)        # a breakpoint penalty as a score
     gs4 = synth.make_config("C4", scale=0.01)
     _same_progressive(ctx, gs4, lcb_scoring=1)
-    with pytest.raises(RuntimeError):
-        ctx.align(_lib.default_params(lcb_scoring=1, extend_lcbs=1))
+    # score-weighted LCBs are not extended (the extension rule counts columns): the flag changes nothing
+    a = ctx.align(_lib.default_params(lcb_scoring=1, extend_lcbs=1)); b = ctx.align(_lib.default_params(lcb_scoring=1, extend_lcbs=0))
+    assert np.array_equal(a["cols"], b["cols"]) and np.array_equal(a["anchor_start"], b["anchor_start"])
 
 
 def test_lcb_extension(ctx):
@@ -375,14 +376,14 @@ def test_lcb_extension(ctx):
                            ("C1", 0.3, {}), ("C3", 0.02, {"mode": 1})):
         gs = synth.make_config(cfg, scale=scale)
         r1 = _same_align(ctx, gs, extend_lcbs=1, **kw)
-        r0 = ctx.align(_lib.default_params(**kw))
+        r0 = ctx.align(_lib.default_params(extend_lcbs=0, **kw))
         assert int(r1["anchor_length"].sum()) >= int(r0["anchor_length"].sum())
     # genomes that are one LCB end to end: nothing outside, nothing changes
     rng = np.random.default_rng(5)
     g = rng.integers(0, 4, 20000, dtype=np.uint8)
     gs = [g, synth.mutate(g, 0.02, rng)]
     ctx.set_genomes(gs)
-    a = ctx.align(_lib.default_params(extend_lcbs=1)); b = ctx.align(_lib.default_params())
+    a = ctx.align(_lib.default_params(extend_lcbs=1)); b = ctx.align(_lib.default_params(extend_lcbs=0))
     assert np.array_equal(a["cols"], b["cols"]) and np.array_equal(a["anchor_start"], b["anchor_start"])
 
 
@@ -592,7 +593,7 @@ def test_align_matches_given_list(ctx):
         assert np.array_equal(whole[k], mixed[k]), k
     # a thinned list: every anchor of the result comes from a kept match
     keep = rng.random(len(ln)) < 0.5
-    thin = ctx.align_matches(_lib.default_params(recursive=0), ln[keep], st[keep])
+    thin = ctx.align_matches(_lib.default_params(recursive=0, extend_lcbs=0), ln[keep], st[keep])      # (neither stage may add anchors of its own)
     kept = {tuple(r) for r in np.abs(st[keep]).tolist()}
     a0 = thin["anchor_start"][:, 0]
     assert thin["n_mums"] == int(keep.sum()) and len(a0) > 0
@@ -928,3 +929,23 @@ def test_dp_scan_kernels():
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", SCAN_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and r.stdout.strip().endswith("OK"), str(extra) + "\n" + r.stdout + r.stderr[-3000:]
+
+
+def test_lcb_extension_on_the_device(ctx):
+    """Lists of more than 16 k matches keep their chains on the device; the extension rounds then work on the LCB table alone
+    (extend_dev.hip: pieces outside the LCBs gathered into small virtual genomes, the new matches re-chained against the LCBs
+    as units, slipped into the device-resident anchor list).  Same result as the oracle's match-level rule: a clean C3, a
+    5 %-divergent set where rounds do add anchors, a smaller seed with two rounds, and a C5-shaped pair whose gaps still need
+    the recursion afterwards (the anchors then come back to the host)."""
+    from mauvealigner_amd import _lib
+    gs = synth.make_config("C3", scale=0.4)
+    r1 = _same_align(ctx, gs, extend_lcbs=1, seed_weight=15)
+    assert r1["n_mums"] > 16384
+    gs = synth.star_genomes(4, 1_500_000, 0.05, 77, inversions=24)
+    r1 = _same_align(ctx, gs, extend_lcbs=1, seed_weight=15)
+    r0 = ctx.align(_lib.default_params(seed_weight=15, extend_lcbs=0))
+    assert r1["n_mums"] > 16384 and int(r1["anchor_length"].sum()) > int(r0["anchor_length"].sum()) and r1["n_anchor"] > r0["n_anchor"]
+    _same_align(ctx, gs, extend_lcbs=1, seed_weight=13, max_extension_iters=2)
+    gs = synth.make_config("C5", scale=0.04)
+    r1 = _same_align(ctx, gs, extend_lcbs=1)
+    assert r1["n_mums"] > 16384
