@@ -89,12 +89,13 @@ def make_workload(name, scale, rank, track=False):
 def pack_pinned(genomes):
     """the packed genomes in host RAM, in page-locked caller buffers (where the timed region starts)"""
     from mauvealigner_amd import _lib
-    out = []
-    for g in genomes:
-        w = _lib.pack_codes(g)
-        p = _lib.pinned_empty(len(w), np.uint64)
-        p[:] = w
-        out.append(p)
+    ws = [_lib.pack_codes(g) for g in genomes]
+    block = _lib.pinned_empty(sum(len(w) for w in ws), np.uint64)      # one block, genome behind genome: the upload is one DMA
+    out, at = [], 0
+    for w in ws:
+        block[at:at + len(w)] = w
+        out.append(block[at:at + len(w)])
+        at += len(w)
     return out, [len(g) for g in genomes]
 
 

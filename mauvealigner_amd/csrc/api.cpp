@@ -15,6 +15,20 @@ GenomeSet main_genome_set(mauve_ctx *c)
     return gs;
 }
 
+// tails of freshly uploaded genomes: the bits past the last base of genome blockIdx.x cleared, its padding words (and, behind the
+// last genome, the buffer's four slack words) zeroed -- window reads beyond a genome's end are deterministic
+struct GenomeTails { uint64_t off[MAUVE_MAX_SEQ]; int64_t len[MAUVE_MAX_SEQ]; uint64_t total_words; };
+__global__ void genome_tail_fix(uint64_t *__restrict__ words, GenomeTails gt)
+{
+    const int g = blockIdx.x;
+    const int64_t len = gt.len[g];
+    const uint64_t data = (uint64_t)((len + 31) / 32);
+    uint64_t *w = words + gt.off[g];
+    const uint64_t end = (g + 1 == (int)gridDim.x ? gt.total_words + 4 : gt.off[g + 1]) - gt.off[g];      // words this genome owns (padding included)
+    if (threadIdx.x == 0 && (len & 31)) w[data - 1] &= (1ULL << (2 * (len & 31))) - 1ULL;
+    for (uint64_t k = data + threadIdx.x; k < end; k += 64) w[k] = 0;
+}
+
 // is p inside a page-locked (hipHostMalloc / hipHostRegister) allocation?  Plain pointers make the query fail: that error is swallowed.
 bool host_pointer_is_pinned(const void *p)
 {
@@ -87,7 +101,7 @@ void mauve_ctx_destroy(mauve_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     delete c->pool; c->pool = nullptr;
     DevBuf *bufs[] = {&c->genomes, &c->keysA, &c->keysB, &c->valsA, &c->valsB, &c->hist, &c->totals, &c->posmask,
-                      &c->hit_mask, &c->hit_pos, &c->hit_seg, &c->base_invalid, &c->contig_mask, &c->node_cmask, &c->run_sum, &c->join_ovf, &c->join_bound, &c->dpf_anch, &c->dpf_work, &c->dpf_tot, &c->ch_len, &c->ch_st, &c->ch_crop, &c->ch_ent, &c->ch_ord, &c->ch_rank, &c->ch_node, &c->ch_graph, &c->ch_cnt, &c->ch_anch, &c->ch_lw, &c->ch_anch2, &c->ext_work, &c->sorted_rec_keep, &c->ch_big, &c->as_work, &c->as_isl, &c->res_cols, &c->sorted_rec, &c->canon_k1, &c->canon_k2, &c->canon_v1, &c->canon_v2, &c->rec_genomes, &c->rec_seg, &c->rec_vinv, &c->rec_vcm, &c->placed_mask, &c->bb_cols, &c->bb_work, &c->bb_query, &c->cand, &c->mlen, &c->mstart, &c->counters, &c->dp_desc, &c->dp_list, &c->dp_codes, &c->dp_off,
+                      &c->hit_mask, &c->hit_pos, &c->hit_seg, &c->base_invalid, &c->contig_mask, &c->node_cmask, &c->run_sum, &c->join_ovf, &c->join_bound, &c->dpf_anch, &c->dpf_work, &c->dpf_tot, &c->ch_len, &c->ch_st, &c->ch_crop, &c->ch_ent, &c->ch_ord, &c->ch_rank, &c->ch_node, &c->ch_graph, &c->ch_cnt, &c->ch_anch, &c->ch_lw, &c->ch_anch2, &c->ext_work, &c->sorted_rec_keep, &c->ch_big, &c->as_wide, &c->as_work, &c->as_isl, &c->res_cols, &c->sorted_rec, &c->canon_k1, &c->canon_k2, &c->canon_v1, &c->canon_v2, &c->rec_genomes, &c->rec_seg, &c->rec_vinv, &c->rec_vcm, &c->placed_mask, &c->bb_cols, &c->bb_work, &c->bb_query, &c->cand, &c->mlen, &c->mstart, &c->counters, &c->dp_desc, &c->dp_list, &c->dp_codes, &c->dp_off,
                       &c->dp_prof_cnt, &c->dp_prof_mask, &c->dp_prof2_cnt, &c->dp_prof2_mask, &c->dp_tb, &c->dp_meta,
                       &c->dp_score, &c->dp_cols, &c->dp_rows};
     for (DevBuf *b : bufs) b->release();
@@ -132,7 +146,10 @@ int mauve_set_genomes(mauve_ctx *c, int nseq, const uint64_t *const *packed, con
     if (!c) return MAUVE_ERR_ARG;
     if (nseq < 1 || nseq > MAUVE_MAX_SEQ || !packed || !lens) { c->err = "set_genomes: 1..32 sequences required"; return MAUVE_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
-    { int rcm = materialize_tables(c); if (rcm) return rcm; }           // a result still in HBM refers to the genomes it was made from
+    // A result still in the context was made from the genomes that are being replaced: it ends here (mauve_hip.h: results are held
+    // until the next call).  What of it is still on the device is not brought over -- in a loop of set_genomes / align / fetch that
+    // would copy every result twice -- and a later fetch is refused instead of handing out half a result.
+    if (c->res.dev_pending || c->res.cols_pending) { c->res.dev_pending = false; c->res.cols_pending = false; c->res.stale = true; }
     size_t total_words = 0;
     std::vector<uint64_t> off(nseq);
     int64_t total_len = 0;
@@ -154,19 +171,23 @@ int mauve_set_genomes(mauve_ctx *c, int nseq, const uint64_t *const *packed, con
     c->host_packed.assign((size_t)nseq, nullptr);
     uint64_t *dev = c->genomes.as<uint64_t>();
     if (all_pinned) {
-        HIPCHK(c, c->pin_tail.ensure((size_t)nseq * 8 * sizeof(uint64_t) + 64));
-        uint64_t *tails = c->pin_tail.as<uint64_t>();
-        for (int g = 0; g < nseq; g++) {
-            const size_t nw = mauve_packed_words(lens[g]), data = (size_t)((lens[g] + 31) / 32);
-            const size_t body = data ? data - 1 : 0;                     // whole words that need no fix-up
-            uint64_t *t = tails + (size_t)g * 8;
-            size_t nt = 0;
-            if (data) { t[nt] = packed[g][data - 1]; if (lens[g] & 31) t[nt] &= (1ULL << (2 * (lens[g] & 31))) - 1ULL; nt++; }
-            for (size_t k = data; k < nw; k++) t[nt++] = 0;              // nw - data <= 4
-            if (body) HIPCHK(c, hipMemcpyAsync(dev + off[g], packed[g], body * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-            if (nt) HIPCHK(c, hipMemcpyAsync(dev + off[g] + body, t, nt * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-        }
-        HIPCHK(c, hipMemsetAsync(dev + total_words, 0, 4 * sizeof(uint64_t), c->stream));
+        // one DMA when the caller's genomes lie one behind the other in the boundary's own layout (mauve_packed_words(len) words
+        // each), else one per genome; the tails -- bits past the last base, the padding words -- are put right on the device
+        bool contiguous = true;
+        for (int g = 0; g + 1 < nseq && contiguous; g++) contiguous = packed[g + 1] == packed[g] + mauve_packed_words(lens[g]);
+        if (contiguous) {
+            const size_t body = total_words - mauve_packed_words(lens[nseq - 1]) + (size_t)((lens[nseq - 1] + 31) / 32);      // up to the last data word
+            if (body) HIPCHK(c, hipMemcpyAsync(dev, packed[0], body * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        } else
+            for (int g = 0; g < nseq; g++) {
+                const size_t data = (size_t)((lens[g] + 31) / 32);
+                if (data) HIPCHK(c, hipMemcpyAsync(dev + off[g], packed[g], data * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+            }
+        GenomeTails gt; memset(&gt, 0, sizeof gt);
+        for (int g = 0; g < nseq; g++) { gt.off[g] = off[g]; gt.len[g] = lens[g]; }
+        gt.total_words = total_words;
+        hipLaunchKernelGGL(genome_tail_fix, dim3((unsigned)nseq), dim3(64), 0, c->stream, dev, gt);
+        HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->host_copy_valid = false;
     } else {

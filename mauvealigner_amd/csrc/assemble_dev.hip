@@ -149,6 +149,15 @@ __global__ void __launch_bounds__(256) sp_score_matches(const uint64_t *__restri
     }
 }
 
+// the anchor table in the caller's width (int64), for a fetch straight into page-locked caller buffers
+__global__ void __launch_bounds__(256) as_widen_anchors(const int32_t *__restrict__ alen, const int32_t *__restrict__ ast, const int32_t *__restrict__ alcb, uint32_t na, int N,
+                                                        int64_t *__restrict__ olen, int64_t *__restrict__ ost, int64_t *__restrict__ olcb)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < na) { olen[i] = alen[i]; olcb[i] = alcb[i]; }
+    if (i < na * (uint32_t)N) ost[i] = ast[i];
+}
+
 }  // namespace
 
 int64_t sp_default_min_weight(int w, int n, const mauve_scoring *sc)
@@ -348,6 +357,38 @@ int materialize_tables(mauve_ctx *c)
     }
     R.dev_pending = false;
     return MAUVE_OK;
+}
+
+// The bulk tables of a device-assembled result straight into the caller's buffers when those are page-locked (mauve_host_alloc):
+// the match list is on the device in the caller's layout already (sorted_rec: int64 length[n], start[n * N]), the anchor table
+// is widened to int64 there; every copy is one DMA, no staging block, no conversion loop on the host.  Returns true when it
+// took care of both tables (the context keeps no host copy of them then: they are still pending for a later call).
+bool fetch_tables_direct(mauve_ctx *c, int64_t *mum_length, int64_t *mum_start, int64_t *anchor_length, int64_t *anchor_start, int64_t *anchor_lcb, int *rc_out)
+{
+    AlignResult &R = c->res;
+    *rc_out = MAUVE_OK;
+    if (!R.dev_pending) return false;
+    const int N = c->ast.N; const size_t na = R.dev_na, nm = R.dev_nm;
+    if (nm && !(host_pointer_is_pinned(mum_length) && host_pointer_is_pinned(mum_start))) return false;
+    if (na && !(host_pointer_is_pinned(anchor_length) && host_pointer_is_pinned(anchor_start) && host_pointer_is_pinned(anchor_lcb))) return false;
+    auto chk = [&](hipError_t e) { if (e != hipSuccess && *rc_out == MAUVE_OK) { c->err = std::string("fetch: ") + hipGetErrorString(e); *rc_out = MAUVE_ERR_HIP; } };
+    chk(hipSetDevice(c->device));
+    if (na) {
+        chk(c->as_wide.ensure(na * (2 + (size_t)N) * 8 + 64));
+        if (*rc_out) return true;
+        int64_t *wl = c->as_wide.as<int64_t>(), *ws = wl + na, *wb = ws + na * N;
+        hipLaunchKernelGGL(as_widen_anchors, dim3((uint32_t)((na * N + 255) / 256)), dim3(256), 0, c->stream, R.dev_alen, R.dev_ast, R.dev_alcb, (uint32_t)na, N, wl, ws, wb);
+        chk(hipGetLastError());
+        chk(hipMemcpyAsync(anchor_length, wl, na * 8, hipMemcpyDeviceToHost, c->stream));
+        chk(hipMemcpyAsync(anchor_start, ws, na * N * 8, hipMemcpyDeviceToHost, c->stream));
+        chk(hipMemcpyAsync(anchor_lcb, wb, na * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (nm) {
+        const int64_t *rec = c->sorted_rec.as<int64_t>();
+        chk(hipMemcpyAsync(mum_length, rec, nm * 8, hipMemcpyDeviceToHost, c->stream));
+        chk(hipMemcpyAsync(mum_start, rec + nm, nm * N * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    return true;                                              // (the stream is drained by the column copy that follows, or by the caller)
 }
 
 // ... and the columns into page-locked staging (the XMFA writer, a fetch into pageable memory); idempotent

@@ -427,6 +427,7 @@ int mauve_backbone(mauve_ctx *c, int64_t island_gap_size, int64_t *n_seg, int64_
     if (!c || !n_seg || !n_islands) return MAUVE_ERR_ARG;
     if (island_gap_size < 0 || island_gap_size > 0x7fffffff) { c->err = "backbone: island_gap_size out of range"; return MAUVE_ERR_ARG; }
     AlignResult &R = c->res;
+    if (R.stale) { c->err = "backbone: the genomes were replaced after this alignment was made"; return MAUVE_ERR_STATE; }
     const int64_t n_iv = R.sz.n_iv;
     if ((int64_t)R.col_off.size() != n_iv + 1) { c->err = "backbone: no alignment in this context"; return MAUVE_ERR_STATE; }
     if (n_iv == 0) { c->bb = mauve_ctx::BackboneResult(); c->bb.N = c->nseq; c->bb.valid = true; *n_seg = *n_islands = 0; return MAUVE_OK; }   // nothing was aligned

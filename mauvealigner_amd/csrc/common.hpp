@@ -128,6 +128,7 @@ struct AlignResult {
     std::vector<std::pair<size_t, size_t>> cols_dirty;   // (offset, length) ranges holding gap columns
     std::vector<int64_t> dp_score;
     // device-assembled result (assemble_dev.hip): the columns (res_cols), the anchor table and maybe the match list are still in HBM
+    bool stale = false;                     // the genomes were replaced after this result was made: a fetch is refused (mauve_set_genomes)
     bool dev_pending = false;               // anchor table / match list still on the device
     bool cols_pending = false;              // columns only in res_cols (cols_ext not set)
     size_t dev_na = 0, dev_nm = 0;          // anchors; matches still on the device (0: mum_* are filled)
@@ -226,6 +227,7 @@ struct mauve_ctx {
     DevBuf ch_anch, ch_lw;               // the chains in chain order and the LCB weights (chain_order_device)
     DevBuf ch_anch2, ext_work, sorted_rec_keep;   // device-resident LCB extension (extend_dev.hip): the extended anchor list, its work area, the main pass's match list set aside
     PinnedBuf pin_ext;
+    DevBuf as_wide;                      // the anchor table widened to int64 for a direct fetch
     DevBuf as_work, as_isl, res_cols;    // device assembly (assemble_dev.hip): work area, islands, result columns
     PinnedBuf pin_tab;                   // anchor table and match list of a device-assembled result on their way to the host
     PinnedBuf pin_asm, pin_cols;         // ... its per-LCB rows coming back; the columns and anchors on their way to a fetch
@@ -378,6 +380,7 @@ int assemble_device(mauve_ctx *c, int64_t na, int64_t cells, mauve_align_sizes *
 int materialize_result(mauve_ctx *c);
 int materialize_tables(mauve_ctx *c);
 int fetch_columns(mauve_ctx *c, uint32_t *dst);
+bool fetch_tables_direct(mauve_ctx *c, int64_t *mum_length, int64_t *mum_start, int64_t *anchor_length, int64_t *anchor_start, int64_t *anchor_lcb, int *rc_out);
 bool host_pointer_is_pinned(const void *p);
 int host_genomes(mauve_ctx *c);
 int seed_matches_to_host(mauve_ctx *ctx);

@@ -256,7 +256,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
     R.mum_length.clear(); R.mum_start.clear(); R.lcb_left.clear(); R.lcb_right.clear(); R.lcb_weight.clear();
     R.anchor_length.clear(); R.anchor_start.clear(); R.anchor_lcb.clear(); R.iv_left.clear(); R.iv_right.clear();
     R.iv_reverse.clear(); R.col_off.clear(); R.n_cols = 0; R.dp_score.clear();
-    R.dev_pending = false; R.cols_pending = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr;
+    R.dev_pending = false; R.cols_pending = false; R.stale = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr;
     memset(&c->stage, 0, sizeof c->stage);
 
     int64_t sum = 0; for (int g = 0; g < N; g++) sum += c->lens[g];
@@ -898,14 +898,24 @@ int mauve_align_fetch(mauve_ctx *c, int64_t *mum_length, int64_t *mum_start, int
                       int64_t *dp_score)
 {
     if (!c) return MAUVE_ERR_ARG;
-    { int rcm = materialize_tables(c); if (rcm) return rcm; }
+    if (c->res.stale) { c->err = "align_fetch: the genomes were replaced after this alignment was made; its device-resident part is gone"; return MAUVE_ERR_STATE; }
+    // the two bulk tables of a device-assembled result: straight from HBM into page-locked caller buffers when all of them are
+    // asked for and are such; through the context's host copy otherwise
+    bool direct = false;
+    if (c->res.dev_pending && mum_length && mum_start && anchor_length && anchor_start && anchor_lcb) {
+        int rcd = MAUVE_OK;
+        direct = fetch_tables_direct(c, mum_length, mum_start, anchor_length, anchor_start, anchor_lcb, &rcd);
+        if (rcd) return rcd;
+    }
+    if (!direct) { int rcm = materialize_tables(c); if (rcm) return rcm; }
     const AlignResult &R = c->res;
-    CPY(mum_length, R.mum_length); CPY(mum_start, R.mum_start);
+    if (!direct || R.dev_nm == 0) { CPY(mum_length, R.mum_length); CPY(mum_start, R.mum_start); }        // (direct: only what was still on the device)
+    if (!direct || R.dev_na == 0) { CPY(anchor_length, R.anchor_length); CPY(anchor_start, R.anchor_start); CPY(anchor_lcb, R.anchor_lcb); }
     CPY(lcb_left, R.lcb_left); CPY(lcb_right, R.lcb_right); CPY(lcb_weight, R.lcb_weight);
-    CPY(anchor_length, R.anchor_length); CPY(anchor_start, R.anchor_start); CPY(anchor_lcb, R.anchor_lcb);
     CPY(iv_left, R.iv_left); CPY(iv_right, R.iv_right); CPY(iv_reverse, R.iv_reverse);
     CPY(col_off, R.col_off); CPY(dp_score, R.dp_score);
-    if (cols && R.n_cols) return fetch_columns(c, cols);
+    if (cols && R.n_cols) { const int rcc = fetch_columns(c, cols); if (rcc) return rcc; }
+    if (direct) HIPCHK(c, hipStreamSynchronize(c->stream));         // the table copies are in flight on the same stream
     return MAUVE_OK;
 }
 
@@ -914,6 +924,7 @@ int mauve_align_fetch(mauve_ctx *c, int64_t *mum_length, int64_t *mum_start, int
 int mauve_write_xmfa(mauve_ctx *c, const char *const *names, char *buf, int64_t *len)
 {
     if (!c || !len) return MAUVE_ERR_ARG;
+    if (c->res.stale) { c->err = "write_xmfa: the genomes were replaced after this alignment was made"; return MAUVE_ERR_STATE; }
     { int rcm = materialize_result(c); if (rcm) return rcm; }
     { int rcm = host_genomes(c); if (rcm) return rcm; }
     const AlignResult &R = c->res;

@@ -417,7 +417,7 @@ static int progressive_core(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     R.mum_length.clear(); R.mum_start.clear(); R.lcb_left.clear(); R.lcb_right.clear(); R.lcb_weight.clear();
     R.anchor_length.clear(); R.anchor_start.clear(); R.anchor_lcb.clear(); R.iv_left.clear(); R.iv_right.clear();
     R.iv_reverse.clear(); R.col_off.clear(); R.cols.clear(); R.dp_score.clear();
-    R.dev_pending = false; R.cols_pending = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr; R.cols_fill = 0; R.cols_dirty.clear();
+    R.dev_pending = false; R.cols_pending = false; R.stale = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr; R.cols_fill = 0; R.cols_dirty.clear();
     R.cols_fill = 0; R.cols_dirty.clear();           // mauve_align's prefilled-buffer invariant no longer holds
     P.R = &R;
     P.rest.assign((size_t)N, FreePool());

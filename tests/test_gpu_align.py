@@ -949,3 +949,19 @@ def test_lcb_extension_on_the_device(ctx):
     gs = synth.make_config("C5", scale=0.04)
     r1 = _same_align(ctx, gs, extend_lcbs=1)
     assert r1["n_mums"] > 16384
+
+
+def test_result_ends_with_its_genomes(ctx):
+    """mauve_set_genomes ends the result the context holds: what of it is still on the device is not carried over, and a fetch
+    afterwards is refused (MAUVE_ERR_STATE) instead of handing out half a result; the next alignment is whole again."""
+    from mauvealigner_amd import _lib
+    gs = synth.make_config("C3", scale=0.4)
+    ctx.set_genomes(gs)
+    p = _lib.default_params(seed_weight=15)
+    sz = ctx.align(p, fetch=False)
+    ctx.set_genomes(gs)
+    sz_t = _lib.AlignSizes(**{k: sz[k] for k, _ in _lib.AlignSizes._fields_})
+    with pytest.raises(RuntimeError, match=r"\(-5\)"):
+        ctx._fetch(sz_t)
+    r = ctx.align(p)
+    assert r["n_anchor"] == sz["n_anchor"] and len(r["cols"]) == sz["n_cols"]
