@@ -395,6 +395,115 @@ __global__ void __launch_bounds__(256) co_gather(const uint32_t *__restrict__ ke
     }
 }
 
+
+// ---- the collinear rule of a recursion batch on the device (one collinear chain per gap) ----
+// Every gap's nodes are consecutive node ids (genome-0 order).  gap_node_gap: the gap of a node, from any of its matches;
+// gap_ranges: the node range of every gap that holds more than one node (the others survive as they are); gap_greedy: one wave
+// per such gap runs lcb_greedy's collinear form on the gap's sub-graph in LDS -- the lightest node (lowest id on ties) is
+// deleted and its neighbours re-merged, until one node is left -- and marks the nodes that end up in the survivor.
+__global__ void __launch_bounds__(256) gap_node_gap(const int32_t *__restrict__ len, const int32_t *__restrict__ node_of, const uint32_t *__restrict__ gapid, uint32_t n,
+                                                    uint32_t *__restrict__ node_gap)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n && len[i] > 0) node_gap[node_of[i]] = gapid[i];
+}
+__global__ void __launch_bounds__(256) gap_ranges(const uint32_t *__restrict__ node_gap, uint32_t K, uint8_t *__restrict__ node_ok, uint32_t *__restrict__ ranges /* pairs */,
+                                                  uint32_t *__restrict__ count)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= K) return;
+    node_ok[j] = 1;                                               // (gap_greedy clears what the rule drops)
+    const uint32_t g = node_gap[j];
+    if (j > 0 && node_gap[j - 1] == g) return;                    // not the first node of its gap
+    uint32_t e = j + 1;
+    while (e < K && node_gap[e] == g) e++;
+    if (e - j > 1) { const uint32_t o = atomicAdd(count, 1u); ranges[2 * (size_t)o] = j; ranges[2 * (size_t)o + 1] = e; }
+}
+constexpr int GAP_KMAX = 512;                                     // nodes of one gap the wave keeps in LDS (more: the host does that batch)
+constexpr int GAP_LINKS = 2560;                                   // ... and node x genome link entries
+__global__ void __launch_bounds__(64) gap_greedy(const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ nranges_p, int N, const unsigned long long *__restrict__ weight,
+                                                 const int32_t *__restrict__ prevv, const int32_t *__restrict__ nextv, uint8_t *__restrict__ node_ok,
+                                                 uint32_t *__restrict__ fail)
+{
+    __shared__ unsigned long long s_w[GAP_KMAX];
+    __shared__ int16_t s_pv[GAP_LINKS], s_nx[GAP_LINKS], s_merged[GAP_KMAX];
+    __shared__ uint8_t s_alive[GAP_KMAX];
+    const int lane = threadIdx.x;
+    const uint32_t nranges = *nranges_p;                          // (a device value: the launch is sized for the worst case)
+    for (uint32_t r = blockIdx.x; r < nranges; r += gridDim.x) {
+        const uint32_t n0 = ranges[2 * (size_t)r], n1 = ranges[2 * (size_t)r + 1];
+        const int kk = (int)(n1 - n0);
+        if (kk > GAP_KMAX || kk * N > GAP_LINKS) { if (lane == 0) atomicAdd(fail, 1u); continue; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        for (int j = lane; j < kk; j += 64) { s_w[j] = weight[n0 + j]; s_alive[j] = 1; s_merged[j] = -1; }
+        for (int t = lane; t < kk * N; t += 64) {
+            const int32_t p = prevv[(size_t)n0 * N + t], q = nextv[(size_t)n0 * N + t];
+            s_pv[t] = (p >= (int32_t)n0 && p < (int32_t)n1) ? (int16_t)(p - (int32_t)n0) : (int16_t)-1;
+            s_nx[t] = (q >= (int32_t)n0 && q < (int32_t)n1) ? (int16_t)(q - (int32_t)n0) : (int16_t)-1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        int alive_cnt = kk;
+        while (alive_cnt > 1) {
+            // the lightest alive node, lowest id on ties (weights are sums of match lengths x N: far below 2^48)
+            unsigned long long best = ~0ULL;
+            for (int j = lane; j < kk; j += 64) if (s_alive[j]) { const unsigned long long key = (s_w[j] << 16) | (unsigned long long)j; best = key < best ? key : best; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(best, o); best = t < best ? t : best; }
+            const int x = (int)(best & 0xffffULL);
+            if (lane == 0) {
+                // unlink x, then let its former neighbours merge where they have become collinear neighbours (all matches of a batch are forward)
+                int16_t ca[MAUVE_MAX_SEQ], cb[MAUVE_MAX_SEQ];
+                for (int g = 0; g < N; g++) { ca[g] = s_pv[x * N + g]; cb[g] = s_nx[x * N + g]; }
+                for (int g = 0; g < N; g++) {
+                    const int p = s_pv[x * N + g], q = s_nx[x * N + g];
+                    if (p >= 0) s_nx[p * N + g] = (int16_t)q;
+                    if (q >= 0) s_pv[q * N + g] = (int16_t)p;
+                }
+                s_alive[x] = 0; alive_cnt--;
+                for (int g = 0; g < N; g++) {
+                    int a = ca[g], b = cb[g];
+                    while (a >= 0 && !s_alive[a] && s_merged[a] >= 0) a = s_merged[a];
+                    while (b >= 0 && !s_alive[b] && s_merged[b] >= 0) b = s_merged[b];
+                    if (a < 0 || b < 0 || a == b || !s_alive[a] || !s_alive[b]) continue;
+                    if (s_nx[b * N] == a) { const int t = a; a = b; b = t; }
+                    if (s_nx[a * N] != b) continue;
+                    bool ok = true;
+                    for (int h = 1; h < N && ok; h++) ok = s_nx[a * N + h] == b;
+                    if (!ok) continue;
+                    s_w[a] += s_w[b];
+                    for (int h = 0; h < N; h++) {
+                        const int p = s_pv[b * N + h], q = s_nx[b * N + h];
+                        if (p >= 0) s_nx[p * N + h] = (int16_t)q;
+                        if (q >= 0) s_pv[q * N + h] = (int16_t)p;
+                    }
+                    s_alive[b] = 0; s_merged[b] = (int16_t)a; alive_cnt--;
+                }
+            }
+            alive_cnt = __shfl(alive_cnt, 0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        }
+        for (int j = lane; j < kk; j += 64) {
+            int v = j;
+            while (!s_alive[v] && s_merged[v] >= 0) v = s_merged[v];
+            node_ok[n0 + j] = s_alive[v] ? 1 : 0;
+        }
+    }
+}
+// the survivors of a recursion batch, in list order: record (length, starts), gap id
+struct GapSurvivors {
+    const int32_t *len, *st, *node_of; const uint32_t *gapid; const uint8_t *node_ok; uint32_t n; int N;
+    int32_t *olen, *ost; uint32_t *ogap; uint32_t *total_out;
+    __device__ uint32_t domain(int) const { return n; }
+    __device__ bool flag(uint32_t i, int) const { return len[i] > 0 && node_ok[node_of[i]]; }
+    __device__ void each(uint32_t, uint32_t, bool, int) const {}
+    __device__ void emit(uint32_t i, uint32_t o, int) const
+    {
+        olen[o] = len[i]; ogap[o] = gapid[i];
+        for (int g = 0; g < N; g++) ost[(size_t)o * N + g] = st[(size_t)i * N + g];
+    }
+    __device__ void total(uint32_t t, int) const { *total_out = t; }
+};
+
 }  // namespace
 
 // The chains stay on the device: anchors in chain order in c->ch_anch (capacity layout: alen[n], ast[n * N], alcb[n]),
@@ -431,7 +540,7 @@ int chain_order_device(mauve_ctx *c, int N, int64_t nl, int64_t min_gap, int64_t
 // Elimination and LCB graph of the device-resident list (cropped records in c->ch_len / c->ch_st, node of every match behind
 // the lengths).  The compact graph arrives on the host in c->pin_chain (ChainGraphHost): weight[K], orient[K], prev[K*N],
 // next[K*N].  seg0 != nullptr: a recursion batch (forward matches only, nodes confined to their gaps).
-int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *seg0, uint32_t nseg, ChainGraphHost *G)
+int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *seg0, uint32_t nseg, ChainGraphHost *G, bool graph_to_host)
 {
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     const double t0 = now_ms();
@@ -508,7 +617,7 @@ int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *s
     if (hc[3]) { c->err = "chain_device: overlap cluster beyond the per-thread limit"; return MAUVE_ERR_LIMIT; }      // caller falls back to the host chain
     const uint32_t na = hc[0], K = hc[1];
     G->na = na; G->K = K; G->weight = nullptr; G->orient = nullptr; G->prev = nullptr; G->next = nullptr; G->final_stage = nullptr; G->final_dev = final_dev;
-    if (K) {
+    if (K && graph_to_host) {
         // graph to the host: weight[K], orient[K], prev[K*N], next[K*N]
         const size_t gbytes = (size_t)K * (8 + 4 + (size_t)N * 8) + 64;
         HIPCHK(c, c->pin_chain.ensure(256 + gbytes + (size_t)K * 4));
@@ -617,6 +726,67 @@ int chain_device_gaps(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0_
         for (uint32_t i = 0; i < n; i++) survive[i] = hl[i] > 0 && node_ok[(size_t)hnode[i]];
         *hl_out = hl; *hs_out = hs;
     }
+    return MAUVE_OK;
+}
+
+
+// The same with the collinear rule on the device as well (gap_greedy) and only the SURVIVORS coming back: cropped records
+// (hl, hs: int32) and the gap of each (hgap), in list order; *ns_out of them.  MAUVE_ERR_LIMIT: a gap beyond the kernel's LDS
+// slice, or an overlap cluster beyond the per-thread limit -- the caller takes the host route for the batch.
+int chain_device_gaps_compact(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0_dev, uint32_t nseg, const int32_t **hl_out, const int32_t **hs_out,
+                              const uint32_t **hgap_out, uint32_t *ns_out)
+{
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    ChainGraphHost G;
+    int rc = chain_device_graph(c, N, maxlen, seg0_dev, nseg, &G, false);
+    if (rc) return rc;
+    const double t0 = now_ms();
+    const uint32_t n = (uint32_t)c->dev_rec_n, K = G.K, blocks = (n + 255) / 256, nb = (n + TILE - 1) / TILE;
+    *ns_out = 0;
+    if (K == 0) return MAUVE_OK;
+    const int32_t *len = c->ch_len.as<int32_t>(), *node_of = len + n;
+    const uint32_t *gapid = reinterpret_cast<const uint32_t *>(len + 3 * (size_t)n);
+    const int32_t *st = c->ch_st.as<int32_t>();
+    const unsigned long long *weight = c->ch_graph.as<unsigned long long>();
+    const uint32_t *orient = reinterpret_cast<const uint32_t *>(weight + n);
+    const int32_t *prevv = reinterpret_cast<const int32_t *>(orient + n), *nextv = prevv + (size_t)n * N;
+    // work area: node_gap[K], ranges[2K], counters, node_ok[K], tile counts, compact records
+    auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    const size_t o_rng = (size_t)K * 4, o_cnt = o_rng + (size_t)K * 8, o_ok = o_cnt + 64, o_bc = up8(o_ok + K), o_len = o_bc + (size_t)nb * 4 + 64,
+                 o_st = o_len + (size_t)n * 4, o_gap = o_st + (size_t)n * N * 4, total = o_gap + (size_t)n * 4;
+    HIPCHK(c, c->gap_work.ensure(total + 64));
+    char *wk = c->gap_work.as<char>();
+    uint32_t *node_gap = reinterpret_cast<uint32_t *>(wk), *ranges = reinterpret_cast<uint32_t *>(wk + o_rng), *cnt = reinterpret_cast<uint32_t *>(wk + o_cnt);
+    uint8_t *node_ok = reinterpret_cast<uint8_t *>(wk + o_ok);
+    uint32_t *bcnt = reinterpret_cast<uint32_t *>(wk + o_bc);
+    int32_t *olen = reinterpret_cast<int32_t *>(wk + o_len), *ost = reinterpret_cast<int32_t *>(wk + o_st);
+    uint32_t *ogap = reinterpret_cast<uint32_t *>(wk + o_gap);
+    HIPCHK(c, hipMemsetAsync(cnt, 0, 64, c->stream));
+    hipLaunchKernelGGL(gap_node_gap, dim3(blocks), dim3(256), 0, c->stream, len, node_of, gapid, n, node_gap);
+    hipLaunchKernelGGL(gap_ranges, dim3((K + 255) / 256), dim3(256), 0, c->stream, node_gap, K, node_ok, ranges, cnt);
+    // (the number of ranges is a device value: the greedy launch is sized for the worst case and strides over what there is)
+    hipLaunchKernelGGL(gap_greedy, dim3(std::min<uint32_t>((K + 1) / 2, 256 * 16)), dim3(64), 0, c->stream, ranges, cnt, N, weight, prevv, nextv, node_ok, cnt + 1);
+    const GapSurvivors gs{len, st, node_of, gapid, node_ok, n, N, olen, ost, ogap, cnt + 2};
+    hipLaunchKernelGGL((cmp_count<GapSurvivors>), dim3(nb), dim3(256), 0, c->stream, gs, bcnt);
+    hipLaunchKernelGGL((cmp_write<GapSurvivors>), dim3(nb), dim3(256), 0, c->stream, gs, bcnt);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, c->pin_chain.ensure(256));
+    HIPCHK(c, hipMemcpyAsync(c->pin_chain.p, cnt, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint32_t *hc = c->pin_chain.as<uint32_t>();
+    if (hc[1]) { c->err = "chain_device_gaps: a gap beyond the device kernel's node limit"; return MAUVE_ERR_LIMIT; }
+    const uint32_t ns = hc[2], nr = hc[0];
+    HIPCHK(c, c->pin_chain.ensure(256 + (size_t)ns * 4 * (2 + (size_t)N) + 64));
+    int32_t *hl = reinterpret_cast<int32_t *>(c->pin_chain.as<char>() + 256), *hs = hl + ns;
+    uint32_t *hg = reinterpret_cast<uint32_t *>(hs + (size_t)ns * N);
+    if (ns) {
+        HIPCHK(c, hipMemcpyAsync(hl, olen, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hs, ost, (size_t)ns * N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hg, ogap, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    *hl_out = hl; *hs_out = hs; *hgap_out = hg; *ns_out = ns;
+    if (trace) fprintf(stderr, "[trace] chain (device): collinear rule on %u gaps with several nodes, %u of %u matches survive, %.3f ms\n", nr, ns, n, now_ms() - t0);
     return MAUVE_OK;
 }
 

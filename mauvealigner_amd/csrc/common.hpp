@@ -223,6 +223,7 @@ struct mauve_ctx {
     DevBuf join_bound;                   // join_hash: first bucket boundary at or after every chunk edge
     DevBuf join_ovf;                     // join_hash: [count, pad, (lo, hi) ...] ranges handed back to the full sort + serial join
     DevBuf ch_len, ch_st, ch_crop, ch_ent, ch_ord, ch_rank, ch_node, ch_graph, ch_cnt;   // device chain (chain_dev.hip)
+    DevBuf gap_work;                     // recursion batches: collinear rule and survivor compaction on the device (chain_device_gaps_compact)
     DevBuf ch_big;                       // working arrays of overlap clusters beyond the per-thread limit (recursion batches)
     DevBuf ch_anch, ch_lw;               // the chains in chain order and the LCB weights (chain_order_device)
     DevBuf ch_anch2, ext_work, sorted_rec_keep;   // device-resident LCB extension (extend_dev.hip): the extended anchor list, its work area, the main pass's match list set aside
@@ -341,7 +342,9 @@ int sort_pairs_u32(mauve_ctx *ctx, uint32_t n, int key_bits, uint32_t **keys_io,
 // device chain (chain_dev.hip): EliminateOverlaps + LCBs of the N-way list the seed pass left in ctx->sorted_rec
 int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchVec &m, std::vector<int64_t> &match_lcb, int64_t &n_lcb);
 struct ChainGraphHost { uint32_t na, K; int64_t *weight; uint32_t *orient; int32_t *prev, *next; int32_t *final_stage; int32_t *final_dev; };
-int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0, uint32_t nseg, ChainGraphHost *G);
+int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0, uint32_t nseg, ChainGraphHost *G, bool graph_to_host = true);
+int chain_device_gaps_compact(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0_dev, uint32_t nseg, const int32_t **hl_out, const int32_t **hs_out,
+                              const uint32_t **hgap_out, uint32_t *ns_out);
 int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, int64_t &n_lcb);
 int chain_device_gaps(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0_dev, uint32_t nseg, const int32_t **hl_out, const int32_t **hs_out,
                       std::vector<uint8_t> &survive);

@@ -223,7 +223,11 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
             HIPCHK(c, hipStreamSynchronize(c->stream));    // the host vectors must outlive the copies
             for (auto &x : glo) x += 1;                    // back to 1-based for the coordinate mapping below
             int64_t nm = 0;
+            static const bool host_gaps = getenv("MAUVE_HOST_GAP_CHAIN") != nullptr;      // A/B switch
+            static const bool old_gaps = getenv("MAUVE_GAP_CHAIN_ALL_BACK") != nullptr;   // A/B switch: the device chain that copies every record and graph back
+            c->lazy_matches_ok = !host_gaps && !old_gaps;     // a large batch is chained where its list is: no host copy of it
             int rc = seedpass_run(c, vs, pat, MAUVE_MODE_MEM, full, 1, c->rec_seg.as<uint32_t>(), K, &nm);
+            c->lazy_matches_ok = false;
             if (rc) return rc;
             if (trace) fprintf(stderr, "[trace] recursion level %d weight %d: %u gaps, %lld bases, %lld matches, %.3f ms\n", level, w, K,
                                (long long)vs.lens[0], (long long)nm, now_ms() - tc0);
@@ -238,14 +242,57 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
             // Large batches are chained on the device, all gaps at once (chain_device_gaps); the host loop below then only
             // maps the survivors back.  Small batches (host-sorted lists), ties in the canonical order and clusters beyond
             // the device kernel's limit are chained here, gap by gap.  MAUVE_HOST_GAP_CHAIN: A/B switch.
-            static const bool host_gaps = getenv("MAUVE_HOST_GAP_CHAIN") != nullptr;
-            bool dev_chain = false;
-            const int32_t *dl = nullptr, *ds = nullptr; std::vector<uint8_t> survive;
+            bool dev_chain = false, compact = false;
+            const int32_t *dl = nullptr, *ds = nullptr; const uint32_t *dg = nullptr; uint32_t ns = 0; std::vector<uint8_t> survive;
             if (!host_gaps && nm > 0 && c->dev_rec_n == nm) {
                 int64_t maxlen = 1; for (int g = 0; g < N; g++) maxlen = std::max(maxlen, vs.lens[(size_t)g]);
-                const int rcg = chain_device_gaps(c, N, maxlen, c->rec_seg.as<uint32_t>(), K, &dl, &ds, survive);
-                if (rcg == MAUVE_OK) dev_chain = true;
+                int rcg = old_gaps ? MAUVE_ERR_LIMIT : chain_device_gaps_compact(c, N, maxlen, c->rec_seg.as<uint32_t>(), K, &dl, &ds, &dg, &ns);
+                if (rcg == MAUVE_OK) compact = true;
                 else if (rcg != MAUVE_ERR_LIMIT) return rcg;
+                else {
+                    if (c->matches_pending) { rc = seed_matches_to_host(c); if (rc) return rc; }
+                    rcg = chain_device_gaps(c, N, maxlen, c->rec_seg.as<uint32_t>(), K, &dl, &ds, survive);
+                    if (rcg == MAUVE_OK) dev_chain = true;
+                    else if (rcg != MAUVE_ERR_LIMIT) return rcg;
+                }
+            }
+            if (c->matches_pending && !compact) { rc = seed_matches_to_host(c); if (rc) return rc; }
+            // what a gap's surviving matches (loc: 1-based inside the gap, one collinear chain) mean for the next level
+            auto emit_gap = [&](uint32_t k) {
+                const size_t wi = ids[k];
+                const int64_t *A = work.a(wi);
+                glob.d.clear();
+                for (size_t q = 0; q < loc.size(); q++) {
+                    if (ml[q] < 0) continue;
+                    int64_t rec[1 + MAUVE_MAX_SEQ]; rec[0] = loc.len(q);
+                    for (int g = 0; g < N; g++) {
+                        const int64_t s = loc.st(q)[g], lo = glo[(size_t)g * K + k], ln = glen[(size_t)g * K + k];
+                        if (A[1 + g] > 0) rec[1 + g] = lo + s - 1;
+                        else { const int64_t hi = lo + ln - 1; rec[1 + g] = -(hi - (s - 1) - rec[0] + 1); }
+                    }
+                    glob.push(rec);
+                }
+                if (glob.empty()) return;
+                glob.sort_by_start0();
+                const int64_t lcb = work.lcb(wi);
+                for (size_t q = 0; q <= glob.size(); q++)
+                    next.push(lcb, w, q == 0 ? work.a(wi) : glob.rec(q - 1), q == glob.size() ? work.b(wi) : glob.rec(q));
+                for (size_t q = 0; q < glob.size(); q++) found[(size_t)lcb].push(glob.rec(q));
+            };
+            if (compact) {
+                // only the survivors came back, with their gaps, in list order (gap by gap)
+                for (uint32_t q = 0; q < ns;) {
+                    const uint32_t k = dg[q];
+                    loc.d.clear();
+                    for (; q < ns && dg[q] == k; q++) {
+                        int64_t rec[1 + MAUVE_MAX_SEQ]; rec[0] = dl[q];
+                        for (int g = 0; g < N; g++) rec[1 + g] = (int64_t)ds[(size_t)q * N + g] - seg[(size_t)g * (K + 1) + k];
+                        loc.push(rec);
+                    }
+                    ml.assign(loc.size(), 0);
+                    emit_gap(k);
+                }
+                i = nm;
             }
             while (i < nm) {
                 const int64_t s0 = c->match_start[(size_t)i * N];      // genome 0 is always forward
@@ -281,35 +328,31 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                 host_lcb_chain(loc, 0, true, ml, nl, &orders);
                 if (trace) { t_elim += te1 - te0; t_lcb += now_ms() - te1; }
                 }
-                const size_t wi = ids[k];
-                const int64_t *A = work.a(wi);
-                glob.d.clear();
-                for (size_t q = 0; q < loc.size(); q++) {
-                    if (ml[q] < 0) continue;
-                    int64_t rec[1 + MAUVE_MAX_SEQ]; rec[0] = loc.len(q);
-                    for (int g = 0; g < N; g++) {
-                        const int64_t s = loc.st(q)[g], lo = glo[(size_t)g * K + k], ln = glen[(size_t)g * K + k];
-                        if (A[1 + g] > 0) rec[1 + g] = lo + s - 1;
-                        else { const int64_t hi = lo + ln - 1; rec[1 + g] = -(hi - (s - 1) - rec[0] + 1); }
-                    }
-                    glob.push(rec);
-                }
-                if (glob.empty()) continue;
-                glob.sort_by_start0();
-                const int64_t lcb = work.lcb(wi);
-                for (size_t q = 0; q <= glob.size(); q++)
-                    next.push(lcb, w, q == 0 ? work.a(wi) : glob.rec(q - 1), q == glob.size() ? work.b(wi) : glob.rec(q));
-                for (size_t q = 0; q < glob.size(); q++) found[(size_t)lcb].push(glob.rec(q));
+                emit_gap(k);
             }
-            if (trace) fprintf(stderr, "[trace]   per-gap chaining %.3f ms (%s; eliminate %.3f, lcb %.3f)\n", now_ms() - tch0, dev_chain ? "device" : "host", t_elim, t_lcb);
+            if (trace) fprintf(stderr, "[trace]   per-gap chaining %.3f ms (%s; eliminate %.3f, lcb %.3f)\n", now_ms() - tch0, compact ? "device, survivors only" : (dev_chain ? "device" : "host"), t_elim, t_lcb);
         }
         work.d.swap(next.d);
     }
     const double tm0 = now_ms();
+    // the new anchors into their chains: the chain is in genome-0 order already, so the (few) new ones are sorted and the two
+    // lists merged -- distinct starts in genome 0, as anchors of one chain never overlap
+    std::vector<int64_t> merged;
     for (size_t l = 0; l < chains.size(); l++) {
         if (found[l].empty()) continue;
-        chains[l].d.insert(chains[l].d.end(), found[l].d.begin(), found[l].d.end());
-        chains[l].sort_by_start0();
+        found[l].sort_by_start0();
+        const size_t R1 = (size_t)(1 + N), na = chains[l].size(), nb = found[l].size();
+        merged.resize((na + nb) * R1);
+        const int64_t *A = chains[l].d.data(), *B = found[l].d.data();
+        size_t a = 0, b = 0, o = 0;
+        while (a < na || b < nb) {
+            const bool take_a = b == nb || (a < na && std::llabs(A[a * R1 + 1]) <= std::llabs(B[b * R1 + 1]));
+            const int64_t *src = take_a ? A + a * R1 : B + b * R1;
+            std::copy(src, src + R1, merged.begin() + (std::ptrdiff_t)(o * R1));
+            if (take_a) a++; else b++;
+            o++;
+        }
+        chains[l].d.swap(merged);
     }
     if (trace) fprintf(stderr, "[trace] recursion: merge into chains %.3f ms, whole stage %.3f ms\n", now_ms() - tm0, now_ms() - t_stage0);
     return MAUVE_OK;
