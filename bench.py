@@ -383,11 +383,10 @@ def main():
     if shard_lcb:
         from mauvealigner_amd import parallel
 
+        parallel.attach_shard(ctx, dist)          # mauve_set_shard: the same calls on every rank, the independent units dealt out inside them
+
         def step():
-            rn.upload()
-            if rn.progressive:
-                return parallel.progressive_align_sharded(ctx, params, dist, fetch=True, out=rn.bufs)
-            return parallel.align_sharded(ctx, params, dist, fetch=True, out=rn.bufs)
+            return rn.step_host()
         for _ in range(args.warmup):
             res = step()
         barrier()

@@ -242,6 +242,19 @@ int mauve_align_dp(mauve_ctx *ctx, const int64_t *idx, int64_t n, uint32_t *cols
                    int64_t *score, int64_t *cells);
 int mauve_align_finish(mauve_ctx *ctx, const uint32_t *cols, const int64_t *col_off, const int64_t *score,
                        int64_t cells, mauve_align_sizes *sizes);
+/* ---- the same work spread over several contexts, one per GPU, without splitting the call: every rank holds the same genomes and
+        makes the SAME calls (mauve_align, mauve_progressive_align, mauve_guide_tree); inside them the independent units SURVEY.md 8e
+        names -- the pairwise finder passes of the guide tree (progressiveMauve.cpp:490-501), the gaps of every recursion level
+        (mauveAligner.cpp:130-131: "for parallelization of LCB alignment"), the gapped-alignment intervals of a guide-tree node --
+        are LPT-partitioned over the ranks, each rank works on its share, and the (small) results are exchanged through the
+        caller's all-gather, so that every rank ends with the whole result, bit-identical to a single context's.  The seed pass
+        over the whole genomes and the breakpoint elimination are not partitioned (every rank runs them).
+        allgather(user, send, send_bytes, &recv, recv_bytes[world]): blocking; on return *recv points to the contributions of all
+        ranks one behind the other in rank order (valid until the next call), recv_bytes[r] their sizes; returns 0 on success.
+        world <= 1 or fn == NULL switches the sharding off. ---- */
+typedef int (*mauve_allgather_fn)(void *user, const void *send, int64_t send_bytes, const void **recv, int64_t *recv_bytes);
+int mauve_set_shard(mauve_ctx *ctx, int rank, int world, mauve_allgather_fn fn, void *user);
+
 /* ---- progressiveMauve path: guide tree + ProgressiveAligner::align(seq_table, interval_list)
         (progressiveMauve.cpp:575-710; distance matrix / guide tree mauveAligner.cpp:616-623).  Frozen replacement
         ("guide-tree recursive anchoring"): UPGMA over pairwise-match coverage; the root aligns

@@ -19,7 +19,7 @@ KERNEL_NAMES = ["seed_extract", "rs_hist", "rs_rowscan", "rs_scatter", "mum_join
 # every symbol include/mauve_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = [
     "mauve_ctx_create", "mauve_ctx_destroy", "mauve_last_error", "mauve_device_name", "mauve_synchronize",
-    "mauve_host_alloc", "mauve_host_free",
+    "mauve_host_alloc", "mauve_host_free", "mauve_set_shard",
     "mauve_get_seed", "mauve_seed_length", "mauve_seed_weight", "mauve_default_seed_weight", "mauve_default_scoring",
     "mauve_default_params", "mauve_packed_words", "mauve_pack_ascii", "mauve_pack_codes", "mauve_set_genomes", "mauve_set_genomes_contigs",
     "mauve_ambiguity_bitmap",
@@ -88,6 +88,10 @@ def load():
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+# int (*mauve_allgather_fn)(void *user, const void *send, int64_t send_bytes, const void **recv, int64_t *recv_bytes)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
 
 
 class _PinnedBlock:
@@ -263,6 +267,35 @@ class Context:
         buf = C.create_string_buffer(256)
         self.L.mauve_device_name(self.h, buf, 256)
         return buf.value.decode()
+
+    def set_shard(self, rank, world, allgather=None):
+        """mauve_set_shard: `allgather(payload: bytes-like) -> list of per-rank bytes-like` is the caller's collective (e.g.
+        parallel.make_allgather(dist)); None / world <= 1 switches the sharding off.  The callback object is kept alive here."""
+        if allgather is None or world <= 1:
+            self._shard_cb = None
+            self._chk(self.L.mauve_set_shard(self.h, 0, 1, C.cast(None, ALLGATHER_FN), None), "mauve_set_shard")
+            return
+        state = {"keep": None}
+
+        def cb(user, send, nbytes, recv_out, sizes_out):
+            try:
+                mine = (C.c_char * nbytes).from_address(send) if nbytes else b""
+                parts = allgather(bytes(mine))
+                if len(parts) != world:
+                    return 2
+                blob = b"".join(bytes(x) for x in parts)
+                buf = C.create_string_buffer(blob, max(len(blob), 1))
+                state["keep"] = buf                          # valid until the next call
+                recv_out[0] = C.cast(buf, C.c_void_p).value
+                for r in range(world):
+                    sizes_out[r] = len(parts[r])
+                return 0
+            except Exception as ex:                          # never let an exception cross the C boundary
+                state["error"] = repr(ex)
+                return 1
+        self._shard_cb = ALLGATHER_FN(cb)
+        self._shard_state = state
+        self._chk(self.L.mauve_set_shard(self.h, int(rank), int(world), self._shard_cb, None), "mauve_set_shard")
 
     def synchronize(self):
         self._chk(self.L.mauve_synchronize(self.h), "mauve_synchronize")

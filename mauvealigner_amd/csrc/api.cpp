@@ -53,6 +53,38 @@ int host_genomes(mauve_ctx *c)
     return MAUVE_OK;
 }
 
+int shard_allgather(mauve_ctx *c, const void *send, size_t bytes, std::vector<std::pair<const char *, size_t>> &parts)
+{
+    parts.clear();
+    if (c->shard_world <= 1 || !c->shard_fn) { parts.push_back({static_cast<const char *>(send), bytes}); return MAUVE_OK; }
+    const void *recv = nullptr;
+    std::vector<int64_t> sz((size_t)c->shard_world, 0);
+    const int rc = c->shard_fn(c->shard_user, send, (int64_t)bytes, &recv, sz.data());
+    if (rc || (!recv && bytes)) { c->err = "shard: the caller's all-gather failed (" + std::to_string(rc) + ")"; return MAUVE_ERR_STATE; }
+    const char *p = static_cast<const char *>(recv);
+    for (int r = 0; r < c->shard_world; r++) {
+        if (sz[(size_t)r] < 0) { c->err = "shard: negative size from the all-gather"; return MAUVE_ERR_STATE; }
+        parts.push_back({p, (size_t)sz[(size_t)r]}); p += sz[(size_t)r];
+    }
+    return MAUVE_OK;
+}
+
+void shard_lpt(const std::vector<int64_t> &cost, int world, std::vector<int> &owner)
+{
+    const size_t n = cost.size();
+    owner.assign(n, 0);
+    if (world <= 1) return;
+    std::vector<size_t> idx(n);
+    for (size_t i = 0; i < n; i++) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+    std::vector<int64_t> load((size_t)world, 0);
+    for (size_t i : idx) {
+        int best = 0;
+        for (int r = 1; r < world; r++) if (load[(size_t)r] < load[(size_t)best]) best = r;
+        owner[i] = best; load[(size_t)best] += cost[i] > 0 ? cost[i] : 1;
+    }
+}
+
 extern "C" {
 
 int mauve_ctx_create(int device, mauve_ctx **out)
@@ -128,6 +160,15 @@ int mauve_synchronize(mauve_ctx *c)
 {
     if (!c) return MAUVE_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MAUVE_OK;
+}
+
+int mauve_set_shard(mauve_ctx *c, int rank, int world, mauve_allgather_fn fn, void *user)
+{
+    if (!c) return MAUVE_ERR_ARG;
+    if (world <= 1 || !fn) { c->shard_rank = 0; c->shard_world = 1; c->shard_fn = nullptr; c->shard_user = nullptr; return MAUVE_OK; }
+    if (rank < 0 || rank >= world) { c->err = "set_shard: rank outside the world"; return MAUVE_ERR_ARG; }
+    c->shard_rank = rank; c->shard_world = world; c->shard_fn = fn; c->shard_user = user;
     return MAUVE_OK;
 }
 

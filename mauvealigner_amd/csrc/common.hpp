@@ -298,6 +298,9 @@ struct mauve_ctx {
 
     SpinPool *pool = nullptr;            // host helpers, armed for the duration of an align call (workers.hpp)
 
+    // one alignment spread over several contexts (mauve_set_shard): this rank, their number, the caller's all-gather
+    int shard_rank = 0, shard_world = 1; mauve_allgather_fn shard_fn = nullptr; void *shard_user = nullptr;
+
     AlignResult res;
     AlignState ast;
     mauve_stage_times stage{};
@@ -328,6 +331,10 @@ static inline double now_ms()
 }
 
 // ---- internal entry points between translation units ----
+// the contributions of all ranks to one exchange: parts[r] = (pointer, bytes), valid until the next exchange (api.cpp)
+int shard_allgather(mauve_ctx *c, const void *send, size_t bytes, std::vector<std::pair<const char *, size_t>> &parts);
+// deterministic LPT packing of `cost` into the ranks (ties: lower index first, lower rank first): owner[i] = rank of unit i
+void shard_lpt(const std::vector<int64_t> &cost, int world, std::vector<int> &owner);
 bool make_seed_shape(uint64_t pattern, SeedShape *out);
 GenomeSet main_genome_set(mauve_ctx *ctx);
 int seedpass_run(mauve_ctx *ctx, const GenomeSet &gs, uint64_t pattern, int mode, uint64_t mask, int extend,
@@ -371,7 +378,7 @@ void lcb_greedy(int N, int32_t K, int64_t *weight, const uint32_t *orient_bits, 
 
 // DP (dp_batch.hip)
 int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *sc,
-                      uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells);
+                      uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells, bool may_shard = false);
 // gapped-alignment eligibility of an inter-anchor interval by its longest sequence: full DP up to max_gapped_len, banded
 // DP above it up to max_banded_len
 inline int64_t dp_len_limit(const mauve_params *p) { return p->max_banded_len > p->max_gapped_len ? p->max_banded_len : p->max_gapped_len; }

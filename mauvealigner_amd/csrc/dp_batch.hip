@@ -2240,9 +2240,67 @@ int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, c
 }
 
 int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *scoring,
-                      uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells)
+                      uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells, bool may_shard)
 {
-    std::vector<int64_t> &seq_off = ctx->dph.seq_off; seq_off.resize((size_t)(n_iv * nseq + 1));
+    std::vector<int64_t> &seq_off = ctx->dph.seq_off;
+    if (may_shard && ctx->shard_world > 1 && n_iv >= 2 * ctx->shard_world) {
+        // Several contexts, one alignment (mauve_set_shard): the intervals are LPT-dealt by their cell bound, this rank aligns its
+        // share, and everybody's columns, lengths and scores are exchanged -- [n, cells, len[n], score[n], cols...] per rank.
+        std::vector<int64_t> cost((size_t)n_iv);
+        for (int64_t k = 0; k < n_iv; k++) {
+            int64_t m = 0, cl = 0;
+            for (int g = 0; g < nseq; g++) { const int64_t n = desc[k * nseq + g].len; if (!n) continue; if (!m) { m = n; continue; } cl += m * n; m += n; }
+            cost[(size_t)k] = cl;
+        }
+        std::vector<int> owner; shard_lpt(cost, ctx->shard_world, owner);
+        std::vector<int64_t> mine;
+        for (int64_t k = 0; k < n_iv; k++) if (owner[(size_t)k] == ctx->shard_rank) mine.push_back(k);
+        const int64_t nmine = (int64_t)mine.size();
+        std::vector<DpSeqDesc> sub((size_t)nmine * nseq);
+        int64_t cap = 0;
+        for (int64_t q = 0; q < nmine; q++)
+            for (int g = 0; g < nseq; g++) { sub[(size_t)(q * nseq + g)] = desc[mine[(size_t)q] * nseq + g]; cap += desc[mine[(size_t)q] * nseq + g].len; }
+        std::vector<uint32_t> mcols((size_t)cap + 1); std::vector<int64_t> moff((size_t)nmine + 1, 0), mscore((size_t)nmine + 1, 0);
+        int64_t mcells = 0;
+        seq_off.resize((size_t)(nmine * nseq + 1));
+        { int64_t t = 0; for (int64_t i = 0; i < nmine * nseq; i++) { seq_off[(size_t)i] = t; t += sub[(size_t)i].len; } seq_off[(size_t)(nmine * nseq)] = t; }
+        int rc = dp_core(ctx, nseq, nmine, nullptr, sub.data(), seq_off.data(), scoring, mcols.data(), moff.data(), mscore.data(), &mcells);
+        if (rc) return rc;
+        const int64_t ncol = moff[(size_t)nmine];
+        std::vector<char> msg((size_t)(2 + 2 * nmine) * 8 + (size_t)ncol * 4);
+        int64_t *h = reinterpret_cast<int64_t *>(msg.data());
+        h[0] = nmine; h[1] = mcells;
+        for (int64_t q = 0; q < nmine; q++) { h[2 + q] = moff[(size_t)q + 1] - moff[(size_t)q]; h[2 + nmine + q] = mscore[(size_t)q]; }
+        if (ncol) memcpy(msg.data() + (size_t)(2 + 2 * nmine) * 8, mcols.data(), (size_t)ncol * 4);
+        std::vector<std::pair<const char *, size_t>> parts;
+        rc = shard_allgather(ctx, msg.data(), msg.size(), parts);
+        if (rc) return rc;
+        // lengths first (the offsets of ALL intervals in table order), then every rank's columns to their places
+        std::vector<int64_t> len_of((size_t)n_iv, 0);
+        std::vector<std::vector<int64_t>> ids((size_t)ctx->shard_world);
+        for (int64_t k = 0; k < n_iv; k++) ids[(size_t)owner[(size_t)k]].push_back(k);
+        int64_t total_cells = 0;
+        for (int r = 0; r < ctx->shard_world; r++) {
+            const int64_t *hr = reinterpret_cast<const int64_t *>(parts[(size_t)r].first);
+            if (parts[(size_t)r].second < 16 || hr[0] != (int64_t)ids[(size_t)r].size()) { ctx->err = "dp shard: ranks disagree about the interval table"; return MAUVE_ERR_STATE; }
+            total_cells += hr[1];
+            for (size_t q = 0; q < ids[(size_t)r].size(); q++) { len_of[(size_t)ids[(size_t)r][q]] = hr[2 + q]; if (score) score[ids[(size_t)r][q]] = hr[2 + ids[(size_t)r].size() + q]; }
+        }
+        col_off[0] = 0;
+        for (int64_t k = 0; k < n_iv; k++) col_off[k + 1] = col_off[k] + len_of[(size_t)k];
+        for (int r = 0; r < ctx->shard_world; r++) {
+            const int64_t nr = (int64_t)ids[(size_t)r].size();
+            const uint32_t *cr = reinterpret_cast<const uint32_t *>(parts[(size_t)r].first + (size_t)(2 + 2 * nr) * 8);
+            for (int64_t q = 0; q < nr; q++) {
+                const int64_t k = ids[(size_t)r][(size_t)q];
+                memcpy(cols + col_off[k], cr, (size_t)len_of[(size_t)k] * 4);
+                cr += len_of[(size_t)k];
+            }
+        }
+        if (cells) *cells = total_cells;
+        return MAUVE_OK;
+    }
+    seq_off.resize((size_t)(n_iv * nseq + 1));
     int64_t t = 0;
     for (int64_t i = 0; i < n_iv * nseq; i++) { seq_off[(size_t)i] = t; t += desc[i].len; }
     seq_off[(size_t)(n_iv * nseq)] = t;

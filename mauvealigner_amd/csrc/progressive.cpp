@@ -251,7 +251,7 @@ int prog_node(Prog &P, int node)
     std::vector<int64_t> dcol_off((size_t)n_dp + 1, 0), dscore((size_t)n_dp + 1, 0);
     int64_t cells = 0;
     c->dp_band_from = INT64_MAX;            // the progressive path splits long intervals instead
-    rc = dp_batch_run_desc(c, n, n_dp, desc.data(), &p->scoring, dcols, dcol_off.data(), dscore.data(), &cells);
+    rc = dp_batch_run_desc(c, n, n_dp, desc.data(), &p->scoring, dcols, dcol_off.data(), dscore.data(), &cells, true);   // (several contexts: the node's intervals are dealt out)
     if (rc) return rc;
     P.n_gap_dp += n_dp; P.n_cells += cells;
     { const double tn4 = now_ms(); P.t_seed += tn1 - tn0; P.t_chain += tn2 - tn1; P.t_rec += tn3 - tn2; P.t_dp += tn4 - tn3; }
@@ -325,6 +325,20 @@ int mauve_guide_tree(mauve_ctx *c, uint64_t pattern, int64_t *dist, int32_t *lef
     c->pair_sums_only = false;
     if (rc) return rc;
     std::vector<int64_t> S((size_t)N * N, 0);
+    if (c->shard_world > 1) {
+        // every rank ran the finder passes of its share of the genome pairs (seed_pass.hip): the sums of the others arrive here
+        std::vector<int64_t> mine((size_t)N * N, 0);
+        if (c->pair_sums.size() == mine.size()) mine = c->pair_sums;
+        std::vector<std::pair<const char *, size_t>> parts;
+        rc = shard_allgather(c, mine.data(), mine.size() * 8, parts);
+        if (rc) return rc;
+        c->pair_sums.assign((size_t)N * N, 0);
+        for (const auto &pt : parts) {
+            if (pt.second != mine.size() * 8) { c->err = "guide_tree: ranks disagree about the genome set"; return MAUVE_ERR_STATE; }
+            const int64_t *v = reinterpret_cast<const int64_t *>(pt.first);
+            for (size_t k = 0; k < mine.size(); k++) c->pair_sums[k] += v[k];
+        }
+    }
     if (c->pair_sums.size() == (size_t)N * N)
         for (int a = 0; a < N; a++) for (int b = a + 1; b < N; b++) { S[(size_t)a * N + b] = S[(size_t)b * N + a] = c->pair_sums[(size_t)a * N + b]; }
     std::vector<int64_t> D((size_t)M * M, 0), size((size_t)M, 0);

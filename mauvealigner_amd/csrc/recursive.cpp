@@ -161,10 +161,52 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
         level++;
         for (auto &cls : classes) {
             const int w = cls.first;
-            const std::vector<size_t> &ids = cls.second;
+            // Several contexts, one alignment (mauve_set_shard): the gaps of the batch are LPT-dealt by their size, this rank searches
+            // and chains its share, and what every gap yields -- its new anchors -- is exchanged below, so that every rank goes on with
+            // the same work list.  ids: this rank's gaps; pos_of[k]: their places in the whole batch (the order results are applied in).
+            const std::vector<size_t> &ids_all = cls.second;
+            std::vector<size_t> ids_mine; std::vector<uint32_t> pos_of;
+            const bool sharded = c->shard_world > 1 && ids_all.size() >= (size_t)(2 * c->shard_world);
+            if (sharded) {
+                std::vector<int64_t> cost(ids_all.size(), 0);
+                for (size_t q = 0; q < ids_all.size(); q++)
+                    for (int g = 0; g < N; g++) { int64_t lo, ln; gap_of(work.a(ids_all[q]), work.b(ids_all[q]), g, lo, ln); cost[q] += ln; }
+                std::vector<int> owner; shard_lpt(cost, c->shard_world, owner);
+                for (size_t q = 0; q < ids_all.size(); q++) if (owner[q] == c->shard_rank) { ids_mine.push_back(ids_all[q]); pos_of.push_back((uint32_t)q); }
+            }
+            const std::vector<size_t> &ids = sharded ? ids_mine : ids_all;
+            std::vector<int64_t> shard_msg;                  // per gap of this rank with new anchors: [place in the batch, n, n records]
             const uint32_t K = (uint32_t)ids.size();
             const double tc0 = now_ms();
             const uint64_t pat = mauve_get_seed(w, 0);
+            // what a gap's new anchors (glob: real coordinates, genome-0 order) mean for the next level
+            auto apply_gap = [&](size_t wi, const MatchVec &gl) {
+                const int64_t lcb = work.lcb(wi);
+                for (size_t q = 0; q <= gl.size(); q++)
+                    next.push(lcb, w, q == 0 ? work.a(wi) : gl.rec(q - 1), q == gl.size() ? work.b(wi) : gl.rec(q));
+                for (size_t q = 0; q < gl.size(); q++) found[(size_t)lcb].push(gl.rec(q));
+            };
+            auto exchange = [&]() -> int {
+                if (!sharded) return MAUVE_OK;
+                std::vector<std::pair<const char *, size_t>> parts;
+                int rcx = shard_allgather(c, shard_msg.data(), shard_msg.size() * 8, parts);
+                if (rcx) return rcx;
+                // every rank's gaps, applied in the order of the whole batch
+                std::vector<std::pair<uint32_t, const int64_t *>> got;
+                for (const auto &pt : parts) {
+                    const int64_t *v = reinterpret_cast<const int64_t *>(pt.first), *e = v + pt.second / 8;
+                    while (v < e) { got.push_back({(uint32_t)v[0], v}); v += 2 + v[1] * (1 + N); }
+                }
+                std::sort(got.begin(), got.end(), [](const std::pair<uint32_t, const int64_t *> &x, const std::pair<uint32_t, const int64_t *> &y) { return x.first < y.first; });
+                MatchVec gl(N);
+                for (const auto &gq : got) {
+                    if (gq.first >= ids_all.size()) { c->err = "recursion shard: ranks disagree about the work list"; return MAUVE_ERR_STATE; }
+                    gl.d.assign(gq.second + 2, gq.second + 2 + gq.second[1] * (1 + N));
+                    apply_gap(ids_all[gq.first], gl);
+                }
+                return MAUVE_OK;
+            };
+            if (K == 0) { int rcx = exchange(); if (rcx) return rcx; continue; }      // (a rank without a gap of this class still takes part)
             // ---- virtual genomes: per genome, the gap sub-sequences in LCB orientation, concatenated ----
             GenomeSet vs; vs.buf = &c->rec_genomes; vs.nseq = N; vs.lens.assign(N, 0); vs.word_off.assign(N, 0);
             std::vector<uint32_t> seg((size_t)N * (K + 1));
@@ -274,10 +316,10 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                 }
                 if (glob.empty()) return;
                 glob.sort_by_start0();
-                const int64_t lcb = work.lcb(wi);
-                for (size_t q = 0; q <= glob.size(); q++)
-                    next.push(lcb, w, q == 0 ? work.a(wi) : glob.rec(q - 1), q == glob.size() ? work.b(wi) : glob.rec(q));
-                for (size_t q = 0; q < glob.size(); q++) found[(size_t)lcb].push(glob.rec(q));
+                if (sharded) {
+                    shard_msg.push_back((int64_t)pos_of[k]); shard_msg.push_back((int64_t)glob.size());
+                    shard_msg.insert(shard_msg.end(), glob.d.begin(), glob.d.end());
+                } else apply_gap(wi, glob);
             };
             if (compact) {
                 // only the survivors came back, with their gaps, in list order (gap by gap)
@@ -330,6 +372,7 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                 }
                 emit_gap(k);
             }
+            { int rcx = exchange(); if (rcx) return rcx; }
             if (trace) fprintf(stderr, "[trace]   per-gap chaining %.3f ms (%s; eliminate %.3f, lcb %.3f)\n", now_ms() - tch0, compact ? "device, survivors only" : (dev_chain ? "device" : "host"), t_elim, t_lcb);
         }
         work.d.swap(next.d);

@@ -106,6 +106,49 @@ def reduce_throughput(elapsed_s, base_pairs, dist=None, group=None):
     return float(t.item()), float(b.item())
 
 
+def make_allgather(dist, group=None):
+    """The collective mauve_set_shard asks for, on torch.distributed: one size exchange + one padded all_gather_into_tensor of
+    the byte payload (gloo: host tensors; nccl = RCCL: through one device buffer per rank).  Returns f(bytes) -> [bytes per rank]."""
+    import torch
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+    def allgather(payload):
+        n = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
+        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(sizes, n, group=group)
+        sizes = [int(x) for x in sizes.cpu().tolist()]
+        mx = max(max(sizes), 1)
+        buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
+        if len(payload):
+            buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
+        out = torch.empty(world * mx, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(out, buf, group=group)
+        host = out.cpu().numpy()
+        return [host[r * mx:r * mx + s].tobytes() for r, s in enumerate(sizes)]
+    return allgather
+
+
+def attach_shard(ctx, dist, group=None):
+    """One alignment over the ranks of `dist` (mauve_set_shard): after this, ctx.align / ctx.progressive_align / ctx.guide_tree on
+    every rank (same genomes, same calls) deal out the guide tree's pairwise finder passes, the gaps of every recursion level and
+    the gapped-alignment intervals of the guide-tree nodes, and every rank ends with the whole result."""
+    world = 1 if dist is None else dist.get_world_size(group)
+    if world <= 1:
+        ctx.set_shard(0, 1, None)
+        return
+    ctx.set_shard(dist.get_rank(group), world, make_allgather(dist, group))
+
+
+def progressive_align_sharded(ctx, params=None, dist=None, group=None, **kw):
+    """mauve_progressive_align with the work of one alignment dealt over the ranks (attach_shard)."""
+    attach_shard(ctx, dist, group)
+    try:
+        return ctx.progressive_align(params, **kw)
+    finally:
+        ctx.set_shard(0, 1, None)
+
+
 def align_sharded(ctx, params=None, dist=None, group=None, names=None, want_xmfa=False, fetch=True, out=None):
     """One alignment, its gapped-alignment intervals sharded over the ranks (LCB sharding).
 

@@ -965,3 +965,34 @@ def test_result_ends_with_its_genomes(ctx):
         ctx._fetch(sz_t)
     r = ctx.align(p)
     assert r["n_anchor"] == sz["n_anchor"] and len(r["cols"]) == sz["n_cols"]
+
+
+def test_sharded_contexts(ctx, tmp_path):
+    """mauve_set_shard: two processes (gloo), each with its own context on the GPU, make the same calls on the same genomes; the
+    gaps of every recursion level, the guide tree's pairwise passes and the intervals of the guide-tree nodes are dealt out and
+    exchanged through the caller's all-gather.  Both ranks end with the whole result, bit-identical to a single context's."""
+    import socket, subprocess, sys
+    from mauvealigner_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+    outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.shard_worker", str(r), "2", port, outs[r]], cwd=root,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-3000:]
+    gs = synth.make_config("C5", scale=0.04)
+    ctx.set_genomes(gs)
+    one = ctx.align(_lib.default_params())
+    gs4 = synth.make_config("C4", scale=0.08)
+    ctx.set_genomes(gs4)
+    onep = ctx.progressive_align(_lib.default_params())
+    for o in outs:
+        z = np.load(o)
+        for k in ("anchor_start", "anchor_length", "cols", "col_off", "dp_score", "left", "right"):
+            assert np.array_equal(z["c5_" + k], one[k]), k
+        for k in ("cols", "col_off", "dp_score", "left", "right", "reverse", "dist"):
+            assert np.array_equal(z["c4_" + k], onep[k]), k
+        assert np.array_equal(z["c4_tree"], np.stack(onep["tree"]))
+        # the work really was dealt out: recursion batches at C5; the guide tree's pairs and the nodes' intervals at C4
+        assert z["c5_exchanges"][0] >= 2 and z["c4_exchanges"][0] >= 3, (z["c5_exchanges"], z["c4_exchanges"])

@@ -137,3 +137,45 @@ def test_dp_sharded_world2_gloo():
         assert score == want_score.tolist()
         assert cols == [c.tolist() for c in want_cols]
         assert t == 2.0 and bp == 3000.0          # MAX over ranks, SUM over ranks
+
+
+def _allgather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ag = parallel.make_allgather(dist)
+        out = []
+        for rnd in range(3):                                   # ragged payloads, an empty one among them
+            mine = bytes([rank + 1]) * (0 if (rnd == 1 and rank == 0) else 5 + 7 * rank + rnd)
+            parts = ag(mine)
+            out.append([bytes(p) for p in parts])
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_allgather_world2_gloo():
+    """The collective behind mauve_set_shard (parallel.make_allgather): every rank gets every rank's bytes, in rank order, for
+    payloads of different and of zero length -- the protocol the C side relies on (include/mauve_hip.h: mauve_allgather_fn)."""
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    ps = [ctxm.Process(target=_allgather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert got[0] == got[1]
+    for rnd in range(3):
+        exp = [bytes([r + 1]) * (0 if (rnd == 1 and r == 0) else 5 + 7 * r + rnd) for r in range(2)]
+        assert got[0][rnd] == exp
+
+
+def test_shard_lpt_is_deterministic():
+    """parallel.lpt_partition (the Python twin of the C side's shard_lpt): heaviest first, ties to the lower index / rank."""
+    parts = parallel.lpt_partition([5, 5, 3, 3, 1], 2)
+    assert [p.tolist() for p in parts] == [[0, 2, 4], [1, 3]]
