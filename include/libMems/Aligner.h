@@ -235,6 +235,38 @@ public:
         il.seq_table = ml.seq_table; il.seq_filename = ml.seq_filename;
         il.fetch(hc, seq_count_);
     }
+    // Aligner::align resumed from LCBs (mauveAligner.cpp:705-722: an IntervalList read back with --lcb-input; :723-744 --realign-lcb
+    // hands the matches of each LCB to align() again): every interval of `lcbs` that holds N-way Matches is one chain -- its matches
+    // stay together, no overlap / breakpoint elimination, no LCB extension (the call site passes false) -- and goes through recursive
+    // anchoring and the gapped alignment of its inter-anchor intervals on the device (mauve_align_lcbs).  Intervals without such
+    // matches (already aligned blocks, single-genome islands) are skipped, as the call site's dynamic_cast skips them.
+    void realign(IntervalList &lcbs, IntervalList &il, boolean recursive, boolean gapped)
+    {
+        HipContext &hc = HipContext::global();
+        if (lcbs.seq_table.size() != seq_count_) throw genome::gnException("Aligner::realign: sequence count mismatch");
+        MatchList ml; ml.seq_table = lcbs.seq_table; ml.seq_filename = lcbs.seq_filename;
+        ml.upload(hc);
+        const uint N = seq_count_;
+        std::vector<int64_t> len, st, id;
+        int64_t nl = 0;
+        for (size_t iv = 0; iv < lcbs.size(); iv++) {
+            bool any = false;
+            for (AbstractMatch *am : lcbs[iv].GetMatches()) {
+                Match *m = dynamic_cast<Match *>(am);
+                if (!m || m->Multiplicity() < N) continue;
+                Match mm(*m);
+                if (mm.Start(0) < 0) mm.Invert();               // anchors are forward in genome 0
+                len.push_back((int64_t)mm.Length()); id.push_back(nl); any = true;
+                for (uint g = 0; g < N; g++) st.push_back(mm.Start(g));
+            }
+            if (any) nl++;
+        }
+        mauve_params p = p_;
+        p.recursive = recursive; p.gapped = gapped; p.extend_lcbs = 0;
+        hc.check(mauve_align_lcbs(hc.get(), &p, (int64_t)len.size(), len.data(), st.data(), id.data(), &il.sizes), "mauve_align_lcbs");
+        il.seq_table = lcbs.seq_table; il.seq_filename = lcbs.seq_filename;
+        il.fetch(hc, seq_count_);
+    }
 private:
     // the LCB sets of the N-way matches between perm_weight_ and LCB_size (the chain align() runs, before recursion)
     void write_permutations(const std::vector<int64_t> &len_in, const std::vector<int64_t> &st_in, int64 LCB_size)

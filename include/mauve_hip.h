@@ -216,6 +216,14 @@ int mauve_align(mauve_ctx *ctx, const mauve_params *p, mauve_align_sizes *sizes)
    length[n], start[n*nseq] signed 1-based. */
 int mauve_align_matches(mauve_ctx *ctx, const mauve_params *p, int64_t n, const int64_t *length, const int64_t *start,
                         mauve_align_sizes *sizes);
+/* The same resumed from LCBs the caller holds (an IntervalList read back from the .mln file of an earlier run, mauveAligner.cpp:
+   705-722 --lcb-input; the matches of one LCB given to Aligner::align again, :723-744 --realign-lcb): anchor i has length[i],
+   start[i*nseq + g] (signed 1-based, a component in every genome, forward in genome 0) and belongs to LCB lcb[i] (ids 0 .. n_lcb-1).
+   The anchors of an LCB must form one collinear, overlap-free chain.  No seed pass, no overlap / breakpoint elimination, no LCB
+   extension: recursive anchoring (p->recursive) and the gapped alignment of every inter-anchor interval (p->gapped) run as in
+   mauve_align; n_mums of the result is 0. */
+int mauve_align_lcbs(mauve_ctx *ctx, const mauve_params *p, int64_t n, const int64_t *length, const int64_t *start, const int64_t *lcb,
+                     mauve_align_sizes *sizes);
 int mauve_align_fetch(mauve_ctx *ctx,
                       int64_t *mum_length, int64_t *mum_start,            /* [n_mums], [n_mums*nseq] */
                       int64_t *lcb_left, int64_t *lcb_right, int64_t *lcb_weight, /* [n_lcb*nseq] x2, [n_lcb] */

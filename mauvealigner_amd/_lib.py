@@ -25,7 +25,7 @@ EXPORTS = [
     "mauve_ambiguity_bitmap",
     "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_extend_hits", "mauve_seed_match_enumerate",
     "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_dp_batch_banded", "mauve_match_sp_scores", "mauve_align", "mauve_align_fetch",
-    "mauve_align_matches", "mauve_align_begin", "mauve_align_begin_matches", "mauve_align_dp_anchors", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
+    "mauve_align_matches", "mauve_align_lcbs", "mauve_align_begin", "mauve_align_begin_matches", "mauve_align_dp_anchors", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
     "mauve_guide_tree", "mauve_progressive_align", "mauve_progressive_align_tree",
     "mauve_backbone", "mauve_backbone_alignment", "mauve_backbone_fetch", "mauve_merge_matches",
     "mauve_write_xmfa", "mauve_profile_enable", "mauve_profile_reset", "mauve_profile_get", "mauve_last_stage_times",
@@ -368,6 +368,19 @@ class Context:
         sz = AlignSizes()
         self._chk(self.L.mauve_align_matches(self.h, C.byref(p), C.c_int64(len(length)), _p(length, C.c_int64), _p(start, C.c_int64),
                                              C.byref(sz)), "mauve_align_matches")
+        if not fetch:
+            return {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
+        return self._fetch(sz, names, want_xmfa)
+
+    def align_lcbs(self, params, length, start, lcb, fetch=True, names=None, want_xmfa=False):
+        """Aligner::align resumed from the caller's LCBs (mauve_align_lcbs): recursion + gapped alignment only"""
+        p = params or default_params()
+        length = np.ascontiguousarray(length, dtype=np.int64)
+        start = np.ascontiguousarray(start, dtype=np.int64)
+        lcb = np.ascontiguousarray(lcb, dtype=np.int64)
+        sz = AlignSizes()
+        self._chk(self.L.mauve_align_lcbs(self.h, C.byref(p), C.c_int64(len(length)), _p(length, C.c_int64), _p(start, C.c_int64),
+                                          _p(lcb, C.c_int64), C.byref(sz)), "mauve_align_lcbs")
         if not fetch:
             return {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
         return self._fetch(sz, names, want_xmfa)

@@ -678,38 +678,54 @@ static int align_finish(mauve_ctx *c, const uint32_t *dcols, const int64_t *dcol
     return MAUVE_OK;
 }
 
-extern "C" {
-
-int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
+// Aligner::align resumed from a list of LCBs (an IntervalList read back from an .mln file, mauveAligner.cpp:705-722; the matches
+// of one LCB handed to Aligner::align again, :723-744 --realign-lcb): the chains are the caller's, no seed pass, no overlap
+// elimination, no breakpoint elimination, no LCB extension; recursive anchoring and the gapped alignment of every inter-anchor
+// interval run as in mauve_align.
+static int align_begin_lcbs(mauve_ctx *c, const mauve_params *p, std::vector<MatchVec> &lcbs)
 {
-    if (!c || !p || !sizes) return MAUVE_ERR_ARG;
-    if (c->nseq < 2) { c->err = "align: at least two genomes required"; return MAUVE_ERR_STATE; }
-    HIPCHK(c, hipSetDevice(c->device));
-    static const bool host_front = getenv("MAUVE_HOST_DP_FRONT") != nullptr;      // A/B switch
-    static const bool no_shadow = getenv("MAUVE_NO_SHADOW") != nullptr;
-    int rc = align_begin(c, p, !host_front, nullptr, !host_front);
-    if (rc) return rc;
+    const int N = c->nseq;
     AlignState &S = c->ast;
+    S.reset();
+    S.p = *p; S.N = N; S.t0 = now_ms();
+    AlignResult &R = c->res;
+    R.sz = mauve_align_sizes();
+    R.mum_length.clear(); R.mum_start.clear(); R.lcb_left.clear(); R.lcb_right.clear(); R.lcb_weight.clear();
+    R.anchor_length.clear(); R.anchor_start.clear(); R.anchor_lcb.clear(); R.iv_left.clear(); R.iv_right.clear();
+    R.iv_reverse.clear(); R.col_off.clear(); R.n_cols = 0; R.dp_score.clear();
+    R.dev_pending = false; R.cols_pending = false; R.stale = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr;
+    memset(&c->stage, 0, sizeof c->stage);
+    c->shadow = nullptr;
+    int64_t sum = 0; for (int g = 0; g < N; g++) sum += c->lens[g];
+    S.sum = sum;
+    int w = p->seed_weight > 0 ? p->seed_weight : mauve_default_seed_weight(sum / N);
+    if (p->seed_pattern) w = mauve_seed_weight(p->seed_pattern);
+    S.full = N >= 32 ? 0xffffffffu : ((1u << N) - 1);
+    S.nm = 0; S.nl = (int64_t)lcbs.size();
+    S.chains.swap(lcbs);
+    R.lcb_weight.assign((size_t)S.nl, 0);
+    for (int64_t l = 0; l < S.nl; l++) for (size_t i = 0; i < S.chains[(size_t)l].size(); i++) R.lcb_weight[(size_t)l] += S.chains[(size_t)l].len(i) * N;
+    const double t2 = now_ms();
+    if (p->recursive) { const int rc = recursive_anchoring(c, p, w, S.chains, N, nullptr); if (rc) return rc; }
+    c->stage.recurse_ms = now_ms() - t2;
+    for (int64_t l = 0; l < S.nl; l++) {
+        const MatchVec &ch = S.chains[(size_t)l];
+        S.n_anchor += (int64_t)ch.size();
+        for (size_t i = 0; i < ch.size(); i++) S.anchor_cols += ch.len(i);
+    }
+    S.t_dp0 = now_ms();
+    S.open = true;
+    return MAUVE_OK;
+}
+
+// The chains are on the host (S.chains: recursion, LCB extension, a small or tied list, a caller's LCBs): the anchors go up
+// once, interval table, DP and -- unless MAUVE_HOST_TAIL -- the assembly run on the device.
+static int align_tail_host_chains(mauve_ctx *c, mauve_align_sizes *sizes)
+{
+    AlignState &S = c->ast;
+    static const bool no_shadow = getenv("MAUVE_NO_SHADOW") != nullptr;
     int64_t cells = 0;
-    if (S.dev_tail) {
-        // chains, DP and assembly on the device: anchors from chain_order_device, results left in HBM until they are fetched
-        const int32_t *d_len = S.dv_len, *d_st = S.dv_st, *d_lcb = S.dv_lcb;
-        c->dp_band_from = dp_band_from_of(&S.p);
-        rc = dp_run_from_anchors(c, S.N, S.n_anchor, d_len, d_st, d_lcb, S.p.gapped, dp_len_limit(&S.p), &S.p.scoring, nullptr, &S.n_dp, &S.code_total,
-                                 nullptr, S.dcol_off, S.dscore, &cells, 1);
-        if (rc) return rc;
-        return assemble_device(c, S.n_anchor, cells, sizes);
-    }
-    if (host_front) {
-        HIPCHK(c, c->pin_dcols.ensure(((size_t)S.code_total + 1) * sizeof(uint32_t)));
-        uint32_t *dcols = c->pin_dcols.as<uint32_t>();
-        S.dcol_off.assign((size_t)S.n_dp + 1, 0); S.dscore.assign((size_t)S.n_dp + 1, 0);
-        if (!no_shadow && S.n_dp) c->shadow = [c]() { fill_anchor_table(c); };       // runs while the DP kernels do
-        rc = align_dp(c, nullptr, S.n_dp, dcols, S.dcol_off.data(), S.dscore.data(), &cells);
-        c->shadow = nullptr;
-        if (rc) return rc;
-        return align_finish(c, dcols, S.dcol_off.data(), S.dscore.data(), cells, sizes);
-    }
+    int rc;
     // the anchors in chain order as flat int32 records (page-locked), then everything up to the DP columns on the device
     const int N = S.N; const int64_t na = S.n_anchor;
     HIPCHK(c, c->pin_anch.ensure((size_t)na * (3 + (size_t)N) * 4 + 64));
@@ -757,6 +773,80 @@ int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
     }
     S.dscore.push_back(0);
     return align_finish(c, c->pin_dcols.as<uint32_t>(), S.dcol_off.data(), S.dscore.data(), cells, sizes);
+}
+
+extern "C" {
+
+int mauve_align(mauve_ctx *c, const mauve_params *p, mauve_align_sizes *sizes)
+{
+    if (!c || !p || !sizes) return MAUVE_ERR_ARG;
+    if (c->nseq < 2) { c->err = "align: at least two genomes required"; return MAUVE_ERR_STATE; }
+    HIPCHK(c, hipSetDevice(c->device));
+    static const bool host_front = getenv("MAUVE_HOST_DP_FRONT") != nullptr;      // A/B switch
+    static const bool no_shadow = getenv("MAUVE_NO_SHADOW") != nullptr;
+    int rc = align_begin(c, p, !host_front, nullptr, !host_front);
+    if (rc) return rc;
+    AlignState &S = c->ast;
+    int64_t cells = 0;
+    if (S.dev_tail) {
+        // chains, DP and assembly on the device: anchors from chain_order_device, results left in HBM until they are fetched
+        const int32_t *d_len = S.dv_len, *d_st = S.dv_st, *d_lcb = S.dv_lcb;
+        c->dp_band_from = dp_band_from_of(&S.p);
+        rc = dp_run_from_anchors(c, S.N, S.n_anchor, d_len, d_st, d_lcb, S.p.gapped, dp_len_limit(&S.p), &S.p.scoring, nullptr, &S.n_dp, &S.code_total,
+                                 nullptr, S.dcol_off, S.dscore, &cells, 1);
+        if (rc) return rc;
+        return assemble_device(c, S.n_anchor, cells, sizes);
+    }
+    if (host_front) {
+        HIPCHK(c, c->pin_dcols.ensure(((size_t)S.code_total + 1) * sizeof(uint32_t)));
+        uint32_t *dcols = c->pin_dcols.as<uint32_t>();
+        S.dcol_off.assign((size_t)S.n_dp + 1, 0); S.dscore.assign((size_t)S.n_dp + 1, 0);
+        if (!no_shadow && S.n_dp) c->shadow = [c]() { fill_anchor_table(c); };       // runs while the DP kernels do
+        rc = align_dp(c, nullptr, S.n_dp, dcols, S.dcol_off.data(), S.dscore.data(), &cells);
+        c->shadow = nullptr;
+        if (rc) return rc;
+        return align_finish(c, dcols, S.dcol_off.data(), S.dscore.data(), cells, sizes);
+    }
+    return align_tail_host_chains(c, sizes);
+}
+
+int mauve_align_lcbs(mauve_ctx *c, const mauve_params *p, int64_t n, const int64_t *length, const int64_t *start, const int64_t *lcb, mauve_align_sizes *sizes)
+{
+    if (!c || !p || !sizes) return MAUVE_ERR_ARG;
+    if (c->nseq < 2) { c->err = "align_lcbs: at least two genomes required"; return MAUVE_ERR_STATE; }
+    if (n < 0 || (n && (!length || !start || !lcb))) { c->err = "align_lcbs: bad anchor list"; return MAUVE_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rcm = materialize_tables(c); if (rcm) return rcm; }
+    const int N = c->nseq;
+    int64_t nl = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (lcb[i] < 0 || lcb[i] >= n) { c->err = "align_lcbs: LCB ids must be 0 .. n_lcb-1"; return MAUVE_ERR_ARG; }
+        nl = std::max(nl, lcb[i] + 1);
+        if (length[i] <= 0) { c->err = "align_lcbs: anchor of length <= 0"; return MAUVE_ERR_ARG; }
+        for (int g = 0; g < N; g++) {
+            const int64_t s = start[i * N + g];
+            if (!s) { c->err = "align_lcbs: anchors have a component in every genome"; return MAUVE_ERR_ARG; }
+            if (std::llabs(s) + length[i] - 1 > c->lens[(size_t)g]) { c->err = "align_lcbs: anchor outside its genome"; return MAUVE_ERR_ARG; }
+        }
+        if (start[i * N] < 0) { c->err = "align_lcbs: anchors are forward in genome 0 (Match::Invert them first)"; return MAUVE_ERR_ARG; }
+    }
+    std::vector<MatchVec> chains((size_t)nl, MatchVec(N));
+    for (int64_t i = 0; i < n; i++) chains[(size_t)lcb[i]].push(length[i], start + i * N);
+    for (int64_t l = 0; l < nl; l++) {
+        MatchVec &ch = chains[(size_t)l];
+        if (ch.empty()) { c->err = "align_lcbs: an LCB id without anchors"; return MAUVE_ERR_ARG; }
+        ch.sort_by_start0();
+        // one collinear chain: the same strand relation all along, and in every genome the anchors follow each other without overlap
+        for (size_t i = 0; i + 1 < ch.size(); i++)
+            for (int g = 0; g < N; g++) {
+                const int64_t a = ch.st(i)[g], b = ch.st(i + 1)[g];
+                const bool ok = (a > 0) == (b > 0) && (a > 0 ? a + ch.len(i) <= b : -b + ch.len(i + 1) <= -a);
+                if (!ok) { c->err = "align_lcbs: the anchors of an LCB must be collinear and free of overlaps"; return MAUVE_ERR_ARG; }
+            }
+    }
+    int rc = align_begin_lcbs(c, p, chains);
+    if (rc) return rc;
+    return align_tail_host_chains(c, sizes);
 }
 
 // Aligner::align(MatchList&, ...) with the caller's own match list: chaining, recursion and gapped alignment as in

@@ -996,3 +996,33 @@ def test_sharded_contexts(ctx, tmp_path):
         assert np.array_equal(z["c4_tree"], np.stack(onep["tree"]))
         # the work really was dealt out: recursion batches at C5; the guide tree's pairs and the nodes' intervals at C4
         assert z["c5_exchanges"][0] >= 2 and z["c4_exchanges"][0] >= 3, (z["c5_exchanges"], z["c4_exchanges"])
+
+
+def test_align_lcbs_resumes_from_an_lcb_table(ctx):
+    """mauve_align_lcbs (--lcb-input / --realign-lcb, mauveAligner.cpp:705-744): from the LCB table -- the anchors of a run without
+    recursion and gapped alignment, with their LCB ids -- recursion and gapped alignment give the alignment of the whole call;
+    begun from the ORACLE's LCB table they give the oracle's whole alignment.  A list that is not a set of collinear chains is
+    refused."""
+    from mauvealigner_amd import _lib
+    keys = ("anchor_start", "anchor_length", "anchor_lcb", "lcb_weight", "left", "right", "reverse", "col_off", "cols", "dp_score")
+    for cfg, scale, kw in (("C3", 0.03, {}), ("C5", 0.02, {}), ("C3", 0.4, {"seed_weight": 15})):
+        gs = synth.make_config(cfg, scale=scale)
+        ctx.set_genomes(gs)
+        whole = ctx.align(_lib.default_params(**kw))
+        tab = ctx.align(_lib.default_params(recursive=0, gapped=0, **kw))          # seed pass, chaining and LCB extension only
+        res = ctx.align_lcbs(_lib.default_params(**kw), tab["anchor_length"], tab["anchor_start"], tab["anchor_lcb"])
+        for k in keys:
+            assert np.array_equal(res[k], whole[k]), (cfg, k)
+        assert res["n_mums"] == 0 and res["n_dp_cells"] == whole["n_dp_cells"]
+        if scale <= 0.03:                                                           # ... and from the oracle's table (its own restart)
+            ot = O.align(gs, O.default_params(recursive=0, gapped=0, **kw))["aln"]
+            ow = O.align(gs, O.default_params(**kw))["aln"]
+            perm = np.random.default_rng(3).permutation(len(ot["anchor_length"]))   # any order
+            res = ctx.align_lcbs(_lib.default_params(**kw), ot["anchor_length"][perm], ot["anchor_start"][perm], ot["anchor_lcb"][perm])
+            for k in ("anchor_start", "anchor_length", "anchor_lcb", "left", "right", "reverse", "col_off", "cols", "dp_score"):
+                assert np.array_equal(res[k], ow[k]), (cfg, k)
+    ln, st, lc = tab["anchor_length"].copy(), tab["anchor_start"].copy(), tab["anchor_lcb"].copy()
+    st[1], st[0] = st[0].copy(), st[1].copy()                                       # two anchors of a chain swapped in every genome but the first...
+    st[0, 0], st[1, 0] = st[1, 0], st[0, 0]
+    with pytest.raises(RuntimeError, match=r"\(-1\)"):
+        ctx.align_lcbs(_lib.default_params(), ln, st, lc)
