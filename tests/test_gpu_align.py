@@ -471,7 +471,7 @@ def test_golden_alignment(ctx, name):
         assert f.read() == r["xmfa"]
 
 
-@pytest.mark.parametrize("cfg,scale", [("C1", 0.25), ("C2", 0.02), ("C3", 0.03), ("C4", 0.02)])
+@pytest.mark.parametrize("cfg,scale", [("C1", 1.0), ("C2", 0.02), ("C3", 0.03), ("C4", 0.02)])     # C1: BASELINE config 1 at its full size (2 x 200 kbp), XMFA text included
 def test_align_equals_oracle(ctx, cfg, scale):
     gs = synth.make_config(cfg, scale=scale)
     _same_align(ctx, gs, recursive=0)

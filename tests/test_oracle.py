@@ -703,3 +703,35 @@ def test_sp_scoring_oracle():
     assert e1["lcbs"]["n_lcb"] >= 1
     ml, ms = e1["aln"]["anchor_length"], e1["aln"]["anchor_start"]
     assert int(e1["lcbs"]["weight"].sum()) > int(e0["lcbs"]["weight"].sum())       # scores (~95 per pair and column) against lengths
+
+
+def test_c1_full_size_plumbing():
+    """BASELINE config 1 at its full size (2 x 200 kbp, default seed weight, XMFA out) through the CPU restatement: every base of
+    both genomes in exactly one interval, the rows of the XMFA text spell the genomes, the text parses back into the same
+    intervals (the same checks the GPU suite makes at this size, tests/test_gpu_align.py::test_align_equals_oracle[C1-1.0])."""
+    gs = synth.make_config("C1", scale=1.0)
+    names = ["c1a.fas", "c1b.fas"]
+    r = O.align(gs, O.default_params(), names=names, want_xmfa=True)
+    a = r["aln"]
+    assert r["lcbs"]["n_lcb"] >= 1 and len(a["anchor_length"]) > 300
+    N = 2
+    for g in range(N):
+        cover = np.zeros(len(gs[g]) + 1, np.int64)
+        pres = a["left"][:, g] != 0
+        np.add.at(cover, a["left"][pres, g] - 1, 1); np.add.at(cover, a["right"][pres, g], -1)
+        assert np.all(np.cumsum(cover)[:-1] == 1)
+    # the XMFA text: one block per interval, rows without gaps equal the genome stretch (reverse rows: reverse complement)
+    blocks = r["xmfa"].split("=\n")[:-1]
+    assert len(blocks) == a["n_iv"]
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    for blk in blocks[:50] + blocks[-5:]:
+        rows = blk.split(">")[1:]
+        for row in rows:
+            head, *lines = row.split("\n")
+            g = int(head.split(":")[0]) - 1
+            lo, hi = [int(x) for x in head.split(":")[1].split()[0].split("-")]
+            seq = "".join(lines).replace("-", "")
+            want = _asc(gs[g])[lo - 1:hi]
+            if " - " in head:
+                want = "".join(comp[ch] for ch in reversed(want))
+            assert seq == want

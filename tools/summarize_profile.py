@@ -91,7 +91,7 @@ def main():
     dur = {}
     for r in trace:
         dur.setdefault(klass(r, mx, "Grid_Size_X"), []).append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
-    passes = len(dur.get("dp_step", [])) or 1
+    passes = len(dur.get("dp_step2", []) or dur.get("dp_step", [])) or 1
     total = sum(sum(v) for v in dur.values())
     fetch = read_pmc(src, "pmc_fetch", ("FETCH_SIZE",))
     write = read_pmc(src, "pmc_write", ("WRITE_SIZE",))
@@ -102,8 +102,8 @@ def main():
     traffic = {}
     lines = ["# rocprofv3 summary, round %s" % tag, "",
              "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
-             "--no-cpu-baseline --no-secondary` (%d passes of the hot path in the process: warmup, timed, HIP-event, "
-             "fetch-inclusive and H2D-inclusive legs, all over BASELINE config C3, 5 x 5 Mbp, w = 15, P = %d windows).  PMC "
+             "--no-cpu-baseline --no-secondary` (%d passes of the hot path in the process: warmup, timed host-to-host, device-resident and HIP-event "
+             "legs, all over BASELINE config C3, 5 x 5 Mbp, w = 15, P = %d windows).  PMC "
              "passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and `--pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES "
              "SQ_WAIT_ANY`, separate runs (tools/profile_gpu.sh).  The raw `--stats` table is %s_kernel_stats.csv; the table "
              "below is built from the kernel trace of the same run so that the main sort and the ~20 small sorts per pass "
@@ -138,6 +138,16 @@ def main():
               "Bench line of the profiled run:", "", "```json", json.dumps(bench), "```"]
     with open(os.path.join(DST, "%s_summary.md" % tag), "w") as f:
         f.write("\n".join(lines) + "\n")
+    # bench.py quotes roofline.traffic from this file only while the kernel sources are the ones that were profiled
+    sys.path.insert(0, ROOT)
+    import subprocess
+    from bench import kernel_source_digest
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        commit = "?"
+    traffic["_meta"] = {"round": tag, "commit": commit, "kernel_source_digest": kernel_source_digest(),
+                        "command": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"}
     with open(os.path.join(DST, "roofline_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
     shutil.copy(stats, os.path.join(DST, "%s_kernel_stats.csv" % tag))
