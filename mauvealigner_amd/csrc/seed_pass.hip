@@ -669,6 +669,82 @@ __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, 
 }
 
 // hits found by a host-side finder (mauve_extend_hits): record h = {component set, value of genome 0 .. N-1} -> hit table
+// ---- tiny passes: extract + group + rule in ONE workgroup ------------------------------------------------------------------
+// A seed pass over a few thousand windows (a round of the LCB extension over the pieces between the LCBs, a small guide-tree
+// node) spends its time in launches: count, scan, extract, four sort passes, bounds, join -- a dozen kernels of 5-20 us each
+// for a few kilobytes.  Here one workgroup of 1024 threads computes the canonical mers of ALL valid windows, groups them in an
+// LDS hash table (compare-and-swap claim, linear probing; the same once / multi genome sets and the same finder rule as
+// join_hash) and writes the hit table -- no key array, no sort.  <= TJ_MAX windows, <= 16 genomes, mers of <= 32 bits.
+constexpr int TJ_SLOTS = 16384;                  // 128 KB of LDS: key word + genome sets per slot
+constexpr int TJ_MAX = 9216;                     // load factor <= 0.5625
+constexpr int TJ_ROWS = TJ_MAX / 1024;
+__global__ void __launch_bounds__(1024) tiny_join(const uint64_t *__restrict__ packed, GenomeTab tab, SeedShape sh, uint32_t P,
+                                                  const uint64_t *__restrict__ vmask, const uint64_t *__restrict__ cmask, int mode, uint32_t want_mask,
+                                                  uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos, uint32_t *__restrict__ err_cnt)
+{
+    extern __shared__ uint32_t tj_lds[];
+    uint32_t *skey = tj_lds, *som = tj_lds + TJ_SLOTS;
+    constexpr uint32_t EMPTY = 0xffffffffu;       // never a canonical mer (the smaller of a mer and its reverse complement)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < TJ_SLOTS; i += 1024) { skey[i] = EMPTY; som[i] = 0; }
+    uint32_t v[TJ_ROWS], slot[TJ_ROWS], gbit[TJ_ROWS], key[TJ_ROWS];
+#pragma unroll
+    for (int r = 0; r < TJ_ROWS; r++) {
+        const uint32_t gp = (uint32_t)r * 1024u + (uint32_t)tid;
+        key[r] = EMPTY; v[r] = 0; gbit[r] = 0;
+        if (!window_valid(gp, P, tab, sh.span, vmask, cmask)) continue;
+        const int g = genome_of(gp, tab);
+        const uint32_t p = gp - tab.gpos_off[g];
+        uint32_t k, sflag;
+        if (sh.span <= 32 && sh.weight <= 15) {
+            const uint32_t kp = kprime_narrow(packed + tab.word_off[g], p, sh);
+            const uint32_t f = digit_reverse32(kp, sh.weight), rr = (~kp) & (uint32_t)sh.keymask;
+            sflag = rr < f; k = sflag ? rr : f;
+        } else {
+            const uint64_t kp = kprime_at(packed + tab.word_off[g], p, sh);
+            const uint64_t f = digit_reverse(kp, sh.weight), rr = (~kp) & sh.keymask;
+            sflag = rr < f; k = (uint32_t)(sflag ? rr : f);
+        }
+        key[r] = k; v[r] = gp | (sflag << 31); gbit[r] = 1u << g;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TJ_ROWS; r++) {
+        slot[r] = EMPTY;
+        if (key[r] == EMPTY) continue;
+        uint32_t sl = (key[r] * 0x9E3779B1u) >> 18;          // 14 bits
+        for (;;) {
+            const uint32_t old = atomicCAS(&skey[sl], EMPTY, key[r]);
+            if (old == EMPTY || old == key[r]) break;
+            sl = (sl + 1) & (TJ_SLOTS - 1);
+        }
+        const uint32_t old = atomicOr(&som[sl], gbit[r]);
+        if (old & gbit[r]) atomicOr(&som[sl], gbit[r] << 16);
+        slot[r] = sl;
+    }
+    __syncthreads();
+    uint32_t mm[TJ_ROWS];
+#pragma unroll
+    for (int r = 0; r < TJ_ROWS; r++) {
+        mm[r] = 0;
+        if (slot[r] == EMPTY) continue;
+        const uint32_t om = som[slot[r]], once = om & 0xffffu, multi = om >> 16, m = once & ~multi;
+        if (mode == MAUVE_MODE_MEM && multi) continue;
+        if (__popc(m) < 2 || (want_mask && m != want_mask) || !(m & gbit[r])) continue;
+        mm[r] = m;
+        if ((m & (0u - m)) == gbit[r]) skey[slot[r]] = v[r];          // grouping is over: the slot's mer makes room for the anchor
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TJ_ROWS; r++) {
+        if (!mm[r]) continue;
+        const uint32_t ap = skey[slot[r]] & 0x7fffffffu;
+        if (ap >= P) { atomicAdd(err_cnt, 1u); continue; }     // cannot happen (the anchor is one of the group's own windows)
+        tpos[(size_t)ap * tab.nseq + (__ffs(gbit[r]) - 1)] = v[r];
+        if ((mm[r] & (0u - mm[r])) == gbit[r]) tmask[ap] = mm[r];
+    }
+}
+
 __global__ void __launch_bounds__(256) hits_scatter(const uint32_t *__restrict__ rec, uint32_t nh, int N, uint32_t P,
                                                     uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos)
 {
@@ -1233,7 +1309,11 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         if (SEG) G = std::max(G, (segbits + 7) / 8 * 8);
         return full_bits - std::min(G, full_bits);
     };
+    // a pass of a few thousand windows: no key arrays at all (tiny_join).  MAUVE_NO_TINY: A/B switch
+    static const bool no_tiny = getenv("MAUVE_NO_TINY") != nullptr;
+    const bool tiny = hash_path && !SEG && only_seq < 0 && !no_tiny && n <= (uint32_t)TJ_MAX && tab.nseq <= 16 && 2 * sh.weight <= 32;
     if (hh) sorted_n = 1;
+    else if (tiny) sorted_n = n;
     else if (only_seq < 0 && masked && !SEG) {
         // masked pass: only the valid windows go into the sort (see valid_count / seed_extract_compact)
         const uint32_t nblk = (n + 4095) / 4096;
@@ -1286,7 +1366,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     const int has_invalid = masked && !compacted;
     const uint32_t ns = sorted_n;                   // entries of the sorted list (all windows, or the valid ones)
     const int L = low_bits(ns);                     // the passes order bits [L, key_bits); 0 = full sort
-    int rc = hh ? MAUVE_OK : sort_pairs<KeyT>(ctx, sorted_n, key_bits, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>(), have_hist0, -1, L);
+    int rc = (hh || tiny) ? MAUVE_OK : sort_pairs<KeyT>(ctx, sorted_n, key_bits, &keys, &vals, ctx->keysB.as<KeyT>(), ctx->valsB.as<uint32_t>(), have_hist0, -1, L);
     if (rc) return rc;
     TRACE(ctx, "sort");
 
@@ -1386,6 +1466,12 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             if (nruns)
                 hipLaunchKernelGGL(join_pair, dim3((nruns + 255) / 256), dim3(256), 0, ctx->stream, vals, tab, rstart, rlen, runiq, nruns,
                                    __builtin_ctz(fp.consider), 31 - __builtin_clz(fp.consider), tmask, tpos);
+        } else if (tiny) {
+            static const bool tj_attr = []() { return hipFuncSetAttribute(reinterpret_cast<const void *>(tiny_join), hipFuncAttributeMaxDynamicSharedMemorySize, TJ_SLOTS * 8) == hipSuccess; }();
+            if (!tj_attr) { ctx->err = "tiny_join: cannot reserve its LDS"; return MAUVE_ERR_HIP; }
+            KernelTimer t(ctx, MAUVE_K_JOIN, P);
+            hipLaunchKernelGGL(tiny_join, dim3(1), dim3(1024), TJ_SLOTS * 8, ctx->stream, packed, tab, sh, P, vmask, cmask, fp.rule, fp.want, tmask, tpos,
+                               ctx->counters.as<uint32_t>() + 9);
         } else if (hash_path) {
             const uint32_t nchunk = (ns + HJ_T - 1) / HJ_T;
             HIPCHK(ctx, ctx->join_ovf.ensure((2 + 2 * (size_t)HJ_OVF_CAP) * 4));        // the ranges; their count sits in the counter block (words 8, 9)
@@ -1415,7 +1501,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 48, hipMemcpyDeviceToHost, ctx->stream));     // run counters + join_hash's overflow count
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         uint32_t nc = ctx->pin_seed.as<uint32_t>()[1];
-        const uint32_t novf = hash_path ? ctx->pin_seed.as<uint32_t>()[8] : 0u;
+        const uint32_t novf = hash_path && !tiny ? ctx->pin_seed.as<uint32_t>()[8] : 0u;
         if (hash_path && ctx->pin_seed.as<uint32_t>()[9]) { ctx->err = "join_hash: anchor out of range (internal error)"; return MAUVE_ERR_HIP; }
         if (novf) {
             // ranges join_hash declined (a bucket beyond its LDS table): full sort + serial join of each slice, or of
