@@ -283,7 +283,9 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
     // LCB extension without taking the chains off the device (extend_dev.hip): plain genomes, length-weighted LCBs.  MAUVE_HOST_EXTEND: A/B switch
     static const bool host_extend = getenv("MAUVE_HOST_EXTEND") != nullptr;
     const bool do_extend = p->extend_lcbs && p->lcb_scoring == MAUVE_LCB_SCORE_LENGTH;      // (score-weighted LCBs are not extended: the rule counts columns)
-    const bool ext_on_device = do_extend && !host_extend && !c->has_invalid && !c->has_contigs;
+    // (collinear: the greedy step runs down to ONE node, so an old LCB can lose against the new matches -- the unit-level re-chaining
+    //  of extend_dev.hip assumes old LCBs survive; that rare option takes the host rounds)
+    const bool ext_on_device = do_extend && !host_extend && !c->has_invalid && !c->has_contigs && !p->collinear;
     bool chains_ready = false;                       // S.chains filled from the device anchors (extension done there, recursion to follow on the host)
     MatchVec family(N);
     if (!given && p->seed_family) {

@@ -951,6 +951,16 @@ def test_lcb_extension_on_the_device(ctx):
     assert r1["n_mums"] > 16384
 
 
+def test_collinear_extension_takes_the_host_rounds(ctx):
+    """--collinear (mauveAligner.cpp:118) runs the greedy step down to one LCB, so the new matches of an extension round can
+    outweigh an old LCB; the unit-level re-chaining of the device rounds assumes old LCBs survive, therefore that option keeps
+    the match-level rounds on the host.  (Found by the randomised sweep of round 3: the device rounds then indexed with the id
+    of a dead LCB.)  Same result as the oracle on a list long enough for the device-resident chains."""
+    gs = synth.star_genomes(4, 1_500_000, 0.05, 78, inversions=12)
+    r1 = _same_align(ctx, gs, extend_lcbs=1, seed_weight=15, collinear=1)
+    assert r1["n_mums"] > 16384 and r1["n_lcb"] == 1
+
+
 def test_result_ends_with_its_genomes(ctx):
     """mauve_set_genomes ends the result the context holds: what of it is still on the device is not carried over, and a fetch
     afterwards is refused (MAUVE_ERR_STATE) instead of handing out half a result; the next alignment is whole again."""
