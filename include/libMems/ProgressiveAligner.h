@@ -12,21 +12,23 @@ namespace mems {
 
 // ---- ProgressiveAligner: setters and align() as called at progressiveMauve.cpp:575-710 -------------------
 // The guide tree and the progressive anchoring run on the device (mauve_progressive_align); the extant
-// sum-of-pairs LCB scoring is DESIGN.md S11.  The setters that tune libMems' penalty scaling and refinement have no
-// counterpart in the frozen replacement; they are accepted so that the call site compiles, and documented as inert.
+// sum-of-pairs LCB scoring is DESIGN.md S11, the penalty scaling by conservation and breakpoint distance S11b / S11c, the
+// refinement S13 (frozen forms of library-internal stages).  Not reproducible without libMems: the two ancestral scoring
+// schemes (they need its ancestral sequence reconstruction) -- they fall back to the extant scheme -- and the cache database.
 class ProgressiveAligner {
 public:
     explicit ProgressiveAligner(uint seq_count) : seq_count_(seq_count), tree_left_(2 * seq_count - 1, -1), tree_right_(2 * seq_count - 1, -1)
     {
         mauve_default_params(&p_);
-        p_.weight_scaling = 1; p_.conservation_scale_ppm = 500000;       // the library's defaults: scaling on, scale 0.5 (progressiveMauve.cpp:285-287)
+        p_.weight_scaling = 1; p_.conservation_scale_ppm = 500000; p_.bp_dist_scale_ppm = 500000;       // the library's defaults: scaling on, both scales 0.5 (progressiveMauve.cpp:285-287)
+        p_.refine_rounds = 2;                                            // refinement on unless --skip-refinement (:578-579)
     }
     // --weight, :584-593: a length (x seq_count) under LengthScoring, a score under the sum-of-pairs scheme
     void setBreakpointPenalty(double w) { if (w >= 0) bp_penalty_ = w; }
     void setMinimumBreakpointPenalty(double w) { if (w >= 0) p_.min_scaled_penalty = (int64_t)w; }   // :649-652: floor of the scaled weight
     void setCollinear(boolean c) { p_.collinear = c; }                        // :594-597
     void setGappedAlignment(boolean g) { p_.gapped = g; }                     // --skip-gapped-alignment
-    void setRefinement(boolean) {}                                            // :578-579 (no refinement stage)
+    void setRefinement(boolean r) { p_.refine_rounds = r ? 2 : 0; }           // :578-579; DESIGN.md S13: two rotated orders per interval, best sum-of-pairs score kept
     void setRecursion(boolean r) { p_.recursive = r; }
     void SetRecursive(boolean r) { p_.recursive = r; }                        // :661-664
     void SetMaxGappedAlignmentLength(gnSeqI n) { p_.max_gapped_len = (int64_t)n; }
@@ -40,13 +42,13 @@ public:
     // reconstruction and fall back to it as well.  LengthScoring (not in libMems) keeps the Aligner::align weights.
     enum LcbScoringScheme { AncestralScoring, AncestralSumOfPairsScoring, ExtantSumOfPairsScoring, LengthScoring };
     void setLcbScoringScheme(int s) { p_.lcb_scoring = s == LengthScoring ? MAUVE_LCB_SCORE_LENGTH : MAUVE_LCB_SCORE_SP; score_set_ = true; }
-    // :626-637.  The conservation-distance factor is live (a node's minimum LCB weight shrinks with the
-    // mean pairwise distance between its two subtrees); the breakpoint-distance factor needs libMems' internal pairwise
-    // breakpoint estimate and is not reproduced (its two knobs are accepted).
+    // :626-642.  A node's minimum LCB weight shrinks with the mean pairwise conservation distance between its two subtrees
+    //  and with their mean breakpoint distance (S11c: broken adjacencies between the pairwise matches of at least
+    // the given length, relative to the most rearranged pair).
     void setUseLcbWeightScaling(boolean b) { p_.weight_scaling = b ? 1 : 0; }
-    void setBreakpointDistanceScale(double) {}                                // :628-632 (see above)
+    void setBreakpointDistanceScale(double d) { if (d >= 0 && d <= 1) p_.bp_dist_scale_ppm = (int32_t)(d * 1e6 + 0.5); }      // :628-632
     void setConservationDistanceScale(double d) { if (d >= 0 && d <= 1) p_.conservation_scale_ppm = (int32_t)(d * 1e6 + 0.5); }
-    void setBpDistEstimateMinScore(double) {}
+    void setBpDistEstimateMinScore(double d) { if (d >= 0) p_.bp_dist_min_score = (int64_t)d; }                               // :638-642
     // :689-692.  The input tree replaces the UPGMA one (mauve_progressive_align_tree); the output file receives the
     // tree the alignment used, NEWICK both ways with leaves seq1..seqN (GuideTree.h).
     void setInputGuideTreeFileName(const std::string &fn) { input_tree_fn_ = fn; }

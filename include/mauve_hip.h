@@ -78,6 +78,14 @@ typedef struct {
     int32_t seed_family;      /* search with the family of three seeds of the weight instead of one (progressiveMauve.cpp:502-546 --seed-family;
                                  ProgressiveAligner::setUseSeedFamilies :604-605); default 0 */
     int64_t min_scaled_penalty;       /* setMinimumBreakpointPenalty (:649-652): floor of the scaled weight; default 0 */
+    int32_t refine_rounds;    /* progressive path, ProgressiveAligner::setRefinement (progressiveMauve.cpp:578-579): every gapped interval of >= 3
+                                 sequences is also aligned in up to this many rotated orders and the alignment with the best sum-of-pairs score
+                                 is kept (frozen form DESIGN.md S13); default 0 = off, the mirror's ProgressiveAligner starts with 2 */
+    int32_t bp_dist_scale_ppm;/* setBreakpointDistanceScale in parts per million (--max-breakpoint-distance-scale, :628-632; call-site default
+                                 0.5): with weight_scaling, a node's minimum weight also shrinks with the breakpoint distance between its two
+                                 subtrees (frozen form DESIGN.md S11c); default 0 */
+    int64_t bp_dist_min_score;/* setBpDistEstimateMinScore (:638-642): pairwise matches shorter than this do not count towards the breakpoint
+                                 estimate; -1 (default) = 2 x seed weight */
 } mauve_params;
 
 /* sizes of the result of mauve_align(), for the caller to allocate the fill buffers */
@@ -272,6 +280,11 @@ int mauve_set_shard(mauve_ctx *ctx, int rank, int world, mauve_allgather_fn fn, 
         mauve_align_fetch / mauve_write_xmfa: intervals with >= 2 genomes first (n_lcb of them), then the
         single-genome leftovers; absent genomes have left = right = 0. ------------------------------------- */
 int mauve_guide_tree(mauve_ctx *ctx, uint64_t pattern, int64_t *dist, int32_t *tree_left, int32_t *tree_right);
+/* The pairwise breakpoint estimate behind ProgressiveAligner::setBreakpointDistanceScale / setBpDistEstimateMinScore
+   (progressiveMauve.cpp:628-642; the estimate is libMems-internal, frozen form DESIGN.md S11c): for every genome pair, the
+   adjacencies between its pairwise matches of length >= min_len (ordered along the lower genome) that are not conserved
+   in the other genome.  bp: [nseq*nseq], symmetric, zero diagonal. */
+int mauve_breakpoint_counts(mauve_ctx *ctx, uint64_t pattern, int64_t min_len, int64_t *bp);
 int mauve_progressive_align(mauve_ctx *ctx, const mauve_params *p, mauve_align_sizes *sizes,
                             int32_t *tree_left, int32_t *tree_right, int64_t *dist);
 /* ProgressiveAligner::setInputGuideTreeFileName (progressiveMauve.cpp:689-690): the same alignment along the caller's

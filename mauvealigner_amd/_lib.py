@@ -26,7 +26,7 @@ EXPORTS = [
     "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_extend_hits", "mauve_seed_match_enumerate",
     "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_dp_batch_banded", "mauve_match_sp_scores", "mauve_align", "mauve_align_fetch",
     "mauve_align_matches", "mauve_align_lcbs", "mauve_align_begin", "mauve_align_begin_matches", "mauve_align_dp_anchors", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
-    "mauve_guide_tree", "mauve_progressive_align", "mauve_progressive_align_tree",
+    "mauve_guide_tree", "mauve_breakpoint_counts", "mauve_progressive_align", "mauve_progressive_align_tree",
     "mauve_backbone", "mauve_backbone_alignment", "mauve_backbone_fetch", "mauve_merge_matches",
     "mauve_write_xmfa", "mauve_profile_enable", "mauve_profile_reset", "mauve_profile_get", "mauve_last_stage_times",
 ]
@@ -43,7 +43,8 @@ class Params(C.Structure):
                 ("extend_lcbs", C.c_int32), ("max_extension_iters", C.c_int32),
                 ("min_recursive_gap", C.c_int64), ("max_gapped_len", C.c_int64), ("scoring", Scoring),
                 ("max_banded_len", C.c_int64), ("lcb_scoring", C.c_int32), ("weight_scaling", C.c_int32),
-                ("conservation_scale_ppm", C.c_int32), ("seed_family", C.c_int32), ("min_scaled_penalty", C.c_int64)]
+                ("conservation_scale_ppm", C.c_int32), ("seed_family", C.c_int32), ("min_scaled_penalty", C.c_int64),
+                ("refine_rounds", C.c_int32), ("bp_dist_scale_ppm", C.c_int32), ("bp_dist_min_score", C.c_int64)]
 
 
 class AlignSizes(C.Structure):
@@ -537,6 +538,14 @@ class Context:
         self._chk(self.L.mauve_guide_tree(self.h, C.c_uint64(pattern), _p(dist, C.c_int64), _p(left, C.c_int32),
                                           _p(right, C.c_int32)), "mauve_guide_tree")
         return dist, left, right
+
+    def breakpoint_counts(self, pattern, min_len):
+        """mauve_breakpoint_counts: broken adjacencies between the pairwise matches (length >= min_len) of every genome pair."""
+        N = self.nseq
+        bp = np.zeros((N, N), np.int64)
+        self.L.mauve_breakpoint_counts.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_int64)]
+        self._chk(self.L.mauve_breakpoint_counts(self.h, C.c_uint64(pattern), C.c_int64(min_len), _p(bp, C.c_int64)), "mauve_breakpoint_counts")
+        return bp
 
     def progressive_align(self, params=None, fetch=True, names=None, want_xmfa=False, tree=None, out=None):
         """tree=(left, right): align along the caller's guide tree (mauve_progressive_align_tree).  out: ResultBuffers."""

@@ -256,11 +256,14 @@ struct mauve_ctx {
 
     // DP workspace
     DevBuf dp_desc, dp_list, dp_codes, dp_off, dp_prof_cnt, dp_prof_mask, dp_prof2_cnt, dp_prof2_mask, dp_tb, dp_meta, dp_score,
-        dp_cols, dp_rows;
+        dp_cols, dp_rows, dp_sp;
 
     // the seed pass may leave its match list on the device only (sorted_rec) when the caller says so: mauve_align's device tail
     bool pair_sums_only = false;          // seed pass for the guide tree: per-pair length sums instead of the match list
     std::vector<int64_t> pair_sums;
+    int64_t bp_min_len = -1;              // >= 0 with pair_sums_only: also count the broken adjacencies of every pair's matches of at least this length
+    std::vector<int64_t> pair_bp;         // [N*N], upper triangle (a < b)
+    DevBuf bp_work;
     bool lazy_matches_ok = false, matches_pending = false;
     int match_nseq = 0;
     // where dp_run_from_anchors left its device-side results (valid until the next DP launch)
@@ -378,7 +381,7 @@ void lcb_greedy(int N, int32_t K, int64_t *weight, const uint32_t *orient_bits, 
 
 // DP (dp_batch.hip)
 int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *sc,
-                      uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells, bool may_shard = false);
+                      uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells, bool may_shard = false, int64_t *sp = nullptr);
 // gapped-alignment eligibility of an inter-anchor interval by its longest sequence: full DP up to max_gapped_len, banded
 // DP above it up to max_banded_len
 inline int64_t dp_len_limit(const mauve_params *p) { return p->max_banded_len > p->max_gapped_len ? p->max_banded_len : p->max_gapped_len; }

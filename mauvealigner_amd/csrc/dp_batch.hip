@@ -1607,6 +1607,35 @@ __global__ void __launch_bounds__(256) dp_gather(int nseq, int64_t n_iv, const i
     }
 }
 
+// DESIGN.md S13 (refinement objective): sum-of-pairs score of every interval's columns.  One thread per (interval, pair of
+// sequence slots): it walks the interval's columns once -- both -> substitution score, a run of one-sided columns -> open +
+// extends -- and adds its pair's sum to the interval's total.  The threads of an interval read the same column words.
+__global__ void __launch_bounds__(256) dp_sp_scores(int nseq, int64_t n_iv, const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
+                                                    const uint32_t *__restrict__ cols, const int64_t *__restrict__ col_off, DpScoring sc,
+                                                    unsigned long long *__restrict__ out)
+{
+    const int npair = nseq * (nseq - 1) / 2;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_iv * npair) return;
+    const int64_t iv = t / npair; int q = (int)(t % npair);
+    int a = 0; while (q >= nseq - 1 - a) { q -= nseq - 1 - a; a++; }
+    const int b = a + 1 + q;
+    const int64_t oa = seq_off[iv * nseq + a], ob = seq_off[iv * nseq + b];
+    if (seq_off[iv * nseq + a + 1] == oa || seq_off[iv * nseq + b + 1] == ob) return;
+    const uint8_t *sa = codes + oa, *sb = codes + ob;
+    const int64_t c0 = col_off[iv], c1 = col_off[iv + 1];
+    int64_t total = 0; int prev = 0;
+    for (int64_t c = c0; c < c1; c++) {
+        const uint32_t m = cols[c];
+        const uint32_t ha = m >> a & 1u, hb = m >> b & 1u;
+        if (ha & hb) { total += sc.s[*sa & 3][*sb & 3]; prev = 0; }
+        else if (ha) { total += prev == 1 ? sc.ge : sc.go; prev = 1; }
+        else if (hb) { total += prev == 2 ? sc.ge : sc.go; prev = 2; }
+        sa += ha; sb += hb;
+    }
+    atomicAdd(&out[iv], (unsigned long long)total);
+}
+
 // bases of the interval sequences, gathered on the device from the resident packed genomes:
 // one wave per (interval, genome) descriptor; reverse descriptors are reverse-complemented.
 struct DpGenomeWords { uint64_t word_off[MAUVE_MAX_SEQ]; };
@@ -1725,7 +1754,7 @@ static int dp_launch_rounds(mauve_ctx *ctx, int nseq, int64_t n_iv, int64_t n_bi
 // shared core: seq_off is a host array; the codes are either uploaded from `codes` or gathered from `desc`
 static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const DpSeqDesc *desc,
                    const int64_t *seq_off, const mauve_scoring *scoring, uint32_t *cols, int64_t *col_off,
-                   int64_t *score, int64_t *cells)
+                   int64_t *score, int64_t *cells, int64_t *sp = nullptr)
 {
     if (cells) *cells = 0;
     col_off[0] = 0;
@@ -1893,9 +1922,20 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
                            ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_mask.as<uint32_t>(), d_col_off,
                            ctx->dp_cols.as<uint32_t>());
         HIPCHK(ctx, hipGetLastError());
+        if (sp && nseq >= 2) {                  // the refinement's objective, from the columns while they are here
+            HIPCHK(ctx, ctx->dp_sp.ensure((size_t)n_iv * 8 + 64));
+            HIPCHK(ctx, hipMemsetAsync(ctx->dp_sp.p, 0, (size_t)n_iv * 8, ctx->stream));
+            const int64_t nthreads = n_iv * (nseq * (nseq - 1) / 2);
+            hipLaunchKernelGGL(dp_sp_scores, dim3((uint32_t)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream, nseq, n_iv, ctx->dp_codes.as<uint8_t>(), d_seq_off,
+                               ctx->dp_cols.as<uint32_t>(), d_col_off, sc, ctx->dp_sp.as<unsigned long long>());
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemcpyAsync(ctx->pin_meta.p, ctx->dp_sp.p, (size_t)n_iv * 8, hipMemcpyDeviceToHost, ctx->stream));   // (the meta records were read above)
+        }
         HIPCHK(ctx, hipMemcpyAsync(cols, ctx->dp_cols.p, (size_t)tc * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (sp && nseq >= 2) memcpy(sp, ctx->pin_meta.p, (size_t)n_iv * 8);
     }
+    if (sp && (!tc || nseq < 2)) for (int64_t iv = 0; iv < n_iv; iv++) sp[iv] = 0;
     if (trace) {
         std::vector<int64_t> e2(est); std::sort(e2.begin(), e2.end(), std::greater<int64_t>());
         fprintf(stderr, "[trace] dp_core: %d round(s); %lld intervals: %lld workgroup, %lld one-wave, %lld two/wave, %lld four/wave; single-wave steps: total %lld (balanced %lld), top", rounds, (long long)n_iv,
@@ -2240,7 +2280,7 @@ int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, c
 }
 
 int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *scoring,
-                      uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells, bool may_shard)
+                      uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells, bool may_shard, int64_t *sp)
 {
     std::vector<int64_t> &seq_off = ctx->dph.seq_off;
     if (may_shard && ctx->shard_world > 1 && n_iv >= 2 * ctx->shard_world) {
@@ -2260,18 +2300,18 @@ int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *d
         int64_t cap = 0;
         for (int64_t q = 0; q < nmine; q++)
             for (int g = 0; g < nseq; g++) { sub[(size_t)(q * nseq + g)] = desc[mine[(size_t)q] * nseq + g]; cap += desc[mine[(size_t)q] * nseq + g].len; }
-        std::vector<uint32_t> mcols((size_t)cap + 1); std::vector<int64_t> moff((size_t)nmine + 1, 0), mscore((size_t)nmine + 1, 0);
+        std::vector<uint32_t> mcols((size_t)cap + 1); std::vector<int64_t> moff((size_t)nmine + 1, 0), mscore((size_t)nmine + 1, 0), msp((size_t)nmine + 1, 0);
         int64_t mcells = 0;
         seq_off.resize((size_t)(nmine * nseq + 1));
         { int64_t t = 0; for (int64_t i = 0; i < nmine * nseq; i++) { seq_off[(size_t)i] = t; t += sub[(size_t)i].len; } seq_off[(size_t)(nmine * nseq)] = t; }
-        int rc = dp_core(ctx, nseq, nmine, nullptr, sub.data(), seq_off.data(), scoring, mcols.data(), moff.data(), mscore.data(), &mcells);
+        int rc = dp_core(ctx, nseq, nmine, nullptr, sub.data(), seq_off.data(), scoring, mcols.data(), moff.data(), mscore.data(), &mcells, sp ? msp.data() : nullptr);
         if (rc) return rc;
         const int64_t ncol = moff[(size_t)nmine];
-        std::vector<char> msg((size_t)(2 + 2 * nmine) * 8 + (size_t)ncol * 4);
+        std::vector<char> msg((size_t)(2 + 3 * nmine) * 8 + (size_t)ncol * 4);         // [n, cells, len[n], score[n], sp[n], cols...]
         int64_t *h = reinterpret_cast<int64_t *>(msg.data());
         h[0] = nmine; h[1] = mcells;
-        for (int64_t q = 0; q < nmine; q++) { h[2 + q] = moff[(size_t)q + 1] - moff[(size_t)q]; h[2 + nmine + q] = mscore[(size_t)q]; }
-        if (ncol) memcpy(msg.data() + (size_t)(2 + 2 * nmine) * 8, mcols.data(), (size_t)ncol * 4);
+        for (int64_t q = 0; q < nmine; q++) { h[2 + q] = moff[(size_t)q + 1] - moff[(size_t)q]; h[2 + nmine + q] = mscore[(size_t)q]; h[2 + 2 * nmine + q] = msp[(size_t)q]; }
+        if (ncol) memcpy(msg.data() + (size_t)(2 + 3 * nmine) * 8, mcols.data(), (size_t)ncol * 4);
         std::vector<std::pair<const char *, size_t>> parts;
         rc = shard_allgather(ctx, msg.data(), msg.size(), parts);
         if (rc) return rc;
@@ -2284,13 +2324,13 @@ int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *d
             const int64_t *hr = reinterpret_cast<const int64_t *>(parts[(size_t)r].first);
             if (parts[(size_t)r].second < 16 || hr[0] != (int64_t)ids[(size_t)r].size()) { ctx->err = "dp shard: ranks disagree about the interval table"; return MAUVE_ERR_STATE; }
             total_cells += hr[1];
-            for (size_t q = 0; q < ids[(size_t)r].size(); q++) { len_of[(size_t)ids[(size_t)r][q]] = hr[2 + q]; if (score) score[ids[(size_t)r][q]] = hr[2 + ids[(size_t)r].size() + q]; }
+            for (size_t q = 0; q < ids[(size_t)r].size(); q++) { len_of[(size_t)ids[(size_t)r][q]] = hr[2 + q]; if (score) score[ids[(size_t)r][q]] = hr[2 + ids[(size_t)r].size() + q]; if (sp) sp[ids[(size_t)r][q]] = hr[2 + 2 * ids[(size_t)r].size() + q]; }
         }
         col_off[0] = 0;
         for (int64_t k = 0; k < n_iv; k++) col_off[k + 1] = col_off[k] + len_of[(size_t)k];
         for (int r = 0; r < ctx->shard_world; r++) {
             const int64_t nr = (int64_t)ids[(size_t)r].size();
-            const uint32_t *cr = reinterpret_cast<const uint32_t *>(parts[(size_t)r].first + (size_t)(2 + 2 * nr) * 8);
+            const uint32_t *cr = reinterpret_cast<const uint32_t *>(parts[(size_t)r].first + (size_t)(2 + 3 * nr) * 8);
             for (int64_t q = 0; q < nr; q++) {
                 const int64_t k = ids[(size_t)r][(size_t)q];
                 memcpy(cols + col_off[k], cr, (size_t)len_of[(size_t)k] * 4);
@@ -2304,7 +2344,7 @@ int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *d
     int64_t t = 0;
     for (int64_t i = 0; i < n_iv * nseq; i++) { seq_off[(size_t)i] = t; t += desc[i].len; }
     seq_off[(size_t)(n_iv * nseq)] = t;
-    return dp_core(ctx, nseq, n_iv, nullptr, desc, seq_off.data(), scoring, cols, col_off, score, cells);
+    return dp_core(ctx, nseq, n_iv, nullptr, desc, seq_off.data(), scoring, cols, col_off, score, cells, sp);
 }
 
 extern "C" int mauve_dp_batch(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,

@@ -64,6 +64,7 @@ struct Prog {
     mauve_ctx *c; const mauve_params *p; int N;
     std::vector<int32_t> left, right;
     std::vector<int64_t> dist;         // [N*N] ppm, filled when the node weights are scaled
+    std::vector<int64_t> bpd;          // [N*N] ppm breakpoint distance, filled when bp_dist_scale_ppm is set as well
     std::vector<FreePool> rest;        // per genome: bases not placed in any block yet
     AlignResult *R;
     int64_t n_gap_dp = 0, n_cells = 0, n_anchor = 0, n_multi = 0;
@@ -172,6 +173,12 @@ int prog_node(Prog &P, int node)
         for (int a : la) for (int b : lb) sum += P.dist[(size_t)a * P.N + b];
         const int64_t c_ppm = sum / ((int64_t)la.size() * (int64_t)lb.size());
         factor_ppm = std::max<int64_t>(0, 1000000 - (int64_t)p->conservation_scale_ppm * c_ppm / 1000000);
+        if (!P.bpd.empty()) {                                 // the breakpoint-distance factor multiplies in
+            int64_t bsum = 0;
+            for (int a : la) for (int b : lb) bsum += P.bpd[(size_t)a * P.N + b];
+            const int64_t f2 = std::max<int64_t>(0, 1000000 - (int64_t)p->bp_dist_scale_ppm * (bsum / ((int64_t)la.size() * (int64_t)lb.size())) / 1000000);
+            factor_ppm = factor_ppm * f2 / 1000000;
+        }
         lcbw = std::max(lcbw * factor_ppm / 1000000, p->min_scaled_penalty);
     }
     std::vector<int64_t> match_lcb; int64_t nl = 0;
@@ -251,8 +258,68 @@ int prog_node(Prog &P, int node)
     std::vector<int64_t> dcol_off((size_t)n_dp + 1, 0), dscore((size_t)n_dp + 1, 0);
     int64_t cells = 0;
     c->dp_band_from = INT64_MAX;            // the progressive path splits long intervals instead
-    rc = dp_batch_run_desc(c, n, n_dp, desc.data(), &p->scoring, dcols, dcol_off.data(), dscore.data(), &cells, true);   // (several contexts: the node's intervals are dealt out)
+    const bool refine = p->refine_rounds > 0 && n >= 3 && n_dp > 0;
+    std::vector<int64_t> dsp; if (refine) dsp.assign((size_t)n_dp + 1, 0);
+    rc = dp_batch_run_desc(c, n, n_dp, desc.data(), &p->scoring, dcols, dcol_off.data(), dscore.data(), &cells, true, refine ? dsp.data() : nullptr);   // (several contexts: the node's intervals are dealt out)
     if (rc) return rc;
+    if (refine) {
+        // DESIGN.md S13 (setRefinement): every interval of k >= 3 sequences is aligned again in the rotated orders r = 1 .. min(rounds, k-1)
+        // -- ONE more batch with all candidates -- and keeps the alignment whose sum-of-pairs score (dp_sp_scores) is highest, lowest
+        // rotation on ties.  A candidate's slots hold the rotated sequences, so its column bits are slots of the rotation.
+        struct Cand { int64_t iv; int r, k; int nz[MAUVE_MAX_SEQ]; };
+        std::vector<Cand> cands; std::vector<DpSeqDesc> cdesc; int64_t ccodes = 0;
+        for (int64_t iv = 0; iv < n_dp; iv++) {
+            Cand cd; cd.iv = iv; cd.k = 0;
+            int64_t tot = 0;
+            for (int j = 0; j < n; j++) if (desc[(size_t)(iv * n + j)].len) { cd.nz[cd.k++] = j; tot += desc[(size_t)(iv * n + j)].len; }
+            if (cd.k < 3) continue;
+            for (int r = 1; r <= p->refine_rounds && r < cd.k; r++) {
+                cd.r = r; cands.push_back(cd);
+                for (int j = 0; j < n; j++) {
+                    DpSeqDesc d; d.genome = gm[0]; d.rev = 0; d.lo0 = 0; d.len = 0;
+                    if (j < cd.k) d = desc[(size_t)(iv * n + cd.nz[(j + r) % cd.k])];
+                    cdesc.push_back(d);
+                }
+                ccodes += tot;
+            }
+        }
+        const int64_t nc = (int64_t)cands.size();
+        if (nc) {
+            std::vector<uint32_t> ccols((size_t)ccodes + 1);
+            std::vector<int64_t> ccol_off((size_t)nc + 1, 0), cscore((size_t)nc + 1, 0), csp((size_t)nc + 1, 0);
+            int64_t cells2 = 0;
+            rc = dp_batch_run_desc(c, n, nc, cdesc.data(), &p->scoring, ccols.data(), ccol_off.data(), cscore.data(), &cells2, true, csp.data());
+            if (rc) return rc;
+            cells += cells2;
+            std::vector<int64_t> pick((size_t)n_dp, -1);
+            int64_t replaced = 0;
+            for (int64_t q = 0; q < nc; q++) {                 // candidates of an interval are consecutive, rotations ascending
+                const int64_t iv = cands[(size_t)q].iv;
+                if (csp[(size_t)q] > dsp[(size_t)iv]) { dsp[(size_t)iv] = csp[(size_t)q]; replaced += pick[(size_t)iv] < 0; pick[(size_t)iv] = q; }
+            }
+            if (replaced) {
+                std::vector<uint32_t> ncols; ncols.reserve((size_t)dcol_off[(size_t)n_dp]);
+                std::vector<int64_t> noff((size_t)n_dp + 1, 0);
+                for (int64_t iv = 0; iv < n_dp; iv++) {
+                    noff[(size_t)iv] = (int64_t)ncols.size();
+                    const int64_t q = pick[(size_t)iv];
+                    if (q < 0) { ncols.insert(ncols.end(), dcols + dcol_off[(size_t)iv], dcols + dcol_off[(size_t)iv + 1]); continue; }
+                    const Cand &cd = cands[(size_t)q];
+                    for (int64_t k = ccol_off[(size_t)q]; k < ccol_off[(size_t)q + 1]; k++) {
+                        const uint32_t mc = ccols[(size_t)k]; uint32_t o = 0;
+                        for (int j = 0; j < cd.k; j++) if (mc >> j & 1u) o |= 1u << cd.nz[(j + cd.r) % cd.k];
+                        ncols.push_back(o);
+                    }
+                    dscore[(size_t)iv] = cscore[(size_t)q];
+                }
+                noff[(size_t)n_dp] = (int64_t)ncols.size();
+                if ((int64_t)ncols.size() > code_total) { c->err = "refinement: more columns than bases"; return MAUVE_ERR_STATE; }
+                memcpy(dcols, ncols.data(), ncols.size() * sizeof(uint32_t));
+                dcol_off.swap(noff);
+            }
+            if (trace) fprintf(stderr, "[trace] node %d: refinement: %lld candidate alignments of %lld intervals, %lld replaced\n", node, (long long)nc, (long long)n_dp, (long long)replaced);
+        }
+    }
     P.n_gap_dp += n_dp; P.n_cells += cells;
     { const double tn4 = now_ms(); P.t_seed += tn1 - tn0; P.t_chain += tn2 - tn1; P.t_rec += tn3 - tn2; P.t_dp += tn4 - tn3; }
     if (trace) {
@@ -310,8 +377,25 @@ int prog_node(Prog &P, int node)
 
 extern "C" {
 
+static int guide_tree_core(mauve_ctx *c, uint64_t pattern, int64_t *dist, int32_t *left, int32_t *right, int64_t bp_min_len, int64_t *bp);
+
 // guide tree only (distance matrix in ppm, UPGMA merge order); dist may be NULL
 int mauve_guide_tree(mauve_ctx *c, uint64_t pattern, int64_t *dist, int32_t *left, int32_t *right)
+{
+    return guide_tree_core(c, pattern, dist, left, right, -1, nullptr);
+}
+
+// the pairwise breakpoint estimate on its own (symmetric counts, bp[nseq*nseq])
+int mauve_breakpoint_counts(mauve_ctx *c, uint64_t pattern, int64_t min_len, int64_t *bp)
+{
+    if (!c || !bp) return MAUVE_ERR_ARG;
+    if (min_len < 0) { c->err = "breakpoint_counts: min_len must not be negative"; return MAUVE_ERR_ARG; }
+    if (c->nseq < 2) { c->err = "breakpoint_counts: at least two genomes required"; return MAUVE_ERR_STATE; }
+    std::vector<int32_t> l((size_t)(2 * c->nseq - 1)), r((size_t)(2 * c->nseq - 1));
+    return guide_tree_core(c, pattern, nullptr, l.data(), r.data(), min_len, bp);
+}
+
+static int guide_tree_core(mauve_ctx *c, uint64_t pattern, int64_t *dist, int32_t *left, int32_t *right, int64_t bp_min_len, int64_t *bp)
 {
     if (!c || !left || !right) return MAUVE_ERR_ARG;
     if (c->nseq < 2) { c->err = "guide_tree: at least two genomes required"; return MAUVE_ERR_STATE; }
@@ -320,24 +404,31 @@ int mauve_guide_tree(mauve_ctx *c, uint64_t pattern, int64_t *dist, int32_t *lef
     const int N = c->nseq, M = 2 * N - 1;
     int64_t nm = 0;
     // similarity = sum of the pairwise match lengths per genome pair: summed on the device, the matches themselves stay there
-    c->pair_sums_only = true;
+    c->pair_sums_only = true; c->bp_min_len = bp ? bp_min_len : -1;
     int rc = seedpass_run(c, main_genome_set(c), pattern, MAUVE_MODE_PAIRWISE, 0, 1, nullptr, 0, &nm);
-    c->pair_sums_only = false;
+    c->pair_sums_only = false; c->bp_min_len = -1;
     if (rc) return rc;
     std::vector<int64_t> S((size_t)N * N, 0);
     if (c->shard_world > 1) {
         // every rank ran the finder passes of its share of the genome pairs (seed_pass.hip): the sums of the others arrive here
-        std::vector<int64_t> mine((size_t)N * N, 0);
-        if (c->pair_sums.size() == mine.size()) mine = c->pair_sums;
+        const size_t nn = (size_t)N * N;
+        std::vector<int64_t> mine(2 * nn, 0);                 // length sums, then breakpoints
+        if (c->pair_sums.size() == nn) std::copy(c->pair_sums.begin(), c->pair_sums.end(), mine.begin());
+        if (bp && c->pair_bp.size() == nn) std::copy(c->pair_bp.begin(), c->pair_bp.end(), mine.begin() + (ptrdiff_t)nn);
         std::vector<std::pair<const char *, size_t>> parts;
         rc = shard_allgather(c, mine.data(), mine.size() * 8, parts);
         if (rc) return rc;
-        c->pair_sums.assign((size_t)N * N, 0);
+        c->pair_sums.assign(nn, 0); c->pair_bp.assign(nn, 0);
         for (const auto &pt : parts) {
             if (pt.second != mine.size() * 8) { c->err = "guide_tree: ranks disagree about the genome set"; return MAUVE_ERR_STATE; }
             const int64_t *v = reinterpret_cast<const int64_t *>(pt.first);
-            for (size_t k = 0; k < mine.size(); k++) c->pair_sums[k] += v[k];
+            for (size_t k = 0; k < nn; k++) { c->pair_sums[k] += v[k]; c->pair_bp[k] += v[nn + k]; }
         }
+    }
+    if (bp) {
+        std::fill(bp, bp + (size_t)N * N, 0);
+        if (c->pair_bp.size() == (size_t)N * N)
+            for (int a = 0; a < N; a++) for (int b = a + 1; b < N; b++) bp[(size_t)a * N + b] = bp[(size_t)b * N + a] = c->pair_bp[(size_t)a * N + b];
     }
     if (c->pair_sums.size() == (size_t)N * N)
         for (int a = 0; a < N; a++) for (int b = a + 1; b < N; b++) { S[(size_t)a * N + b] = S[(size_t)b * N + a] = c->pair_sums[(size_t)a * N + b]; }
@@ -411,15 +502,23 @@ static int progressive_core(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     P.left.assign((size_t)(2 * N - 1), -1); P.right.assign((size_t)(2 * N - 1), -1);
     int rc = 0;
     if (given_left) { std::copy(given_left, given_left + (2 * N - 1), P.left.begin()); std::copy(given_right, given_right + (2 * N - 1), P.right.begin()); }
-    else rc = mauve_guide_tree(c, pat, dist, P.left.data(), P.right.data());
+    const bool need_bp = p->weight_scaling && p->bp_dist_scale_ppm > 0;
+    const int64_t bp_min = p->bp_dist_min_score >= 0 ? p->bp_dist_min_score : 2 * (int64_t)mauve_seed_weight(pat);
+    if (need_bp) P.bpd.assign((size_t)N * N, 0);
+    bool have_bp = false;
+    if (!given_left) { rc = guide_tree_core(c, pat, dist, P.left.data(), P.right.data(), bp_min, need_bp ? P.bpd.data() : nullptr); have_bp = need_bp; }
     if (rc) return rc;
     if (p->weight_scaling) {                // the distances come from the pairwise matches even when the tree is the caller's
         P.dist.assign((size_t)N * N, 0);
         if (given_left || !dist) {
             std::vector<int32_t> tl((size_t)(2 * N - 1)), tr((size_t)(2 * N - 1));
-            rc = mauve_guide_tree(c, pat, P.dist.data(), tl.data(), tr.data());
+            rc = guide_tree_core(c, pat, P.dist.data(), tl.data(), tr.data(), bp_min, need_bp && !have_bp ? P.bpd.data() : nullptr);
             if (rc) return rc;
         } else std::copy(dist, dist + (size_t)N * N, P.dist.begin());
+        if (need_bp) {                      // relative to the most rearranged pair
+            int64_t mx = 0; for (int64_t v : P.bpd) mx = std::max(mx, v);
+            for (int64_t &v : P.bpd) v = mx ? v * 1000000 / mx : 0;
+        }
     }
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     const double tg1 = now_ms();

@@ -1140,6 +1140,61 @@ __global__ void __launch_bounds__(256) pair_length_sums(const int32_t *__restric
     for (int i = threadIdx.x; i < nseq * nseq; i += 256) if (s[i]) atomicAdd(&sums[i], s[i]);
 }
 
+// ---- pairwise breakpoint estimate (progressive.cpp scales node weights by it) ----
+// Of every genome pair's matches (length >= min_len): order by position in the lower genome, rank by position in the higher one,
+// and count the adjacencies that are not conserved.  Three small kernels around two radix sorts of (pair, position) keys.
+__global__ void __launch_bounds__(256) bp_keys_a(const int32_t *__restrict__ mlen, const int32_t *__restrict__ mstart, uint32_t ncand, int nseq, int pos_bits,
+                                                 int32_t min_len, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ n_valid)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool valid = false;
+    if (i < ncand) {
+        uint64_t key = (uint64_t)(nseq * nseq) << pos_bits;           // not counted: behind every pair
+        const int32_t len = mlen[i];
+        if (len != 0 && len >= min_len) {
+            int a = -1, b = -1;
+            for (int g = 0; g < nseq; g++) if (mstart[(size_t)i * nseq + g]) { if (a < 0) a = g; else if (b < 0) b = g; }
+            if (b >= 0) { const int32_t sa = mstart[(size_t)i * nseq + a]; key = ((uint64_t)(a * nseq + b) << pos_bits) | (uint64_t)(sa < 0 ? -sa : sa); valid = true; }
+        }
+        keys[i] = key; vals[i] = i;
+    }
+    const uint64_t bal = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_valid, (uint32_t)__popcll(bal));
+}
+// second key: same pair, position in the higher genome; the value is the place in the first order
+__global__ void __launch_bounds__(256) bp_keys_b(const uint64_t *__restrict__ keys_a, const uint32_t *__restrict__ order_a, const int32_t *__restrict__ mstart, uint32_t nv,
+                                                 int nseq, int pos_bits, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= nv) return;
+    const uint32_t pair = (uint32_t)(keys_a[j] >> pos_bits), b = pair % (uint32_t)nseq;
+    const int32_t sb = mstart[(size_t)order_a[j] * nseq + b];
+    keys[j] = ((uint64_t)pair << pos_bits) | (uint64_t)(sb < 0 ? -sb : sb); vals[j] = j;
+}
+__global__ void __launch_bounds__(256) bp_rank(const uint32_t *__restrict__ order_b, uint32_t nv, uint32_t *__restrict__ rank)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < nv) rank[order_b[t]] = t;
+}
+__global__ void __launch_bounds__(256) bp_count(const uint64_t *__restrict__ keys_a, const uint32_t *__restrict__ order_a, const uint32_t *__restrict__ rank,
+                                                const int32_t *__restrict__ mstart, uint32_t nv, int nseq, int pos_bits, unsigned long long *__restrict__ out)
+{
+    __shared__ uint32_t s[MAUVE_MAX_SEQ * MAUVE_MAX_SEQ];
+    for (int i = threadIdx.x; i < nseq * nseq; i += 256) s[i] = 0;
+    __syncthreads();
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j + 1 < nv; j += gridDim.x * 256u) {
+        const uint32_t pair = (uint32_t)(keys_a[j] >> pos_bits);
+        if ((uint32_t)(keys_a[j + 1] >> pos_bits) != pair) continue;
+        const uint32_t b = pair % (uint32_t)nseq;
+        const int32_t s0 = mstart[(size_t)order_a[j] * nseq + b], s1 = mstart[(size_t)order_a[j + 1] * nseq + b];
+        const uint32_t r0 = rank[j], r1 = rank[j + 1];
+        const bool conserved = (s0 > 0 && s1 > 0 && r1 == r0 + 1) || (s0 < 0 && s1 < 0 && r1 + 1 == r0);
+        if (!conserved) atomicAdd(&s[pair], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nseq * nseq; i += 256) if (s[i]) atomicAdd(&out[i], (unsigned long long)s[i]);
+}
+
 __global__ void __launch_bounds__(256) canon_keys(const int32_t *__restrict__ mlen, const int32_t *__restrict__ mstart, uint32_t ncand,
                                                   int nseq, int pos_bits, int inval, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                   uint32_t *__restrict__ n_valid)
@@ -1568,6 +1623,48 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             memcpy(ctx->pair_sums.data(), ctx->pin_seed.as<char>() + 64, (size_t)N * N * 8);
         }
         TRACE(ctx, "pair length sums");
+        if (ctx->bp_min_len >= 0) {              // broken adjacencies per pair, from the same records
+            ctx->pair_bp.assign((size_t)N * N, 0);
+            if (ncand >= 2) {
+                HIPCHK(ctx, ctx->canon_k1.ensure((size_t)ncand * 8 + 64)); HIPCHK(ctx, ctx->canon_k2.ensure((size_t)ncand * 8 + 64));
+                HIPCHK(ctx, ctx->canon_v1.ensure((size_t)ncand * 4 + 64)); HIPCHK(ctx, ctx->canon_v2.ensure((size_t)ncand * 4 + 64));
+                HIPCHK(ctx, ctx->bp_work.ensure((size_t)ncand * 8 * 2 + (size_t)ncand * 4 * 3 + (size_t)N * N * 8 + 256));
+                uint64_t *ck = ctx->canon_k1.as<uint64_t>(), *ck2 = ctx->canon_k2.as<uint64_t>();
+                uint32_t *cv = ctx->canon_v1.as<uint32_t>(), *cv2 = ctx->canon_v2.as<uint32_t>();
+                uint64_t *bk = ctx->bp_work.as<uint64_t>(), *bk2 = bk + ncand;
+                uint32_t *bv = reinterpret_cast<uint32_t *>(bk2 + ncand), *bv2 = bv + ncand, *rank = bv2 + ncand;
+                unsigned long long *dbp = reinterpret_cast<unsigned long long *>(ctx->bp_work.as<char>() + (((size_t)ncand * 28 + 63) & ~(size_t)63));
+                HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync(dbp, 0, (size_t)N * N * 8, ctx->stream));
+                int64_t maxlen = 1; for (int g = 0; g < N; g++) maxlen = std::max<int64_t>(maxlen, gs.lens[(size_t)g]);
+                int pos_bits = 1; while (pos_bits < 32 && (1LL << pos_bits) <= maxlen) pos_bits++;
+                int pid_bits = 1; while ((1 << pid_bits) <= N * N) pid_bits++;
+                const int32_t min_len = (int32_t)std::min<int64_t>(ctx->bp_min_len, INT32_MAX);
+                hipLaunchKernelGGL(bp_keys_a, dim3((ncand + 255) / 256), dim3(256), 0, ctx->stream, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(), ncand, N, pos_bits,
+                                   min_len, ck, cv, ctx->counters.as<uint32_t>() + 3);
+                HIPCHK(ctx, hipGetLastError());
+                int rc2 = sort_pairs<uint64_t>(ctx, ncand, pos_bits + pid_bits, &ck, &cv, ck2, cv2, false, MAUVE_K_CANON);
+                if (rc2) return rc2;
+                HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.as<char>(), ctx->counters.as<uint32_t>() + 3, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                const uint32_t nv = ctx->pin_seed.as<uint32_t>()[0];
+                if (nv >= 2) {
+                    hipLaunchKernelGGL(bp_keys_b, dim3((nv + 255) / 256), dim3(256), 0, ctx->stream, ck, cv, ctx->mstart.as<int32_t>(), nv, N, pos_bits, bk, bv);
+                    HIPCHK(ctx, hipGetLastError());
+                    uint64_t *sk = bk; uint32_t *sv = bv;
+                    rc2 = sort_pairs<uint64_t>(ctx, nv, pos_bits + pid_bits, &sk, &sv, bk2, bv2, false, MAUVE_K_CANON);
+                    if (rc2) return rc2;
+                    hipLaunchKernelGGL(bp_rank, dim3((nv + 255) / 256), dim3(256), 0, ctx->stream, sv, nv, rank);
+                    hipLaunchKernelGGL(bp_count, dim3(std::min<uint32_t>((nv + 255) / 256, 1024)), dim3(256), 0, ctx->stream, ck, cv, rank, ctx->mstart.as<int32_t>(), nv, N, pos_bits, dbp);
+                    HIPCHK(ctx, hipGetLastError());
+                    HIPCHK(ctx, ctx->pin_seed.ensure(64 + (size_t)N * N * 8));
+                    HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.as<char>() + 64, dbp, (size_t)N * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+                    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                    memcpy(ctx->pair_bp.data(), ctx->pin_seed.as<char>() + 64, (size_t)N * N * 8);
+                }
+            }
+            TRACE(ctx, "pair breakpoints");
+        }
         return MAUVE_OK;
     }
     if (ncand == 0) return MAUVE_OK;

@@ -90,6 +90,9 @@ typedef struct {
     int32_t conservation_scale_ppm;
     int32_t seed_family;      /* search with the three seeds of the weight, longest first, contained matches dropped */
     int64_t min_scaled_penalty;
+    int32_t refine_rounds;    /* every gapped interval of >= 3 sequences is also aligned in up to this many rotated orders, the best sum-of-pairs score is kept; 0 = off */
+    int32_t bp_dist_scale_ppm;/* node weight x (1 - scale x breakpoint distance of the node); with weight_scaling only */
+    int64_t bp_dist_min_score;/* pairwise matches shorter than this do not count towards the breakpoint estimate; -1 = 2 x seed weight */
 } orc_params;
 
 /* ---- seeds ---------------------------------------------------------------------------------- */
@@ -159,6 +162,13 @@ int orc_align(int nseq, const uint8_t *const *codes, const int64_t *lens, const 
 void orc_free_alignment(orc_alignment *a);
 /* guide tree + guide-tree recursive anchoring (ProgressiveAligner::align stand-in);
    dist: [nseq*nseq] ppm distances (may be NULL), tree_left/right: [2*nseq-1] */
+/* sum-of-pairs score of the columns of one interval (substitution scores of both-columns, affine gap runs per pair) */
+int64_t orc_sp_score_cols(int nseq, const uint8_t *const *seqs, const int64_t *lens, const uint32_t *cols, int64_t ncols, const orc_scoring *sc);
+/* orc_align_interval + the rotated orders; cells counts every DP that was run */
+int64_t orc_align_interval_refined(int nseq, const uint8_t *const *seqs, const int64_t *lens, const orc_scoring *sc, int rounds,
+                                   uint32_t *cols_out, int64_t *score, int64_t *cells);
+/* broken adjacencies between the pairwise matches (length >= min_len) of every genome pair; bp[nseq*nseq], symmetric */
+int orc_breakpoint_counts(int nseq, const uint8_t *const *codes, const int64_t *lens, uint64_t pattern, int64_t min_len, int64_t *bp);
 int orc_guide_tree(int nseq, const uint8_t *const *codes, const int64_t *lens, uint64_t pattern,
                    int64_t *dist, int32_t *left, int32_t *right);
 int orc_progressive_align(int nseq, const uint8_t *const *codes, const int64_t *lens, const orc_params *p,

@@ -52,7 +52,8 @@ class Params(C.Structure):
                 ("extend_lcbs", C.c_int32), ("max_extension_iters", C.c_int32),
                 ("min_recursive_gap", C.c_int64), ("max_gapped_len", C.c_int64), ("scoring", Scoring),
                 ("max_banded_len", C.c_int64), ("lcb_scoring", C.c_int32), ("weight_scaling", C.c_int32),
-                ("conservation_scale_ppm", C.c_int32), ("seed_family", C.c_int32), ("min_scaled_penalty", C.c_int64)]
+                ("conservation_scale_ppm", C.c_int32), ("seed_family", C.c_int32), ("min_scaled_penalty", C.c_int64),
+                ("refine_rounds", C.c_int32), ("bp_dist_scale_ppm", C.c_int32), ("bp_dist_min_score", C.c_int64)]
 
 
 def build(force=False):
@@ -314,6 +315,39 @@ def align_interval(seqs, scoring=None, banded=False, want_cells=False):
     if want_cells:
         return cols[:nc].copy(), int(score.value), int(cells.value)
     return cols[:nc].copy(), int(score.value)
+
+
+def sp_score_cols(seqs, cols, scoring=None):
+    """sum-of-pairs score of the columns of one interval."""
+    sc = scoring or default_scoring()
+    seqs, arr, lens = _seq_args(seqs)
+    cols = np.ascontiguousarray(cols, np.uint32)
+    lib().orc_sp_score_cols.restype = C.c_int64
+    return int(lib().orc_sp_score_cols(len(seqs), arr, lens, cols.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int64(len(cols)), C.byref(sc)))
+
+
+def align_interval_refined(seqs, rounds, scoring=None):
+    """progressive alignment + rotated orders, best sum-of-pairs score.  -> (cols, dp score, cells)"""
+    sc = scoring or default_scoring()
+    seqs, arr, lens = _seq_args(seqs)
+    total = sum(len(s) for s in seqs)
+    cols = np.zeros(max(total, 1), dtype=np.uint32)
+    score, cells = C.c_int64(), C.c_int64()
+    lib().orc_align_interval_refined.restype = C.c_int64
+    nc = lib().orc_align_interval_refined(len(seqs), arr, lens, C.byref(sc), int(rounds), cols.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                          C.byref(score), C.byref(cells))
+    return cols[:nc].copy(), int(score.value), int(cells.value)
+
+
+def breakpoint_counts(codes, pattern, min_len):
+    """broken adjacencies between the pairwise matches of every genome pair.  -> [N, N] int64"""
+    codes, arr, lens = _seq_args(codes)
+    N = len(codes)
+    bp = np.zeros((N, N), np.int64)
+    rc = lib().orc_breakpoint_counts(N, arr, lens, C.c_uint64(pattern), C.c_int64(min_len), bp.ctypes.data_as(C.POINTER(C.c_int64)))
+    if rc:
+        raise RuntimeError("orc_breakpoint_counts failed: %d" % rc)
+    return bp
 
 
 def align(codes, params=None, names=None, want_xmfa=False):

@@ -800,6 +800,59 @@ def test_progressive_weight_scaling(ctx):
     _same_progressive(ctx, synth.make_config("C3", scale=0.02), weight_scaling=1, conservation_scale_ppm=500000)
 
 
+def test_breakpoint_distance_scaling(ctx):
+    """DESIGN.md S11c (ProgressiveAligner::setBreakpointDistanceScale / setBpDistEstimateMinScore, progressiveMauve.cpp:628-642):
+    the pairwise breakpoint estimate -- broken adjacencies between every pair's matches, counted on the device from the
+    guide tree's pairwise records (two sorts of (pair, position) keys, ranks, one adjacency kernel) -- equals the oracle's for
+    several length floors, grows with the rearrangements of the inputs, and the node weights scaled by it give the oracle's
+    alignment along the UPGMA and along a given tree."""
+    from mauvealigner_amd import _lib
+    gs = synth.make_config("C4", scale=0.02)
+    N = len(gs)
+    pat = O.get_seed(11, 0)
+    ctx.set_genomes(gs)
+    for min_len in (0, 22, 40):
+        bp = ctx.breakpoint_counts(pat, min_len)
+        assert np.array_equal(bp, O.breakpoint_counts(gs, pat, min_len)), min_len
+    assert np.array_equal(bp, bp.T) and not bp.diagonal().any() and bp.max() > 0
+    flat = synth.star_genomes(3, 30000, 0.02, 5, inversions=0)
+    ctx.set_genomes(flat)
+    b0 = ctx.breakpoint_counts(pat, 22)
+    assert np.array_equal(b0, O.breakpoint_counts(flat, pat, 22)) and b0.max() == 0        # collinear genomes: no breakpoints
+    half = _same_progressive(ctx, gs, weight_scaling=1, conservation_scale_ppm=500000, bp_dist_scale_ppm=500000)
+    cons = _same_progressive(ctx, gs, weight_scaling=1, conservation_scale_ppm=500000)
+    assert half["xmfa"] != cons["xmfa"]                         # the second factor moves the thresholds of the nodes
+    _same_progressive(ctx, gs, weight_scaling=1, conservation_scale_ppm=0, bp_dist_scale_ppm=1000000, bp_dist_min_score=30)
+    _same_progressive(ctx, gs, weight_scaling=1, conservation_scale_ppm=500000, bp_dist_scale_ppm=500000, lcb_scoring=1)
+    rng = np.random.default_rng(11)
+    _same_progressive(ctx, gs, tree=_random_tree(N, rng), weight_scaling=1, conservation_scale_ppm=300000, bp_dist_scale_ppm=700000)
+    off = _same_progressive(ctx, gs, bp_dist_scale_ppm=500000)  # without weight_scaling the scale is not looked at
+    assert off["xmfa"] == _same_progressive(ctx, gs)["xmfa"]
+
+
+def test_progressive_refinement(ctx):
+    """DESIGN.md S13 (ProgressiveAligner::setRefinement, progressiveMauve.cpp:578-579): every gapped interval of >= 3 sequences is
+    also aligned in its rotated orders -- one more batch through the same DP kernels -- scored by the sum-of-pairs kernel
+    (dp_sp_scores) and the best alignment kept.  Bit-exact against the oracle for 1, 2 and more rounds than sequences; the
+    refinement only ever raises the sum-of-pairs score of an interval's columns; with two genomes it changes nothing."""
+    from mauvealigner_amd import _lib
+    def family(n, length, div, seed):                           # indel-rich descendants of one ancestor: many intervals with k >= 3
+        rng = np.random.default_rng(seed)
+        anc = rng.integers(0, 4, length, dtype=np.uint8)
+        return [np.ascontiguousarray(synth.mutate(anc, div, rng, indel_frac=0.3)) for _ in range(n)]
+    gs = family(5, 60000, 0.06, 21)
+    plain = _same_progressive(ctx, gs, seed_weight=11)
+    r1 = _same_progressive(ctx, gs, seed_weight=11, refine_rounds=1)
+    r2 = _same_progressive(ctx, gs, seed_weight=11, refine_rounds=2)
+    r9 = _same_progressive(ctx, gs, seed_weight=11, refine_rounds=9)
+    assert r1["n_dp_cells"] > plain["n_dp_cells"] and r2["n_dp_cells"] > r1["n_dp_cells"] and r9["n_dp_cells"] >= r2["n_dp_cells"]
+    assert r2["xmfa"] != plain["xmfa"]                          # some interval found a better order
+    assert r2["n_iv"] == plain["n_iv"] and np.array_equal(r2["left"], plain["left"]) and np.array_equal(r2["right"], plain["right"])
+    _same_progressive(ctx, synth.make_config("C4", scale=0.02), refine_rounds=2, weight_scaling=1, conservation_scale_ppm=500000, bp_dist_scale_ppm=500000)
+    two = family(2, 40000, 0.05, 3)
+    assert _same_progressive(ctx, two, refine_rounds=2)["xmfa"] == _same_progressive(ctx, two)["xmfa"]
+
+
 def test_guide_tree_and_progressive_align(ctx):
     """ProgressiveAligner stand-in: guide tree + guide-tree recursive anchoring, bit-exact vs oracle."""
     gs = synth.make_config("C4", scale=0.02)

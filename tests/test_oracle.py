@@ -735,3 +735,61 @@ def test_c1_full_size_plumbing():
             if " - " in head:
                 want = "".join(comp[ch] for ch in reversed(want))
             assert seq == want
+
+
+def test_sp_score_and_refinement():
+    """the sum-of-pairs objective against a plain restatement (pair by pair, column by column), and the
+    refined interval alignment: never a lower objective than the progressive one, rows still spell the sequences."""
+    rng = np.random.default_rng(31)
+    anc = rng.integers(0, 4, 120, dtype=np.uint8)
+    sc = O.default_scoring()
+    mat = [[sc.matrix[i][j] for j in range(4)] for i in range(4)]
+    for trial in range(6):
+        seqs = [np.ascontiguousarray(synth.mutate(anc, 0.2, rng, indel_frac=0.4)) for _ in range(int(rng.integers(2, 6)))]
+        if trial == 3:
+            seqs[1] = seqs[1][:0]                               # an absent sequence takes part in no pair
+        cols, _ = O.align_interval(seqs)
+        want = 0
+        for a in range(len(seqs)):
+            for b in range(a + 1, len(seqs)):
+                if not len(seqs[a]) or not len(seqs[b]):
+                    continue
+                pa = pb = 0
+                prev = 0
+                for m in cols.tolist():
+                    ha, hb = m >> a & 1, m >> b & 1
+                    if ha and hb:
+                        want += mat[seqs[a][pa]][seqs[b][pb]]; prev = 0
+                    elif ha:
+                        want += sc.gap_extend if prev == 1 else sc.gap_open; prev = 1
+                    elif hb:
+                        want += sc.gap_extend if prev == 2 else sc.gap_open; prev = 2
+                    pa += ha; pb += hb
+        assert O.sp_score_cols(seqs, cols) == want
+        base = want
+        for rounds in (1, 2, 7):
+            rc, rs, cells = O.align_interval_refined(seqs, rounds)
+            assert O.sp_score_cols(seqs, rc) >= base
+            for g, sq in enumerate(seqs):                       # every sequence still runs through the columns once
+                assert int(((rc >> g) & 1).sum()) == len(sq)
+            assert not (rc == 0).any()
+        k = sum(1 for sq in seqs if len(sq))
+        if k < 3:
+            assert np.array_equal(O.align_interval_refined(seqs, 3)[0], cols)
+
+
+def test_breakpoint_counts_of_known_rearrangements():
+    """identical genomes have no breakpoint; one inversion in the middle breaks two adjacencies; a
+    translocated block breaks three."""
+    rng = np.random.default_rng(41)
+    a = rng.integers(0, 4, 12000, dtype=np.uint8)
+    pat = O.get_seed(11, 0)
+    cut = lambda x, div: np.ascontiguousarray(synth.mutate(x, div, np.random.default_rng(7), indel_frac=0.0))
+    same = cut(a, 0.02)                                         # substitutions only: many matches, all collinear
+    assert O.breakpoint_counts([a, same], pat, 22)[0, 1] == 0
+    inv = same.copy(); inv[4000:8000] = synth.revcomp(inv[4000:8000])
+    assert O.breakpoint_counts([a, inv], pat, 22)[0, 1] == 2
+    moved = np.concatenate([same[:2000], same[6000:9000], same[2000:6000], same[9000:]])
+    bp = O.breakpoint_counts([a, moved, inv], pat, 22)
+    assert bp[0, 1] == 3 and bp[0, 2] == 2 and np.array_equal(bp, bp.T) and not bp.diagonal().any()
+    assert O.breakpoint_counts([a, inv], pat, 10 ** 6)[0, 1] == 0          # no match passes the floor
