@@ -47,6 +47,13 @@ int main(int argc, char **argv)
             aligner.align(match_list.seq_table, interval_list);          // :710
             if (const char *bp = getenv("MAUVE_BACKBONE_OUT")) {         // applyBackbone, :226-260 (:712-719)
                 backbone_list_t bb_list;
+                interval_list.seq_table = match_list.seq_table;
+                const double gc_content = computeGC(interval_list.seq_table);                     // :231
+                Params hmm_params = getAdaptedHoxdMatrixParameters(gc_content);                   // :234
+                hmm_params.iGoHomologous = 0.00001; hmm_params.iGoUnrelated = 0.000000001;        // pgh, pgu: :319-320
+                adaptToPercentIdentity(hmm_params, 0.7);                                          // hmm_identity, :321
+                detectAndApplyBackbone(interval_list, bb_list, hmm_params);                       // :239 (the homology pass rewrites the intervals)
+                bb_list.clear();                                         // :240
                 BigGapsDetector bgd(20);                                 // island_gap_size, :322
                 detectBackbone(interval_list, bb_list, &bgd);            // :242-243
                 std::ofstream bb_out(bp);

@@ -6,8 +6,9 @@
 //   .backbone : header "seq0_leftend\tseq0_rightend\tseq1_leftend..." then one row per segment, two signed numbers per
 //               sequence (negative = reverse strand, 0 0 = not in the segment)          (bbFilter.cpp:28-31 reads them so)
 //   .bbcols   : one row per segment: interval, first column, columns, then the sequences in it (bbAnalyze.cpp:1010-1012)
-// The homology HMM behind detectAndApplyBackbone (HomologyHMM, not in the reference tree) is not reproduced: the call
-// is accepted, the alignment stays as it is and the backbone is the big-gaps one.
+// The homology HMM behind detectAndApplyBackbone (HomologyHMM, not in the reference tree) has a frozen form (DESIGN.md S12b:
+// a two-state Viterbi path per interval and genome pair, mauve_apply_homology_alignment): residues the path classes as unrelated
+// to every other genome of their column leave it; the backbone is the big-gaps one of the alignment after that.
 #ifndef MAUVE_HIP_BACKBONE_H
 #define MAUVE_HIP_BACKBONE_H
 
@@ -99,7 +100,8 @@ inline void detectBackbone(IntervalList &il, backbone_list_t &bb_list, const Hss
     detectBackboneAndIslands(il, bgd->gapSize(), bb_list, nullptr);
 }
 
-// ---- the homology HMM's knobs (progressiveMauve.cpp:231-237): carried, not used (see the header comment) ----
+// ---- the homology HMM's knobs (progressiveMauve.cpp:231-237).  The GC adaptation of libMems' emission matrix is not reproduced
+// (the frozen form scores match / mismatch from the identity alone); gc is carried. ----
 struct Params {
     double iGoHomologous, iGoUnrelated, identity, gc;
     Params() : iGoHomologous(0.00001), iGoUnrelated(0.000000001), identity(0.7), gc(0.5) {}
@@ -115,8 +117,50 @@ inline double computeGC(const std::vector<genome::gnSequence *> &seq_table)
 }
 inline Params getAdaptedHoxdMatrixParameters(double gc_content) { Params p; p.gc = gc_content; return p; }
 inline void adaptToPercentIdentity(Params &p, double identity) { p.identity = identity; }
-inline void detectAndApplyBackbone(IntervalList &il, backbone_list_t &bb_list, const Params &)
+inline void detectAndApplyBackbone(IntervalList &il, backbone_list_t &bb_list, const Params &hp)
 {
+    HipContext &hc = HipContext::global();
+    const size_t K = il.size();
+    const uint N = (uint)il.seq_table.size();
+    if (K && N) {
+        {   // the interval list refers to its own sequence table: those are the genomes the pass compares
+            std::vector<std::vector<uint64_t>> packed(N); std::vector<const uint64_t *> ptr; std::vector<int64_t> lens;
+            for (uint g = 0; g < N; g++) {
+                const std::string &t = il.seq_table[g]->str();
+                packed[g].assign(mauve_packed_words((int64_t)t.size()), 0);
+                mauve_pack_ascii(t.data(), (int64_t)t.size(), packed[g].data());
+                ptr.push_back(packed[g].data()); lens.push_back((int64_t)t.size());
+            }
+            hc.check(mauve_set_genomes(hc.get(), (int)N, ptr.data(), lens.data()), "mauve_set_genomes");
+        }
+        std::vector<int64_t> left(K * N, 0), right(K * N, 0), col_off(K + 1, 0), noff(K + 1, 0);
+        std::vector<int8_t> rev(K * N, 0);
+        std::vector<uint32_t> cols; size_t residues = 0;
+        for (size_t i = 0; i < K; i++) {
+            const Interval &iv = il[i];
+            for (uint g = 0; g < iv.SeqCount() && g < N; g++) {
+                left[i * N + g] = (int64_t)iv.LeftEnd(g); right[i * N + g] = iv.LeftEnd(g) ? (int64_t)iv.RightEnd(g) : 0;
+                rev[i * N + g] = iv.LeftEnd(g) && iv.Orientation(g) == AbstractMatch::reverse;
+                if (iv.LeftEnd(g)) residues += (size_t)(right[i * N + g] - left[i * N + g] + 1);
+            }
+            cols.insert(cols.end(), iv.Columns().begin(), iv.Columns().end());
+            col_off[i + 1] = (int64_t)cols.size();
+        }
+        if (!cols.empty()) {
+            mauve_hmm_params h;
+            mauve_hmm_params_from(hp.identity, hp.iGoHomologous, hp.iGoUnrelated, &h);
+            std::vector<uint32_t> ncols(std::max(residues, cols.size()) + 1);
+            int64_t moved = 0;
+            hc.check(mauve_apply_homology_alignment(hc.get(), (int)N, (int64_t)K, left.data(), right.data(), rev.data(), col_off.data(), cols.data(), &h, noff.data(), ncols.data(), &moved),
+                     "mauve_apply_homology_alignment");
+            if (moved)
+                for (size_t i = 0; i < K; i++) {
+                    std::vector<int64> l(left.begin() + i * N, left.begin() + (i + 1) * N), r(right.begin() + i * N, right.begin() + (i + 1) * N);
+                    std::vector<char> rv(rev.begin() + i * N, rev.begin() + (i + 1) * N);
+                    il[i] = Interval(l, r, rv, std::vector<uint32_t>(ncols.begin() + noff[i], ncols.begin() + noff[i + 1]));
+                }
+        }
+    }
     BigGapsDetector bgd(20);
     detectBackbone(il, bb_list, &bgd);
 }

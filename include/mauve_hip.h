@@ -308,6 +308,20 @@ int mauve_backbone(mauve_ctx *ctx, int64_t island_gap_size, int64_t *n_seg, int6
 int mauve_backbone_alignment(mauve_ctx *ctx, int nseq, int64_t n_iv, const int64_t *left, const int64_t *right,
                              const int8_t *reverse, const int64_t *col_off, const uint32_t *cols,
                              int64_t island_gap_size, int64_t *n_seg, int64_t *n_islands);
+/* The homology pass in front of the backbone: detectAndApplyBackbone(iv_list, bb_list, hmm_params) (progressiveMauve.cpp:226-243; its
+   HomologyHMM is libMems-internal, frozen form DESIGN.md S12b).  A two-state Viterbi path (homologous / unrelated) per interval and
+   genome pair over the resident alignment's columns, in integer log-odds x 1000; residues that are homologous to no other genome of
+   their column move to columns of their own.  The context's alignment is rewritten in place (column count and offsets change: *sizes
+   receives the new sizes for mauve_align_fetch); n_moved = residues taken out of multi-genome columns.  Call before mauve_backbone. */
+typedef struct { int32_t match, mismatch, gap, go_homologous, go_unrelated; } mauve_hmm_params;
+/* the call site's knobs (progressiveMauve.cpp:319-322: identity 0.7, pgh 1e-5, pgu 1e-9) as integer scores: match = 1000 ln(id / .25),
+   mismatch = 1000 ln((1 - id) / .75), gap = -500, transitions = 1000 ln(p) */
+void mauve_hmm_params_from(double identity, double pgh, double pgu, mauve_hmm_params *h);
+int mauve_apply_homology(mauve_ctx *ctx, const mauve_hmm_params *h, mauve_align_sizes *sizes, int64_t *n_moved);
+/* ... of the caller's alignment (the genomes it refers to are the context's): cols_out holds up to one column per residue, col_off_out [n_iv+1] */
+int mauve_apply_homology_alignment(mauve_ctx *ctx, int nseq, int64_t n_iv, const int64_t *left, const int64_t *right, const int8_t *reverse,
+                                   const int64_t *col_off, const uint32_t *cols, const mauve_hmm_params *h, int64_t *col_off_out, uint32_t *cols_out,
+                                   int64_t *n_moved);
 int mauve_backbone_fetch(mauve_ctx *ctx, int64_t *seg_iv, int64_t *seg_col, int64_t *seg_len, uint32_t *seg_mask,
                          int64_t *seg_left, int64_t *seg_right, int64_t *islands);
 /* IntervalList::WriteStandardAlignment (mauveAligner.cpp:746-760; format mfa2xmfa.cpp:64-115).

@@ -26,7 +26,7 @@ EXPORTS = [
     "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_extend_hits", "mauve_seed_match_enumerate",
     "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_dp_batch_banded", "mauve_match_sp_scores", "mauve_align", "mauve_align_fetch",
     "mauve_align_matches", "mauve_align_lcbs", "mauve_align_begin", "mauve_align_begin_matches", "mauve_align_dp_anchors", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
-    "mauve_guide_tree", "mauve_breakpoint_counts", "mauve_progressive_align", "mauve_progressive_align_tree",
+    "mauve_guide_tree", "mauve_breakpoint_counts", "mauve_hmm_params_from", "mauve_apply_homology", "mauve_apply_homology_alignment", "mauve_progressive_align", "mauve_progressive_align_tree",
     "mauve_backbone", "mauve_backbone_alignment", "mauve_backbone_fetch", "mauve_merge_matches",
     "mauve_write_xmfa", "mauve_profile_enable", "mauve_profile_reset", "mauve_profile_get", "mauve_last_stage_times",
 ]
@@ -45,6 +45,10 @@ class Params(C.Structure):
                 ("max_banded_len", C.c_int64), ("lcb_scoring", C.c_int32), ("weight_scaling", C.c_int32),
                 ("conservation_scale_ppm", C.c_int32), ("seed_family", C.c_int32), ("min_scaled_penalty", C.c_int64),
                 ("refine_rounds", C.c_int32), ("bp_dist_scale_ppm", C.c_int32), ("bp_dist_min_score", C.c_int64)]
+
+
+class HmmParams(C.Structure):
+    _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("gap", C.c_int32), ("go_homologous", C.c_int32), ("go_unrelated", C.c_int32)]
 
 
 class AlignSizes(C.Structure):
@@ -579,6 +583,28 @@ class Context:
                                               _p(out["seg_mask"], C.c_uint32), _p(out["seg_left"], C.c_int64), _p(out["seg_right"], C.c_int64),
                                               _p(out["islands"], C.c_int64)), "mauve_backbone_fetch")
         return out
+
+    def hmm_params(self, identity=0.7, pgh=1e-5, pgu=1e-9, **kw):
+        """mauve_hmm_params_from: the call site's knobs (progressiveMauve.cpp:319-322) as integer scores; kw overrides fields."""
+        h = HmmParams()
+        self.L.mauve_hmm_params_from.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(HmmParams)]
+        self.L.mauve_hmm_params_from.restype = None
+        self.L.mauve_hmm_params_from(identity, pgh, pgu, C.byref(h))
+        for k, v in kw.items():
+            setattr(h, k, v)
+        return h
+
+    def apply_homology(self, hmm=None, fetch=True, names=None, want_xmfa=False):
+        """mauve_apply_homology: un-align what the pair HMM classes as unrelated in the alignment this context holds.
+        -> the rewritten result (or its sizes) with 'n_moved'."""
+        h = hmm or self.hmm_params()
+        sz = AlignSizes()
+        moved = C.c_int64(0)
+        self.L.mauve_apply_homology.argtypes = [C.c_void_p, C.POINTER(HmmParams), C.POINTER(AlignSizes), C.POINTER(C.c_int64)]
+        self._chk(self.L.mauve_apply_homology(self.h, C.byref(h), C.byref(sz), C.byref(moved)), "mauve_apply_homology")
+        res = self._fetch(sz, names, want_xmfa) if fetch else {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
+        res["n_moved"] = int(moved.value)
+        return res
 
     def backbone(self, island_gap=20, nseq=None):
         """Backbone segments and islands of the alignment this context holds (mauve_backbone)."""

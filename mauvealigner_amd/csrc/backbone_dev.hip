@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include <algorithm>
 #include <cstring>
+#include <cmath>
 
 namespace {
 
@@ -210,6 +211,149 @@ void bb_components(const uint32_t *adj, uint32_t gmask, std::vector<uint32_t> &o
         }
         left &= ~comp;
         if (comp & (comp - 1)) out.push_back(comp);
+    }
+}
+
+// ================================================================================================
+// Homology pass: the two-state pair HMM in front of the backbone, on the device.
+//   hom_viterbi  one wave per (interval, genome pair): 64 columns per step on the lanes.  A column is a max-plus 2 x 2 matrix
+//                (new H / new U from old H / old U); the wave's inclusive scan of the matrices applied to the carried (vH, vU)
+//                gives every column's Viterbi values at once, the predecessor choices of all 64 columns are two ballot words
+//                kept in HBM (16 bytes per 64 columns and pair).  The way back replays the two words bit by bit on the scalar
+//                unit and ORs the pair's bits into keep[column] where the state is H and both genomes have a base.
+//   hom_count / hom_write / hom_offsets  the columns split by keep: tile totals, (host prefix over the tiles), the new
+//                columns written in order, the new column offset of every interval.
+struct HomItem { uint32_t ivx; uint32_t a, b; uint32_t pad; int64_t slot; };                 // slot: first pred-word pair of this (interval, pair)
+struct HomIv { int64_t col0, ncols; uint32_t iv, nchunks; };
+struct HomGenomes { uint64_t word_off[MAUVE_MAX_SEQ]; };
+struct HomScores { int64_t match, mismatch, gap, go_h, go_u; };
+constexpr int64_t HOM_NEG = -((int64_t)1 << 60);
+
+__device__ __forceinline__ int hom_base(const uint64_t *__restrict__ G, int64_t pos0) { return (int)(G[pos0 >> 5] >> ((pos0 & 31) * 2) & 3u); }
+__device__ __forceinline__ int64_t hom_clamp(int64_t x) { return x < HOM_NEG ? HOM_NEG : x; }
+
+__global__ void __launch_bounds__(64) hom_viterbi(const uint32_t *__restrict__ cols, const HomItem *__restrict__ items, uint32_t n_items, const HomIv *__restrict__ ivs,
+                                                  const int64_t *__restrict__ left, const int64_t *__restrict__ right, const int8_t *__restrict__ rev, int N,
+                                                  const uint64_t *__restrict__ genomes, HomGenomes gw, HomScores sc, uint64_t *__restrict__ pred, uint32_t *__restrict__ keep)
+{
+    const int lane = threadIdx.x;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const HomItem item = items[it];
+        const HomIv iv = ivs[item.ivx];
+        const int a = (int)item.a, b = (int)item.b;
+        const int64_t la = left[(size_t)iv.iv * N + a], ra = right[(size_t)iv.iv * N + a], lb = left[(size_t)iv.iv * N + b], rb = right[(size_t)iv.iv * N + b];
+        const bool rva = rev[(size_t)iv.iv * N + a] != 0, rvb = rev[(size_t)iv.iv * N + b] != 0;
+        const uint64_t *Ga = genomes + gw.word_off[a], *Gb = genomes + gw.word_off[b];
+        int64_t vh = HOM_NEG, vu = 0, ka = 0, kb = 0;
+        for (uint32_t ch = 0; ch < iv.nchunks; ch++) {
+            const int64_t c = (int64_t)ch * 64 + lane;
+            const uint32_t m = c < iv.ncols ? cols[iv.col0 + c] : 0u;
+            const bool ha = m >> a & 1u, hb = m >> b & 1u, none = !(ha || hb);
+            const uint64_t BA = __ballot(ha), BB = __ballot(hb);
+            int64_t s = sc.gap;
+            if (ha && hb) {
+                const int64_t ia = ka + __popcll(BA & below(lane)), ib = kb + __popcll(BB & below(lane));
+                int xa = hom_base(Ga, (rva ? ra - ia : la + ia) - 1), xb = hom_base(Gb, (rvb ? rb - ib : lb + ib) - 1);
+                if (rva) xa = 3 - xa;
+                if (rvb) xb = 3 - xb;
+                s = xa == xb ? sc.match : sc.mismatch;
+            }
+            int64_t hh = none ? 0 : s, hu = none ? HOM_NEG : s + sc.go_h, uh = none ? HOM_NEG : sc.go_u, uu = 0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {                // inclusive scan: this lane's product after (the earlier lanes' product)
+                const int64_t ehh = __shfl_up(hh, d, 64), ehu = __shfl_up(hu, d, 64), euh = __shfl_up(uh, d, 64), euu = __shfl_up(uu, d, 64);
+                if (lane >= d) {
+                    const int64_t nhh = max(hh + ehh, hu + euh), nhu = max(hh + ehu, hu + euu), nuh = max(uh + ehh, uu + euh), nuu = max(uh + ehu, uu + euu);
+                    hh = hom_clamp(nhh); hu = hom_clamp(nhu); uh = hom_clamp(nuh); uu = hom_clamp(nuu);
+                }
+            }
+            const int64_t wh = hom_clamp(max(hh + vh, hu + vu)), wu = hom_clamp(max(uh + vh, uu + vu));      // values after this lane's column
+            int64_t bh = __shfl_up(wh, 1, 64), bu = __shfl_up(wu, 1, 64);                                   // ... and before it
+            if (lane == 0) { bh = vh; bu = vu; }
+            const bool ph = none || bh >= bu + sc.go_h, pu = none || bu >= bh + sc.go_u;
+            const uint64_t PH = __ballot(ph), PU = __ballot(pu);
+            if (lane == 0) { pred[(size_t)(item.slot + ch) * 2] = PH; pred[(size_t)(item.slot + ch) * 2 + 1] = PU; }
+            vh = __shfl(wh, 63, 64); vu = __shfl(wu, 63, 64);
+            ka += __popcll(BA); kb += __popcll(BB);
+        }
+        int st = vh >= vu;                                    // 1 = H; wave-uniform from here on
+        for (int64_t ch = (int64_t)iv.nchunks - 1; ch >= 0; ch--) {
+            const int64_t c = ch * 64 + lane;
+            const uint32_t m = c < iv.ncols ? cols[iv.col0 + c] : 0u;
+            const bool both = (m >> a & 1u) && (m >> b & 1u);
+            const uint64_t PH = pred[(size_t)(item.slot + ch) * 2], PU = pred[(size_t)(item.slot + ch) * 2 + 1];
+            uint64_t S = 0;
+            for (int l = 63; l >= 0; l--) {                   // (columns neither genome is in carry PH = PU = 1: the state passes through)
+                if (st) S |= 1ull << l;
+                st = st ? (int)(PH >> l & 1ull) : (int)(~PU >> l & 1ull);
+            }
+            if (both && (S >> lane & 1ull)) atomicOr(&keep[iv.col0 + c], 1u << a | 1u << b);
+        }
+    }
+}
+
+// columns a column becomes: the genomes that stay (one column, if any) + one column per genome that leaves
+__device__ __forceinline__ uint32_t hom_out_count(uint32_t m, uint32_t k) { return (k ? 1u : 0u) + (uint32_t)__popc(m & ~k); }
+
+__global__ void __launch_bounds__(256) hom_count(const uint32_t *__restrict__ cols, const uint32_t *__restrict__ keep, int64_t n, uint32_t *__restrict__ tile_out,
+                                                 unsigned long long *__restrict__ moved)
+{
+    __shared__ uint32_t acc[2];
+    if (threadIdx.x < 2) acc[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t t0 = (int64_t)blockIdx.x * BB_CHUNK;
+    uint32_t mine = 0, mv = 0;
+    for (int k = 0; k < BB_CHUNK / 256; k++) {
+        const int64_t c = t0 + k * 256 + threadIdx.x;
+        if (c >= n) break;
+        const uint32_t m = cols[c], kp = keep[c] & m;
+        mine += hom_out_count(m, kp);
+        if (m & (m - 1)) mv += (uint32_t)__popc(m & ~kp);
+    }
+    atomicAdd(&acc[0], mine); atomicAdd(&acc[1], mv);
+    __syncthreads();
+    if (threadIdx.x == 0) { tile_out[blockIdx.x] = acc[0]; if (acc[1]) atomicAdd(moved, (unsigned long long)acc[1]); }
+}
+
+__global__ void __launch_bounds__(256) hom_write(const uint32_t *__restrict__ cols, const uint32_t *__restrict__ keep, int64_t n, const int64_t *__restrict__ tile_base,
+                                                 uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t base = tile_base[blockIdx.x];
+    const int64_t t0 = (int64_t)blockIdx.x * BB_CHUNK;
+    for (int k = 0; k < BB_CHUNK / 256; k++) {                // 256 columns per round, in column order
+        const int64_t c = t0 + k * 256 + threadIdx.x;
+        const uint32_t m = c < n ? cols[c] : 0u, kp = c < n ? keep[c] & m : 0u;
+        const uint32_t cnt = c < n ? hom_out_count(m, kp) : 0u;
+        uint32_t x = cnt;                                     // inclusive scan over the wave, then over the four waves
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int w = 0; w < 4; w++) { if (w < wave) before += wsum[w]; total += wsum[w]; }
+        int64_t o = base + before + x - cnt;
+        if (kp) out[o++] = kp;
+        for (uint32_t r = m & ~kp; r; r &= r - 1) out[o++] = r & (0u - r);
+        base += total;
+        __syncthreads();
+    }
+}
+
+// new offset of every interval start: the tile's base + the columns the tile puts out before it
+__global__ void __launch_bounds__(64) hom_offsets(const uint32_t *__restrict__ cols, const uint32_t *__restrict__ keep, int64_t n, const int64_t *__restrict__ tile_base,
+                                                  const int64_t *__restrict__ col_off, int64_t n_off, int64_t *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    (void)n;
+    for (int64_t q = blockIdx.x; q < n_off; q += gridDim.x) {
+        const int64_t x = col_off[q], t0 = x & ~(int64_t)(BB_CHUNK - 1);
+        uint32_t mine = 0;
+        for (int64_t c = t0 + lane; c < x; c += 64) { const uint32_t m = cols[c]; mine += hom_out_count(m, keep[c] & m); }
+#pragma unroll
+        for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d, 64);
+        if (lane == 0) out[q] = tile_base[x / BB_CHUNK] + mine;          // (tile_base has one entry behind the last tile: x == n on a tile boundary)
     }
 }
 
@@ -463,6 +607,152 @@ int mauve_backbone_alignment(mauve_ctx *c, int nseq, int64_t n_iv, const int64_t
     const int rc = backbone_run(c, nseq, n_iv, left, right, reverse, col_off, c->bb_cols.as<uint32_t>(), island_gap_size);
     if (rc) return rc;
     *n_seg = (int64_t)c->bb.seg_iv.size(); *n_islands = (int64_t)c->bb.islands.size() / 8;
+    return MAUVE_OK;
+}
+
+
+void mauve_hmm_params_from(double identity, double pgh, double pgu, mauve_hmm_params *h)
+{
+    if (!h) return;
+    h->match = (int32_t)lround(1000.0 * log(identity / 0.25));
+    h->mismatch = (int32_t)lround(1000.0 * log((1.0 - identity) / 0.75));
+    h->gap = -500;
+    h->go_homologous = (int32_t)lround(1000.0 * log(pgh));
+    h->go_unrelated = (int32_t)lround(1000.0 * log(pgu));
+}
+
+// the work behind mauve_apply_homology / mauve_apply_homology_alignment: columns on the device (n_cols entries), interval table on the
+// host; the re-split columns are left in c->hom_cols (*n_new of them, offsets in noff) unless nothing moved
+static int homology_core(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const int64_t *right, const int8_t *reverse, const int64_t *col_off,
+                         const uint32_t *d_cols, const mauve_hmm_params *h, std::vector<int64_t> &noff, int64_t *n_new_out, int64_t *moved_out)
+{
+    const int64_t n_cols = col_off[n_iv];
+    *moved_out = 0; *n_new_out = n_cols;
+    if (h->go_homologous > 0 || h->go_unrelated > 0) { c->err = "apply_homology: transition scores are log probabilities (<= 0)"; return MAUVE_ERR_ARG; }
+    if (N != c->nseq) { c->err = "apply_homology: the alignment does not belong to the genomes of this context"; return MAUVE_ERR_STATE; }
+    if (n_cols == 0) return MAUVE_OK;
+    // work items: (interval with >= 2 genomes, pair), longest intervals first
+    std::vector<HomIv> ivs; std::vector<HomItem> items; int64_t slots = 0, residues = 0;
+    for (int64_t iv = 0; iv < n_iv; iv++) {
+        int g[MAUVE_MAX_SEQ], n = 0;
+        for (int x = 0; x < N; x++) if (left[(size_t)(iv * N + x)]) {
+            const int64_t l = left[(size_t)(iv * N + x)], r = right[(size_t)(iv * N + x)];
+            if (l < 1 || r < l || r > c->lens[(size_t)x]) { c->err = "apply_homology: an interval lies outside its genome"; return MAUVE_ERR_ARG; }
+            g[n++] = x; residues += r - l + 1;
+        }
+        const int64_t nc = col_off[(size_t)iv + 1] - col_off[(size_t)iv];
+        if (n < 2 || nc <= 0) continue;
+        const int64_t nch = (nc + 63) / 64;
+        if (nch > 0x7fffffff) { c->err = "apply_homology: interval too long"; return MAUVE_ERR_LIMIT; }
+        ivs.push_back(HomIv{col_off[(size_t)iv], nc, (uint32_t)iv, (uint32_t)nch});
+        for (int x = 0; x < n; x++) for (int y = x + 1; y < n; y++) { items.push_back(HomItem{(uint32_t)(ivs.size() - 1), (uint32_t)g[x], (uint32_t)g[y], 0u, slots}); slots += nch; }
+    }
+    std::stable_sort(items.begin(), items.end(), [&](const HomItem &x, const HomItem &y) { return ivs[x.ivx].nchunks > ivs[y.ivx].nchunks; });
+    const size_t n_tiles = (size_t)((n_cols + BB_CHUNK - 1) / BB_CHUNK);
+    auto up = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t o_items = up(ivs.size() * sizeof(HomIv)), o_left = o_items + up(items.size() * sizeof(HomItem)), o_right = o_left + up((size_t)n_iv * N * 8),
+                 o_rev = o_right + up((size_t)n_iv * N * 8), o_off = o_rev + up((size_t)n_iv * N), o_noff = o_off + up(((size_t)n_iv + 1) * 8), o_tile = o_noff + up(((size_t)n_iv + 1) * 8),
+                 o_base = o_tile + up(n_tiles * 4), o_cnt = o_base + up((n_tiles + 1) * 8), o_keep = o_cnt + 64, o_pred = o_keep + up((size_t)n_cols * 4), total = o_pred + (size_t)slots * 16 + 64;
+    HIPCHK(c, c->bb_work.ensure(total));
+    char *wk = c->bb_work.as<char>();
+    HIPCHK(c, hipMemcpyAsync(wk, ivs.data(), ivs.size() * sizeof(HomIv), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(wk + o_items, items.data(), items.size() * sizeof(HomItem), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(wk + o_left, left, (size_t)n_iv * N * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(wk + o_right, right, (size_t)n_iv * N * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(wk + o_rev, reverse, (size_t)n_iv * N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(wk + o_off, col_off, ((size_t)n_iv + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(wk + o_cnt, 0, 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(wk + o_keep, 0, (size_t)n_cols * 4, c->stream));
+    uint32_t *keep = reinterpret_cast<uint32_t *>(wk + o_keep);
+    if (!items.empty()) {
+        HomGenomes gw; memset(&gw, 0, sizeof gw);
+        for (int g = 0; g < c->nseq; g++) gw.word_off[g] = c->word_off[(size_t)g];
+        const HomScores sc{h->match, h->mismatch, h->gap, h->go_homologous, h->go_unrelated};
+        hipLaunchKernelGGL(hom_viterbi, dim3((uint32_t)std::min<size_t>(items.size(), 256 * 32)), dim3(64), 0, c->stream, d_cols, reinterpret_cast<const HomItem *>(wk + o_items),
+                           (uint32_t)items.size(), reinterpret_cast<const HomIv *>(wk), reinterpret_cast<const int64_t *>(wk + o_left), reinterpret_cast<const int64_t *>(wk + o_right),
+                           reinterpret_cast<const int8_t *>(wk + o_rev), N, c->genomes.as<uint64_t>(), gw, sc, reinterpret_cast<uint64_t *>(wk + o_pred), keep);
+        HIPCHK(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(hom_count, dim3((uint32_t)n_tiles), dim3(256), 0, c->stream, d_cols, keep, n_cols, reinterpret_cast<uint32_t *>(wk + o_tile),
+                       reinterpret_cast<unsigned long long *>(wk + o_cnt));
+    HIPCHK(c, hipGetLastError());
+    std::vector<uint32_t> tile_out(n_tiles); unsigned long long moved = 0;
+    HIPCHK(c, hipMemcpyAsync(tile_out.data(), wk + o_tile, n_tiles * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&moved, wk + o_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *moved_out = (int64_t)moved;
+    if (moved == 0) return MAUVE_OK;                          // every residue stays where it is
+    std::vector<int64_t> tile_base(n_tiles + 1, 0);
+    for (size_t t = 0; t < n_tiles; t++) tile_base[t + 1] = tile_base[t] + tile_out[t];
+    const int64_t n_new = tile_base[n_tiles];
+    if (n_new > residues) { c->err = "apply_homology: more columns than residues"; return MAUVE_ERR_STATE; }
+    HIPCHK(c, c->hom_cols.ensure(((size_t)n_new + 64) * 4));
+    HIPCHK(c, hipMemcpyAsync(wk + o_base, tile_base.data(), (n_tiles + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(hom_write, dim3((uint32_t)n_tiles), dim3(256), 0, c->stream, d_cols, keep, n_cols, reinterpret_cast<const int64_t *>(wk + o_base), c->hom_cols.as<uint32_t>());
+    hipLaunchKernelGGL(hom_offsets, dim3((uint32_t)std::min<int64_t>(n_iv + 1, 4096)), dim3(64), 0, c->stream, d_cols, keep, n_cols, reinterpret_cast<const int64_t *>(wk + o_base),
+                       reinterpret_cast<const int64_t *>(wk + o_off), n_iv + 1, reinterpret_cast<int64_t *>(wk + o_noff));
+    HIPCHK(c, hipGetLastError());
+    noff.resize((size_t)n_iv + 1);
+    HIPCHK(c, hipMemcpyAsync(noff.data(), wk + o_noff, ((size_t)n_iv + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (noff[0] != 0 || noff[(size_t)n_iv] != n_new) { c->err = "apply_homology: column offsets do not add up"; return MAUVE_ERR_STATE; }
+    *n_new_out = n_new;
+    return MAUVE_OK;
+}
+
+int mauve_apply_homology(mauve_ctx *c, const mauve_hmm_params *h, mauve_align_sizes *sizes, int64_t *n_moved)
+{
+    if (!c || !h) return MAUVE_ERR_ARG;
+    AlignResult &R = c->res;
+    if (R.stale) { c->err = "apply_homology: the genomes were replaced after this alignment was made"; return MAUVE_ERR_STATE; }
+    const int64_t n_iv = R.sz.n_iv;
+    if ((int64_t)R.col_off.size() != n_iv + 1) { c->err = "apply_homology: no alignment in this context"; return MAUVE_ERR_STATE; }
+    if (n_moved) *n_moved = 0;
+    if (sizes) *sizes = R.sz;
+    if (n_iv == 0) return MAUVE_OK;
+    const int N = (int)(R.iv_left.size() / (size_t)n_iv);
+    const int64_t n_cols = R.col_off[(size_t)n_iv];
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!R.cols_pending && n_cols) {                          // the columns back to where the assembly stage keeps them
+        HIPCHK(c, c->res_cols.ensure(((size_t)n_cols + 64) * 4));
+        HIPCHK(c, hipMemcpyAsync(c->res_cols.p, R.cols_data(), (size_t)n_cols * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    std::vector<int64_t> noff; int64_t n_new = 0, moved = 0;
+    const int rc = homology_core(c, N, n_iv, R.iv_left.data(), R.iv_right.data(), R.iv_reverse.data(), R.col_off.data(), c->res_cols.as<uint32_t>(), h, noff, &n_new, &moved);
+    if (rc) return rc;
+    if (n_moved) *n_moved = moved;
+    if (moved == 0) return MAUVE_OK;
+    // the new columns are the result's columns from here on, resident like a device-assembled result
+    std::swap(c->res_cols, c->hom_cols);
+    R.col_off.swap(noff);
+    R.n_cols = (size_t)n_new; R.sz.n_cols = n_new;
+    R.cols_pending = true; R.cols_ext = nullptr; R.cols_fill = 0; R.cols_dirty.clear();
+    c->bb = mauve_ctx::BackboneResult();                       // a backbone of the old columns no longer applies
+    if (sizes) *sizes = R.sz;
+    return MAUVE_OK;
+}
+
+int mauve_apply_homology_alignment(mauve_ctx *c, int nseq, int64_t n_iv, const int64_t *left, const int64_t *right, const int8_t *reverse, const int64_t *col_off,
+                                   const uint32_t *cols, const mauve_hmm_params *h, int64_t *col_off_out, uint32_t *cols_out, int64_t *n_moved)
+{
+    if (!c || !h || nseq < 1 || nseq > MAUVE_MAX_SEQ || n_iv < 0 || !col_off_out || (n_iv && (!left || !right || !reverse || !col_off || !cols || !cols_out))) return MAUVE_ERR_ARG;
+    if (n_moved) *n_moved = 0;
+    col_off_out[0] = 0;
+    if (n_iv == 0) return MAUVE_OK;
+    for (int64_t iv = 0; iv < n_iv; iv++) if (col_off[iv + 1] < col_off[iv] || col_off[0] != 0) { c->err = "apply_homology: col_off must ascend from 0"; return MAUVE_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t n_cols = col_off[n_iv];
+    HIPCHK(c, c->bb_cols.ensure((size_t)n_cols * 4 + 64));
+    if (n_cols) HIPCHK(c, hipMemcpyAsync(c->bb_cols.p, cols, (size_t)n_cols * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                            // cols is the caller's (pageable) memory
+    std::vector<int64_t> noff; int64_t n_new = 0, moved = 0;
+    const int rc = homology_core(c, nseq, n_iv, left, right, reverse, col_off, c->bb_cols.as<uint32_t>(), h, noff, &n_new, &moved);
+    if (rc) return rc;
+    if (n_moved) *n_moved = moved;
+    if (moved == 0) { memcpy(col_off_out, col_off, ((size_t)n_iv + 1) * 8); if (n_cols) memcpy(cols_out, cols, (size_t)n_cols * 4); return MAUVE_OK; }
+    memcpy(col_off_out, noff.data(), ((size_t)n_iv + 1) * 8);
+    HIPCHK(c, hipMemcpy(cols_out, c->hom_cols.p, (size_t)n_new * 4, hipMemcpyDeviceToHost));
     return MAUVE_OK;
 }
 

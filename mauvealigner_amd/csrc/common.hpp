@@ -229,6 +229,7 @@ struct mauve_ctx {
     DevBuf ch_anch2, ext_work, sorted_rec_keep;   // device-resident LCB extension (extend_dev.hip): the extended anchor list, its work area, the main pass's match list set aside
     PinnedBuf pin_ext;
     DevBuf as_wide;                      // the anchor table widened to int64 for a direct fetch
+    DevBuf hom_cols;                     // homology pass (backbone_dev.hip): the re-split columns, swapped with res_cols when done
     DevBuf as_work, as_isl, res_cols;    // device assembly (assemble_dev.hip): work area, islands, result columns
     PinnedBuf pin_tab;                   // anchor table and match list of a device-assembled result on their way to the host
     PinnedBuf pin_asm, pin_cols;         // ... its per-LCB rows coming back; the columns and anchors on their way to a fetch

@@ -1142,34 +1142,36 @@ __global__ void __launch_bounds__(256) pair_length_sums(const int32_t *__restric
 
 // ---- pairwise breakpoint estimate (progressive.cpp scales node weights by it) ----
 // Of every genome pair's matches (length >= min_len): order by position in the lower genome, rank by position in the higher one,
-// and count the adjacencies that are not conserved.  Three small kernels around two radix sorts of (pair, position) keys.
-__global__ void __launch_bounds__(256) bp_keys_a(const int32_t *__restrict__ mlen, const int32_t *__restrict__ mstart, uint32_t ncand, int nseq, int pos_bits,
-                                                 int32_t min_len, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ n_valid)
+// and count the adjacencies that are not conserved.  Small kernels around three stable radix sorts of (pair, position) keys: by the
+// higher genome first (position, strand), so that the order along the lower genome breaks its ties that way, then the ranks.
+__device__ __forceinline__ bool bp_pair_of(const int32_t *__restrict__ st, int nseq, int *a, int *b)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    bool valid = false;
-    if (i < ncand) {
-        uint64_t key = (uint64_t)(nseq * nseq) << pos_bits;           // not counted: behind every pair
-        const int32_t len = mlen[i];
-        if (len != 0 && len >= min_len) {
-            int a = -1, b = -1;
-            for (int g = 0; g < nseq; g++) if (mstart[(size_t)i * nseq + g]) { if (a < 0) a = g; else if (b < 0) b = g; }
-            if (b >= 0) { const int32_t sa = mstart[(size_t)i * nseq + a]; key = ((uint64_t)(a * nseq + b) << pos_bits) | (uint64_t)(sa < 0 ? -sa : sa); valid = true; }
-        }
-        keys[i] = key; vals[i] = i;
-    }
-    const uint64_t bal = __ballot(valid);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_valid, (uint32_t)__popcll(bal));
+    int x = -1, y = -1;
+    for (int g = 0; g < nseq; g++) if (st[g]) { if (x < 0) x = g; else if (y < 0) y = g; }
+    *a = x; *b = y;
+    return y >= 0;
 }
-// second key: same pair, position in the higher genome; the value is the place in the first order
-__global__ void __launch_bounds__(256) bp_keys_b(const uint64_t *__restrict__ keys_a, const uint32_t *__restrict__ order_a, const int32_t *__restrict__ mstart, uint32_t nv,
-                                                 int nseq, int pos_bits, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+// which = 1: key by the higher genome (position, strand bit); 0: by the lower genome.  order == nullptr: record j itself (first sort:
+// records that do not count get the pair id nseq * nseq, behind every pair).  vals: the record index (keep_record) or j.
+__global__ void __launch_bounds__(256) bp_keys(const int32_t *__restrict__ mlen, const int32_t *__restrict__ mstart, const uint32_t *__restrict__ order, uint32_t n, int nseq,
+                                               int pos_bits, int32_t min_len, int which, int keep_record, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                               uint32_t *__restrict__ n_valid)
 {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= nv) return;
-    const uint32_t pair = (uint32_t)(keys_a[j] >> pos_bits), b = pair % (uint32_t)nseq;
-    const int32_t sb = mstart[(size_t)order_a[j] * nseq + b];
-    keys[j] = ((uint64_t)pair << pos_bits) | (uint64_t)(sb < 0 ? -sb : sb); vals[j] = j;
+    bool valid = false;
+    if (j < n) {
+        const uint32_t i = order ? order[j] : j;
+        uint64_t key = (uint64_t)(nseq * nseq) << (pos_bits + 1);
+        const int32_t len = mlen[i];
+        int a, b;
+        if (len != 0 && len >= min_len && bp_pair_of(mstart + (size_t)i * nseq, nseq, &a, &b)) {
+            const int32_t sx = mstart[(size_t)i * nseq + (which ? b : a)];
+            key = ((uint64_t)(a * nseq + b) << (pos_bits + 1)) | ((uint64_t)(sx < 0 ? -sx : sx) << 1) | (uint64_t)(sx < 0);
+            valid = true;
+        }
+        keys[j] = key; vals[j] = keep_record ? i : j;
+    }
+    if (n_valid) { const uint64_t bal = __ballot(valid); if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_valid, (uint32_t)__popcll(bal)); }
 }
 __global__ void __launch_bounds__(256) bp_rank(const uint32_t *__restrict__ order_b, uint32_t nv, uint32_t *__restrict__ rank)
 {
@@ -1183,8 +1185,8 @@ __global__ void __launch_bounds__(256) bp_count(const uint64_t *__restrict__ key
     for (int i = threadIdx.x; i < nseq * nseq; i += 256) s[i] = 0;
     __syncthreads();
     for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j + 1 < nv; j += gridDim.x * 256u) {
-        const uint32_t pair = (uint32_t)(keys_a[j] >> pos_bits);
-        if ((uint32_t)(keys_a[j + 1] >> pos_bits) != pair) continue;
+        const uint32_t pair = (uint32_t)(keys_a[j] >> (pos_bits + 1));
+        if ((uint32_t)(keys_a[j + 1] >> (pos_bits + 1)) != pair) continue;
         const uint32_t b = pair % (uint32_t)nseq;
         const int32_t s0 = mstart[(size_t)order_a[j] * nseq + b], s1 = mstart[(size_t)order_a[j + 1] * nseq + b];
         const uint32_t r0 = rank[j], r1 = rank[j + 1];
@@ -1640,20 +1642,32 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
                 int pos_bits = 1; while (pos_bits < 32 && (1LL << pos_bits) <= maxlen) pos_bits++;
                 int pid_bits = 1; while ((1 << pid_bits) <= N * N) pid_bits++;
                 const int32_t min_len = (int32_t)std::min<int64_t>(ctx->bp_min_len, INT32_MAX);
-                hipLaunchKernelGGL(bp_keys_a, dim3((ncand + 255) / 256), dim3(256), 0, ctx->stream, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(), ncand, N, pos_bits,
-                                   min_len, ck, cv, ctx->counters.as<uint32_t>() + 3);
+                const int kb = pos_bits + 1 + pid_bits;
+                // 1. by the higher genome (position, strand): only to break the ties of the next order
+                hipLaunchKernelGGL(bp_keys, dim3((ncand + 255) / 256), dim3(256), 0, ctx->stream, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(), (const uint32_t *)nullptr, ncand, N,
+                                   pos_bits, min_len, 1, 1, ck, cv, ctx->counters.as<uint32_t>() + 3);
                 HIPCHK(ctx, hipGetLastError());
-                int rc2 = sort_pairs<uint64_t>(ctx, ncand, pos_bits + pid_bits, &ck, &cv, ck2, cv2, false, MAUVE_K_CANON);
+                int rc2 = sort_pairs<uint64_t>(ctx, ncand, kb, &ck, &cv, ck2, cv2, false, MAUVE_K_CANON);
                 if (rc2) return rc2;
                 HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.as<char>(), ctx->counters.as<uint32_t>() + 3, 4, hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
                 const uint32_t nv = ctx->pin_seed.as<uint32_t>()[0];
                 if (nv >= 2) {
-                    hipLaunchKernelGGL(bp_keys_b, dim3((nv + 255) / 256), dim3(256), 0, ctx->stream, ck, cv, ctx->mstart.as<int32_t>(), nv, N, pos_bits, bk, bv);
+                    // 2. along the lower genome: record indices in that order (stable: ties stay in the order of 1.)
+                    hipLaunchKernelGGL(bp_keys, dim3((nv + 255) / 256), dim3(256), 0, ctx->stream, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(), cv, nv, N, pos_bits, min_len, 0, 1,
+                                       bk, bv, (uint32_t *)nullptr);
                     HIPCHK(ctx, hipGetLastError());
-                    uint64_t *sk = bk; uint32_t *sv = bv;
-                    rc2 = sort_pairs<uint64_t>(ctx, nv, pos_bits + pid_bits, &sk, &sv, bk2, bv2, false, MAUVE_K_CANON);
+                    uint64_t *ak = bk; uint32_t *av = bv;
+                    rc2 = sort_pairs<uint64_t>(ctx, nv, kb, &ak, &av, bk2, bv2, false, MAUVE_K_CANON);
                     if (rc2) return rc2;
+                    // 3. ranks along the higher genome (ties in the order of 2.); the canonical-sort buffers are free again
+                    uint64_t *sk = ctx->canon_k1.as<uint64_t>(); uint32_t *sv = ctx->canon_v1.as<uint32_t>();
+                    hipLaunchKernelGGL(bp_keys, dim3((nv + 255) / 256), dim3(256), 0, ctx->stream, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(), av, nv, N, pos_bits, min_len, 1, 0,
+                                       sk, sv, (uint32_t *)nullptr);
+                    HIPCHK(ctx, hipGetLastError());
+                    rc2 = sort_pairs<uint64_t>(ctx, nv, kb, &sk, &sv, ctx->canon_k2.as<uint64_t>(), ctx->canon_v2.as<uint32_t>(), false, MAUVE_K_CANON);
+                    if (rc2) return rc2;
+                    ck = ak; cv = av;                        // the order along the lower genome, for the count
                     hipLaunchKernelGGL(bp_rank, dim3((nv + 255) / 256), dim3(256), 0, ctx->stream, sv, nv, rank);
                     hipLaunchKernelGGL(bp_count, dim3(std::min<uint32_t>((nv + 255) / 256, 1024)), dim3(256), 0, ctx->stream, ck, cv, rank, ctx->mstart.as<int32_t>(), nv, N, pos_bits, dbp);
                     HIPCHK(ctx, hipGetLastError());

@@ -187,6 +187,12 @@ typedef struct {
     int64_t n_isl;
     int64_t *isl;                         /* [n_isl*8] interval, a, b (a < b), who has the residues, first col, last col, signed left, right */
 } orc_backbone;
+/* the homology pass in front of the backbone (detectAndApplyBackbone's HMM, progressiveMauve.cpp:226-243 [EXT]) */
+typedef struct { int32_t match, mismatch, gap, go_homologous, go_unrelated; } orc_hmm_params;      /* log-odds and log transition probabilities x 1000 */
+void orc_hmm_params_from(double identity, double pgh, double pgu, orc_hmm_params *h);
+/* columns in, columns out (cols_out holds up to the number of residues; col_off_out [n_iv+1]); returns the residues taken out of their columns, < 0 on error */
+int64_t orc_homology_apply(int nseq, const uint8_t *const *codes, int64_t n_iv, const int64_t *left, const int64_t *right, const int8_t *reverse,
+                           const int64_t *col_off, const uint32_t *cols, const orc_hmm_params *h, int64_t *col_off_out, uint32_t *cols_out);
 int orc_backbone_detect(int nseq, int64_t n_iv, const int64_t *left, const int64_t *right, const int8_t *reverse,
                         const int64_t *col_off, const uint32_t *cols, int64_t island_gap, orc_backbone *out);
 void orc_free_backbone(orc_backbone *o);

@@ -506,6 +506,40 @@ def backbone(left, right, reverse, col_off, cols, island_gap=20):
     return out
 
 
+class HmmParams(C.Structure):
+    _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("gap", C.c_int32), ("go_homologous", C.c_int32), ("go_unrelated", C.c_int32)]
+
+
+def hmm_params(identity=0.7, pgh=1e-5, pgu=1e-9, **kw):
+    """the call site's knobs (progressiveMauve.cpp:319-322) as the integer scores of DESIGN.md S12b"""
+    h = HmmParams()
+    lib().orc_hmm_params_from(C.c_double(identity), C.c_double(pgh), C.c_double(pgu), C.byref(h))
+    for k, v in kw.items():
+        setattr(h, k, v)
+    return h
+
+
+def homology_apply(codes, left, right, reverse, col_off, cols, hmm=None):
+    """un-align what the two-state pair HMM classes as unrelated.  -> (col_off, cols, residues moved)"""
+    h = hmm or hmm_params()
+    codes, arr, lens = _seq_args(codes)
+    left = np.ascontiguousarray(left, np.int64); right = np.ascontiguousarray(right, np.int64)
+    reverse = np.ascontiguousarray(reverse, np.int8); col_off = np.ascontiguousarray(col_off, np.int64)
+    cols = np.ascontiguousarray(cols, np.uint32)
+    niv, N = left.shape
+    nres = int(np.unpackbits(cols.view(np.uint8)).sum()) if len(cols) else 0
+    out = np.zeros(max(nres, 1), np.uint32)
+    off = np.zeros(niv + 1, np.int64)
+    lib().orc_homology_apply.restype = C.c_int64
+    moved = lib().orc_homology_apply(N, arr, C.c_int64(niv), left.ctypes.data_as(C.POINTER(C.c_int64)), right.ctypes.data_as(C.POINTER(C.c_int64)),
+                                     reverse.ctypes.data_as(C.POINTER(C.c_int8)), col_off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                     (cols if len(cols) else np.zeros(1, np.uint32)).ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(h),
+                                     off.ctypes.data_as(C.POINTER(C.c_int64)), out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if moved < 0:
+        raise RuntimeError("orc_homology_apply failed: %d" % moved)
+    return off, out[:int(off[niv])].copy(), int(moved)
+
+
 def merge_matches(len_a, st_a, len_b, st_b):
     """Seed-family union: a, then the matches of b that no match of a contains; canonical order."""
     la = np.ascontiguousarray(len_a, np.int64); sa = np.ascontiguousarray(st_a, np.int64)

@@ -377,7 +377,9 @@ def test_example_matches_c_abi(flag):
                                           names=paths, want_xmfa=True)
             else:
                 r = ctx.align(_lib.default_params(extend_lcbs=1), names=paths, want_xmfa=True)    # the call site passes lcb_extension = true
-            if flag == "-p":        # applyBackbone in the example: the .bbcols rows are the segments of mauve_backbone on the same alignment
+            if flag == "-p":        # applyBackbone in the example: homology pass (it rewrites the intervals that are written afterwards), then the
+                                    # .bbcols rows are the segments of mauve_backbone on that alignment
+                r = ctx.apply_homology(names=paths, want_xmfa=True)
                 bb = ctx.backbone(island_gap=20)
                 rows = [ln.split("\t") for ln in open(env["MAUVE_BACKBONE_OUT"] + ".bbcols").read().splitlines()]
                 assert len(rows) == len(bb["seg_iv"]) > 0

@@ -853,6 +853,60 @@ def test_progressive_refinement(ctx):
     assert _same_progressive(ctx, two, refine_rounds=2)["xmfa"] == _same_progressive(ctx, two)["xmfa"]
 
 
+def test_homology_pass_before_the_backbone(ctx):
+    """DESIGN.md S12b (detectAndApplyBackbone's homology HMM, progressiveMauve.cpp:226-243,319-322): the two-state Viterbi path per
+    interval and genome pair -- one wave per (interval, pair), 64 columns per step as a max-plus matrix scan, the way back on two
+    ballot words per step -- and the re-split columns equal the oracle's, bit for bit: on a clean alignment nothing moves; a
+    stretch of unrelated sequence that the gapped aligner forced into columns is taken apart again; reverse-strand intervals,
+    a progressive alignment with absent genomes, other scores; the backbone afterwards is the oracle's backbone of the new columns."""
+    from mauvealigner_amd import _lib
+    rng = np.random.default_rng(3)
+    anc = rng.integers(0, 4, 30000, dtype=np.uint8)
+
+    def check(gs, progressive=False, hmm_kw=None, **kw):
+        ctx.set_genomes(gs)
+        if progressive:
+            ctx.progressive_align(_lib.default_params(**kw), fetch=False)
+            a = O.progressive_align(gs, O.default_params(**kw))["aln"]
+        else:
+            ctx.align(_lib.default_params(**kw), fetch=False)
+            a = O.align(gs, O.default_params(**kw))["aln"]
+        hk = hmm_kw or {}
+        r = ctx.apply_homology(ctx.hmm_params(**hk))
+        off, cols, moved = O.homology_apply(gs, a["left"], a["right"], a["reverse"], a["col_off"], a["cols"], O.hmm_params(**hk))
+        assert r["n_moved"] == moved and r["n_cols"] == len(cols)
+        assert np.array_equal(r["col_off"], off) and np.array_equal(r["cols"], cols)
+        assert np.array_equal(r["left"], a["left"]) and np.array_equal(r["right"], a["right"])
+        for g in range(len(gs)):                                # every residue is still in exactly one column
+            assert int(((r["cols"] >> g) & 1).sum()) == int(((a["cols"] >> g) & 1).sum())
+        b = ctx.backbone(island_gap=20)
+        eb = O.backbone(a["left"], a["right"], a["reverse"], off, cols, island_gap=20)
+        for k in ("seg_iv", "seg_col", "seg_len", "seg_mask", "seg_left", "seg_right", "islands"):
+            assert np.array_equal(b[k], eb[k]), k
+        return r, a
+
+    h = ctx.hmm_params()
+    oh = O.hmm_params()
+    assert (h.match, h.mismatch, h.gap, h.go_homologous, h.go_unrelated) == (oh.match, oh.mismatch, oh.gap, oh.go_homologous, oh.go_unrelated) == (1030, -916, -500, -11513, -20723)
+    clean = [np.ascontiguousarray(synth.mutate(anc, 0.03, rng, indel_frac=0.1)) for _ in range(3)]
+    r, a = check(clean, seed_weight=11)
+    assert r["n_moved"] == 0 and np.array_equal(r["cols"], a["cols"])
+    gs = [np.ascontiguousarray(synth.mutate(anc, 0.05, rng, indel_frac=0.2)) for _ in range(3)]
+    g1 = gs[1].copy(); g1[12000:12600] = rng.integers(0, 4, 600, dtype=np.uint8); gs[1] = g1        # unrelated sequence of the same length
+    r, a = check(gs, seed_weight=11)
+    assert r["n_moved"] > 100 and r["n_cols"] > len(a["cols"])
+    inv = [g.copy() for g in gs]
+    inv[2][5000:20000] = synth.revcomp(inv[2][5000:20000])     # the stretch now lies in a reverse-strand interval of genome 2
+    r, _ = check(inv, seed_weight=11)
+    assert r["n_moved"] > 100
+    check(gs, seed_weight=11, hmm_kw=dict(identity=0.9, pgh=1e-3, pgu=1e-3))
+    check(gs, seed_weight=11, hmm_kw=dict(gap=-3000, go_unrelated=-2000))
+    c4 = synth.make_config("C4", scale=0.02)
+    c4[3] = c4[3].copy(); c4[3][9000:9500] = rng.integers(0, 4, 500, dtype=np.uint8)
+    check(c4, progressive=True)
+    check(synth.make_config("C3", scale=0.4), seed_weight=15)   # device-assembled result: the columns never left HBM
+
+
 def test_guide_tree_and_progressive_align(ctx):
     """ProgressiveAligner stand-in: guide tree + guide-tree recursive anchoring, bit-exact vs oracle."""
     gs = synth.make_config("C4", scale=0.02)

@@ -793,3 +793,70 @@ def test_breakpoint_counts_of_known_rearrangements():
     bp = O.breakpoint_counts([a, moved, inv], pat, 22)
     assert bp[0, 1] == 3 and bp[0, 2] == 2 and np.array_equal(bp, bp.T) and not bp.diagonal().any()
     assert O.breakpoint_counts([a, inv], pat, 10 ** 6)[0, 1] == 0          # no match passes the floor
+
+
+def test_homology_pass_restated():
+    """orc_homology_apply against a plain restatement (explicit Viterbi tables per pair, then the split), on
+    hand-made intervals with a reverse strand and an absent genome; identical rows stay, a block of mismatches is taken apart
+    once it outweighs the two transitions."""
+    rng = np.random.default_rng(17)
+    h = O.hmm_params(pgh=1e-2, pgu=1e-2)                        # cheap transitions: short stretches already flip
+    assert (h.match, h.mismatch, h.gap) == (1030, -916, -500) and h.go_homologous == h.go_unrelated == -4605
+
+    def restate(gs, left, right, reverse, col_off, cols):
+        N = len(gs); out_cols = []; out_off = [0]; moved = 0
+        for iv in range(len(left)):
+            cs = [int(x) for x in cols[col_off[iv]:col_off[iv + 1]]]
+            keep = [0] * len(cs)
+            for a in range(N):
+                for b in range(a + 1, N):
+                    if not left[iv][a] or not left[iv][b]:
+                        continue
+                    ka = kb = 0; vh, vu = -(1 << 60), 0; tb = []
+                    for c, m in enumerate(cs):
+                        ha, hb = m >> a & 1, m >> b & 1
+                        if not (ha or hb):
+                            tb.append(None); continue
+                        s = h.gap
+                        if ha and hb:
+                            pa = right[iv][a] - ka if reverse[iv][a] else left[iv][a] + ka
+                            pb = right[iv][b] - kb if reverse[iv][b] else left[iv][b] + kb
+                            xa = int(gs[a][pa - 1]); xb = int(gs[b][pb - 1])
+                            xa = 3 - xa if reverse[iv][a] else xa; xb = 3 - xb if reverse[iv][b] else xb
+                            s = h.match if xa == xb else h.mismatch
+                        ph, pu = vh >= vu + h.go_homologous, vu >= vh + h.go_unrelated
+                        vh, vu = max(s + (vh if ph else vu + h.go_homologous), -(1 << 60)), max(vu if pu else vh + h.go_unrelated, -(1 << 60))
+                        tb.append((ph, pu)); ka += ha; kb += hb
+                    st = vh >= vu
+                    for c in range(len(cs) - 1, -1, -1):
+                        if tb[c] is None:
+                            continue
+                        if st and cs[c] >> a & 1 and cs[c] >> b & 1:
+                            keep[c] |= 1 << a | 1 << b
+                        st = tb[c][0] if st else not tb[c][1]
+            for c, m in enumerate(cs):
+                k = keep[c] & m
+                if k:
+                    out_cols.append(k)
+                for g in range(N):
+                    if (m & ~k) >> g & 1:
+                        out_cols.append(1 << g); moved += bool(m & (m - 1))
+            out_off.append(len(out_cols))
+        return np.array(out_off, np.int64), np.array(out_cols, np.uint32), moved
+
+    anc = rng.integers(0, 4, 400, dtype=np.uint8)
+    g0 = anc.copy(); g1 = anc.copy(); g1[150:230] = (g1[150:230] + 1 + rng.integers(0, 3, 80)) % 4       # 80 mismatching columns in the middle
+    g2 = synth.revcomp(anc[100:300])
+    gs = [g0, g1.astype(np.uint8), np.ascontiguousarray(g2), rng.integers(0, 4, 50, dtype=np.uint8)]
+    left = np.array([[1, 1, 0, 0], [101, 101, 1, 0]], np.int64); right = np.array([[100, 100, 0, 0], [400, 400, 200, 0]], np.int64)
+    reverse = np.array([[0, 0, 0, 0], [0, 0, 1, 0]], np.int8)
+    cols = np.concatenate([np.full(100, 0b011, np.uint32), np.full(200, 0b111, np.uint32), np.full(100, 0b011, np.uint32)])
+    col_off = np.array([0, 100, 400], np.int64)
+    off, oc, moved = O.homology_apply(gs, left, right, reverse, col_off, cols, h)
+    eoff, ec, emoved = restate(gs, left, right, reverse, col_off, cols)
+    assert np.array_equal(off, eoff) and np.array_equal(oc, ec) and moved == emoved
+    assert moved > 0 and np.array_equal(oc[:100], cols[:100])                 # the clean interval stays; genome 1 leaves its mismatching stretch
+    assert int(((oc >> 1) & 1).sum()) == 400 and int(((oc >> 2) & 1).sum()) == 200
+    same = [g0, g0.copy()]
+    off, oc, moved = O.homology_apply(same, left[:1, :2] * 0 + [[1, 1]], np.array([[400, 400]]), np.zeros((1, 2), np.int8), np.array([0, 400]), np.full(400, 3, np.uint32), h)
+    assert moved == 0 and np.array_equal(oc, np.full(400, 3, np.uint32))
