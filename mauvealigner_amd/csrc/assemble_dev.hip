@@ -245,6 +245,10 @@ int assemble_device(mauve_ctx *c, int64_t na64, int64_t cells, mauve_align_sizes
     // fetched from where they are: both stay untouched until this context's next seed pass / chain.
     // (host_chains: both are on the host already -- the chains came from there)
     R.dev_nm = !host_chains && c->matches_pending ? (size_t)c->n_matches : 0;
+    if (S.mums_kept >= 0) {                  // the main pass's list was set aside for the recursion (pipeline.cpp): back in place, fetched from there
+        std::swap(c->sorted_rec, c->sorted_rec_keep);
+        R.dev_nm = (size_t)S.mums_kept; S.mums_kept = -1;
+    }
     R.dev_alen = fo.alen; R.dev_ast = fo.ast; R.dev_alcb = fo.alcb;
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -140,6 +140,11 @@ void host_merge_matches(MatchVec &kept, const MatchVec &add)
 void MatchVec::sort_by_start0()
 {
     const size_t n = size();
+    {   // already in order (the usual case for lists that come out of a genome-0-ordered pass): nothing to do
+        bool sorted = true;
+        for (size_t i = 1; i < n && sorted; i++) sorted = std::llabs(st(i - 1)[0]) <= std::llabs(st(i)[0]);
+        if (sorted) return;
+    }
     static thread_local std::vector<uint64_t> key, tmp;
     static thread_local std::vector<int64_t> nd;        // swapped with d: both buffers live on, no fresh allocation
     key.resize(n);

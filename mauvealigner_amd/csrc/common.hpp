@@ -167,6 +167,7 @@ struct AlignState {
     bool dev_tail = false;              // the chains stayed on the device: DP front end and assembly run there (mauve_align)
     const int32_t *dv_len = nullptr, *dv_st = nullptr, *dv_lcb = nullptr;   // ... where: anchors in chain order (chain_order_device, or the extended list)
     bool lw_from_host = false;          // the LCB weights of the result are those align_begin left in R.lcb_weight (device extension)
+    int64_t mums_kept = -1;             // >= 0: the main pass's match list (that many records) sits in ctx->sorted_rec_keep while the recursion's passes use sorted_rec
     mauve_params p{};
     int N = 0; uint32_t full = 0;
     int64_t sum = 0, nm = 0, nl = 0, n_dp = 0, code_total = 0, n_anchor = 0, anchor_cols = 0;
@@ -184,7 +185,7 @@ struct AlignState {
     // start a new alignment: scalars to zero, vectors emptied but not released
     void reset()
     {
-        open = false; anchor_table_done = false; dev_tail = false; dv_len = dv_st = dv_lcb = nullptr; lw_from_host = false; p = mauve_params(); N = 0; full = 0;
+        open = false; anchor_table_done = false; dev_tail = false; dv_len = dv_st = dv_lcb = nullptr; lw_from_host = false; mums_kept = -1; p = mauve_params(); N = 0; full = 0;
         sum = nm = nl = n_dp = code_total = n_anchor = anchor_cols = 0; t0 = t_dp0 = 0;
         gaps.clear(); desc.clear(); dcol_off.clear(); dscore.clear();
         match_lcb.clear(); match_weight.clear(); items.clear();

@@ -392,18 +392,30 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
                     std::vector<MatchVec> &chs = S.chains;
                     chs.resize((size_t)nl);
                     for (auto &ch : chs) { ch.N = N; ch.d.clear(); }
-                    int64_t rec[1 + MAUVE_MAX_SEQ];
-                    for (int64_t a = 0; a < na; a++) {
-                        rec[0] = hl[a];
-                        for (int g = 0; g < N; g++) rec[1 + g] = hs[(size_t)a * N + g];
-                        chs[(size_t)hb[a]].push(rec);
+                    // (chain order: LCB by LCB, so every chain is one contiguous stretch of the list -- sized once, filled in place)
+                    for (int64_t a = 0; a < na;) {
+                        int64_t e = a + 1;
+                        while (e < na && hb[e] == hb[a]) e++;
+                        MatchVec &ch = chs[(size_t)hb[a]];
+                        const size_t at = ch.d.size();
+                        ch.d.resize(at + (size_t)(e - a) * (1 + (size_t)N));
+                        int64_t *o = ch.d.data() + at;
+                        for (int64_t q = a; q < e; q++) { *o++ = hl[q]; for (int g = 0; g < N; g++) *o++ = hs[(size_t)q * N + g]; }
+                        a = e;
                     }
                     chains_ready = true;
                     if (g_trace_pipeline) fprintf(stderr, "[trace] chain (device): %lld extended anchors to the host (recursion to follow)\n", (long long)na);
                     S.dv_len = S.dv_st = S.dv_lcb = nullptr; S.lw_from_host = false;
                 }
             }
-            if (c->matches_pending) {                    // the host goes on: it needs its copy of the list after all
+            static const bool no_keep = getenv("MAUVE_NO_KEEP_MUMS") != nullptr;      // A/B switch
+            if (c->matches_pending && chains_ready && !no_keep && c->dev_rec_n == c->n_matches) {
+                // the chains came over as anchors; nothing on the host reads the match list before the caller fetches it: it stays in HBM,
+                // set aside while the recursion's passes use the seed workspace (back in place for the assembly: assemble_device)
+                std::swap(c->sorted_rec, c->sorted_rec_keep);
+                S.mums_kept = c->n_matches;
+                c->matches_pending = false; c->dev_rec_n = -1;
+            } else if (c->matches_pending) {             // the host goes on: it needs its copy of the list after all
                 rc = seed_matches_to_host(c);
                 if (rc) return rc;
                 R.mum_length = c->match_len; R.mum_start = c->match_start;
@@ -720,6 +732,21 @@ static int align_begin_lcbs(mauve_ctx *c, const mauve_params *p, std::vector<Mat
     return MAUVE_OK;
 }
 
+// the main pass's match list that was set aside in HBM (S.mums_kept) -> back in place and into the result's host tables
+static int kept_mums_to_host(mauve_ctx *c)
+{
+    AlignState &S = c->ast; AlignResult &R = c->res;
+    if (S.mums_kept < 0) return MAUVE_OK;
+    std::swap(c->sorted_rec, c->sorted_rec_keep);
+    const size_t n = (size_t)S.mums_kept, N = (size_t)S.N;
+    S.mums_kept = -1;
+    HIPCHK(c, c->pin_tab.ensure(n * (1 + N) * 8 + 64));
+    if (n) HIPCHK(c, hipMemcpy(c->pin_tab.p, c->sorted_rec.p, n * (1 + N) * 8, hipMemcpyDeviceToHost));
+    const int64_t *hm = c->pin_tab.as<int64_t>();
+    R.mum_length.assign(hm, hm + n); R.mum_start.assign(hm + n, hm + n * (1 + N));
+    return MAUVE_OK;
+}
+
 // The chains are on the host (S.chains: recursion, LCB extension, a small or tied list, a caller's LCBs): the anchors go up
 // once, interval table, DP and -- unless MAUVE_HOST_TAIL -- the assembly run on the device.
 static int align_tail_host_chains(mauve_ctx *c, mauve_align_sizes *sizes)
@@ -755,6 +782,7 @@ static int align_tail_host_chains(mauve_ctx *c, mauve_align_sizes *sizes)
         if (rc) return rc;
         return assemble_device(c, na, cells, sizes, true);
     }
+    { const int rck = kept_mums_to_host(c); if (rck) return rck; }        // (the host assembly fills every table on the host)
     rc = dp_run_from_anchors(c, N, na, h_len, h_st, h_lcb, S.p.gapped, dp_len_limit(&S.p), &S.p.scoring, gapcode, &S.n_dp, &S.code_total,
                              &c->pin_dcols, S.dcol_off, S.dscore, &cells);
     c->shadow = nullptr;

@@ -13,6 +13,7 @@
 // Every node is one pass of the same device pipeline (seed pass, batched recursive anchoring, batched DP).
 #include "common.hpp"
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -330,6 +331,16 @@ int prog_node(Prog &P, int node)
     // ---- blocks ----
     const double tb0 = now_ms();
     uint32_t gfull = 0; for (int j = 0; j < n; j++) gfull |= 1u << gm[j];
+    // local genome bits -> global ones, a byte at a time
+    bool same_bits = true; for (int j = 0; j < n; j++) same_bits = same_bits && gm[j] == j;
+    std::vector<std::array<uint32_t, 256>> lut(4);
+    if (!same_bits)
+        for (int by = 0; by < 4; by++)
+            for (int v = 0; v < 256; v++) {
+                uint32_t o = 0;
+                for (int bit = 0; bit < 8; bit++) { const int j = by * 8 + bit; if ((v >> bit & 1) && j < n) o |= 1u << gm[j]; }
+                lut[(size_t)by][(size_t)v] = o;
+            }
     std::vector<std::vector<std::pair<int64_t, int64_t>>> placed((size_t)n);
     size_t gi = 0;
     const int N = P.N;
@@ -343,10 +354,13 @@ int prog_node(Prog &P, int node)
             if (gi < gaps.size() && gaps[gi].piece == q && gaps[gi].idx == i) {
                 const GapRef &gr = gaps[gi++];
                 if (gr.dp) {
-                    for (int64_t k = dcol_off[(size_t)gr.slot]; k < dcol_off[(size_t)gr.slot + 1]; k++) {
-                        const uint32_t mloc = dcols[(size_t)k]; uint32_t o = 0;         // local genome bits -> global
-                        for (int j = 0; j < n; j++) if (mloc >> j & 1) o |= 1u << gm[j];
-                        R.cols.push_back(o);
+                    const uint32_t *src = dcols + dcol_off[(size_t)gr.slot], *end = dcols + dcol_off[(size_t)gr.slot + 1];
+                    if (same_bits) R.cols.insert(R.cols.end(), src, end);               // (the root, and any node of genomes 0 .. n-1)
+                    else {
+                        const size_t at = R.cols.size();
+                        R.cols.resize(at + (size_t)(end - src));
+                        uint32_t *dst = R.cols.data() + at;
+                        for (; src < end; src++) { const uint32_t m = *src; *dst++ = lut[0][m & 255] | lut[1][m >> 8 & 255] | lut[2][m >> 16 & 255] | lut[3][m >> 24]; }
                     }
                     R.dp_score.back() += dscore[(size_t)gr.slot];
                 } else {

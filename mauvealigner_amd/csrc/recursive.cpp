@@ -158,6 +158,7 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
             if (w) classes[w].push_back(i);
         }
         WorkList next(N);
+        next.d.reserve(work.d.size() + work.d.size() / 2);
         level++;
         for (auto &cls : classes) {
             const int w = cls.first;
@@ -322,17 +323,28 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                 } else apply_gap(wi, glob);
             };
             if (compact) {
-                // only the survivors came back, with their gaps, in list order (gap by gap)
+                // only the survivors came back, with their gaps, in list order (gap by gap): straight to real coordinates
                 for (uint32_t q = 0; q < ns;) {
                     const uint32_t k = dg[q];
-                    loc.d.clear();
-                    for (; q < ns && dg[q] == k; q++) {
-                        int64_t rec[1 + MAUVE_MAX_SEQ]; rec[0] = dl[q];
-                        for (int g = 0; g < N; g++) rec[1 + g] = (int64_t)ds[(size_t)q * N + g] - seg[(size_t)g * (K + 1) + k];
-                        loc.push(rec);
+                    uint32_t e = q + 1;
+                    while (e < ns && dg[e] == k) e++;
+                    const size_t wi = ids[k];
+                    const int64_t *A = work.a(wi);
+                    glob.d.resize((size_t)(e - q) * (1 + (size_t)N));
+                    int64_t *o = glob.d.data();
+                    for (; q < e; q++) {
+                        const int64_t len = dl[q];
+                        *o++ = len;
+                        for (int g = 0; g < N; g++) {
+                            const int64_t s = (int64_t)ds[(size_t)q * N + g] - seg[(size_t)g * (K + 1) + k], lo = glo[(size_t)g * K + k], ln = glen[(size_t)g * K + k];
+                            *o++ = A[1 + g] > 0 ? lo + s - 1 : -((lo + ln - 1) - (s - 1) - len + 1);
+                        }
                     }
-                    ml.assign(loc.size(), 0);
-                    emit_gap(k);
+                    glob.sort_by_start0();
+                    if (sharded) {
+                        shard_msg.push_back((int64_t)pos_of[k]); shard_msg.push_back((int64_t)glob.size());
+                        shard_msg.insert(shard_msg.end(), glob.d.begin(), glob.d.end());
+                    } else apply_gap(wi, glob);
                 }
                 i = nm;
             }
