@@ -674,13 +674,15 @@ __global__ void __launch_bounds__(256) join_hash(const KeyT *__restrict__ keys, 
 // node) spends its time in launches: count, scan, extract, four sort passes, bounds, join -- a dozen kernels of 5-20 us each
 // for a few kilobytes.  Here one workgroup of 1024 threads computes the canonical mers of ALL valid windows, groups them in an
 // LDS hash table (compare-and-swap claim, linear probing; the same once / multi genome sets and the same finder rule as
-// join_hash) and writes the hit table -- no key array, no sort.  <= TJ_MAX windows, <= 16 genomes, mers of <= 32 bits.
+// join_hash) and writes the hit table -- no key array, no sort.  <= TJ_MAX windows, <= 16 genomes, mer (+ gap id of a segmented
+// set: the small batches of the deeper recursion levels) of <= 32 bits.
 constexpr int TJ_SLOTS = 16384;                  // 128 KB of LDS: key word + genome sets per slot
 constexpr int TJ_MAX = 9216;                     // load factor <= 0.5625
 constexpr int TJ_ROWS = TJ_MAX / 1024;
 __global__ void __launch_bounds__(1024) tiny_join(const uint64_t *__restrict__ packed, GenomeTab tab, SeedShape sh, uint32_t P,
                                                   const uint64_t *__restrict__ vmask, const uint64_t *__restrict__ cmask, int mode, uint32_t want_mask,
-                                                  uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos, uint32_t *__restrict__ err_cnt)
+                                                  uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos, uint32_t *__restrict__ err_cnt,
+                                                  const uint32_t *__restrict__ seg, uint32_t nseg)
 {
     extern __shared__ uint32_t tj_lds[];
     uint32_t *skey = tj_lds, *som = tj_lds + TJ_SLOTS;
@@ -704,6 +706,12 @@ __global__ void __launch_bounds__(1024) tiny_join(const uint64_t *__restrict__ p
             const uint64_t kp = kprime_at(packed + tab.word_off[g], p, sh);
             const uint64_t f = digit_reverse(kp, sh.weight), rr = (~kp) & sh.keymask;
             sflag = rr < f; k = (uint32_t)(sflag ? rr : f);
+        }
+        if (seg) {                                  // segmented set (a batch of recursion gaps): the gap id rides above the mer, no window across gaps
+            const uint32_t *sg = seg + (size_t)g * (nseg + 1);
+            const uint32_t sk = seg_of(sg, nseg, p);
+            if (p + (uint32_t)sh.span > sg[sk + 1]) continue;
+            k |= sk << (2 * sh.weight);
         }
         key[r] = k; v[r] = gp | (sflag << 31); gbit[r] = 1u << g;
     }
@@ -1368,7 +1376,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     };
     // a pass of a few thousand windows: no key arrays at all (tiny_join).  MAUVE_NO_TINY: A/B switch
     static const bool no_tiny = getenv("MAUVE_NO_TINY") != nullptr;
-    const bool tiny = hash_path && !SEG && only_seq < 0 && !no_tiny && n <= (uint32_t)TJ_MAX && tab.nseq <= 16 && 2 * sh.weight <= 32;
+    const bool tiny = hash_path && only_seq < 0 && !no_tiny && n <= (uint32_t)TJ_MAX && tab.nseq <= 16 && 2 * sh.weight + (SEG ? segbits : 0) <= 32;
     if (hh) sorted_n = 1;
     else if (tiny) sorted_n = n;
     else if (only_seq < 0 && masked && !SEG) {
@@ -1528,7 +1536,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             if (!tj_attr) { ctx->err = "tiny_join: cannot reserve its LDS"; return MAUVE_ERR_HIP; }
             KernelTimer t(ctx, MAUVE_K_JOIN, P);
             hipLaunchKernelGGL(tiny_join, dim3(1), dim3(1024), TJ_SLOTS * 8, ctx->stream, packed, tab, sh, P, vmask, cmask, fp.rule, fp.want, tmask, tpos,
-                               ctx->counters.as<uint32_t>() + 9);
+                               ctx->counters.as<uint32_t>() + 9, SEG ? seg : (const uint32_t *)nullptr, nseg);
         } else if (hash_path) {
             const uint32_t nchunk = (ns + HJ_T - 1) / HJ_T;
             HIPCHK(ctx, ctx->join_ovf.ensure((2 + 2 * (size_t)HJ_OVF_CAP) * 4));        // the ranges; their count sits in the counter block (words 8, 9)
