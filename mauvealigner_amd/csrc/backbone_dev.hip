@@ -216,78 +216,191 @@ void bb_components(const uint32_t *adj, uint32_t gmask, std::vector<uint32_t> &o
 
 // ================================================================================================
 // Homology pass: the two-state pair HMM in front of the backbone, on the device.
-//   hom_viterbi  one wave per (interval, genome pair): 64 columns per step on the lanes.  A column is a max-plus 2 x 2 matrix
-//                (new H / new U from old H / old U); the wave's inclusive scan of the matrices applied to the carried (vH, vU)
-//                gives every column's Viterbi values at once, the predecessor choices of all 64 columns are two ballot words
-//                kept in HBM (16 bytes per 64 columns and pair).  The way back replays the two words bit by bit on the scalar
-//                unit and ORs the pair's bits into keep[column] where the state is H and both genomes have a base.
+// With x = vH - vU the Viterbi recurrence of a pair-column with emission score s is ONE clamp:  x' = s + clamp(x, go_h, -go_u)
+// (x <= go_h: H is entered from U; x >= -go_u: U is entered from H; in between both stay), the predecessor choices are
+// "x >= go_h" (H came from H) and "x <= -go_u" (U came from U), the final state is "x >= 0".  Functions x -> clamp(x + t, L, U)
+// are closed under composition, so the columns are an associative scan over (t, L, U) triples of int32 -- and the way back
+// (state -> predecessor state, a map on two elements = two bits per column) is one too.  Intervals are cut into segments of
+// 4096 columns (64 steps of 64 lanes); every (interval, pair, segment) is one wave:
+//   hom_seg_count  residues of every genome per segment (base positions at the segment starts: host prefix per interval)
+//   hom_fn         the segment's composed function                      -> host: x at every segment start, final state
+//   hom_pred       the same sweep with x known: predecessor words (2 x 64 bits per step), step maps, the segment's map
+//                                                                       -> host: state at every segment end
+//   hom_keep       states of all columns from the words and the end state; ORs the pair's bits into keep[column] where the
+//                  state is H and both genomes have a base
 //   hom_count / hom_write / hom_offsets  the columns split by keep: tile totals, (host prefix over the tiles), the new
 //                columns written in order, the new column offset of every interval.
-struct HomItem { uint32_t ivx; uint32_t a, b; uint32_t pad; int64_t slot; };                 // slot: first pred-word pair of this (interval, pair)
-struct HomIv { int64_t col0, ncols; uint32_t iv, nchunks; };
+constexpr int HOM_SEG = 4096;                     // columns per segment = 64 steps of 64 lanes
+struct HomItem { uint32_t ivx, seg; uint8_t a, b; uint16_t pad; };                            // one wave's work: segment `seg` of interval ivx, pair (a, b)
+struct HomIv { int64_t col0, ncols; uint32_t iv, nseg; uint32_t seg0, pad; };                  // seg0: the interval's first row in the per-segment tables
 struct HomGenomes { uint64_t word_off[MAUVE_MAX_SEQ]; };
-struct HomScores { int64_t match, mismatch, gap, go_h, go_u; };
-constexpr int64_t HOM_NEG = -((int64_t)1 << 60);
+struct HomScores { int32_t match, mismatch, gap, go_h, go_u; };
+struct HomFn { int32_t t, lo, hi, pad; };                                                     // x -> clamp(x + t, lo, hi)
+constexpr int32_t HOM_MINF = -(1 << 30), HOM_PINF = 1 << 30;
 
 __device__ __forceinline__ int hom_base(const uint64_t *__restrict__ G, int64_t pos0) { return (int)(G[pos0 >> 5] >> ((pos0 & 31) * 2) & 3u); }
-__device__ __forceinline__ int64_t hom_clamp(int64_t x) { return x < HOM_NEG ? HOM_NEG : x; }
+__device__ __forceinline__ int32_t hom_clamp(int32_t x, int32_t lo, int32_t hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// g2 after g1
+__device__ __forceinline__ void hom_compose(int32_t &t, int32_t &lo, int32_t &hi, int32_t t1, int32_t lo1, int32_t hi1)
+{
+    const int32_t t2 = t, lo2 = lo, hi2 = hi;
+    t = t1 + t2; lo = hom_clamp(lo1 + t2, lo2, hi2); hi = hom_clamp(hi1 + t2, lo2, hi2);
+    if (lo1 == HOM_MINF && lo2 == HOM_MINF) lo = HOM_MINF;      // two identities stay the identity
+    if (hi1 == HOM_PINF && hi2 == HOM_PINF) hi = HOM_PINF;
+}
+// maps on {U = 0, H = 1} as two bits (bit s = image of s); p after q
+__device__ __forceinline__ uint32_t hom_map_after(uint32_t p, uint32_t q) { return ((p >> (q & 1u)) & 1u) | (((p >> (q >> 1 & 1u)) & 1u) << 1); }
 
-__global__ void __launch_bounds__(64) hom_viterbi(const uint32_t *__restrict__ cols, const HomItem *__restrict__ items, uint32_t n_items, const HomIv *__restrict__ ivs,
-                                                  const int64_t *__restrict__ left, const int64_t *__restrict__ right, const int8_t *__restrict__ rev, int N,
-                                                  const uint64_t *__restrict__ genomes, HomGenomes gw, HomScores sc, uint64_t *__restrict__ pred, uint32_t *__restrict__ keep)
+struct HomPair {          // what a wave knows about its (interval, pair, segment)
+    const uint64_t *Ga, *Gb; int64_t la, ra, lb, rb; bool rva, rvb; int a, b; int64_t c0, n; int64_t ka, kb;
+};
+__device__ __forceinline__ HomPair hom_setup(const HomItem &item, const HomIv &iv, const int64_t *__restrict__ left, const int64_t *__restrict__ right,
+                                             const int8_t *__restrict__ rev, int N, const uint64_t *__restrict__ genomes, const HomGenomes &gw,
+                                             const int64_t *__restrict__ rank0)
+{
+    HomPair P;
+    P.a = item.a; P.b = item.b;
+    P.la = left[(size_t)iv.iv * N + P.a]; P.ra = right[(size_t)iv.iv * N + P.a]; P.lb = left[(size_t)iv.iv * N + P.b]; P.rb = right[(size_t)iv.iv * N + P.b];
+    P.rva = rev[(size_t)iv.iv * N + P.a] != 0; P.rvb = rev[(size_t)iv.iv * N + P.b] != 0;
+    P.Ga = genomes + gw.word_off[P.a]; P.Gb = genomes + gw.word_off[P.b];
+    P.c0 = iv.col0 + (int64_t)item.seg * HOM_SEG;
+    P.n = min((int64_t)HOM_SEG, iv.ncols - (int64_t)item.seg * HOM_SEG);
+    P.ka = rank0[(size_t)(iv.seg0 + item.seg) * N + P.a]; P.kb = rank0[(size_t)(iv.seg0 + item.seg) * N + P.b];
+    return P;
+}
+// the column of this lane in step `ch` as a function (identity where neither genome has a base); advances the base counters
+__device__ __forceinline__ void hom_column(HomPair &P, const uint32_t *__restrict__ cols, int ch, int lane, const HomScores &sc, int32_t &t, int32_t &lo, int32_t &hi,
+                                           bool &none, bool &both)
+{
+    const int64_t c = (int64_t)ch * 64 + lane;
+    const uint32_t m = c < P.n ? cols[P.c0 + c] : 0u;
+    const bool ha = m >> P.a & 1u, hb = m >> P.b & 1u;
+    none = !(ha || hb); both = ha && hb;
+    const uint64_t BA = __ballot(ha), BB = __ballot(hb);
+    int32_t s = sc.gap;
+    if (both) {
+        const int64_t ia = P.ka + __popcll(BA & below(lane)), ib = P.kb + __popcll(BB & below(lane));
+        int xa = hom_base(P.Ga, (P.rva ? P.ra - ia : P.la + ia) - 1), xb = hom_base(P.Gb, (P.rvb ? P.rb - ib : P.lb + ib) - 1);
+        if (P.rva) xa = 3 - xa;
+        if (P.rvb) xb = 3 - xb;
+        s = xa == xb ? sc.match : sc.mismatch;
+    }
+    t = none ? 0 : s; lo = none ? HOM_MINF : sc.go_h + s; hi = none ? HOM_PINF : -sc.go_u + s;
+    P.ka += __popcll(BA); P.kb += __popcll(BB);
+}
+// inclusive scan over the lanes: lane l gets (column l) after ... after (column 0)
+__device__ __forceinline__ void hom_scan(int lane, int32_t &t, int32_t &lo, int32_t &hi)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t t1 = __shfl_up(t, d, 64), lo1 = __shfl_up(lo, d, 64), hi1 = __shfl_up(hi, d, 64);
+        if (lane >= d) hom_compose(t, lo, hi, t1, lo1, hi1);
+    }
+}
+
+__global__ void __launch_bounds__(64) hom_seg_count(const uint32_t *__restrict__ cols, const HomIv *__restrict__ ivs, uint32_t n_ivs, int N, uint32_t *__restrict__ cnt)
+{
+    const int lane = threadIdx.x;
+    // which interval: the segment rows are consecutive per interval
+    uint32_t lo = 0, hi = n_ivs;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ivs[mid].seg0 <= blockIdx.x) lo = mid; else hi = mid; }
+    const HomIv iv = ivs[lo];
+    const uint32_t seg = blockIdx.x - iv.seg0;
+    const int64_t c0 = iv.col0 + (int64_t)seg * HOM_SEG, n = min((int64_t)HOM_SEG, iv.ncols - (int64_t)seg * HOM_SEG);
+    uint32_t mine = 0;
+    for (int ch = 0; ch * 64 < n; ch++) {
+        const int64_t c = (int64_t)ch * 64 + lane;
+        const uint32_t v = c < n ? cols[c0 + c] : 0u;
+        for (int g = 0; g < N; g++) { const uint32_t x = (uint32_t)__popcll(__ballot(v >> g & 1)); if (lane == g) mine += x; }
+    }
+    if (lane < N) cnt[(size_t)blockIdx.x * N + lane] = mine;
+}
+
+__global__ void __launch_bounds__(64) hom_fn(const uint32_t *__restrict__ cols, const HomItem *__restrict__ items, uint32_t n_items, const HomIv *__restrict__ ivs,
+                                             const int64_t *__restrict__ left, const int64_t *__restrict__ right, const int8_t *__restrict__ rev, int N,
+                                             const uint64_t *__restrict__ genomes, HomGenomes gw, HomScores sc, const int64_t *__restrict__ rank0, HomFn *__restrict__ fn)
+{
+    const int lane = threadIdx.x;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const HomItem item = items[it];
+        HomPair P = hom_setup(item, ivs[item.ivx], left, right, rev, N, genomes, gw, rank0);
+        int32_t ft = 0, flo = HOM_MINF, fhi = HOM_PINF;          // the segment so far
+        for (int ch = 0; (int64_t)ch * 64 < P.n; ch++) {
+            int32_t t, lo, hi; bool none, both;
+            hom_column(P, cols, ch, lane, sc, t, lo, hi, none, both);
+            hom_scan(lane, t, lo, hi);
+            int32_t ct = __shfl(t, 63, 64), clo = __shfl(lo, 63, 64), chi = __shfl(hi, 63, 64);        // the step as a whole ...
+            hom_compose(ct, clo, chi, ft, flo, fhi);                                                  // ... after the segment so far
+            ft = ct; flo = clo; fhi = chi;
+        }
+        if (lane == 0) fn[it] = HomFn{ft, flo, fhi, 0};
+    }
+}
+
+__global__ void __launch_bounds__(64) hom_pred(const uint32_t *__restrict__ cols, const HomItem *__restrict__ items, uint32_t n_items, const HomIv *__restrict__ ivs,
+                                               const int64_t *__restrict__ left, const int64_t *__restrict__ right, const int8_t *__restrict__ rev, int N,
+                                               const uint64_t *__restrict__ genomes, HomGenomes gw, HomScores sc, const int64_t *__restrict__ rank0,
+                                               const int32_t *__restrict__ xin, uint64_t *__restrict__ pred, uint8_t *__restrict__ stepmap, uint8_t *__restrict__ segmap)
+{
+    const int lane = threadIdx.x;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const HomItem item = items[it];
+        HomPair P = hom_setup(item, ivs[item.ivx], left, right, rev, N, genomes, gw, rank0);
+        int32_t x = xin[it];
+        uint32_t my_step = 2u;                                  // lane k keeps the map of step k (identity = 0b10)
+        for (int ch = 0; (int64_t)ch * 64 < P.n; ch++) {
+            int32_t t, lo, hi; bool none, both;
+            hom_column(P, cols, ch, lane, sc, t, lo, hi, none, both);
+            hom_scan(lane, t, lo, hi);
+            const int32_t after = hom_clamp(x + t, lo, hi);     // x behind this lane's column
+            int32_t before = __shfl_up(after, 1, 64);
+            if (lane == 0) before = x;
+            const bool ph = none || before >= sc.go_h, pu = none || before <= -sc.go_u;
+            const uint64_t PH = __ballot(ph), PU = __ballot(pu);
+            if (lane == 0) { pred[((size_t)it * 64 + ch) * 2] = PH; pred[((size_t)it * 64 + ch) * 2 + 1] = PU; }
+            // the way back through this step: m_c(state) = state ? ph : !pu; lanes compose m_l after ... wait: m_l o m_{l+1} o .. o m_63
+            uint32_t mp = (ph ? 2u : 0u) | (pu ? 0u : 1u);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_down(mp, d, 64); if (lane + d < 64) mp = hom_map_after(mp, o); }
+            const uint32_t whole = __shfl(mp, 0, 64);           // state behind the step -> state behind the previous step
+            if (lane == ch) my_step = whole;
+            x = __shfl(after, 63, 64);
+        }
+        stepmap[(size_t)it * 64 + lane] = (uint8_t)my_step;
+        uint32_t sm = my_step;                                  // segment: step 0 after step 1 after ... (state behind the segment -> behind the previous one)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_down(sm, d, 64); if (lane + d < 64) sm = hom_map_after(sm, o); }
+        if (lane == 0) segmap[it] = (uint8_t)sm;
+    }
+}
+
+__global__ void __launch_bounds__(64) hom_keep(const uint32_t *__restrict__ cols, const HomItem *__restrict__ items, uint32_t n_items, const HomIv *__restrict__ ivs,
+                                               const uint64_t *__restrict__ pred, const uint8_t *__restrict__ stepmap, const uint8_t *__restrict__ send,
+                                               uint32_t *__restrict__ keep)
 {
     const int lane = threadIdx.x;
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
         const HomItem item = items[it];
         const HomIv iv = ivs[item.ivx];
-        const int a = (int)item.a, b = (int)item.b;
-        const int64_t la = left[(size_t)iv.iv * N + a], ra = right[(size_t)iv.iv * N + a], lb = left[(size_t)iv.iv * N + b], rb = right[(size_t)iv.iv * N + b];
-        const bool rva = rev[(size_t)iv.iv * N + a] != 0, rvb = rev[(size_t)iv.iv * N + b] != 0;
-        const uint64_t *Ga = genomes + gw.word_off[a], *Gb = genomes + gw.word_off[b];
-        int64_t vh = HOM_NEG, vu = 0, ka = 0, kb = 0;
-        for (uint32_t ch = 0; ch < iv.nchunks; ch++) {
-            const int64_t c = (int64_t)ch * 64 + lane;
-            const uint32_t m = c < iv.ncols ? cols[iv.col0 + c] : 0u;
-            const bool ha = m >> a & 1u, hb = m >> b & 1u, none = !(ha || hb);
-            const uint64_t BA = __ballot(ha), BB = __ballot(hb);
-            int64_t s = sc.gap;
-            if (ha && hb) {
-                const int64_t ia = ka + __popcll(BA & below(lane)), ib = kb + __popcll(BB & below(lane));
-                int xa = hom_base(Ga, (rva ? ra - ia : la + ia) - 1), xb = hom_base(Gb, (rvb ? rb - ib : lb + ib) - 1);
-                if (rva) xa = 3 - xa;
-                if (rvb) xb = 3 - xb;
-                s = xa == xb ? sc.match : sc.mismatch;
-            }
-            int64_t hh = none ? 0 : s, hu = none ? HOM_NEG : s + sc.go_h, uh = none ? HOM_NEG : sc.go_u, uu = 0;
+        const int64_t c0 = iv.col0 + (int64_t)item.seg * HOM_SEG, n = min((int64_t)HOM_SEG, iv.ncols - (int64_t)item.seg * HOM_SEG);
+        // state behind every step: lane k = behind step k, from the state behind the segment and the maps of the steps after k
+        uint32_t sm = stepmap[(size_t)it * 64 + lane];
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {                // inclusive scan: this lane's product after (the earlier lanes' product)
-                const int64_t ehh = __shfl_up(hh, d, 64), ehu = __shfl_up(hu, d, 64), euh = __shfl_up(uh, d, 64), euu = __shfl_up(uu, d, 64);
-                if (lane >= d) {
-                    const int64_t nhh = max(hh + ehh, hu + euh), nhu = max(hh + ehu, hu + euu), nuh = max(uh + ehh, uu + euh), nuu = max(uh + ehu, uu + euu);
-                    hh = hom_clamp(nhh); hu = hom_clamp(nhu); uh = hom_clamp(nuh); uu = hom_clamp(nuu);
-                }
-            }
-            const int64_t wh = hom_clamp(max(hh + vh, hu + vu)), wu = hom_clamp(max(uh + vh, uu + vu));      // values after this lane's column
-            int64_t bh = __shfl_up(wh, 1, 64), bu = __shfl_up(wu, 1, 64);                                   // ... and before it
-            if (lane == 0) { bh = vh; bu = vu; }
-            const bool ph = none || bh >= bu + sc.go_h, pu = none || bu >= bh + sc.go_u;
-            const uint64_t PH = __ballot(ph), PU = __ballot(pu);
-            if (lane == 0) { pred[(size_t)(item.slot + ch) * 2] = PH; pred[(size_t)(item.slot + ch) * 2 + 1] = PU; }
-            vh = __shfl(wh, 63, 64); vu = __shfl(wu, 63, 64);
-            ka += __popcll(BA); kb += __popcll(BB);
-        }
-        int st = vh >= vu;                                    // 1 = H; wave-uniform from here on
-        for (int64_t ch = (int64_t)iv.nchunks - 1; ch >= 0; ch--) {
-            const int64_t c = ch * 64 + lane;
-            const uint32_t m = c < iv.ncols ? cols[iv.col0 + c] : 0u;
-            const bool both = (m >> a & 1u) && (m >> b & 1u);
-            const uint64_t PH = pred[(size_t)(item.slot + ch) * 2], PU = pred[(size_t)(item.slot + ch) * 2 + 1];
-            uint64_t S = 0;
-            for (int l = 63; l >= 0; l--) {                   // (columns neither genome is in carry PH = PU = 1: the state passes through)
-                if (st) S |= 1ull << l;
-                st = st ? (int)(PH >> l & 1ull) : (int)(~PU >> l & 1ull);
-            }
-            if (both && (S >> lane & 1ull)) atomicOr(&keep[iv.col0 + c], 1u << a | 1u << b);
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_down(sm, d, 64); if (lane + d < 64) sm = hom_map_after(sm, o); }
+        const uint32_t e = send[it];                            // state behind the segment
+        const uint32_t nxt = __shfl_down(sm, 1, 64);            // steps k+1 .. 63 as one map
+        const uint32_t behind = lane == 63 ? e : ((nxt >> e) & 1u);
+        for (int ch = 0; (int64_t)ch * 64 < n; ch++) {
+            const int64_t c = (int64_t)ch * 64 + lane;
+            const uint32_t m = c < n ? cols[c0 + c] : 0u;
+            const uint64_t PH = pred[((size_t)it * 64 + ch) * 2], PU = pred[((size_t)it * 64 + ch) * 2 + 1];
+            const uint32_t eb = __shfl(behind, ch, 64);         // state of the step's last column... behind the step = state AT its last column
+            uint32_t mp = ((PH >> lane & 1ull) ? 2u : 0u) | ((PU >> lane & 1ull) ? 0u : 1u);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_down(mp, d, 64); if (lane + d < 64) mp = hom_map_after(mp, o); }
+            const uint32_t nx = __shfl_down(mp, 1, 64);         // columns l+1 .. 63 as one map: state at column 63 -> state at column l
+            const uint32_t st = lane == 63 ? eb : ((nx >> eb) & 1u);
+            if (st && (m >> item.a & 1u) && (m >> item.b & 1u)) atomicOr(&keep[c0 + c], 1u << item.a | 1u << item.b);
         }
     }
 }
@@ -631,8 +744,13 @@ static int homology_core(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left,
     if (h->go_homologous > 0 || h->go_unrelated > 0) { c->err = "apply_homology: transition scores are log probabilities (<= 0)"; return MAUVE_ERR_ARG; }
     if (N != c->nseq) { c->err = "apply_homology: the alignment does not belong to the genomes of this context"; return MAUVE_ERR_STATE; }
     if (n_cols == 0) return MAUVE_OK;
-    // work items: (interval with >= 2 genomes, pair), longest intervals first
-    std::vector<HomIv> ivs; std::vector<HomItem> items; int64_t slots = 0, residues = 0;
+    // work items: (interval with >= 2 genomes, pair, segment of 4096 columns)
+    if (std::abs((int64_t)h->match) > 65536 || std::abs((int64_t)h->mismatch) > 65536 || std::abs((int64_t)h->gap) > 65536 || h->go_homologous < -(1 << 28) || h->go_unrelated < -(1 << 28)) {
+        c->err = "apply_homology: scores beyond +-65536 (transitions beyond -2^28) are not supported"; return MAUVE_ERR_ARG;
+    }
+    std::vector<HomIv> ivs; std::vector<HomItem> items; int64_t residues = 0; uint32_t n_segs = 0;
+    struct PairRun { uint32_t first, nseg; };                  // the items of one (interval, pair): consecutive, segment order
+    std::vector<PairRun> runs;
     for (int64_t iv = 0; iv < n_iv; iv++) {
         int g[MAUVE_MAX_SEQ], n = 0;
         for (int x = 0; x < N; x++) if (left[(size_t)(iv * N + x)]) {
@@ -642,21 +760,27 @@ static int homology_core(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left,
         }
         const int64_t nc = col_off[(size_t)iv + 1] - col_off[(size_t)iv];
         if (n < 2 || nc <= 0) continue;
-        const int64_t nch = (nc + 63) / 64;
-        if (nch > 0x7fffffff) { c->err = "apply_homology: interval too long"; return MAUVE_ERR_LIMIT; }
-        ivs.push_back(HomIv{col_off[(size_t)iv], nc, (uint32_t)iv, (uint32_t)nch});
-        for (int x = 0; x < n; x++) for (int y = x + 1; y < n; y++) { items.push_back(HomItem{(uint32_t)(ivs.size() - 1), (uint32_t)g[x], (uint32_t)g[y], 0u, slots}); slots += nch; }
+        const int64_t nsg = (nc + HOM_SEG - 1) / HOM_SEG;
+        if ((int64_t)n_segs + nsg > 0x7fffffff || (int64_t)items.size() + nsg * n * (n - 1) / 2 > 0x7fffffff) { c->err = "apply_homology: too many segments"; return MAUVE_ERR_LIMIT; }
+        ivs.push_back(HomIv{col_off[(size_t)iv], nc, (uint32_t)iv, (uint32_t)nsg, n_segs, 0u});
+        n_segs += (uint32_t)nsg;
+        for (int x = 0; x < n; x++) for (int y = x + 1; y < n; y++) {
+            runs.push_back(PairRun{(uint32_t)items.size(), (uint32_t)nsg});
+            for (int64_t sgi = 0; sgi < nsg; sgi++) items.push_back(HomItem{(uint32_t)(ivs.size() - 1), (uint32_t)sgi, (uint8_t)g[x], (uint8_t)g[y], 0});
+        }
     }
-    std::stable_sort(items.begin(), items.end(), [&](const HomItem &x, const HomItem &y) { return ivs[x.ivx].nchunks > ivs[y.ivx].nchunks; });
+    const size_t n_items = items.size();
     const size_t n_tiles = (size_t)((n_cols + BB_CHUNK - 1) / BB_CHUNK);
     auto up = [](size_t x) { return (x + 63) & ~(size_t)63; };
-    const size_t o_items = up(ivs.size() * sizeof(HomIv)), o_left = o_items + up(items.size() * sizeof(HomItem)), o_right = o_left + up((size_t)n_iv * N * 8),
+    const size_t o_items = up(ivs.size() * sizeof(HomIv)), o_left = o_items + up(n_items * sizeof(HomItem)), o_right = o_left + up((size_t)n_iv * N * 8),
                  o_rev = o_right + up((size_t)n_iv * N * 8), o_off = o_rev + up((size_t)n_iv * N), o_noff = o_off + up(((size_t)n_iv + 1) * 8), o_tile = o_noff + up(((size_t)n_iv + 1) * 8),
-                 o_base = o_tile + up(n_tiles * 4), o_cnt = o_base + up((n_tiles + 1) * 8), o_keep = o_cnt + 64, o_pred = o_keep + up((size_t)n_cols * 4), total = o_pred + (size_t)slots * 16 + 64;
+                 o_base = o_tile + up(n_tiles * 4), o_cnt = o_base + up((n_tiles + 1) * 8), o_keep = o_cnt + 64, o_scnt = o_keep + up((size_t)n_cols * 4),
+                 o_rank = o_scnt + up((size_t)n_segs * N * 4), o_fn = o_rank + up((size_t)n_segs * N * 8), o_xin = o_fn + up(n_items * sizeof(HomFn)), o_smap = o_xin + up(n_items * 4),
+                 o_send = o_smap + up(n_items), o_step = o_send + up(n_items), o_pred = o_step + up(n_items * 64), total = o_pred + n_items * 64 * 16 + 64;
     HIPCHK(c, c->bb_work.ensure(total));
     char *wk = c->bb_work.as<char>();
     HIPCHK(c, hipMemcpyAsync(wk, ivs.data(), ivs.size() * sizeof(HomIv), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(wk + o_items, items.data(), items.size() * sizeof(HomItem), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(wk + o_items, items.data(), n_items * sizeof(HomItem), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(wk + o_left, left, (size_t)n_iv * N * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(wk + o_right, right, (size_t)n_iv * N * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(wk + o_rev, reverse, (size_t)n_iv * N, hipMemcpyHostToDevice, c->stream));
@@ -664,14 +788,56 @@ static int homology_core(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left,
     HIPCHK(c, hipMemsetAsync(wk + o_cnt, 0, 64, c->stream));
     HIPCHK(c, hipMemsetAsync(wk + o_keep, 0, (size_t)n_cols * 4, c->stream));
     uint32_t *keep = reinterpret_cast<uint32_t *>(wk + o_keep);
-    if (!items.empty()) {
+    if (n_items) {
+        const HomIv *d_ivs = reinterpret_cast<const HomIv *>(wk); const HomItem *d_items = reinterpret_cast<const HomItem *>(wk + o_items);
+        const int64_t *d_left = reinterpret_cast<const int64_t *>(wk + o_left), *d_right = reinterpret_cast<const int64_t *>(wk + o_right);
+        const int8_t *d_rev = reinterpret_cast<const int8_t *>(wk + o_rev);
         HomGenomes gw; memset(&gw, 0, sizeof gw);
         for (int g = 0; g < c->nseq; g++) gw.word_off[g] = c->word_off[(size_t)g];
         const HomScores sc{h->match, h->mismatch, h->gap, h->go_homologous, h->go_unrelated};
-        hipLaunchKernelGGL(hom_viterbi, dim3((uint32_t)std::min<size_t>(items.size(), 256 * 32)), dim3(64), 0, c->stream, d_cols, reinterpret_cast<const HomItem *>(wk + o_items),
-                           (uint32_t)items.size(), reinterpret_cast<const HomIv *>(wk), reinterpret_cast<const int64_t *>(wk + o_left), reinterpret_cast<const int64_t *>(wk + o_right),
-                           reinterpret_cast<const int8_t *>(wk + o_rev), N, c->genomes.as<uint64_t>(), gw, sc, reinterpret_cast<uint64_t *>(wk + o_pred), keep);
+        // residues per segment -> base positions at the segment starts
+        hipLaunchKernelGGL(hom_seg_count, dim3(n_segs), dim3(64), 0, c->stream, d_cols, d_ivs, (uint32_t)ivs.size(), N, reinterpret_cast<uint32_t *>(wk + o_scnt));
         HIPCHK(c, hipGetLastError());
+        std::vector<uint32_t> scnt((size_t)n_segs * N); std::vector<int64_t> rank0((size_t)n_segs * N);
+        HIPCHK(c, hipMemcpyAsync(scnt.data(), wk + o_scnt, scnt.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (const HomIv &iv : ivs)
+            for (int g = 0; g < N; g++) { int64_t run = 0; for (uint32_t sgi = 0; sgi < iv.nseg; sgi++) { rank0[(size_t)(iv.seg0 + sgi) * N + g] = run; run += scnt[(size_t)(iv.seg0 + sgi) * N + g]; } }
+        HIPCHK(c, hipMemcpyAsync(wk + o_rank, rank0.data(), rank0.size() * 8, hipMemcpyHostToDevice, c->stream));
+        const uint32_t grid = (uint32_t)std::min<size_t>(n_items, 256 * 64);
+        const int64_t *d_rank = reinterpret_cast<const int64_t *>(wk + o_rank);
+        hipLaunchKernelGGL(hom_fn, dim3(grid), dim3(64), 0, c->stream, d_cols, d_items, (uint32_t)n_items, d_ivs, d_left, d_right, d_rev, N, c->genomes.as<uint64_t>(), gw, sc, d_rank,
+                           reinterpret_cast<HomFn *>(wk + o_fn));
+        HIPCHK(c, hipGetLastError());
+        std::vector<HomFn> fn(n_items); std::vector<int32_t> xin(n_items); std::vector<uint8_t> fin(runs.size());
+        HIPCHK(c, hipMemcpyAsync(fn.data(), wk + o_fn, n_items * sizeof(HomFn), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (size_t r = 0; r < runs.size(); r++) {              // x at every segment start; the path starts in U: x below go_homologous
+            int64_t x = (int64_t)h->go_homologous - 1;
+            for (uint32_t k = 0; k < runs[r].nseg; k++) {
+                const HomFn &f = fn[runs[r].first + k];
+                xin[runs[r].first + k] = (int32_t)x;
+                x = std::min<int64_t>(std::max<int64_t>(x + f.t, f.lo), f.hi);
+            }
+            fin[r] = x >= 0;
+        }
+        HIPCHK(c, hipMemcpyAsync(wk + o_xin, xin.data(), n_items * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(hom_pred, dim3(grid), dim3(64), 0, c->stream, d_cols, d_items, (uint32_t)n_items, d_ivs, d_left, d_right, d_rev, N, c->genomes.as<uint64_t>(), gw, sc, d_rank,
+                           reinterpret_cast<const int32_t *>(wk + o_xin), reinterpret_cast<uint64_t *>(wk + o_pred), reinterpret_cast<uint8_t *>(wk + o_step),
+                           reinterpret_cast<uint8_t *>(wk + o_smap));
+        HIPCHK(c, hipGetLastError());
+        std::vector<uint8_t> smap(n_items), send(n_items);
+        HIPCHK(c, hipMemcpyAsync(smap.data(), wk + o_smap, n_items, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (size_t r = 0; r < runs.size(); r++) {              // state at every segment's last column, from the interval's end backwards
+            uint32_t e = fin[r];
+            for (uint32_t k = runs[r].nseg; k-- > 0;) { send[runs[r].first + k] = (uint8_t)e; e = (smap[runs[r].first + k] >> e) & 1u; }
+        }
+        HIPCHK(c, hipMemcpyAsync(wk + o_send, send.data(), n_items, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(hom_keep, dim3(grid), dim3(64), 0, c->stream, d_cols, d_items, (uint32_t)n_items, d_ivs, reinterpret_cast<const uint64_t *>(wk + o_pred),
+                           reinterpret_cast<const uint8_t *>(wk + o_step), reinterpret_cast<const uint8_t *>(wk + o_send), keep);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));             // (send / xin are host vectors)
     }
     hipLaunchKernelGGL(hom_count, dim3((uint32_t)n_tiles), dim3(256), 0, c->stream, d_cols, keep, n_cols, reinterpret_cast<uint32_t *>(wk + o_tile),
                        reinterpret_cast<unsigned long long *>(wk + o_cnt));
