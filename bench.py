@@ -454,6 +454,15 @@ def main():
         eb = time.perf_counter() - t0
         extras["backbone"] = {"ms_per_call": round(eb / n2 * 1e3, 3), "segments": int(len(bb["seg_iv"])), "islands": int(len(bb["islands"])),
                               "island_gap": 20}
+        # the homology pass in front of it (detectAndApplyBackbone's HMM as a two-state Viterbi scan), on the same resident result
+        th = 0.0
+        for _ in range(n2):
+            rn.run()
+            t0 = time.perf_counter()
+            hres = ctx.apply_homology(fetch=False)
+            th += time.perf_counter() - t0
+        extras["homology_pass"] = {"ms_per_call": round(th / n2 * 1e3, 3), "residues_moved": int(hres["n_moved"]), "columns_after": int(hres["n_cols"]),
+                                   "hmm": "identity 0.7, pgh 1e-5, pgu 1e-9 (progressiveMauve.cpp:319-322)"}
 
     # ---- CPU baseline: the oracle on the same workload, host cores of this box ----
     cpu = None

@@ -963,12 +963,13 @@ template <bool SEG>
 __global__ void __launch_bounds__(256) mum_runs(GenomeTab tab, int span, const uint32_t *__restrict__ tmask,
                                                 const uint32_t *__restrict__ tpos, uint32_t P, int all,
                                                 uint32_t *__restrict__ cand, uint32_t *__restrict__ counters,
-                                                const uint32_t *__restrict__ seg, uint32_t nseg)
+                                                const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t p0 = 0)
 {
     __shared__ uint32_t lds[8];
     __shared__ uint32_t s_base;
-    // 4096 windows per workgroup: one block scan and ONE global atomic per 4096 windows
-    const uint32_t base = blockIdx.x * (256u * RUNS_ITEMS);
+    // 4096 windows per workgroup: one block scan and ONE global atomic per 4096 windows.  [p0, P): the positions looked at (a pass of
+    // the pairwise finder only has hits in its lower genome)
+    const uint32_t base = p0 + blockIdx.x * (256u * RUNS_ITEMS);
     const int N = tab.nseq;
     uint32_t flags = 0, cnt = 0;
     // Inside a conserved stretch nearly every hit has its predecessor right at p - 1, so that test runs first for
@@ -1519,7 +1520,11 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         TRACE(ctx, "run summary");
     }
     for (const FinderPass &fp : passes) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->posmask.p, 0, (size_t)P * 4, ctx->stream));
+        // the hit table is indexed by the anchor's window = a window of the lowest genome of the pass: a pass over one genome pair
+        // (the guide tree runs N (N - 1) / 2 of them) clears and scans that genome's slice only
+        uint32_t s_lo = 0, s_hi = P;
+        if (use_summary && fp.consider) { const int ga = __builtin_ctz(fp.consider); s_lo = tab.gpos_off[ga]; s_hi = std::min<uint32_t>(tab.gpos_off[ga + 1], P); }
+        HIPCHK(ctx, hipMemsetAsync(ctx->posmask.as<uint32_t>() + s_lo, 0, (size_t)(s_hi - s_lo) * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
         if (hh) {
             HIPCHK(ctx, ctx->run_sum.ensure((size_t)hh->n * (N + 1) * 4 + 64));
@@ -1556,10 +1561,10 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         HIPCHK(ctx, hipGetLastError());
         TRACE(ctx, "join");
         // extension phase A: run starts from the table
-        { KernelTimer t(ctx, MAUVE_K_RUNS, P);
-          hipLaunchKernelGGL((mum_runs<SEG>), dim3((P + 256 * RUNS_ITEMS - 1) / (256 * RUNS_ITEMS)), dim3(256), 0, ctx->stream, tab,
-                             sh.span, tmask, tpos, P, extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg,
-                             nseg); }
+        { KernelTimer t(ctx, MAUVE_K_RUNS, s_hi - s_lo);
+          hipLaunchKernelGGL((mum_runs<SEG>), dim3((s_hi - s_lo + 256 * RUNS_ITEMS - 1) / (256 * RUNS_ITEMS)), dim3(256), 0, ctx->stream, tab,
+                             sh.span, tmask, tpos, s_hi, extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg,
+                             nseg, s_lo); }
         HIPCHK(ctx, hipGetLastError());
         if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // the kernels above are still running
         HIPCHK(ctx, ctx->pin_seed.ensure(64));
