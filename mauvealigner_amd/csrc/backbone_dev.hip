@@ -41,8 +41,34 @@ __device__ __forceinline__ void bb_pair_of(uint32_t gmask, uint32_t p, int *a, i
     *a = g[x]; *b = g[x + 1 + (int)p];
 }
 
+// what the last pair-column of every (chunk, pair) is: 0 none in the chunk, 1 both genomes, 2 one of them.  bb_pair_gaps finds the
+// state in front of its chunk from these bytes, 64 chunks per step, instead of walking back over the columns themselves (a pair
+// that is absent over a long stretch of an interval would make every chunk of the stretch walk back to its start)
+__global__ void __launch_bounds__(64) bb_chunk_last(const uint32_t *__restrict__ cols, const BbIv *__restrict__ ivs, uint32_t n_ivs, uint32_t max_pairs, uint8_t *__restrict__ last)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t lo = 0, hi = n_ivs;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (ivs[mid].chunk0 <= blockIdx.x) lo = mid; else hi = mid; }
+    const BbIv d = ivs[lo];
+    const int64_t nc = d.ncols, cs = (int64_t)(blockIdx.x - d.chunk0) * BB_CHUNK, ce = cs + BB_CHUNK < nc ? cs + BB_CHUNK : nc;
+    const uint32_t *m = cols + d.col0;
+    for (uint32_t p = blockIdx.y; p < d.npairs; p += gridDim.y) {
+        int a, b;
+        bb_pair_of(d.gmask, p, &a, &b);
+        uint8_t st = 0;
+        for (int64_t w = ((ce - 1) & ~(int64_t)63); w >= cs; w -= 64) {
+            const int64_t c = w + lane;
+            const uint32_t v = c < ce ? m[c] : 0u;
+            const bool ra = v >> a & 1, rb = v >> b & 1;
+            const uint64_t any = __ballot(ra || rb), both = __ballot(ra && rb);
+            if (any) { const int top = 63 - __clzll((long long)any); st = (both >> top & 1) ? 1 : 2; break; }
+        }
+        if (lane == 0) last[(size_t)blockIdx.x * max_pairs + p] = st;
+    }
+}
+
 __global__ void __launch_bounds__(64) bb_pair_gaps(const uint32_t *__restrict__ cols, const BbIv *__restrict__ ivs, uint32_t n_ivs, uint32_t island_gap,
-                                                    BbRec *__restrict__ rec, uint32_t cap, uint32_t *__restrict__ count)
+                                                    BbRec *__restrict__ rec, uint32_t cap, uint32_t *__restrict__ count, const uint8_t *__restrict__ last, uint32_t max_pairs)
 {
     const int lane = threadIdx.x & 63;
     // which interval this chunk belongs to
@@ -57,12 +83,11 @@ __global__ void __launch_bounds__(64) bb_pair_gaps(const uint32_t *__restrict__ 
         // the nearest column before the chunk that holds a residue of the pair: a both-column (or none) means a region that
         // starts with the chunk's first column is this chunk's to report; a one-sided column means it began earlier
         bool seen_both = false, skipping = false;
-        for (int64_t w = cs - 64; w > -64; w -= 64) {
-            const int64_t c = w + lane;
-            const uint32_t v = c >= 0 ? m[c] : 0u;
-            const bool ra = v >> a & 1, rb = v >> b & 1;
-            const uint64_t any = __ballot(ra || rb), both = __ballot(ra && rb);
-            if (any) { const int top = 63 - __clzll((long long)any); if (both >> top & 1) seen_both = true; else skipping = true; break; }
+        for (int64_t k0 = (int64_t)blockIdx.x - 1; k0 >= (int64_t)d.chunk0; k0 -= 64) {       // the chunks in front of this one, nearest first, 64 per step
+            const int64_t k = k0 - lane;
+            const uint32_t stv = k >= (int64_t)d.chunk0 ? last[(size_t)k * max_pairs + p] : 0u;
+            const uint64_t any = __ballot(stv != 0);
+            if (any) { const int near = __ffsll((long long)any) - 1; if (__shfl((int)stv, near, 64) == 1) seen_both = true; else skipping = true; break; }
         }
         bool in_region = false, leading = false, has_island = false, done = false;
         int run_t = 0;                                   // 1: only a has residues, 2: only b
@@ -497,7 +522,7 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
     const size_t n_tiles = (size_t)((n_cols + BB_CHUNK - 1) / BB_CHUNK);
     // work area: interval table | counter | tile counts | records
     auto up = [](size_t x) { return (x + 63) & ~(size_t)63; };
-    const size_t o_cnt = up(ivs.size() * sizeof(BbIv)), o_tile = o_cnt + 64, o_rec = o_tile + up(n_tiles * (size_t)N * 4);
+    const size_t o_cnt = up(ivs.size() * sizeof(BbIv)), o_tile = o_cnt + 64, o_last = o_tile + up(n_tiles * (size_t)N * 4), o_rec = o_last + up((size_t)chunks * max_pairs);
     size_t cap = std::max<size_t>(1u << 16, c->bb_rec_cap);
     std::vector<BbRec> recs;
     std::vector<uint32_t> tile_cnt(n_tiles * (size_t)N);
@@ -507,8 +532,12 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
         HIPCHK(c, hipMemcpyAsync(wk, ivs.data(), ivs.size() * sizeof(BbIv), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(wk + o_cnt, 0, 64, c->stream));
         const uint32_t gy = std::min<uint32_t>(max_pairs, 64);        // one wave per (chunk, pair): with few pairs, too, every resident wave works
+        // (every attempt: a grown work area is a new allocation)
+        hipLaunchKernelGGL(bb_chunk_last, dim3(chunks, gy), dim3(64), 0, c->stream, d_cols, reinterpret_cast<const BbIv *>(wk), (uint32_t)ivs.size(), max_pairs,
+                           reinterpret_cast<uint8_t *>(wk + o_last));
         hipLaunchKernelGGL(bb_pair_gaps, dim3(chunks, gy), dim3(64), 0, c->stream, d_cols, reinterpret_cast<const BbIv *>(wk), (uint32_t)ivs.size(),
-                           (uint32_t)island_gap, reinterpret_cast<BbRec *>(wk + o_rec), (uint32_t)cap, reinterpret_cast<uint32_t *>(wk + o_cnt));
+                           (uint32_t)island_gap, reinterpret_cast<BbRec *>(wk + o_rec), (uint32_t)cap, reinterpret_cast<uint32_t *>(wk + o_cnt),
+                           reinterpret_cast<const uint8_t *>(wk + o_last), max_pairs);
         if (attempt == 0)
             hipLaunchKernelGGL(bb_tile_count, dim3((uint32_t)n_tiles), dim3(256), 0, c->stream, d_cols, n_cols, N, reinterpret_cast<uint32_t *>(wk + o_tile));
         HIPCHK(c, hipGetLastError());

@@ -11,8 +11,10 @@
 // elimination over that compact graph (10^2 .. 10^4 nodes, inherently sequential) stays on the host (lcb_greedy,
 // chain_host.cpp).  Every kernel is tiled (1024 entries per workgroup, four consecutive entries per thread); the
 // per-tile aggregates of a compaction are summed by each workgroup for itself, which saves the scan launches.
-// The host code of chain_host.cpp remains the path for lists the seed pass sorted on the host (small ones, or with
-// ties in the canonical order) and for the per-gap chains of the recursion.
+// The host code of chain_host.cpp remains the path for lists the seed pass sorted on the host (small ones) and for the small
+// per-gap chains of the recursion.  A list whose canonical order has ties (equal first component and start) does come here:
+// the seed pass finishes the order inside the tie groups on the host and writes the repaired list back to sorted_rec before it
+// sets dev_rec_n, and every pass below breaks equal left ends by the list index, exactly as chain_host.cpp does.
 #include "common.hpp"
 #include "dev_scan.hpp"
 #include <cstring>
@@ -315,13 +317,16 @@ __global__ void __launch_bounds__(256) ch_cluster_pass(int32_t *__restrict__ len
 __global__ void __launch_bounds__(64) ch_cluster_pass_big(int32_t *__restrict__ len, int32_t *__restrict__ st, int N, int g, uint32_t dead_key,
                                                           uint32_t *__restrict__ eleft, uint32_t *__restrict__ eidx,
                                                           const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ cnt_in,
-                                                          uint32_t *__restrict__ ws, uint32_t n, int cl_max)
+                                                          uint32_t *__restrict__ ws, uint32_t n, int cl_max, uint32_t *__restrict__ fail, int big_max)
 {
     const uint32_t j = blockIdx.x * 64u + threadIdx.x;
     if (j >= cnt_in[0]) return;
     const uint32_t a = cstart[j];
     const int s = (int)(cstart[j + 1] - a);
     if (s <= cl_max) return;
+    // one lane walks the whole cluster, every pass an insertion sort over global memory: beyond a few thousand entries that is seconds of
+    // one dependent chain (it would look like a hang on the stream) -- such a list goes back to the host's per-gap chaining instead
+    if (s > big_max) { *fail = 1; return; }
     uint32_t *L = ws + a, *Ln = L + n, *I = Ln + n, *CF = I + n, *CL = CF + n, *pf = CL + n, *pl = pf + n;
     uint8_t *F = reinterpret_cast<uint8_t *>(ws + 7 * (size_t)n) + a;
     ch_cluster_run(len, st, N, g, dead_key, eleft, eidx, a, s, L, Ln, I, CF, CL, pf, pl, F);
@@ -572,6 +577,7 @@ int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *s
                                                                   // [8+g] survivors of genome g
     const int64_t *rlen = c->sorted_rec.as<int64_t>(), *rst = rlen + n;
     const uint32_t blocks = (n + 255) / 256;
+    static const int big_max = []() { const char *e = getenv("MAUVE_CH_BIG_MAX"); const int v = e ? atoi(e) : 2048; return v < 1 ? 1 : v; }();        // cluster size the one-lane kernel still takes (tests lower it)
     static const int cl_max = []() { const char *e = getenv("MAUVE_CH_CL_MAX"); const int v = e ? atoi(e) : CH_CL_MAX; return v < 1 ? 1 : (v > CH_CL_MAX ? CH_CL_MAX : v); }();   // (tests lower it)
     // the graph arrays are sized for the worst case K = n
     HIPCHK(c, c->ch_graph.ensure((size_t)n * (8 + 4 + (size_t)N * 4 * 3 + 4) + 8 + (size_t)n * (8 + 4 + (size_t)N * 8) + 64));     // the arrays + their packed copy
@@ -581,7 +587,8 @@ int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *s
     for (int g = 0; g < N; g++) {
         hipLaunchKernelGGL(ch_keys, dim3(blocks), dim3(256), 0, c->stream, len, st, n, N, g, dead_key, k1, v1);
         uint32_t *kk = k1, *vv = v1;
-        // genome 0: the list is in canonical order, i.e. already ordered by its left ends there (no ties: dev_rec_n), nobody is dead yet
+        // genome 0: the list is in canonical order, i.e. already ordered by its left ends there (equal left ends keep their list order: every pass
+        // below breaks ties by the list index, as the host chain does), nobody is dead yet
         // (a recursion batch starts with its non-forward matches dead: sorted like any other genome)
         if (g > 0 || seg0) { int rc = sort_pairs_u32(c, n, pos_bits + 1, &kk, &vv, k2, v2, MAUVE_K_MISC); if (rc) return rc; }
         hipLaunchKernelGGL(cl_partial, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive);
@@ -591,7 +598,7 @@ int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *s
         hipLaunchKernelGGL((cmp_write<ClusterStarts>), dim3(nb), dim3(256), 0, c->stream, cs, bcnt);
         hipLaunchKernelGGL(ch_cluster_pass, dim3(blocks), dim3(256), 0, c->stream, len, st, N, g, dead_key, kk, vv, sl, cnt + 4, cnt + 3, seg0 ? 1 : 0, cl_max);
         if (seg0) hipLaunchKernelGGL(ch_cluster_pass_big, dim3((n + 63) / 64), dim3(64), 0, c->stream, len, st, N, g, dead_key, kk, vv, sl, cnt + 4,
-                                     c->ch_big.as<uint32_t>(), n, cl_max);
+                                     c->ch_big.as<uint32_t>(), n, cl_max, cnt + 3, big_max);
         const GenomeOrder go{dead_key, kk, vv, cnt, ord + (size_t)g * n, cnt + 8 + g};
         hipLaunchKernelGGL((cmp_count<GenomeOrder>), dim3(nb), dim3(256), 0, c->stream, go, bcnt);
         hipLaunchKernelGGL((cmp_write<GenomeOrder>), dim3(nb), dim3(256), 0, c->stream, go, bcnt);

@@ -283,8 +283,10 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
             ChainOrders orders;
             std::vector<int64_t> ml;
             // Large batches are chained on the device, all gaps at once (chain_device_gaps); the host loop below then only
-            // maps the survivors back.  Small batches (host-sorted lists), ties in the canonical order and clusters beyond
-            // the device kernel's limit are chained here, gap by gap.  MAUVE_HOST_GAP_CHAIN: A/B switch.
+            // maps the survivors back.  Small batches (host-sorted lists: dev_rec_n != nm) and batches with an overlap cluster or a
+            // gap sub-graph beyond the device kernels' limits (MAUVE_ERR_LIMIT) are chained here, gap by gap.  (A list with ties in
+            // its canonical order is repaired by the seed pass before dev_rec_n is set, so it takes the device route like any
+            // other.)  MAUVE_HOST_GAP_CHAIN: A/B switch.
             bool dev_chain = false, compact = false;
             const int32_t *dl = nullptr, *ds = nullptr; const uint32_t *dg = nullptr; uint32_t ns = 0; std::vector<uint8_t> survive;
             if (!host_gaps && nm > 0 && c->dev_rec_n == nm) {

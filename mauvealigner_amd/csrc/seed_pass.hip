@@ -1524,6 +1524,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         // (the guide tree runs N (N - 1) / 2 of them) clears and scans that genome's slice only
         uint32_t s_lo = 0, s_hi = P;
         if (use_summary && fp.consider) { const int ga = __builtin_ctz(fp.consider); s_lo = tab.gpos_off[ga]; s_hi = std::min<uint32_t>(tab.gpos_off[ga + 1], P); }
+        if (s_hi <= s_lo) continue;                              // (a genome shorter than the seed has no window: nothing can be anchored in it)
         HIPCHK(ctx, hipMemsetAsync(ctx->posmask.as<uint32_t>() + s_lo, 0, (size_t)(s_hi - s_lo) * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
         if (hh) {
