@@ -434,6 +434,12 @@ def main():
             from mauvealigner_amd import accuracy
             acc_e = accuracy.score_alignment(r4, origins)
             extras["lcb_extension_%s" % ("on" if other else "off")].update(sensitivity=round(acc_e["sensitivity"], 5), ppv=round(acc_e["ppv"], 5))
+        if not other and roofline is not None:
+            # the seed-pass figure of the MAIN pass alone: with the extension on, a step's kernel time also holds the small extension passes
+            # (a few thousand windows each: launches, no positions worth counting), which B_seed x P does not count
+            roof_off, kern_off = kernel_profile(rn, weight, nprof=2, params=pe)
+            roofline["seed_pass"]["main_pass_only"] = {k: roof_off["seed_pass"][k] for k in ("kernel_ms", "achieved_GBs", "frac", "with_runs_and_extend", "seed_passes_per_step")}
+            roofline["seed_pass"]["main_pass_only"]["how"] = "the same step with extend_lcbs = 0 (one seed pass per step)"
 
     # ---- accuracy of the bench workload's alignment against the generator's truth (not timed) ----
     acc = None
