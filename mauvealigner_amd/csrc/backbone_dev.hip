@@ -52,19 +52,25 @@ __global__ void __launch_bounds__(64) bb_chunk_last(const uint32_t *__restrict__
     const BbIv d = ivs[lo];
     const int64_t nc = d.ncols, cs = (int64_t)(blockIdx.x - d.chunk0) * BB_CHUNK, ce = cs + BB_CHUNK < nc ? cs + BB_CHUNK : nc;
     const uint32_t *m = cols + d.col0;
-    for (uint32_t p = blockIdx.y; p < d.npairs; p += gridDim.y) {
-        int a, b;
-        bb_pair_of(d.gmask, p, &a, &b);
-        uint8_t st = 0;
-        for (int64_t w = ((ce - 1) & ~(int64_t)63); w >= cs; w -= 64) {
-            const int64_t c = w + lane;
-            const uint32_t v = c < ce ? m[c] : 0u;
-            const bool ra = v >> a & 1, rb = v >> b & 1;
-            const uint64_t any = __ballot(ra || rb), both = __ballot(ra && rb);
-            if (any) { const int top = 63 - __clzll((long long)any); st = (both >> top & 1) ? 1 : 2; break; }
+    // one wave per chunk: the last column of every genome in the chunk (lane g keeps genome g's; the chunk's last 64 columns settle nearly
+    // all of them, the rest walk further back), then a pair's last column is the later of its two genomes' -- both if they coincide
+    int64_t lastpos = -1;
+    uint32_t pending = d.gmask;
+    for (int64_t w = (ce - 1) & ~(int64_t)63; w >= cs && pending; w -= 64) {
+        const int64_t c = w + lane;
+        const uint32_t v = c < ce ? m[c] : 0u;
+        for (uint32_t mg = pending; mg; mg &= mg - 1) {
+            const int g = __ffs(mg) - 1;
+            const uint64_t B = __ballot(v >> g & 1u);
+            if (B) { if (lane == g) lastpos = w + 63 - __clzll((long long)B); pending &= ~(1u << g); }
         }
-        if (lane == 0) last[(size_t)blockIdx.x * max_pairs + p] = st;
     }
+    uint32_t p = 0;
+    for (uint32_t ma = d.gmask; ma; ma &= ma - 1)                // pairs in bb_pair_of's order: (g0,g1), (g0,g2), .., (g1,g2), ..
+        for (uint32_t mb = ma & (ma - 1); mb; mb &= mb - 1, p++) {
+            const int64_t la = __shfl(lastpos, __ffs(ma) - 1, 64), lb = __shfl(lastpos, __ffs(mb) - 1, 64);
+            if (lane == 0) last[(size_t)blockIdx.x * max_pairs + p] = (la < 0 && lb < 0) ? 0 : (la == lb ? 1 : 2);
+        }
 }
 
 __global__ void __launch_bounds__(64) bb_pair_gaps(const uint32_t *__restrict__ cols, const BbIv *__restrict__ ivs, uint32_t n_ivs, uint32_t island_gap,
@@ -83,6 +89,15 @@ __global__ void __launch_bounds__(64) bb_pair_gaps(const uint32_t *__restrict__ 
         // the nearest column before the chunk that holds a residue of the pair: a both-column (or none) means a region that
         // starts with the chunk's first column is this chunk's to report; a one-sided column means it began earlier
         bool seen_both = false, skipping = false;
+        if (!last) {                                     // A/B (MAUVE_BB_COLUMN_SCAN): walk back over the columns themselves
+            for (int64_t w = cs - 64; w > -64; w -= 64) {
+                const int64_t c = w + lane;
+                const uint32_t v = c >= 0 ? m[c] : 0u;
+                const bool ra = v >> a & 1, rb = v >> b & 1;
+                const uint64_t any = __ballot(ra || rb), both = __ballot(ra && rb);
+                if (any) { const int top = 63 - __clzll((long long)any); if (both >> top & 1) seen_both = true; else skipping = true; break; }
+            }
+        } else
         for (int64_t k0 = (int64_t)blockIdx.x - 1; k0 >= (int64_t)d.chunk0; k0 -= 64) {       // the chunks in front of this one, nearest first, 64 per step
             const int64_t k = k0 - lane;
             const uint32_t stv = k >= (int64_t)d.chunk0 ? last[(size_t)k * max_pairs + p] : 0u;
@@ -532,12 +547,14 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
         HIPCHK(c, hipMemcpyAsync(wk, ivs.data(), ivs.size() * sizeof(BbIv), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(wk + o_cnt, 0, 64, c->stream));
         const uint32_t gy = std::min<uint32_t>(max_pairs, 64);        // one wave per (chunk, pair): with few pairs, too, every resident wave works
+        static const bool column_scan = getenv("MAUVE_BB_COLUMN_SCAN") != nullptr;
         // (every attempt: a grown work area is a new allocation)
-        hipLaunchKernelGGL(bb_chunk_last, dim3(chunks, gy), dim3(64), 0, c->stream, d_cols, reinterpret_cast<const BbIv *>(wk), (uint32_t)ivs.size(), max_pairs,
-                           reinterpret_cast<uint8_t *>(wk + o_last));
+        if (!column_scan)
+            hipLaunchKernelGGL(bb_chunk_last, dim3(chunks), dim3(64), 0, c->stream, d_cols, reinterpret_cast<const BbIv *>(wk), (uint32_t)ivs.size(), max_pairs,
+                               reinterpret_cast<uint8_t *>(wk + o_last));
         hipLaunchKernelGGL(bb_pair_gaps, dim3(chunks, gy), dim3(64), 0, c->stream, d_cols, reinterpret_cast<const BbIv *>(wk), (uint32_t)ivs.size(),
                            (uint32_t)island_gap, reinterpret_cast<BbRec *>(wk + o_rec), (uint32_t)cap, reinterpret_cast<uint32_t *>(wk + o_cnt),
-                           reinterpret_cast<const uint8_t *>(wk + o_last), max_pairs);
+                           column_scan ? (const uint8_t *)nullptr : reinterpret_cast<const uint8_t *>(wk + o_last), max_pairs);
         if (attempt == 0)
             hipLaunchKernelGGL(bb_tile_count, dim3((uint32_t)n_tiles), dim3(256), 0, c->stream, d_cols, n_cols, N, reinterpret_cast<uint32_t *>(wk + o_tile));
         HIPCHK(c, hipGetLastError());
