@@ -355,17 +355,21 @@ __global__ void __launch_bounds__(256) ch_label(const int32_t *__restrict__ len,
 }
 
 // ---- the chains on the device (align_device_tail, pipeline.cpp) ---------------------------------------------------
-// chain order = LCB by LCB, canonical (genome-0) order inside: a stable sort of the labelled matches by LCB id
-__global__ void __launch_bounds__(256) co_keys(const int32_t *__restrict__ lcb, uint32_t n, uint32_t nl, uint32_t *__restrict__ key,
-                                               uint32_t *__restrict__ val, unsigned long long *__restrict__ lw, uint32_t *__restrict__ out)
+// chain order = LCB by LCB, genome-0 order inside: a stable sort by LCB id of the survivors taken in their genome-0 order AFTER the
+// elimination (ord0: the crops of a pass can carry a match past a neighbour, DESIGN.md S5 -- the list index is not that order)
+__global__ void __launch_bounds__(256) co_keys(const int32_t *__restrict__ lcb, const uint32_t *__restrict__ ord0, const uint32_t *__restrict__ cnt, uint32_t n, uint32_t nl,
+                                               uint32_t *__restrict__ key, uint32_t *__restrict__ val, unsigned long long *__restrict__ lw, uint32_t *__restrict__ out)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < nl) lw[i] = 0;                                    // what co_gather accumulates into (nl <= n)
-    if (i < 2) out[i] = 0;
-    if (i >= n) return;
-    const int32_t l = lcb[i];
-    key[i] = l >= 0 ? (uint32_t)l : nl;                      // dead / eliminated: behind every LCB
-    val[i] = i;
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k < nl) lw[k] = 0;                                    // what co_gather accumulates into (nl <= n)
+    if (k < 2) out[k] = 0;
+    if (k >= n) return;
+    if (k < cnt[0]) {
+        const uint32_t i = ord0[k];
+        const int32_t l = lcb[i];
+        key[k] = l >= 0 ? (uint32_t)l : nl;                  // eliminated with its LCB: behind every LCB
+        val[k] = i;
+    } else { key[k] = nl; val[k] = 0; }                      // (dead matches are not in ord0)
 }
 
 // anchors in chain order (alen[cap], ast[cap * N], alcb[cap]), their number, LCB weights (sum of length * N), and the
@@ -528,7 +532,7 @@ int chain_order_device(mauve_ctx *c, int N, int64_t nl, int64_t min_gap, int64_t
     uint32_t *cnt = c->ch_cnt.as<uint32_t>();
     const uint32_t blocks = (n + 255) / 256;
     int bits = 1; while ((1LL << bits) <= nl) bits++;
-    hipLaunchKernelGGL(co_keys, dim3(blocks), dim3(256), 0, c->stream, lcb, n, (uint32_t)nl, k1, v1, lw, cnt + 16);
+    hipLaunchKernelGGL(co_keys, dim3(blocks), dim3(256), 0, c->stream, lcb, c->ch_ord.as<uint32_t>() + (size_t)n * N /* ordc of genome 0 */, cnt, n, (uint32_t)nl, k1, v1, lw, cnt + 16);
     uint32_t *kk = k1, *vv = v1;
     int rc = sort_pairs_u32(c, n, bits, &kk, &vv, k2, v2, MAUVE_K_MISC);
     if (rc) return rc;

@@ -327,6 +327,23 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
             std::copy(given->st(keep[(size_t)i]), given->st(keep[(size_t)i]) + N, &c->match_start[(size_t)i * N]);
         }
         c->n_matches = nm; c->dev_rec_n = -1;
+        // A long list goes where the seed pass would have left its own: into sorted_rec in the device layout (int64 length[n], start[n * N]),
+        // so that overlap elimination, LCBs, extension and the tail run on the device as they do after a search (chain_dev.hip; a
+        // list the device chain declines -- MAUVE_ERR_LIMIT -- falls back to the host chain below).  Same threshold as the seed pass's
+        // device sort; MAUVE_GIVEN_ON_HOST: A/B switch.
+        static const int64_t dev_min = getenv("MAUVE_CANON_DEVICE_MIN") ? atol(getenv("MAUVE_CANON_DEVICE_MIN")) : 16384;
+        static const bool given_on_host = getenv("MAUVE_GIVEN_ON_HOST") != nullptr;
+        if (!given_on_host && nm >= dev_min && nm < (1LL << 31) && p->lcb_scoring == MAUVE_LCB_SCORE_LENGTH) {
+            const size_t rb = (size_t)nm * (1 + (size_t)N) * 8;
+            HIPCHK(c, c->sorted_rec.ensure(rb + 64));
+            HIPCHK(c, c->pin_tab.ensure(rb + 64));
+            int64_t *hp = c->pin_tab.as<int64_t>();
+            memcpy(hp, c->match_len.data(), (size_t)nm * 8);
+            memcpy(hp + nm, c->match_start.data(), (size_t)nm * N * 8);
+            HIPCHK(c, hipMemcpyAsync(c->sorted_rec.p, hp, rb, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->dev_rec_n = nm; c->match_nseq = N;
+        }
     } else {
         static const bool host_tail_env = getenv("MAUVE_HOST_TAIL") != nullptr;
         c->lazy_matches_ok = want_tail && !host_tail_env && (!do_extend || ext_on_device);     // the list may stay in HBM (device tail below)

@@ -1038,6 +1038,53 @@ def test_dp_scan_kernels():
         assert r.returncode == 0 and r.stdout.strip().endswith("OK"), str(extra) + "\n" + r.stdout + r.stderr[-3000:]
 
 
+ORDER_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from mauvealigner_amd import _lib
+from oracle import pyoracle as O
+z = np.load(%(case)r); gs = [z[k] for k in z.files]
+ctx = _lib.Context(0); ctx.set_genomes(gs)
+for kw in (dict(seed_family=1, recursive=0, extend_lcbs=0, add_unaligned=0, max_gapped_len=300, lcb_weight=240),
+           dict(seed_family=1, recursive=1, extend_lcbs=1, add_unaligned=0, max_gapped_len=300, lcb_weight=240)):
+    r = ctx.align(_lib.default_params(**kw)); a = O.align(gs, O.default_params(**kw))["aln"]
+    for k in ("anchor_length", "anchor_start", "anchor_lcb", "left", "right", "col_off", "cols", "dp_score"):
+        assert np.array_equal(r[k], a[k]), (kw, k)
+print("OK")
+"""
+
+
+def test_chain_order_after_the_elimination():
+    """With three or more matches overlapping, the crops of one elimination pass can carry a match past a neighbour (DESIGN.md S5);
+    the anchors of a chain are ordered by where they are afterwards, not by their place in the list.  A merged seed-family list is
+    where it happens: the case the randomised sweep found (tests/golden/case_family_chain_order.npz: two anchors of 2 and 1
+    columns changed places), on the device route (a caller's / merged list of that size goes there with MAUVE_CANON_DEVICE_MIN=1),
+    equals the oracle."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    case = os.path.join(root, "tests", "golden", "case_family_chain_order.npz")
+    env = dict(os.environ, MAUVE_CANON_DEVICE_MIN="1")
+    r = subprocess.run([sys.executable, "-c", ORDER_SCRIPT % {"root": root, "case": case}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr[-3000:]
+
+
+def test_given_and_merged_lists_take_the_device_route(ctx):
+    """A caller's match list (mauve_align_matches) and the merged list of a seed family (S3b) of more than 16 k matches are put where
+    the seed pass would have left its own, so that overlap elimination, LCBs, extension and the tail run on the device: same result
+    as the oracle (whose elimination works on the dense merged list on the host) and as the host route (MAUVE_GIVEN_ON_HOST is read once
+    per process, so the host route is what the small-list tests cover)."""
+    from mauvealigner_amd import _lib
+    gs = synth.make_config("C3", scale=0.4)
+    r = _same_align(ctx, gs, seed_family=1, seed_weight=15)
+    assert r["n_mums"] > 16384
+    ctx.set_genomes(gs)
+    ln, st = ctx.seed_mums(O.get_seed(15, 0), mode=0, mask=(1 << len(gs)) - 1)
+    g = ctx.align_matches(_lib.default_params(seed_weight=15), ln, st)
+    w = ctx.align(_lib.default_params(seed_weight=15))
+    for k in ("anchor_length", "anchor_start", "anchor_lcb", "left", "right", "col_off", "cols", "dp_score", "lcb_weight"):
+        assert np.array_equal(g[k], w[k]), k
+
+
 def test_lcb_extension_on_the_device(ctx):
     """Lists of more than 16 k matches keep their chains on the device; the extension rounds then work on the LCB table alone
     (extend_dev.hip: pieces outside the LCBs gathered into small virtual genomes, the new matches re-chained against the LCBs
