@@ -780,32 +780,39 @@ __global__ void __launch_bounds__(256) run_summary(const KeyT *__restrict__ keys
                                                    uint32_t *__restrict__ rlen, uint32_t *__restrict__ runiq,
                                                    uint32_t *__restrict__ counter)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    uint32_t uniq = 0, len = 0;
-    if (i < n) {
-        const KeyT k = keys[i];
-        const bool valid = !(has_invalid && k == (KeyT)~0ULL);
-        if (valid && (i == 0 || keys[i - 1] != k) && i + 1 < n && keys[i + 1] == k) {
-            uint32_t once = 0, multi = 0, j = i;
-            while (j < n && keys[j] == k) {
-                const uint32_t bit = 1u << genome_of(vals[j] & 0x7fffffffu, tab);
-                multi |= once & bit; once |= bit; j++;
+    // 1024 entries per workgroup (four per thread, strided), one block scan and ONE global atomic per workgroup: with one atomic per
+    // wave, 250 k of them on the same counter were the kernel's whole run time (2.9 ms for 16 M entries)
+    __shared__ uint32_t lds[8];
+    __shared__ uint32_t s_base;
+    constexpr int ITEMS = 4;
+    const uint32_t base = blockIdx.x * (256u * ITEMS);
+    uint32_t uniq[ITEMS], len[ITEMS], cnt = 0;
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t i = base + it * 256 + threadIdx.x;
+        uniq[it] = 0; len[it] = 0;
+        if (i < n) {
+            const KeyT k = keys[i];
+            const bool valid = !(has_invalid && k == (KeyT)~0ULL);
+            if (valid && (i == 0 || keys[i - 1] != k) && i + 1 < n && keys[i + 1] == k) {
+                uint32_t once = 0, multi = 0, j = i;
+                while (j < n && keys[j] == k) {
+                    const uint32_t bit = 1u << genome_of(vals[j] & 0x7fffffffu, tab);
+                    multi |= once & bit; once |= bit; j++;
+                }
+                uniq[it] = once & ~multi; len[it] = j - i;
             }
-            uniq = once & ~multi; len = j - i;
         }
+        if (__popc(uniq[it]) >= 2) cnt++; else uniq[it] = 0;
     }
-    const bool emit = __popc(uniq) >= 2;
-    const uint64_t b = __ballot(emit);
-    if (!b) return;
-    uint32_t base = 0;
-    const int leader = __ffsll((unsigned long long)b) - 1;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(b));
-    base = __shfl(base, leader);
-    if (emit) {
-        const uint32_t r = base + (uint32_t)__popcll(b & ((1ULL << lane) - 1ULL));
-        rstart[r] = i; rlen[r] = len; runiq[r] = uniq;
-    }
+    uint32_t total;
+    const uint32_t off = block_excl_scan(cnt, &total, lds);
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(counter, total) : 0u;
+    __syncthreads();
+    uint32_t r = s_base + off;
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++)
+        if (uniq[it]) { rstart[r] = base + it * 256 + threadIdx.x; rlen[r] = len[it]; runiq[r] = uniq[it]; r++; }
 }
 
 __global__ void __launch_bounds__(256) join_pair(const uint32_t *__restrict__ vals, GenomeTab tab, const uint32_t *__restrict__ rstart,
@@ -960,10 +967,10 @@ __device__ __forceinline__ bool same_diagonal(const uint32_t *__restrict__ rp, c
 }
 
 template <bool SEG>
-__global__ void __launch_bounds__(256) mum_runs(GenomeTab tab, int span, const uint32_t *__restrict__ tmask,
-                                                const uint32_t *__restrict__ tpos, uint32_t P, int all,
-                                                uint32_t *__restrict__ cand, uint32_t *__restrict__ counters,
-                                                const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t p0 = 0)
+__device__ __forceinline__ void mum_runs_body(const GenomeTab &tab, int span, const uint32_t *__restrict__ tmask,
+                                              const uint32_t *__restrict__ tpos, uint32_t P, int all,
+                                              uint32_t *__restrict__ cand, uint32_t *__restrict__ counters,
+                                              const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t p0)
 {
     __shared__ uint32_t lds[8];
     __shared__ uint32_t s_base;
@@ -1021,6 +1028,60 @@ __global__ void __launch_bounds__(256) mum_runs(GenomeTab tab, int span, const u
 #pragma unroll
     for (int it = 0; it < RUNS_ITEMS; it++)
         if (flags >> it & 1) cand[o++] = base + it * 256 + threadIdx.x;
+}
+template <bool SEG>
+__global__ void __launch_bounds__(256) mum_runs(GenomeTab tab, int span, const uint32_t *__restrict__ tmask,
+                                                const uint32_t *__restrict__ tpos, uint32_t P, int all,
+                                                uint32_t *__restrict__ cand, uint32_t *__restrict__ counters,
+                                                const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t p0 = 0)
+{
+    mum_runs_body<SEG>(tab, span, tmask, tpos, P, all, cand, counters, seg, nseg, p0);
+}
+// Several passes of the pairwise finder at once: pairs with DIFFERENT lower genomes write disjoint slices of the hit table, so a group of
+// them shares the table, one candidate list and one counter (mum_extend tells the pairs apart by the hit's mask).  blockIdx.y = pair.
+struct PairGroup { int n; int ga[MAUVE_MAX_SEQ], gb[MAUVE_MAX_SEQ]; uint32_t lo[MAUVE_MAX_SEQ], hi[MAUVE_MAX_SEQ]; };
+__global__ void __launch_bounds__(256) mum_runs_group(GenomeTab tab, int span, const uint32_t *__restrict__ tmask, const uint32_t *__restrict__ tpos, PairGroup grp, int all,
+                                                      uint32_t *__restrict__ cand, uint32_t *__restrict__ counters)
+{
+    const uint32_t lo = grp.lo[blockIdx.y], hi = grp.hi[blockIdx.y];
+    if (lo + blockIdx.x * (256u * RUNS_ITEMS) >= hi) return;                     // (workgroup-uniform: the grid covers the longest slice)
+    mum_runs_body<false>(tab, span, tmask, tpos, hi, all, cand, counters, nullptr, 0u, lo);
+}
+__global__ void __launch_bounds__(256) join_pair_group(const uint32_t *__restrict__ vals, GenomeTab tab, const uint32_t *__restrict__ rstart,
+                                                       const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ runiq,
+                                                       uint32_t nruns, PairGroup grp, uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nruns) return;
+    const uint32_t u = runiq[r];
+    uint32_t hit = 0;                                   // the pairs of the group this run is a hit of
+    for (int y = 0; y < grp.n; y++) if ((u >> grp.ga[y]) & (u >> grp.gb[y]) & 1u) hit |= 1u << y;
+    if (!hit) return;
+    const uint32_t s = rstart[r], L = rlen[r];
+    // the run's entries once (nearly every run has at most one entry per genome: <= 8 of them stay in registers)
+    constexpr int RC = 8;
+    uint32_t ev[RC]; int eg[RC];
+#pragma unroll
+    for (int t = 0; t < RC; t++) {
+        ev[t] = 0; eg[t] = -1;
+        if ((uint32_t)t < L) { ev[t] = vals[s + t]; eg[t] = genome_of(ev[t] & 0x7fffffffu, tab); }
+    }
+    for (; hit; hit &= hit - 1) {
+        const int y = __ffs(hit) - 1, gi = grp.ga[y], gj = grp.gb[y];
+        uint32_t vi = 0, vj = 0;
+#pragma unroll
+        for (int t = 0; t < RC; t++) { if (eg[t] == gi) vi = ev[t]; if (eg[t] == gj) vj = ev[t]; }
+        for (uint32_t t = s + RC; t < s + L; t++) {     // (longer runs: the rest from memory)
+            const uint32_t v = vals[t];
+            const int g = genome_of(v & 0x7fffffffu, tab);
+            if (g == gi) vi = v;
+            if (g == gj) vj = v;
+        }
+        const uint32_t ap = vi & 0x7fffffffu;           // gi < gj: the anchor is genome gi's window
+        tmask[ap] = (1u << gi) | (1u << gj);
+        tpos[(size_t)ap * tab.nseq + gi] = vi;
+        tpos[(size_t)ap * tab.nseq + gj] = vj;
+    }
 }
 
 // phase B: one wave per candidate; the 64 lanes test 64 consecutive offsets at a time and the resulting
@@ -1510,7 +1571,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         rstart = ctx->run_sum.as<uint32_t>(); rlen = rstart + cap; runiq = rlen + cap;
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
         { KernelTimer t(ctx, MAUVE_K_JOIN, ns);
-          hipLaunchKernelGGL((run_summary<KeyT>), dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, keys, vals, ns, tab,
+          hipLaunchKernelGGL((run_summary<KeyT>), dim3((ns + 1023) / 1024), dim3(256), 0, ctx->stream, keys, vals, ns, tab,
                              has_invalid, rstart, rlen, runiq, ctx->counters.as<uint32_t>() + 2); }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, ctx->pin_seed.ensure(64));
@@ -1518,6 +1579,59 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         nruns = ctx->pin_seed.as<uint32_t>()[2];
         TRACE(ctx, "run summary");
+    }
+    // ---- the passes of the pairwise finder in groups: pairs with different lower genomes write disjoint slices of the hit table, so up to
+    // N - 1 of them share one join launch (the run list is read once per group instead of once per pair), one run-detection launch
+    // (blockIdx.y = pair), one candidate list, one round trip and one extension launch: 28 passes of an 8-genome guide tree are 7 groups.
+    // MAUVE_PAIR_SERIAL: A/B switch (one pass per pair, the loop below).
+    static const bool pair_serial = getenv("MAUVE_PAIR_SERIAL") != nullptr;
+    if (use_summary && nruns && !pair_serial && !hh && !SEG) {
+        std::vector<char> used(passes.size(), 0);
+        for (size_t left = passes.size(); left;) {
+            PairGroup grp; memset(&grp, 0, sizeof grp);
+            uint32_t amask = 0, maxslice = 0, slices = 0;
+            for (size_t q = 0; q < passes.size(); q++) {
+                if (used[q]) continue;
+                const int ga = __builtin_ctz(passes[q].consider), gb = 31 - __builtin_clz(passes[q].consider);
+                if (amask >> ga & 1u) continue;
+                used[q] = 1; left--;
+                const uint32_t lo = tab.gpos_off[ga], hi = std::min<uint32_t>(tab.gpos_off[ga + 1], P);
+                if (hi <= lo) continue;                            // (a genome shorter than the seed has no window)
+                grp.ga[grp.n] = ga; grp.gb[grp.n] = gb; grp.lo[grp.n] = lo; grp.hi[grp.n] = hi; grp.n++;
+                amask |= 1u << ga; maxslice = std::max(maxslice, hi - lo); slices += hi - lo;
+            }
+            if (!grp.n) continue;
+            for (int y = 0; y < grp.n; y++) HIPCHK(ctx, hipMemsetAsync(ctx->posmask.as<uint32_t>() + grp.lo[y], 0, (size_t)(grp.hi[y] - grp.lo[y]) * 4, ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+            { KernelTimer t(ctx, MAUVE_K_JOIN, nruns);
+              hipLaunchKernelGGL(join_pair_group, dim3((nruns + 255) / 256), dim3(256), 0, ctx->stream, vals, tab, rstart, rlen, runiq, nruns, grp, tmask, tpos); }
+            HIPCHK(ctx, hipGetLastError());
+            TRACE(ctx, "join");
+            { KernelTimer t(ctx, MAUVE_K_RUNS, slices);
+              hipLaunchKernelGGL(mum_runs_group, dim3((maxslice + 256 * RUNS_ITEMS - 1) / (256 * RUNS_ITEMS), (uint32_t)grp.n), dim3(256), 0, ctx->stream, tab, sh.span, tmask, tpos, grp,
+                                 extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>()); }
+            HIPCHK(ctx, hipGetLastError());
+            if (ctx->shadow) { std::function<void()> fsh; fsh.swap(ctx->shadow); fsh(); }
+            HIPCHK(ctx, ctx->pin_seed.ensure(64));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            const uint32_t nc = ctx->pin_seed.as<uint32_t>()[1];
+            TRACE(ctx, "runs");
+            if (g_trace) fprintf(stderr, "[trace]   %u candidates of %u windows (%d pairs at once)\n", nc, slices, grp.n);
+            if (nc == 0) continue;
+            HIPCHK(ctx, ctx->mlen.ensure_keep((size_t)(cand_total + nc) * 4 + 4, (size_t)cand_total * 4, ctx->stream));
+            HIPCHK(ctx, ctx->mstart.ensure_keep((size_t)(cand_total + nc) * 4 * N + 4, (size_t)cand_total * 4 * N, ctx->stream));
+            {
+                const uint32_t blocks = std::min<uint32_t>((nc + 3) / 4, 256 * 8);
+                KernelTimer t(ctx, MAUVE_K_EXTEND, nc);
+                hipLaunchKernelGGL((mum_extend<SEG>), dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh, tmask, tpos, P, ctx->cand.as<uint32_t>(), nc, extend,
+                                   ctx->mlen.as<int32_t>() + cand_total, ctx->mstart.as<int32_t>() + (size_t)cand_total * N, seg, nseg, vmask, cmask);
+                HIPCHK(ctx, hipGetLastError());
+            }
+            cand_total += nc;
+            TRACE(ctx, "extend");
+        }
+        passes.clear();                                        // done: nothing left for the loop below
     }
     for (const FinderPass &fp : passes) {
         // the hit table is indexed by the anchor's window = a window of the lowest genome of the pass: a pass over one genome pair
