@@ -266,6 +266,7 @@ struct mauve_ctx {
     int64_t bp_min_len = -1;              // >= 0 with pair_sums_only: also count the broken adjacencies of every pair's matches of at least this length
     std::vector<int64_t> pair_bp;         // [N*N], upper triangle (a < b)
     DevBuf bp_work;
+    std::vector<uint8_t> rec_flags;       // one byte per anchor in chain order (LCB by LCB): the gap behind it is a candidate of the recursion; empty = not known (recursive.cpp tests every gap)
     bool lazy_matches_ok = false, matches_pending = false;
     int match_nseq = 0;
     // where dp_run_from_anchors left its device-side results (valid until the next DP launch)
@@ -337,6 +338,7 @@ static inline double now_ms()
 
 // ---- internal entry points between translation units ----
 // the contributions of all ranks to one exchange: parts[r] = (pointer, bytes), valid until the next exchange (api.cpp)
+int rec_gap_flags_device(mauve_ctx *c, const int32_t *alen, const int32_t *ast, const int32_t *alcb, int64_t na, int N, int64_t min_gap, uint8_t *d_flag);
 int shard_allgather(mauve_ctx *c, const void *send, size_t bytes, std::vector<std::pair<const char *, size_t>> &parts);
 // deterministic LPT packing of `cost` into the ranks (ties: lower index first, lower rank first): owner[i] = rank of unit i
 void shard_lpt(const std::vector<int64_t> &cost, int world, std::vector<int> &owner);

@@ -120,6 +120,27 @@ __global__ void __launch_bounds__(256) ext_count_rec(const int32_t *__restrict__
     if (mx > min_gap) atomicAdd(out, 1u);
 }
 
+// ... and which ones: flag[j] = 1 when the gap behind anchor j (same LCB) is one the recursion has to look at (the host's work list then
+// visits those few thousand instead of testing every anchor pair)
+__global__ void __launch_bounds__(256) ext_flag_rec(const int32_t *__restrict__ alen, const int32_t *__restrict__ ast, const int32_t *__restrict__ alcb, uint32_t na, int N,
+                                                    int64_t min_gap, uint8_t *__restrict__ flag)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= na) return;
+    uint8_t f = 0;
+    if (j + 1 < na && alcb[j] == alcb[j + 1]) {
+        int64_t mx = 0;
+        for (int g = 0; g < N; g++) {
+            const int64_t sa = ast[(size_t)j * N + g], sb = ast[(size_t)(j + 1) * N + g];
+            int64_t lo, hi;
+            if (sa > 0) { lo = sa + alen[j]; hi = sb - 1; } else { lo = -sb + alen[j + 1]; hi = -sa - 1; }
+            mx = max(mx, hi - lo + 1);
+        }
+        f = mx > min_gap;
+    }
+    flag[j] = f;
+}
+
 struct LcbTab {                                                   // the LCBs as the rounds see them
     int N = 0; int64_t n = 0;
     std::vector<int64_t> lo, hi, weight;                          // [n * N] absolute extents, [n]
@@ -127,6 +148,15 @@ struct LcbTab {                                                   // the LCBs as
 };
 
 }  // namespace
+
+// the recursion's candidate gaps of a device-resident anchor list (chain order), as one byte per anchor in d_flag
+int rec_gap_flags_device(mauve_ctx *c, const int32_t *alen, const int32_t *ast, const int32_t *alcb, int64_t na, int N, int64_t min_gap, uint8_t *d_flag)
+{
+    if (na <= 0) return MAUVE_OK;
+    hipLaunchKernelGGL(ext_flag_rec, dim3((uint32_t)((na + 255) / 256)), dim3(256), 0, c->stream, alen, ast, alcb, (uint32_t)na, N, min_gap, d_flag);
+    HIPCHK(c, hipGetLastError());
+    return MAUVE_OK;
+}
 
 // anchors: na records in chain order at (*alen, *ast, *alcb) on the device, nl LCBs with weights in c->ch_lw.  On return the
 // pointers name the extended list (c->ch_anch2 when anything was added), na / nl / n_rec are updated and lcb_weight holds the

@@ -248,6 +248,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
     const int N = c->nseq;
     AlignState &S = c->ast;
     S.reset();
+    c->rec_flags.clear();
     S.p = *p; S.N = N; S.t0 = now_ms();
     AlignResult &R = c->res;
     // keep the capacity of the result vectors across calls (a fresh 20 MB column buffer per call costs more in
@@ -400,12 +401,20 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
                 if (do_extend) {
                     // the extension is done; what follows (recursion) wants the chains on the host: the anchors come over as they are
                     const size_t rb = (size_t)na * (2 + (size_t)N) * 4;
-                    HIPCHK(c, c->pin_chain.ensure(256 + rb));
+                    HIPCHK(c, c->pin_chain.ensure(256 + rb + (size_t)na + 64));
                     int32_t *hl = reinterpret_cast<int32_t *>(c->pin_chain.as<char>() + 256), *hs = hl + na, *hb = hs + (size_t)na * N;
+                    uint8_t *hf = reinterpret_cast<uint8_t *>(hb + na);
                     HIPCHK(c, hipMemcpyAsync(hl, S.dv_len, (size_t)na * 4, hipMemcpyDeviceToHost, c->stream));
                     HIPCHK(c, hipMemcpyAsync(hs, S.dv_st, (size_t)na * N * 4, hipMemcpyDeviceToHost, c->stream));
                     HIPCHK(c, hipMemcpyAsync(hb, S.dv_lcb, (size_t)na * 4, hipMemcpyDeviceToHost, c->stream));
+                    if (p->recursive) {                  // which gaps the recursion will look at: flagged on the device, the work list visits only those
+                        HIPCHK(c, c->ext_work.ensure((size_t)na + 64));
+                        rc = rec_gap_flags_device(c, S.dv_len, S.dv_st, S.dv_lcb, na, N, p->min_recursive_gap, c->ext_work.as<uint8_t>());
+                        if (rc) return rc;
+                        HIPCHK(c, hipMemcpyAsync(hf, c->ext_work.p, (size_t)na, hipMemcpyDeviceToHost, c->stream));
+                    }
                     HIPCHK(c, hipStreamSynchronize(c->stream));
+                    if (p->recursive) c->rec_flags.assign(hf, hf + na); else c->rec_flags.clear();
                     std::vector<MatchVec> &chs = S.chains;
                     chs.resize((size_t)nl);
                     for (auto &ch : chs) { ch.N = N; ch.d.clear(); }

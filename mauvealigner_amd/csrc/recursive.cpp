@@ -143,10 +143,27 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     const double t_stage0 = now_ms();
     WorkList work(N);
-    for (size_t l = 0; l < chains.size(); l++)
-        for (size_t i = 0; i + 1 < chains[l].size(); i++)
-            if (gap_weight(N, chains[l].rec(i), chains[l].rec(i + 1), w0, p->min_recursive_gap))
-                work.push((int64_t)l, w0, chains[l].rec(i), chains[l].rec(i + 1));
+    {
+        // c->rec_flags (one byte per anchor in chain order, from the device: the gap behind it is longer than min_recursive_gap on some side):
+        // consumed once; without it every gap is tested
+        std::vector<uint8_t> flags; flags.swap(c->rec_flags);
+        size_t total = 0; for (const MatchVec &ch : chains) total += ch.size();
+        const bool use_flags = !flags.empty() && flags.size() == total;
+        size_t off = 0;
+        for (size_t l = 0; l < chains.size(); l++) {
+            const size_t n = chains[l].size();
+            if (use_flags) {
+                const uint8_t *fl = flags.data() + off;
+                for (size_t i = 0; i + 1 < n; i++)
+                    if (fl[i] && gap_weight(N, chains[l].rec(i), chains[l].rec(i + 1), w0, p->min_recursive_gap))
+                        work.push((int64_t)l, w0, chains[l].rec(i), chains[l].rec(i + 1));
+            } else
+                for (size_t i = 0; i + 1 < n; i++)
+                    if (gap_weight(N, chains[l].rec(i), chains[l].rec(i + 1), w0, p->min_recursive_gap))
+                        work.push((int64_t)l, w0, chains[l].rec(i), chains[l].rec(i + 1));
+            off += n;
+        }
+    }
     std::vector<MatchVec> found(chains.size(), MatchVec(N));
     int level = 0;
     if (trace) fprintf(stderr, "[trace] recursion: work list of %zu gaps built in %.3f ms\n", work.size(), now_ms() - t_stage0);
@@ -394,22 +411,26 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
     const double tm0 = now_ms();
     // the new anchors into their chains: the chain is in genome-0 order already, so the (few) new ones are sorted and the two
     // lists merged -- distinct starts in genome 0, as anchors of one chain never overlap
-    std::vector<int64_t> merged;
     for (size_t l = 0; l < chains.size(); l++) {
         if (found[l].empty()) continue;
         found[l].sort_by_start0();
+        // in place, from the back: the chain's buffer keeps its capacity from call to call, so no fresh 10 MB vector (and its page
+        // faults) per alignment; every record moves once
         const size_t R1 = (size_t)(1 + N), na = chains[l].size(), nb = found[l].size();
-        merged.resize((na + nb) * R1);
-        const int64_t *A = chains[l].d.data(), *B = found[l].d.data();
-        size_t a = 0, b = 0, o = 0;
-        while (a < na || b < nb) {
-            const bool take_a = b == nb || (a < na && std::llabs(A[a * R1 + 1]) <= std::llabs(B[b * R1 + 1]));
-            const int64_t *src = take_a ? A + a * R1 : B + b * R1;
-            std::copy(src, src + R1, merged.begin() + (std::ptrdiff_t)(o * R1));
-            if (take_a) a++; else b++;
-            o++;
-        }
-        chains[l].d.swap(merged);
+        std::vector<int64_t> &A = chains[l].d;
+        A.resize((na + nb) * R1);
+        const int64_t *B = found[l].d.data();
+        int64_t *D = A.data();
+        size_t a = na, b = nb, o = na + nb;
+        while (b > 0) {
+            if (a > 0 && std::llabs(D[(a - 1) * R1 + 1]) > std::llabs(B[(b - 1) * R1 + 1])) {
+                a--; o--;
+                for (size_t k = 0; k < R1; k++) D[o * R1 + k] = D[a * R1 + k];
+            } else {
+                b--; o--;
+                for (size_t k = 0; k < R1; k++) D[o * R1 + k] = B[b * R1 + k];
+            }
+        }                                                      // (what is left of A is in place already)
     }
     if (trace) fprintf(stderr, "[trace] recursion: merge into chains %.3f ms, whole stage %.3f ms\n", now_ms() - tm0, now_ms() - t_stage0);
     return MAUVE_OK;

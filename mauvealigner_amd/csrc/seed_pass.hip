@@ -1586,6 +1586,9 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     // MAUVE_PAIR_SERIAL: A/B switch (one pass per pair, the loop below).
     static const bool pair_serial = getenv("MAUVE_PAIR_SERIAL") != nullptr;
     if (use_summary && nruns && !pair_serial && !hh && !SEG) {
+        // one candidate list per group: a pair has at most one hit per window of its lower genome, the lower genomes of a group are
+        // different, so a group has at most P candidates (a single pass: P / 2, "a hit needs two entries" -- not enough here)
+        HIPCHK(ctx, ctx->cand.ensure(((size_t)P + 1) * 4));
         std::vector<char> used(passes.size(), 0);
         for (size_t left = passes.size(); left;) {
             PairGroup grp; memset(&grp, 0, sizeof grp);

@@ -323,3 +323,23 @@ def test_error_behaviour(ctx):
     # still alive, and the refused set_genomes did not replace the genomes
     ln, st = ctx.seed_mums(O.get_seed(11, 0))
     assert len(ln) > 0 and st.shape[1] == 2
+
+
+def test_pairwise_passes_in_groups(ctx):
+    """PairwiseMatchFinder on the device runs its N (N - 1) / 2 passes in groups of pairs with different lower genomes (one join, one
+    run detection, one candidate list per group).  Without extension every hit is a candidate, so a group of near-identical genomes
+    has about as many candidates as windows -- more than the P / 2 a single pass can have (the candidate list was sized for that
+    once; found by the randomised sweep as a history-dependent failure).  Six genomes, with and without extension, against the oracle."""
+    rng = np.random.default_rng(431)
+    anc = rng.integers(0, 4, 5300, dtype=np.uint8)
+    gs = [np.ascontiguousarray(synth.mutate(anc, 0.01, rng, indel_frac=0.1)) for _ in range(6)]
+    ctx.set_genomes(gs)
+    for w in (17, 11):
+        pat = O.get_seed(w, 0)
+        for ext in (False, True):
+            ln, st = ctx.seed_mums(pat, mode=2, extend=ext)
+            eln, est = O.find_matches(gs, pat, mode=2, extend=ext)
+            assert np.array_equal(ln, eln) and np.array_equal(st, est), (w, ext)
+        if w == 17:
+            assert len(ln) > 0
+
