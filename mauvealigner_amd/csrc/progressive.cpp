@@ -162,7 +162,6 @@ int prog_node(Prog &P, int node)
     }
     const double tn1 = now_ms();
     ChainOrders orders;
-    host_eliminate_overlaps(m, &orders);
     int64_t lcbw = p->lcb_weight >= 0 ? p->lcb_weight * n / P.N : (int64_t)3 * w * n;
     // the node's minimum weight shrinks with the conservation distance between its two subtrees
     int64_t factor_ppm = 1000000;
@@ -183,7 +182,20 @@ int prog_node(Prog &P, int node)
         lcbw = std::max(lcbw * factor_ppm / 1000000, p->min_scaled_penalty);
     }
     std::vector<int64_t> match_lcb; int64_t nl = 0;
-    if (p->lcb_scoring == MAUVE_LCB_SCORE_SP) {
+    // The root's list (all genomes, tens of thousands of matches) is still in HBM in canonical order: overlap elimination and LCBs on the
+    // device (chain_dev.hip), cropped records and labels back -- what mauve_align does.  Nodes below the root have short lists (and a
+    // genome subset: the device chain takes its position width from the context's genomes), score-weighted LCBs need the matches' scores,
+    // a list the device chain declines comes back as MAUVE_ERR_LIMIT: the host chain for those.  MAUVE_HOST_CHAIN: A/B switch.
+    static const bool host_chain_env = getenv("MAUVE_HOST_CHAIN") != nullptr;
+    bool chained = false;
+    if (!host_chain_env && !p->seed_family && n == P.N && nm > 0 && c->dev_rec_n == nm && p->lcb_scoring == MAUVE_LCB_SCORE_LENGTH) {
+        rc = chain_device(c, n, lcbw, p->collinear != 0, m, match_lcb, nl);
+        if (rc == MAUVE_OK) chained = true;
+        else if (rc != MAUVE_ERR_LIMIT) return rc;
+    }
+    if (!chained) host_eliminate_overlaps(m, &orders);
+    if (chained) {}
+    else if (p->lcb_scoring == MAUVE_LCB_SCORE_SP) {
         std::vector<int64_t> mw;
         rc = match_sp_scores(c, m, gm.data(), &p->scoring, mw);
         if (rc) return rc;
