@@ -37,6 +37,23 @@ def test_struct_layouts_match_oracle_side():
     assert (p.scoring.gap_open, p.scoring.gap_extend) == (-400, -30)
 
 
+def test_hmm_params_conversion_matches_oracle():
+    """mauve_hmm_params_from (host code of the product library, no GPU needed): the call site's three knobs (progressiveMauve.cpp:319-322)
+    as the integer scores of DESIGN.md S12b -- same numbers as the oracle's conversion, for the defaults and for other settings."""
+    L = _lib.load()
+    L.mauve_hmm_params_from.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(_lib.HmmParams)]
+    L.mauve_hmm_params_from.restype = None
+    for ident, pgh, pgu in ((0.7, 1e-5, 1e-9), (0.9, 1e-3, 1e-3), (0.55, 0.5, 1e-12)):
+        h = _lib.HmmParams()
+        L.mauve_hmm_params_from(ident, pgh, pgu, C.byref(h))
+        o = O.hmm_params(ident, pgh, pgu)
+        assert (h.match, h.mismatch, h.gap, h.go_homologous, h.go_unrelated) == (o.match, o.mismatch, o.gap, o.go_homologous, o.go_unrelated)
+    h = _lib.HmmParams()
+    L.mauve_hmm_params_from(0.7, 1e-5, 1e-9, C.byref(h))
+    assert (h.match, h.mismatch, h.gap, h.go_homologous, h.go_unrelated) == (1030, -916, -500, -11513, -20723)
+    assert C.sizeof(_lib.HmmParams) == C.sizeof(O.HmmParams) == 20
+
+
 def test_seed_helpers_and_packing():
     for w in range(0, 34):
         for r in (0, 1, 2, 3, _lib.SOLID_SEED, 7, -1):
