@@ -248,8 +248,8 @@ def cpu_baseline(name, scale, weight, gpu_result, genomes, sample_scale):
         gs = synth.make_config(name, scale * sample_scale)
     kw = dict(seed_weight=weight) if cfg["weight"] else {}
     tc0 = time.perf_counter()
-    if cfg["path"] == "progressive":
-        ref = O.progressive_align(gs, O.default_params(**kw))
+    if cfg["path"] == "progressive":                      # the progressiveMauve call site's option set, like the GPU leg (params_for)
+        ref = O.progressive_align(gs, O.default_progressive_params(**kw))
     else:
         ref = O.align(gs, O.default_params(**kw))
     tc = time.perf_counter() - tc0
@@ -291,11 +291,29 @@ def all_cores_baseline(config, scale, weight):
 
 
 def params_for(name, **kw):
+    """the reference call site's defaults for the workload's path: mauveAligner.cpp:92-99 (mauve_default_params) for the mauveAligner
+    configs, progressiveMauve.cpp:578-579,624-637 (mauve_default_progressive_params: SP scoring, weight scaling 0.5 / 0.5,
+    refinement on) for the progressive one"""
     from mauvealigner_amd import _lib
     cfg = WORKLOADS[name]
     if cfg["weight"]:
         kw.setdefault("seed_weight", cfg["weight"])
+    if cfg["path"] == "progressive":
+        return _lib.default_progressive_params(**kw)
     return _lib.default_params(**kw)
+
+
+def option_set(params, progressive):
+    o = {"extend_lcbs": int(params.extend_lcbs), "max_extension_iters": int(params.max_extension_iters), "recursive": int(params.recursive),
+         "gapped": int(params.gapped)}
+    if progressive:
+        o.update(lcb_scoring="sp" if params.lcb_scoring == 1 else "length", weight_scaling=int(params.weight_scaling),
+                 conservation_scale_ppm=int(params.conservation_scale_ppm), bp_dist_scale_ppm=int(params.bp_dist_scale_ppm),
+                 refine_rounds=int(params.refine_rounds), seed_family=int(params.seed_family),
+                 source="mauve_default_progressive_params (progressiveMauve.cpp:578-579,624-637)")
+    else:
+        o["source"] = "mauve_default_params (mauveAligner.cpp:92-99)"
+    return o
 
 
 def secondary_leg(ctx, name, scale, steps, warmup, barrier, cpu_sample):
@@ -316,11 +334,19 @@ def secondary_leg(ctx, name, scale, steps, warmup, barrier, cpu_sample):
            "timed_region": "packed genomes in page-locked host RAM -> upload -> %s -> every result array in page-locked host RAM" %
                            ("mauve_progressive_align" if rn.progressive else "mauve_align"),
            "total_bp": rn.total_bp, "seed_weight": weight, "extend_lcbs": int(params.extend_lcbs),
+           "config": option_set(params, rn.progressive),
            "device_resident": {"ms_per_step": round(e_r / steps * 1e3, 3), "Mbp_s": round(rn.total_bp / 1e6 / (e_r / steps), 2),
                                "note": "genomes resident in HBM, results left there"},
            "stages_ms": stages, "kernels_ms": kern, "roofline": roof, "result_sizes": sizes, "generate_s": round(tgen, 1)}
     if cpu_sample:
         out["cpu_baseline"] = cpu_baseline(name, scale, weight, gpu_result, genomes, cpu_sample)
+    if rn.progressive:
+        # last round's option set (length-weighted LCBs, no weight scaling, no refinement) as a named extra, never the leg's value
+        from mauvealigner_amd import _lib
+        pl = _lib.default_params(**({"seed_weight": cfg["weight"]} if cfg["weight"] else {}))
+        e_l, _ = rn.time_host(steps, 1, pl)
+        out["length_scoring_no_refinement"] = {"value": round(rn.total_bp / 1e6 / (e_l / steps), 2), "unit": "Mbp/s",
+                                               "ms_per_step": round(e_l / steps * 1e3, 3), "config": option_set(pl, True)}
     return out
 
 
@@ -502,6 +528,7 @@ def main():
             "config": {"workload": (cfg["text"] % L) + ", recursive anchoring + gapped DP on",
                        "genomes_per_gpu": cfg["n"], "genome_length": L, "seed_weight": weight, "parallelism": par,
                        "extend_lcbs": int(params.extend_lcbs), "max_extension_iters": int(params.max_extension_iters),
+                       "options": option_set(params, cfg["path"] == "progressive"),
                        "timed_region": "packed genomes in page-locked host RAM -> upload -> %s -> every result array in page-locked host RAM (SURVEY.md 8d)" %
                                        ("mauve_progressive_align" if cfg["path"] == "progressive" else "mauve_align")},
             "roofline": roofline, "cpu_baseline": cpu, "accuracy_vs_truth": acc,

@@ -42,6 +42,7 @@ int main(int argc, char **argv)
             ProgressiveAligner aligner(n);                               // progressiveMauve.cpp:575
             PairwiseScoringScheme pss;                                   // :666-687 (hoxd_matrix, -400, -30)
             aligner.setPairwiseScoringScheme(pss);
+            aligner.setLcbScoringScheme(ProgressiveAligner::ExtantSumOfPairsScoring);   // :624-625 "default to extant sp"
             IntervalList interval_list;
             interval_list.seq_filename = match_list.seq_filename;
             aligner.align(match_list.seq_table, interval_list);          // :710

@@ -123,15 +123,11 @@ inline void detectAndApplyBackbone(IntervalList &il, backbone_list_t &bb_list, c
     const size_t K = il.size();
     const uint N = (uint)il.seq_table.size();
     if (K && N) {
-        {   // the interval list refers to its own sequence table: those are the genomes the pass compares
-            std::vector<std::vector<uint64_t>> packed(N); std::vector<const uint64_t *> ptr; std::vector<int64_t> lens;
-            for (uint g = 0; g < N; g++) {
-                const std::string &t = il.seq_table[g]->str();
-                packed[g].assign(mauve_packed_words((int64_t)t.size()), 0);
-                mauve_pack_ascii(t.data(), (int64_t)t.size(), packed[g].data());
-                ptr.push_back(packed[g].data()); lens.push_back((int64_t)t.size());
-            }
-            hc.check(mauve_set_genomes(hc.get(), (int)N, ptr.data(), lens.data()), "mauve_set_genomes");
+        {   // the interval list refers to its own sequence table: those are the genomes the pass compares.  Uploaded like a MatchList's
+            // (contig starts and ambiguity bitmaps go along, so that a later search on this context sees them; the homology pass itself
+            // reads an ambiguous base as A)
+            MatchList tmp; tmp.seq_table = il.seq_table;
+            tmp.upload(hc);
         }
         std::vector<int64_t> left(K * N, 0), right(K * N, 0), col_off(K + 1, 0), noff(K + 1, 0);
         std::vector<int8_t> rev(K * N, 0);

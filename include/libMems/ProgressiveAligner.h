@@ -6,6 +6,7 @@
 #include "Aligner.h"
 #include "GuideTree.h"
 #include <fstream>
+#include <iostream>
 #include <sstream>
 
 namespace mems {
@@ -19,9 +20,9 @@ class ProgressiveAligner {
 public:
     explicit ProgressiveAligner(uint seq_count) : seq_count_(seq_count), tree_left_(2 * seq_count - 1, -1), tree_right_(2 * seq_count - 1, -1)
     {
-        mauve_default_params(&p_);
-        p_.weight_scaling = 1; p_.conservation_scale_ppm = 500000; p_.bp_dist_scale_ppm = 500000;       // the library's defaults: scaling on, both scales 0.5 (progressiveMauve.cpp:285-287)
-        p_.refine_rounds = 2;                                            // refinement on unless --skip-refinement (:578-579)
+        // the call site's defaults: extant sum-of-pairs scoring (progressiveMauve.cpp:624-625), scaling on with both scales 0.5
+        // (:285-287), refinement on unless --skip-refinement (:578-579)
+        mauve_default_progressive_params(&p_);
     }
     // --weight, :584-593: a length (x seq_count) under LengthScoring, a score under the sum-of-pairs scheme
     void setBreakpointPenalty(double w) { if (w >= 0) bp_penalty_ = w; }
@@ -41,7 +42,18 @@ public:
     // anchors (MAUVE_LCB_SCORE_SP); the two ancestral schemes need libMems' ancestral sequence
     // reconstruction and fall back to it as well.  LengthScoring (not in libMems) keeps the Aligner::align weights.
     enum LcbScoringScheme { AncestralScoring, AncestralSumOfPairsScoring, ExtantSumOfPairsScoring, LengthScoring };
-    void setLcbScoringScheme(int s) { p_.lcb_scoring = s == LengthScoring ? MAUVE_LCB_SCORE_LENGTH : MAUVE_LCB_SCORE_SP; score_set_ = true; }
+    void setLcbScoringScheme(int s)
+    {
+        if (s == AncestralScoring || s == AncestralSumOfPairsScoring) {      // said once where the caller sees it, not only in DESIGN.md
+            static bool told = false;
+            if (!told) {
+                told = true;
+                std::cerr << "mauve_hip: the ancestral LCB scoring schemes need libMems' ancestral sequence reconstruction, which this "
+                             "library does not reproduce; scoring LCBs with the extant sum-of-pairs scheme instead\n";
+            }
+        }
+        p_.lcb_scoring = s == LengthScoring ? MAUVE_LCB_SCORE_LENGTH : MAUVE_LCB_SCORE_SP; score_set_ = true;
+    }
     // :626-642.  A node's minimum LCB weight shrinks with the mean pairwise conservation distance between its two subtrees
     //  and with their mean breakpoint distance (S11c: broken adjacencies between the pairwise matches of at least
     // the given length, relative to the most rearranged pair).

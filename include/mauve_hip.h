@@ -119,7 +119,11 @@ int mauve_seed_length(uint64_t pattern);
 int mauve_seed_weight(uint64_t pattern);
 int mauve_default_seed_weight(int64_t avg_len);
 void mauve_default_scoring(mauve_scoring *s);              /* hoxd_matrix, -400, -30 */
-void mauve_default_params(mauve_params *p);
+void mauve_default_params(mauve_params *p);                /* mauveAligner's call site (mauveAligner.cpp:92-99) */
+/* progressiveMauve's call site: what a ProgressiveAligner does when main() sets nothing -- ExtantSumOfPairsScoring
+   (progressiveMauve.cpp:624-625), LCB weight scaling on with conservation and breakpoint distance scales 0.5 (:285-287,626-637),
+   refinement on (:578-579): lcb_scoring = SP, weight_scaling = 1, both *_scale_ppm = 500000, refine_rounds = 2. */
+void mauve_default_progressive_params(mauve_params *p);
 /* 2-bit packing used at the boundary: base i -> 64-bit word i/32, bits 2*(i%32); A,C,G,T=0..3,
    anything else -> 0.  words must hold mauve_packed_words(len) entries. */
 size_t mauve_packed_words(int64_t len);
@@ -315,10 +319,13 @@ int mauve_backbone_alignment(mauve_ctx *ctx, int nseq, int64_t n_iv, const int64
    receives the new sizes for mauve_align_fetch); n_moved = residues taken out of multi-genome columns.  Call before mauve_backbone. */
 typedef struct { int32_t match, mismatch, gap, go_homologous, go_unrelated; } mauve_hmm_params;
 /* the call site's knobs (progressiveMauve.cpp:319-322: identity 0.7, pgh 1e-5, pgu 1e-9) as integer scores: match = 1000 ln(id / .25),
-   mismatch = 1000 ln((1 - id) / .75), gap = -500, transitions = 1000 ln(p) */
+   mismatch = 1000 ln((1 - id) / .75), gap = -500, transitions = 1000 ln(p).  identity outside (0.25, 1) or a probability outside (0, 1]
+   has no such score: *h then carries positive transition scores, which mauve_apply_homology* refuse with MAUVE_ERR_ARG */
 void mauve_hmm_params_from(double identity, double pgh, double pgu, mauve_hmm_params *h);
 int mauve_apply_homology(mauve_ctx *ctx, const mauve_hmm_params *h, mauve_align_sizes *sizes, int64_t *n_moved);
-/* ... of the caller's alignment (the genomes it refers to are the context's): cols_out holds up to one column per residue, col_off_out [n_iv+1] */
+/* ... of the caller's alignment (the genomes it refers to are the context's): cols_out holds up to one column per residue, col_off_out [n_iv+1].
+   The column array must be consistent with the interval table -- right - left + 1 residues of every present genome, none of an absent one, no bit
+   at or above nseq -- or the call returns MAUVE_ERR_ARG (mauve_backbone_alignment checks the same) */
 int mauve_apply_homology_alignment(mauve_ctx *ctx, int nseq, int64_t n_iv, const int64_t *left, const int64_t *right, const int8_t *reverse,
                                    const int64_t *col_off, const uint32_t *cols, const mauve_hmm_params *h, int64_t *col_off_out, uint32_t *cols_out,
                                    int64_t *n_moved);

@@ -21,7 +21,7 @@ EXPORTS = [
     "mauve_ctx_create", "mauve_ctx_destroy", "mauve_last_error", "mauve_device_name", "mauve_synchronize",
     "mauve_host_alloc", "mauve_host_free", "mauve_set_shard",
     "mauve_get_seed", "mauve_seed_length", "mauve_seed_weight", "mauve_default_seed_weight", "mauve_default_scoring",
-    "mauve_default_params", "mauve_packed_words", "mauve_pack_ascii", "mauve_pack_codes", "mauve_set_genomes", "mauve_set_genomes_contigs",
+    "mauve_default_params", "mauve_default_progressive_params", "mauve_packed_words", "mauve_pack_ascii", "mauve_pack_codes", "mauve_set_genomes", "mauve_set_genomes_contigs",
     "mauve_ambiguity_bitmap",
     "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_extend_hits", "mauve_seed_match_enumerate",
     "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_dp_batch_banded", "mauve_match_sp_scores", "mauve_align", "mauve_align_fetch",
@@ -167,6 +167,15 @@ def default_seed_weight(avg_len):
 def default_params(**kw):
     p = Params()
     load().mauve_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def default_progressive_params(**kw):
+    """the progressiveMauve call site's option set (SP scoring, weight scaling 0.5 / 0.5, refinement on)"""
+    p = Params()
+    load().mauve_default_progressive_params(C.byref(p))
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -627,6 +636,26 @@ class Context:
                                                   C.c_int64(island_gap), C.byref(ns), C.byref(ni)), "mauve_backbone_alignment")
         self._bb_nseq = N
         return self._backbone_fetch(ns.value, ni.value)
+
+    def apply_homology_alignment(self, left, right, reverse, col_off, cols, hmm=None):
+        """mauve_apply_homology_alignment: the homology pass on the caller's alignment (its genomes are the context's) -> (col_off, cols, n_moved)"""
+        left = np.ascontiguousarray(left, np.int64)
+        right = np.ascontiguousarray(right, np.int64)
+        reverse = np.ascontiguousarray(reverse, np.int8)
+        col_off = np.ascontiguousarray(col_off, np.int64)
+        cols = np.ascontiguousarray(cols, np.uint32)
+        n_iv, N = left.shape
+        h = hmm or self.hmm_params()
+        residues = int(np.sum(np.where(left != 0, right - left + 1, 0)))
+        ncols = np.zeros(max(residues, len(cols)) + 1, np.uint32)
+        noff = np.zeros(n_iv + 1, np.int64)
+        moved = C.c_int64(0)
+        self.L.mauve_apply_homology_alignment.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int8), C.POINTER(C.c_int64),
+                                                          C.POINTER(C.c_uint32), C.POINTER(HmmParams), C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
+        self._chk(self.L.mauve_apply_homology_alignment(self.h, N, n_iv, _p(left, C.c_int64), _p(right, C.c_int64), _p(reverse, C.c_int8), _p(col_off, C.c_int64),
+                                                        _p(cols if len(cols) else np.zeros(1, np.uint32), C.c_uint32), C.byref(h), _p(noff, C.c_int64), _p(ncols, C.c_uint32),
+                                                        C.byref(moved)), "mauve_apply_homology_alignment")
+        return noff, ncols[:noff[-1]].copy(), int(moved.value)
 
     def stage_times(self):
         t = StageTimes()

@@ -191,6 +191,7 @@ int mauve_set_genomes(mauve_ctx *c, int nseq, const uint64_t *const *packed, con
     // until the next call).  What of it is still on the device is not brought over -- in a loop of set_genomes / align / fetch that
     // would copy every result twice -- and a later fetch is refused instead of handing out half a result.
     if (c->res.dev_pending || c->res.cols_pending) { c->res.dev_pending = false; c->res.cols_pending = false; c->res.stale = true; }
+    c->res.genomes_replaced = true;       // what is on the host can still be fetched; mauve_apply_homology / mauve_write_xmfa on it are refused
     size_t total_words = 0;
     std::vector<uint64_t> off(nseq);
     int64_t total_len = 0;

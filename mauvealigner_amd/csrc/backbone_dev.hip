@@ -213,6 +213,37 @@ __global__ void __launch_bounds__(256) bb_tile_count(const uint32_t *__restrict_
     if ((int)threadIdx.x < N) tile_cnt[(size_t)blockIdx.x * N + threadIdx.x] = acc[threadIdx.x];
 }
 
+// residues of every genome in every interval of a caller's column array (check_columns): a tile inside one interval adds its ballot
+// counts once, a tile that spans interval borders adds per column
+__global__ void __launch_bounds__(256) bb_iv_residues(const uint32_t *__restrict__ cols, int64_t n, int N, const int64_t *__restrict__ off, int64_t n_iv,
+                                                      unsigned long long *__restrict__ cnt, uint32_t *__restrict__ bad)
+{
+    auto iv_of = [&](int64_t c) {                              // the last interval whose first column is <= c (empty intervals are skipped over)
+        int64_t lo = 0, hi = n_iv;                             // off[lo] <= c < off[hi]
+        while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (off[mid] <= c) lo = mid; else hi = mid; }
+        return lo;
+    };
+    const int lane = threadIdx.x & 63;
+    const int64_t t0 = (int64_t)blockIdx.x * BB_CHUNK, t1 = min(n, t0 + (int64_t)BB_CHUNK);
+    if (t0 >= t1) return;
+    const int64_t iv0 = iv_of(t0), iv1 = iv_of(t1 - 1);
+    const uint32_t above = N >= 32 ? 0u : ~0u << N;
+    uint32_t mine = 0; bool wrong = false;
+    for (int k = 0; k < BB_CHUNK / 256; k++) {
+        const int64_t c = t0 + k * 256 + threadIdx.x;
+        const uint32_t v = c < t1 ? cols[c] : 0u;
+        wrong |= (v & above) != 0;
+        if (iv0 == iv1) {
+            for (int g = 0; g < N; g++) { const uint32_t x = (uint32_t)__popcll(__ballot(v >> g & 1)); if (lane == g) mine += x; }
+        } else if (v) {
+            const int64_t iv = iv_of(c);
+            for (uint32_t m = v & ~above; m; m &= m - 1) atomicAdd(&cnt[(size_t)iv * N + (__ffs(m) - 1)], 1ull);
+        }
+    }
+    if (iv0 == iv1 && lane < N && mine) atomicAdd(&cnt[(size_t)iv0 * N + lane], (unsigned long long)mine);
+    if (wrong) atomicOr(bad, 1u);
+}
+
 // residues of every genome in [tile start of x, x) for every query column x: the tile's 64 words are split over the four
 // waves of the workgroup, four words in flight per lane
 __global__ void __launch_bounds__(256) bb_rank(const uint32_t *__restrict__ cols, const int64_t *__restrict__ query, int N, uint32_t *__restrict__ out)
@@ -723,6 +754,40 @@ int backbone_run(mauve_ctx *c, int N, int64_t n_iv, const int64_t *left, const i
     return MAUVE_OK;
 }
 
+// A caller's alignment (the _alignment entry points; the mirror hands over iv.Columns() of user Intervals): every genome's residue count
+// in an interval's columns must be what its ends say -- right - left + 1, none for an absent genome -- and no column may carry a bit at or
+// above nseq.  The homology pass turns these counts into base addresses (hom_column), so an inconsistent array would read outside the genomes.
+static int check_columns(mauve_ctx *c, const char *who, int N, int64_t n_iv, const int64_t *left, const int64_t *right, const int64_t *col_off, const uint32_t *d_cols)
+{
+    const int64_t n_cols = col_off[n_iv];
+    auto up = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t o_cnt = up(((size_t)n_iv + 1) * 8), o_bad = o_cnt + up((size_t)n_iv * N * 8), total = o_bad + 64;
+    HIPCHK(c, c->bb_work.ensure(total));
+    char *wk = c->bb_work.as<char>();
+    HIPCHK(c, hipMemcpyAsync(wk, col_off, ((size_t)n_iv + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(wk + o_cnt, 0, total - o_cnt, c->stream));
+    if (n_cols) {
+        hipLaunchKernelGGL(bb_iv_residues, dim3((uint32_t)((n_cols + BB_CHUNK - 1) / BB_CHUNK)), dim3(256), 0, c->stream, d_cols, n_cols, N, reinterpret_cast<const int64_t *>(wk), n_iv,
+                           reinterpret_cast<unsigned long long *>(wk + o_cnt), reinterpret_cast<uint32_t *>(wk + o_bad));
+        HIPCHK(c, hipGetLastError());
+    }
+    std::vector<unsigned long long> cnt((size_t)n_iv * N); uint32_t bad = 0;
+    HIPCHK(c, hipMemcpyAsync(cnt.data(), wk + o_cnt, cnt.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&bad, wk + o_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (bad) { c->err = std::string(who) + ": a column carries a genome bit at or above nseq"; return MAUVE_ERR_ARG; }
+    for (int64_t iv = 0; iv < n_iv; iv++) for (int g = 0; g < N; g++) {
+        const int64_t l = left[(size_t)(iv * N + g)], r = right[(size_t)(iv * N + g)];
+        const int64_t want = l ? r - l + 1 : 0;
+        if (l < 0 || want < 0 || (int64_t)cnt[(size_t)(iv * N + g)] != want) {
+            c->err = std::string(who) + ": the columns of interval " + std::to_string(iv) + " hold " + std::to_string(cnt[(size_t)(iv * N + g)]) + " residues of genome " + std::to_string(g) +
+                     ", its ends say " + std::to_string(want);
+            return MAUVE_ERR_ARG;
+        }
+    }
+    return MAUVE_OK;
+}
+
 extern "C" {
 
 int mauve_backbone(mauve_ctx *c, int64_t island_gap_size, int64_t *n_seg, int64_t *n_islands)
@@ -763,6 +828,7 @@ int mauve_backbone_alignment(mauve_ctx *c, int nseq, int64_t n_iv, const int64_t
     HIPCHK(c, c->bb_cols.ensure(nb + 64));
     if (nb) HIPCHK(c, hipMemcpyAsync(c->bb_cols.p, cols, nb, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));                            // cols is the caller's (pageable) memory
+    if (const int rcc = check_columns(c, "backbone", nseq, n_iv, left, right, col_off, c->bb_cols.as<uint32_t>())) return rcc;
     const int rc = backbone_run(c, nseq, n_iv, left, right, reverse, col_off, c->bb_cols.as<uint32_t>(), island_gap_size);
     if (rc) return rc;
     *n_seg = (int64_t)c->bb.seg_iv.size(); *n_islands = (int64_t)c->bb.islands.size() / 8;
@@ -773,6 +839,10 @@ int mauve_backbone_alignment(mauve_ctx *c, int nseq, int64_t n_iv, const int64_t
 void mauve_hmm_params_from(double identity, double pgh, double pgu, mauve_hmm_params *h)
 {
     if (!h) return;
+    if (!(identity > 0.25 && identity < 1.0) || !(pgh > 0.0 && pgh <= 1.0) || !(pgu > 0.0 && pgu <= 1.0)) {
+        h->match = h->mismatch = h->gap = 0; h->go_homologous = h->go_unrelated = 1;
+        return;
+    }
     h->match = (int32_t)lround(1000.0 * log(identity / 0.25));
     h->mismatch = (int32_t)lround(1000.0 * log((1.0 - identity) / 0.75));
     h->gap = -500;
@@ -916,7 +986,7 @@ int mauve_apply_homology(mauve_ctx *c, const mauve_hmm_params *h, mauve_align_si
 {
     if (!c || !h) return MAUVE_ERR_ARG;
     AlignResult &R = c->res;
-    if (R.stale) { c->err = "apply_homology: the genomes were replaced after this alignment was made"; return MAUVE_ERR_STATE; }
+    if (R.stale || R.genomes_replaced) { c->err = "apply_homology: the genomes were replaced after this alignment was made"; return MAUVE_ERR_STATE; }
     const int64_t n_iv = R.sz.n_iv;
     if ((int64_t)R.col_off.size() != n_iv + 1) { c->err = "apply_homology: no alignment in this context"; return MAUVE_ERR_STATE; }
     if (n_moved) *n_moved = 0;
@@ -958,6 +1028,8 @@ int mauve_apply_homology_alignment(mauve_ctx *c, int nseq, int64_t n_iv, const i
     HIPCHK(c, c->bb_cols.ensure((size_t)n_cols * 4 + 64));
     if (n_cols) HIPCHK(c, hipMemcpyAsync(c->bb_cols.p, cols, (size_t)n_cols * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));                            // cols is the caller's (pageable) memory
+    if (nseq != c->nseq) { c->err = "apply_homology: the alignment does not belong to the genomes of this context"; return MAUVE_ERR_STATE; }
+    if (const int rcc = check_columns(c, "apply_homology", nseq, n_iv, left, right, col_off, c->bb_cols.as<uint32_t>())) return rcc;
     std::vector<int64_t> noff; int64_t n_new = 0, moved = 0;
     const int rc = homology_core(c, nseq, n_iv, left, right, reverse, col_off, c->bb_cols.as<uint32_t>(), h, noff, &n_new, &moved);
     if (rc) return rc;

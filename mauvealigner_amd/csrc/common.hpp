@@ -129,6 +129,8 @@ struct AlignResult {
     std::vector<int64_t> dp_score;
     // device-assembled result (assemble_dev.hip): the columns (res_cols), the anchor table and maybe the match list are still in HBM
     bool stale = false;                     // the genomes were replaced after this result was made: a fetch is refused (mauve_set_genomes)
+    bool genomes_replaced = false;          // ... also set when the result was wholly on the host already: it can still be fetched, but the calls that read
+                                            // bases against it (mauve_apply_homology, mauve_write_xmfa) are refused -- they would pair the new genomes with the old alignment
     bool dev_pending = false;               // anchor table / match list still on the device
     bool cols_pending = false;              // columns only in res_cols (cols_ext not set)
     size_t dev_na = 0, dev_nm = 0;          // anchors; matches still on the device (0: mum_* are filled)

@@ -2304,17 +2304,27 @@ int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *d
         int64_t mcells = 0;
         seq_off.resize((size_t)(nmine * nseq + 1));
         { int64_t t = 0; for (int64_t i = 0; i < nmine * nseq; i++) { seq_off[(size_t)i] = t; t += sub[(size_t)i].len; } seq_off[(size_t)(nmine * nseq)] = t; }
-        int rc = dp_core(ctx, nseq, nmine, nullptr, sub.data(), seq_off.data(), scoring, mcols.data(), moff.data(), mscore.data(), &mcells, sp ? msp.data() : nullptr);
-        if (rc) return rc;
-        const int64_t ncol = moff[(size_t)nmine];
-        std::vector<char> msg((size_t)(2 + 3 * nmine) * 8 + (size_t)ncol * 4);         // [n, cells, len[n], score[n], sp[n], cols...]
+        const int rc_local = dp_core(ctx, nseq, nmine, nullptr, sub.data(), seq_off.data(), scoring, mcols.data(), moff.data(), mscore.data(), &mcells, sp ? msp.data() : nullptr);
+        // a rank that failed still takes part in the exchange -- with the marker n = -1 -- so that the others do not wait in the collective for ever
+        const int64_t ncol = rc_local ? 0 : moff[(size_t)nmine];
+        std::vector<char> msg(rc_local ? 16 : (size_t)(2 + 3 * nmine) * 8 + (size_t)ncol * 4);         // [n, cells, len[n], score[n], sp[n], cols...]
         int64_t *h = reinterpret_cast<int64_t *>(msg.data());
-        h[0] = nmine; h[1] = mcells;
-        for (int64_t q = 0; q < nmine; q++) { h[2 + q] = moff[(size_t)q + 1] - moff[(size_t)q]; h[2 + nmine + q] = mscore[(size_t)q]; h[2 + 2 * nmine + q] = msp[(size_t)q]; }
-        if (ncol) memcpy(msg.data() + (size_t)(2 + 3 * nmine) * 8, mcols.data(), (size_t)ncol * 4);
+        if (rc_local) { h[0] = -1; h[1] = rc_local; }
+        else {
+            h[0] = nmine; h[1] = mcells;
+            for (int64_t q = 0; q < nmine; q++) { h[2 + q] = moff[(size_t)q + 1] - moff[(size_t)q]; h[2 + nmine + q] = mscore[(size_t)q]; h[2 + 2 * nmine + q] = msp[(size_t)q]; }
+            if (ncol) memcpy(msg.data() + (size_t)(2 + 3 * nmine) * 8, mcols.data(), (size_t)ncol * 4);
+        }
         std::vector<std::pair<const char *, size_t>> parts;
-        rc = shard_allgather(ctx, msg.data(), msg.size(), parts);
+        const std::string err_local = ctx->err;
+        int rc = shard_allgather(ctx, msg.data(), msg.size(), parts);
         if (rc) return rc;
+        if (rc_local) { ctx->err = err_local; return rc_local; }
+        for (int r = 0; r < ctx->shard_world; r++)
+            if (parts[(size_t)r].second >= 16 && reinterpret_cast<const int64_t *>(parts[(size_t)r].first)[0] == -1) {
+                ctx->err = "dp shard: rank " + std::to_string(r) + " failed (status " + std::to_string(reinterpret_cast<const int64_t *>(parts[(size_t)r].first)[1]) + ")";
+                return MAUVE_ERR_STATE;
+            }
         // lengths first (the offsets of ALL intervals in table order), then every rank's columns to their places
         std::vector<int64_t> len_of((size_t)n_iv, 0);
         std::vector<std::vector<int64_t>> ids((size_t)ctx->shard_world);
@@ -2324,6 +2334,13 @@ int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *d
             const int64_t *hr = reinterpret_cast<const int64_t *>(parts[(size_t)r].first);
             if (parts[(size_t)r].second < 16 || hr[0] != (int64_t)ids[(size_t)r].size()) { ctx->err = "dp shard: ranks disagree about the interval table"; return MAUVE_ERR_STATE; }
             total_cells += hr[1];
+            {   // the announced lengths must account for the whole part: a short one would be copied past its end below
+                const size_t nr = ids[(size_t)r].size();
+                if (parts[(size_t)r].second < (2 + 3 * nr) * 8) { ctx->err = "dp shard: a rank's part is shorter than its header"; return MAUVE_ERR_STATE; }
+                int64_t sum = 0; bool neg = false;
+                for (size_t q = 0; q < nr; q++) { neg |= hr[2 + q] < 0; sum += hr[2 + q]; }
+                if (neg || parts[(size_t)r].second != (2 + 3 * nr) * 8 + (size_t)sum * 4) { ctx->err = "dp shard: a rank's part does not hold the columns it announces"; return MAUVE_ERR_STATE; }
+            }
             for (size_t q = 0; q < ids[(size_t)r].size(); q++) { len_of[(size_t)ids[(size_t)r][q]] = hr[2 + q]; if (score) score[ids[(size_t)r][q]] = hr[2 + ids[(size_t)r].size() + q]; if (sp) sp[ids[(size_t)r][q]] = hr[2 + 2 * ids[(size_t)r].size() + q]; }
         }
         col_off[0] = 0;

@@ -257,7 +257,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
     R.mum_length.clear(); R.mum_start.clear(); R.lcb_left.clear(); R.lcb_right.clear(); R.lcb_weight.clear();
     R.anchor_length.clear(); R.anchor_start.clear(); R.anchor_lcb.clear(); R.iv_left.clear(); R.iv_right.clear();
     R.iv_reverse.clear(); R.col_off.clear(); R.n_cols = 0; R.dp_score.clear();
-    R.dev_pending = false; R.cols_pending = false; R.stale = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr;
+    R.dev_pending = false; R.cols_pending = false; R.stale = false; R.genomes_replaced = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr;
     memset(&c->stage, 0, sizeof c->stage);
 
     int64_t sum = 0; for (int g = 0; g < N; g++) sum += c->lens[g];
@@ -727,13 +727,14 @@ static int align_begin_lcbs(mauve_ctx *c, const mauve_params *p, std::vector<Mat
     const int N = c->nseq;
     AlignState &S = c->ast;
     S.reset();
+    c->rec_flags.clear();                 // flags of an earlier call that ended before its recursion must not be taken for this one's
     S.p = *p; S.N = N; S.t0 = now_ms();
     AlignResult &R = c->res;
     R.sz = mauve_align_sizes();
     R.mum_length.clear(); R.mum_start.clear(); R.lcb_left.clear(); R.lcb_right.clear(); R.lcb_weight.clear();
     R.anchor_length.clear(); R.anchor_start.clear(); R.anchor_lcb.clear(); R.iv_left.clear(); R.iv_right.clear();
     R.iv_reverse.clear(); R.col_off.clear(); R.n_cols = 0; R.dp_score.clear();
-    R.dev_pending = false; R.cols_pending = false; R.stale = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr;
+    R.dev_pending = false; R.cols_pending = false; R.stale = false; R.genomes_replaced = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr;
     memset(&c->stage, 0, sizeof c->stage);
     c->shadow = nullptr;
     int64_t sum = 0; for (int g = 0; g < N; g++) sum += c->lens[g];
@@ -1070,7 +1071,7 @@ int mauve_align_fetch(mauve_ctx *c, int64_t *mum_length, int64_t *mum_start, int
 int mauve_write_xmfa(mauve_ctx *c, const char *const *names, char *buf, int64_t *len)
 {
     if (!c || !len) return MAUVE_ERR_ARG;
-    if (c->res.stale) { c->err = "write_xmfa: the genomes were replaced after this alignment was made"; return MAUVE_ERR_STATE; }
+    if (c->res.stale || c->res.genomes_replaced) { c->err = "write_xmfa: the genomes were replaced after this alignment was made"; return MAUVE_ERR_STATE; }
     { int rcm = materialize_result(c); if (rcm) return rcm; }
     { int rcm = host_genomes(c); if (rcm) return rcm; }
     const AlignResult &R = c->res;

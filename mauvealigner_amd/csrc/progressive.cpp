@@ -193,19 +193,20 @@ int prog_node(Prog &P, int node)
         if (rc == MAUVE_OK) chained = true;
         else if (rc != MAUVE_ERR_LIMIT) return rc;
     }
-    if (!chained) host_eliminate_overlaps(m, &orders);
-    if (chained) {}
-    else if (p->lcb_scoring == MAUVE_LCB_SCORE_SP) {
-        std::vector<int64_t> mw;
-        rc = match_sp_scores(c, m, gm.data(), &p->scoring, mw);
-        if (rc) return rc;
-        // a given score threshold is for all N genomes: scaled by the node's share of the pairs
-        int64_t minw = p->lcb_weight >= 0 ? p->lcb_weight * ((int64_t)n * (n - 1) / 2) / ((int64_t)P.N * (P.N - 1) / 2)
-                                          : sp_default_min_weight(w, n, &p->scoring);
-        if (scaled) minw = std::max(minw * factor_ppm / 1000000, p->min_scaled_penalty);
-        host_lcb_chain(m, minw, p->collinear != 0, match_lcb, nl, &orders, mw.data());
-    } else
-    host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl, &orders);
+    if (!chained) {
+        host_eliminate_overlaps(m, &orders);
+        if (p->lcb_scoring == MAUVE_LCB_SCORE_SP) {
+            std::vector<int64_t> mw;
+            rc = match_sp_scores(c, m, gm.data(), &p->scoring, mw);
+            if (rc) return rc;
+            // a given score threshold is for all N genomes: scaled by the node's share of the pairs
+            int64_t minw = p->lcb_weight >= 0 ? p->lcb_weight * ((int64_t)n * (n - 1) / 2) / ((int64_t)P.N * (P.N - 1) / 2)
+                                              : sp_default_min_weight(w, n, &p->scoring);
+            if (scaled) minw = std::max(minw * factor_ppm / 1000000, p->min_scaled_penalty);
+            host_lcb_chain(m, minw, p->collinear != 0, match_lcb, nl, &orders, mw.data());
+        } else
+            host_lcb_chain(m, lcbw, p->collinear != 0, match_lcb, nl, &orders);
+    }
     if (trace) {
         int64_t surv = 0; for (size_t i = 0; i < m.size(); i++) if (match_lcb[i] >= 0) surv++;
         fprintf(stderr, "[trace] node %d (n=%d, w=%d): %lld n-way matches, %zu after overlap elimination, %lld lcbs, %lld anchors\n", node, n, w,
@@ -518,6 +519,7 @@ static int progressive_core(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     if (p->lcb_scoring != MAUVE_LCB_SCORE_LENGTH && p->lcb_scoring != MAUVE_LCB_SCORE_SP) { c->err = "progressive_align: unknown lcb_scoring"; return MAUVE_ERR_ARG; }
     if (p->seed_family && p->seed_pattern) { c->err = "progressive_align: seed_family takes its patterns from the weight, not from seed_pattern"; return MAUVE_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
+    c->rec_flags.clear();                 // (an earlier call that ended before its recursion may have left its flags behind)
     const double t0 = now_ms();
     const int N = c->nseq;
     int64_t sum = 0; for (int g = 0; g < N; g++) sum += c->lens[g];
@@ -556,7 +558,7 @@ static int progressive_core(mauve_ctx *c, const mauve_params *p, mauve_align_siz
     R.mum_length.clear(); R.mum_start.clear(); R.lcb_left.clear(); R.lcb_right.clear(); R.lcb_weight.clear();
     R.anchor_length.clear(); R.anchor_start.clear(); R.anchor_lcb.clear(); R.iv_left.clear(); R.iv_right.clear();
     R.iv_reverse.clear(); R.col_off.clear(); R.cols.clear(); R.dp_score.clear();
-    R.dev_pending = false; R.cols_pending = false; R.stale = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr; R.cols_fill = 0; R.cols_dirty.clear();
+    R.dev_pending = false; R.cols_pending = false; R.stale = false; R.genomes_replaced = false; R.dev_na = 0; R.dev_nm = 0; R.cols_ext = nullptr; R.cols_fill = 0; R.cols_dirty.clear();
     R.cols_fill = 0; R.cols_dirty.clear();           // mauve_align's prefilled-buffer invariant no longer holds
     P.R = &R;
     P.rest.assign((size_t)N, FreePool());

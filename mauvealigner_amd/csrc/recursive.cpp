@@ -204,16 +204,27 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                     next.push(lcb, w, q == 0 ? work.a(wi) : gl.rec(q - 1), q == gl.size() ? work.b(wi) : gl.rec(q));
                 for (size_t q = 0; q < gl.size(); q++) found[(size_t)lcb].push(gl.rec(q));
             };
-            auto exchange = [&]() -> int {
-                if (!sharded) return MAUVE_OK;
+            // rc_local: what this rank's share of the batch came to.  A rank that failed still takes part in the exchange -- its message is the
+            // marker [-1, status] -- so that the others do not wait in the collective for ever; every rank then returns an error.
+            auto exchange = [&](int rc_local) -> int {
+                if (!sharded) return rc_local;
                 std::vector<std::pair<const char *, size_t>> parts;
+                const std::string err_local = c->err;
+                if (rc_local) { shard_msg.assign(2, 0); shard_msg[0] = -1; shard_msg[1] = rc_local; }
                 int rcx = shard_allgather(c, shard_msg.data(), shard_msg.size() * 8, parts);
                 if (rcx) return rcx;
+                if (rc_local) { c->err = err_local; return rc_local; }
                 // every rank's gaps, applied in the order of the whole batch
                 std::vector<std::pair<uint32_t, const int64_t *>> got;
-                for (const auto &pt : parts) {
+                for (size_t r = 0; r < parts.size(); r++) {
+                    const auto &pt = parts[r];
                     const int64_t *v = reinterpret_cast<const int64_t *>(pt.first), *e = v + pt.second / 8;
-                    while (v < e) { got.push_back({(uint32_t)v[0], v}); v += 2 + v[1] * (1 + N); }
+                    if (pt.second % 8) { c->err = "recursion shard: a rank's part is not a whole number of words"; return MAUVE_ERR_STATE; }
+                    if (e - v >= 2 && v[0] == -1) { c->err = "recursion shard: rank " + std::to_string(r) + " failed (status " + std::to_string(v[1]) + ")"; return MAUVE_ERR_STATE; }
+                    while (v < e) {
+                        if (e - v < 2 || v[0] < 0 || v[1] < 0 || v[1] > (e - v - 2) / (1 + N)) { c->err = "recursion shard: a rank's part ends inside a record"; return MAUVE_ERR_STATE; }
+                        got.push_back({(uint32_t)v[0], v}); v += 2 + v[1] * (1 + N);
+                    }
                 }
                 std::sort(got.begin(), got.end(), [](const std::pair<uint32_t, const int64_t *> &x, const std::pair<uint32_t, const int64_t *> &y) { return x.first < y.first; });
                 MatchVec gl(N);
@@ -224,7 +235,10 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                 }
                 return MAUVE_OK;
             };
-            if (K == 0) { int rcx = exchange(); if (rcx) return rcx; continue; }      // (a rank without a gap of this class still takes part)
+            double tch0 = 0, t_elim = 0, t_lcb = 0;
+            bool dev_chain = false, compact = false;
+            auto body = [&]() -> int {                        // this rank's share of the batch; what it yields is applied (or put into shard_msg) by emit_gap
+            if (K == 0) return MAUVE_OK;                      // (a rank without a gap of this class still takes part in the exchange)
             // ---- virtual genomes: per genome, the gap sub-sequences in LCB orientation, concatenated ----
             GenomeSet vs; vs.buf = &c->rec_genomes; vs.nseq = N; vs.lens.assign(N, 0); vs.word_off.assign(N, 0);
             std::vector<uint32_t> seg((size_t)N * (K + 1));
@@ -292,8 +306,7 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
             if (trace) fprintf(stderr, "[trace] recursion level %d weight %d: %u gaps, %lld bases, %lld matches, %.3f ms\n", level, w, K,
                                (long long)vs.lens[0], (long long)nm, now_ms() - tc0);
             // ---- per-gap chaining of the N-way forward matches ----
-            const double tch0 = now_ms();
-            double t_elim = 0, t_lcb = 0;
+            tch0 = now_ms();
             const uint32_t *seg0 = seg.data();
             int64_t i = 0;
             MatchVec loc(N), glob(N);            // reused from gap to gap (thousands of gaps per batch)
@@ -304,7 +317,6 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
             // gap sub-graph beyond the device kernels' limits (MAUVE_ERR_LIMIT) are chained here, gap by gap.  (A list with ties in
             // its canonical order is repaired by the seed pass before dev_rec_n is set, so it takes the device route like any
             // other.)  MAUVE_HOST_GAP_CHAIN: A/B switch.
-            bool dev_chain = false, compact = false;
             const int32_t *dl = nullptr, *ds = nullptr; const uint32_t *dg = nullptr; uint32_t ns = 0; std::vector<uint8_t> survive;
             if (!host_gaps && nm > 0 && c->dev_rec_n == nm) {
                 int64_t maxlen = 1; for (int g = 0; g < N; g++) maxlen = std::max(maxlen, vs.lens[(size_t)g]);
@@ -403,7 +415,9 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
                 }
                 emit_gap(k);
             }
-            { int rcx = exchange(); if (rcx) return rcx; }
+            return MAUVE_OK;
+            };
+            { const int rc_body = body(); const int rcx = exchange(rc_body); if (rcx) return rcx; }
             if (trace) fprintf(stderr, "[trace]   per-gap chaining %.3f ms (%s; eliminate %.3f, lcb %.3f)\n", now_ms() - tch0, compact ? "device, survivors only" : (dev_chain ? "device" : "host"), t_elim, t_lcb);
         }
         work.d.swap(next.d);

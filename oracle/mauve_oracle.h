@@ -102,6 +102,7 @@ int orc_seed_weight(uint64_t pattern);
 int orc_default_seed_weight(int64_t avg_len);
 void orc_default_scoring(orc_scoring *s);
 void orc_default_params(orc_params *p);
+void orc_default_progressive_params(orc_params *p);
 
 /* ---- sequence encoding ------------------------------------------------------------------------ */
 void orc_encode(const char *ascii, int64_t n, uint8_t *codes);       /* A,C,G,T -> 0..3, other -> 0 */

@@ -129,6 +129,14 @@ def default_params(**kw):
     return p
 
 
+def default_progressive_params(**kw):
+    p = Params()
+    lib().orc_default_progressive_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
 def encode(ascii_bytes):
     a = np.frombuffer(ascii_bytes if isinstance(ascii_bytes, (bytes, bytearray)) else ascii_bytes.encode(), dtype=np.uint8)
     out = np.empty(len(a), dtype=np.uint8)

@@ -29,10 +29,14 @@ def test_struct_layouts_match_oracle_side():
     # the ctypes mirrors of mauve_params / orc_params must stay field-for-field compatible
     assert [f[0] for f in _lib.Params._fields_] == [f[0] for f in O.Params._fields_]
     assert C.sizeof(_lib.Params) == C.sizeof(O.Params)
+    for p, q in ((_lib.default_params(), O.default_params()), (_lib.default_progressive_params(), O.default_progressive_params())):
+        for name, _ in _lib.Params._fields_:
+            if name != "scoring":
+                assert getattr(p, name) == getattr(q, name), name
+    # the progressiveMauve call site's option set (progressiveMauve.cpp:578-579,624-637)
+    p = _lib.default_progressive_params()
+    assert (p.lcb_scoring, p.weight_scaling, p.conservation_scale_ppm, p.bp_dist_scale_ppm, p.refine_rounds) == (1, 1, 500000, 500000, 2)
     p, q = _lib.default_params(), O.default_params()
-    for name, _ in _lib.Params._fields_:
-        if name != "scoring":
-            assert getattr(p, name) == getattr(q, name), name
     assert [list(r) for r in p.scoring.matrix] == [list(r) for r in q.scoring.matrix]
     assert (p.scoring.gap_open, p.scoring.gap_extend) == (-400, -30)
 
@@ -52,6 +56,10 @@ def test_hmm_params_conversion_matches_oracle():
     L.mauve_hmm_params_from(0.7, 1e-5, 1e-9, C.byref(h))
     assert (h.match, h.mismatch, h.gap, h.go_homologous, h.go_unrelated) == (1030, -916, -500, -11513, -20723)
     assert C.sizeof(_lib.HmmParams) == C.sizeof(O.HmmParams) == 20
+    # knobs outside their domain have no logarithm to round: the sentinel (positive transition scores) is what mauve_apply_homology* refuse
+    for ident, pgh, pgu in ((1.0, 1e-5, 1e-9), (0.25, 1e-5, 1e-9), (0.7, 0.0, 1e-9), (0.7, 1e-5, -1.0), (float("nan"), 1e-5, 1e-9), (0.7, 2.0, 1e-9)):
+        L.mauve_hmm_params_from(ident, pgh, pgu, C.byref(h))
+        assert h.go_homologous > 0 and h.go_unrelated > 0, (ident, pgh, pgu)
 
 
 def test_seed_helpers_and_packing():

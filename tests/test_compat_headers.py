@@ -372,9 +372,8 @@ def test_example_matches_c_abi(flag):
         try:
             ctx.set_genomes(gs)
             if flag == "-p":
-                # ProgressiveAligner's own defaults: weight scaling on, both scales 0.5, refinement on
-                r = ctx.progressive_align(_lib.default_params(weight_scaling=1, conservation_scale_ppm=500000, bp_dist_scale_ppm=500000, refine_rounds=2),
-                                          names=paths, want_xmfa=True)
+                # the progressiveMauve call site's defaults: SP scoring, weight scaling on, both scales 0.5, refinement on
+                r = ctx.progressive_align(_lib.default_progressive_params(), names=paths, want_xmfa=True)
             else:
                 r = ctx.align(_lib.default_params(extend_lcbs=1), names=paths, want_xmfa=True)    # the call site passes lcb_extension = true
             if flag == "-p":        # applyBackbone in the example: homology pass (it rewrites the intervals that are written afterwards), then the

@@ -1140,11 +1140,12 @@ def test_sharded_contexts(ctx, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
     outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(2)]
+    logs = [str(tmp_path / ("rank%d.log" % r)) for r in range(2)]          # files, not pipes: a child that fills its pipe while the other is drained would block
     procs = [subprocess.Popen([sys.executable, "-m", "tests.shard_worker", str(r), "2", port, outs[r]], cwd=root,
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
-    for p in procs:
-        so, se = p.communicate(timeout=600)
-        assert p.returncode == 0, se[-3000:]
+                              stdout=open(logs[r], "w"), stderr=subprocess.STDOUT) for r in range(2)]
+    for r, p in enumerate(procs):
+        p.wait(timeout=600)
+        assert p.returncode == 0, open(logs[r]).read()[-3000:]
     gs = synth.make_config("C5", scale=0.04)
     ctx.set_genomes(gs)
     one = ctx.align(_lib.default_params())

@@ -180,3 +180,35 @@ def test_backbone_of_the_resident_alignment(ctx):
     c2.close()
     with pytest.raises(RuntimeError):
         ctx.backbone(island_gap=-1)
+
+
+def test_inconsistent_columns_are_refused(ctx):
+    """A caller's alignment whose columns do not hold the residues its ends announce (the homology pass would turn the surplus into
+    base addresses outside the interval -- below 0 on the reverse strand) is refused with MAUVE_ERR_ARG by both _alignment entry
+    points, before any kernel reads a genome through it; the consistent array goes through and equals the oracle's."""
+    gs = synth.star_genomes(3, 20_000, 0.05, 5)
+    ctx.set_genomes(gs)
+    e = O.align(gs, O.default_params())["aln"]
+    left, right, rev, off, cols = e["left"], e["right"], e["reverse"], e["col_off"], e["cols"]
+    noff, ncols, moved = ctx.apply_homology_alignment(left, right, rev, off, cols)
+    eoff, ecols, emoved = O.homology_apply(gs, left, right, rev, off, cols)
+    assert moved == emoved and np.array_equal(noff, eoff) and np.array_equal(ncols, ecols)
+    multi = int(np.argmax(np.count_nonzero(left, axis=1) >= 2))
+    # (1) one more residue of genome 0 than its ends allow; (2) a residue of a genome the interval does not have; (3) a bit above nseq;
+    # (4) a reverse-strand interval that starts at base 1 with surplus residues: the unguarded address would be negative
+    bad = []
+    c1 = cols.copy(); k = off[multi] + int(np.argmax((c1[off[multi]:off[multi + 1]] & 1) == 0)); c1[k] |= 1; bad.append((left, right, rev, c1))
+    single = int(np.argmax(np.count_nonzero(left, axis=1) == 1))
+    other = int(np.argmax(left[single] == 0))
+    c2 = cols.copy(); c2[off[single]] |= np.uint32(1 << other); bad.append((left, right, rev, c2))
+    c3 = cols.copy(); c3[off[multi]] |= np.uint32(1 << 7); bad.append((left, right, rev, c3))
+    l4, r4, v4 = left.copy(), right.copy(), rev.copy()
+    n0 = int(right[multi, 0] - left[multi, 0] + 1)
+    l4[multi, 0], r4[multi, 0], v4[multi, 0] = 1, n0 - 5, 1
+    bad.append((l4, r4, v4, cols))
+    for l, r, v, c in bad:
+        with pytest.raises(RuntimeError, match=r"\(-1\)"):
+            ctx.apply_homology_alignment(l, r, v, off, c)
+        with pytest.raises(RuntimeError, match=r"\(-1\)"):
+            ctx.backbone_alignment(l, r, v, off, c)
+    _same(ctx.backbone_alignment(left, right, rev, off, cols), O.backbone(left, right, rev, off, cols, island_gap=20))

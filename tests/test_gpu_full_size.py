@@ -74,12 +74,16 @@ def test_c3_full_size_equals_oracle(ctx):
 
 
 def test_c4_full_size_progressive_equals_oracle(ctx):
-    """BASELINE config 4: 8 x 2 Mbp on a balanced tree, progressive path (guide tree + guide-tree anchoring)."""
+    """BASELINE config 4: 8 x 2 Mbp on a balanced tree, progressive path (guide tree + guide-tree anchoring), at the progressiveMauve
+    call site's defaults (progressiveMauve.cpp:578-579,624-637: extant sum-of-pairs LCB scoring, weight scaling on with both scales
+    0.5, refinement on) -- mauve_default_progressive_params."""
     from mauvealigner_amd import _lib
     gs = synth.make_config("C4", scale=1.0)
     ctx.set_genomes(gs)
-    r = ctx.progressive_align(_lib.default_params())
-    e = O.progressive_align(gs, O.default_params())
+    p = _lib.default_progressive_params()
+    assert (p.lcb_scoring, p.weight_scaling, p.conservation_scale_ppm, p.bp_dist_scale_ppm, p.refine_rounds) == (1, 1, 500000, 500000, 2)
+    r = ctx.progressive_align(p)
+    e = O.progressive_align(gs, O.default_progressive_params())
     assert np.array_equal(r["dist"], e["dist"])
     assert np.array_equal(r["tree"][0], e["tree"][0]) and np.array_equal(r["tree"][1], e["tree"][1])
     a = e["aln"]

@@ -1,14 +1,15 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel trace + stats of bench.py's default workload (C3), and the PMC
 # passes (FETCH_SIZE, WRITE_SIZE, LDS counters in separate runs, as MI355X_MICROARCH.md prescribes).
-# Outputs under gpurun_out/prof_$TAG/.  usage: tools/profile_gpu.sh <tag> [pmc]
+# Outputs under gpurun_out/prof_$TAG/.  usage: tools/profile_gpu.sh <tag> [pmc|nopmc] [C2|C3|C4|C5]   (default config: C3)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r02}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
+CFG=${3:-C3}
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --config $CFG"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace_bench.json 2> $OUT/trace.err
 echo "trace done" >> $OUT/progress.log
 if [ "${2:-}" = "pmc" ]; then
