@@ -87,6 +87,15 @@ void shard_lpt(const std::vector<int64_t> &cost, int world, std::vector<int> &ow
 
 extern "C" {
 
+// The second stream carries the one-wave launch of the DP (dp_step2: thousands of small workgroups) while the workgroup launches -- the tail of
+// the stage -- run on the main stream (dp_launch_steps): lowest priority, so that where the dispatcher has a choice the large workgroups go first.
+static hipError_t create_priority_stream(hipStream_t *out)
+{
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); return hipStreamCreateWithFlags(out, hipStreamNonBlocking); }
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, least);
+}
+
 int mauve_ctx_create(int device, mauve_ctx **out)
 {
     if (!out) return MAUVE_ERR_ARG;
@@ -107,7 +116,7 @@ int mauve_ctx_create(int device, mauve_ctx **out)
         (void)hipSetDevice(device); (void)hipSetDeviceFlags(f); (void)hipGetLastError();
     }
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess ||
+        (e = create_priority_stream(&c->stream2)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {

@@ -197,7 +197,7 @@ struct AlignState {
 struct mauve_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;           // dp_step_big runs here, beside dp_step on `stream`
+    hipStream_t stream2 = nullptr;           // the one-wave DP launch runs here when there are workgroup launches (those go first, on `stream`)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     char devname[256] = {0};

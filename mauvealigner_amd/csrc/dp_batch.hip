@@ -935,17 +935,6 @@ __device__ void dp2_interval(int nseq, int64_t iv, const uint8_t *__restrict__ c
     if (lane == 0) meta[iv] = mt;
 }
 
-__global__ void __launch_bounds__(64 * DP_MW_WAVES) dp_step_big(int nseq, const int64_t *__restrict__ list, const uint8_t *__restrict__ codes,
-                                               const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
-                                               uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
-                                               uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
-                                               uint8_t *__restrict__ tb, const int64_t *__restrict__ tb_off,
-                                               int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
-                                               uint8_t *__restrict__ ops, DpScoring sc, int64_t band_from)
-{
-    dp_interval_mw(nseq, list[blockIdx.x], codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, sc, band_from);
-}
-
 struct DpClasses { int64_t first_med, n_med, first_c, n_c, first_s32, n_s32, first_s16, n_s16; uint32_t blocks_med, blocks_c, blocks_s32; int32_t scan; };   // list = [big | one wave | G = 16 | s32 (G = 8) | s16 (G = 4)]
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) dp_step(int nseq, const int64_t *__restrict__ list, DpClasses cl, const uint8_t *__restrict__ codes,
@@ -1144,7 +1133,16 @@ __host__ __device__ __forceinline__ int64_t dp3_tb_need(int64_t m, int64_t n)
     return a > b ? a : b;
 }
 // parked boundary entries: A keeps the last row of a band for every column, B (more than one band of columns) the last column for every row
-__host__ __device__ __forceinline__ int64_t dp3_rows_need(int64_t m, int64_t n) { return 6 * ((n > DP3_BAND && m > n ? m : n) + 1); }
+// (the wide sweeps below choose their orientation by super-bands, so either dimension may be the parked one)
+__host__ __device__ __forceinline__ int64_t dp3_rows_need(int64_t m, int64_t n) { return 6 * ((m > n ? m : n) + 1); }
+
+// column / row steps of one progressive step on ONE wave (lines x bands in the cheaper orientation): what the launch list weighs an
+// interval by when it picks the ones that get a whole workgroup (the wide sweep)
+__host__ __device__ __forceinline__ int64_t dp3_scan_steps(int64_t m, int64_t n)
+{
+    const int64_t a = (n + 1) * ((m + DP3_BAND - 1) / DP3_BAND), b = m * ((n + DP3_BAND - 1) / DP3_BAND);
+    return a < b ? a : b;
+}
 
 template <int R>
 struct Dp3A {
@@ -1547,6 +1545,489 @@ __device__ void dp3_interval(int nseq, int64_t iv, const uint8_t *__restrict__ c
     if (lane == 0) meta[iv] = mt;
 }
 
+
+// ================================================================================================================
+// Wide sweep: ONE interval over the 16 waves of a workgroup, all of them on the same column (A) / row (B) at the same time.
+// A single wave takes bands(m) x (n + 1) dependent column steps for a step of the progressive alignment (dp3_sweep_a: the bands
+// one after the other); the largest interval of a launch -- 1 600 x 1 600 at C5, a 6.7 kb insertion in five of eight genomes at
+// C4 -- then IS the launch (C5: 4.2 of 5.8 ms for one interval of 302 000).  The scan formulation has no such chain across the
+// bands: M and the element-wise gap state of column j read column j - 1 only, and the scanned state is a max-plus prefix over
+// ALL rows, whichever wave holds them.  So a super-band of 16 x 256 rows advances one column per step: every wave computes its
+// element-wise cells and publishes its last row (barrier), every wave scans its rows with E the prefix sums over the whole
+// super-band and publishes its aggregate max(a - E) (barrier), every wave folds the aggregates of the waves above into its
+// carry -- which also is, plus a constant, the scanned value of the row above its first one, so nothing else has to cross --
+// and finishes its cells.  Two barriers per column, no dependent chain across waves.  The arithmetic is dp3's (same clamp, same
+// tie rules; E stays far from the clamp for every interval dp3_admissible lets in), the traceback layout is dp3's with R = 4
+// (wave w of super-band q is band 16 q + w), so dp3_walk reads it; steps small in both dimensions run the one-wave sweep.
+// ================================================================================================================
+constexpr int DPW_MAXW = 16;                      // waves of a workgroup (two shapes are built: 8 waves x 4 rows per lane, 16 x 2; both super-bands hold 2048 rows)
+constexpr int DPW_SB = 2048;
+struct DpwShared {
+    int32_t botM[DPW_MAXW], botE[DPW_MAXW];      // last cell of every wave in the current line: M and the element-wise gap state (A: Y, B: X)
+    int32_t agg[DPW_MAXW];                        // max over the wave's cells of (local scan value - E)
+    int32_t esum[DPW_MAXW];                       // A: sum of the gap-extension terms of the wave's rows
+    int32_t fin[3];
+    int32_t len;
+};
+__host__ __device__ __forceinline__ bool dpw_orient_b(int64_t m, int64_t n)      // cost: lines x super-bands; ties: the longer dimension on the lanes
+{
+    const int64_t a = (n + 1) * ((m + DPW_SB - 1) / DPW_SB), b = m * ((n + DPW_SB - 1) / DPW_SB);
+    return b < a || (b == a && n > m);
+}
+// maximum over the waves above `wv` of their aggregates (wave-uniform result); DP_NEG_INF when there is none
+__device__ __forceinline__ int32_t dpw_carry(const int32_t *agg, int wv, int lane)
+{
+    int32_t v = (lane & 15) < wv ? agg[lane & 15] : DP_NEG_INF;
+    v = max(v, dpp_keep<0x111, 0xf>(v)); v = max(v, dpp_keep<0x112, 0xf>(v));
+    v = max(v, dpp_keep<0x114, 0xf>(v)); v = max(v, dpp_keep<0x118, 0xf>(v));      // lane 15: maximum of lanes 0 .. 15
+    return __builtin_amdgcn_readlane(v, 15);
+}
+
+// orientation A: rows on the lanes of all waves, column by column.  Dp3A::step cut at its two exchange points.
+template <int R>
+struct DpwA {
+    int32_t M[R], X[R], Y[R];
+    int32_t s0[R], s1[R], s2[R], s3[R], gxo[R], gxe[R], E;
+    int32_t Mn[R], Yn[R], Mu0, Yu0, pv; uint32_t tb;
+    __device__ __forceinline__ int32_t constants(const uint32_t *Pc, int32_t i0, int32_t m, const DpScoring &sc)     // -> the lane's sum of gxe
+    {
+        int32_t bsum = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t cn = i0 + r < m ? Pc[i0 + r] : 0u;
+            const int32_t c0 = cn & 255, c1 = (cn >> 8) & 255, c2 = (cn >> 16) & 255, c3 = cn >> 24;
+            const int32_t rr = c0 + c1 + c2 + c3;
+            s0[r] = c0 * sc.s[0][0] + c1 * sc.s[1][0] + c2 * sc.s[2][0] + c3 * sc.s[3][0];
+            s1[r] = c0 * sc.s[0][1] + c1 * sc.s[1][1] + c2 * sc.s[2][1] + c3 * sc.s[3][1];
+            s2[r] = c0 * sc.s[0][2] + c1 * sc.s[1][2] + c2 * sc.s[2][2] + c3 * sc.s[3][2];
+            s3[r] = c0 * sc.s[0][3] + c1 * sc.s[1][3] + c2 * sc.s[2][3] + c3 * sc.s[3][3];
+            gxo[r] = sc.go * rr; gxe[r] = sc.ge * rr; bsum += gxe[r];
+            M[r] = X[r] = Y[r] = DP_NEG_INF;
+        }
+        return bsum;
+    }
+    // M and Y of column j from column j - 1.  t?o: the row above the wave's first one at column j - 1
+    __device__ __forceinline__ void phase1(uint32_t b, bool j1, int32_t gyo, int32_t gye, int32_t tMo, int32_t tXo, int32_t tYo)
+    {
+        int32_t Md = lane0_set(wave_shr1z(M[R - 1]), tMo), Xd = lane0_set(wave_shr1z(X[R - 1]), tXo), Yd = lane0_set(wave_shr1z(Y[R - 1]), tYo);
+        const bool lo = (b & 1u) != 0, hi = (b & 2u) != 0;
+        tb = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int32_t bd = max(max(Md, Xd), Yd);
+            const uint32_t pm = Md == bd ? 0u : (Xd == bd ? 1u : 2u);
+            const int32_t sa = lo ? s1[r] : s0[r], sb = lo ? s3[r] : s2[r];
+            const int32_t mv = max(bd + (hi ? sb : sa), DP_NEG_INF);
+            const int32_t ya = M[r] + gyo, yb = X[r] + gyo, yc = Y[r] + gye;
+            const int32_t by = max(max(ya, yb), yc);
+            const uint32_t py = ya == by ? 0u : (yb == by ? 16u : 32u);
+            Mn[r] = j1 ? mv : DP_NEG_INF; Yn[r] = j1 ? max(by, DP_NEG_INF) : DP_NEG_INF;
+            tb |= (pm | py) << (8 * r);
+            Md = M[r]; Xd = X[r]; Yd = Y[r];
+        }
+    }
+    // the wave's own part of the scan.  tMn / tYn: the row above the wave's first one at column j
+    __device__ __forceinline__ void phase2(int32_t tMn, int32_t tYn)
+    {
+        Mu0 = lane0_set(wave_shr1z(Mn[R - 1]), tMn); Yu0 = lane0_set(wave_shr1z(Yn[R - 1]), tYn);
+        int32_t a = DP_NEG_INF, Mu = Mu0, Yu = Yu0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int32_t t = max(Mu, Yu) + gxo[r];
+            a = r == 0 ? max(t, DP_NEG_INF) : max(max(t, a + gxe[r]), DP_NEG_INF);
+            Mu = Mn[r]; Yu = Yn[r];
+        }
+        pv = wave_prefix_max(a - E);
+    }
+    // X of column j.  carry: max(X of the row above the super-band, aggregates of the waves above); tXn: X of the row above the wave's first one
+    __device__ __forceinline__ uint32_t phase3(int32_t carry, int32_t tXn)
+    {
+        const int32_t xout = max(E + pv, carry + E);
+        int32_t Xu = lane0_set(wave_shr1z(xout), tXn);
+        int32_t Mu = Mu0, Yu = Yu0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int32_t xa = Mu + gxo[r], xb = Xu + gxe[r], xc = Yu + gxo[r];
+            const int32_t bx = max(max(xa, xb), xc);
+            const uint32_t px = xa == bx ? 0u : (xb == bx ? 4u : 8u);
+            tb |= px << (8 * r);
+            Xu = max(bx, DP_NEG_INF);
+            X[r] = Xu; Mu = Mn[r]; Yu = Yn[r]; M[r] = Mn[r]; Y[r] = Yn[r];
+        }
+        return tb;
+    }
+};
+
+// orientation B: columns on the lanes of all waves, row by row (Dp3B::step cut the same way; Y is the scanned state)
+template <int R>
+struct DpwB {
+    int32_t M[R], X[R], Y[R];
+    uint32_t bases; int32_t E;
+    int32_t Mn[R], Xn[R], Ml0, Xl0, pv; uint32_t tb;
+    __device__ __forceinline__ void phase1(int32_t s0, int32_t s1, int32_t s2, int32_t s3, int32_t gxo, int32_t gxe, int32_t lMo, int32_t lXo, int32_t lYo)
+    {
+        int32_t Md = lane0_set(wave_shr1z(M[R - 1]), lMo), Xd = lane0_set(wave_shr1z(X[R - 1]), lXo), Yd = lane0_set(wave_shr1z(Y[R - 1]), lYo);
+        tb = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int32_t bd = max(max(Md, Xd), Yd);
+            const uint32_t pm = Md == bd ? 0u : (Xd == bd ? 1u : 2u);
+            const uint32_t b = (bases >> (2 * r)) & 3u;
+            const int32_t sa = (b & 1u) ? s1 : s0, sb = (b & 1u) ? s3 : s2;
+            Mn[r] = max(bd + ((b & 2u) ? sb : sa), DP_NEG_INF);
+            const int32_t xa = M[r] + gxo, xb = X[r] + gxe, xc = Y[r] + gxo;
+            const int32_t bx = max(max(xa, xb), xc);
+            const uint32_t px = xa == bx ? 0u : (xb == bx ? 4u : 8u);
+            Xn[r] = max(bx, DP_NEG_INF);
+            tb |= (pm | px) << (8 * r);
+            Md = M[r]; Xd = X[r]; Yd = Y[r];
+        }
+    }
+    __device__ __forceinline__ void phase2(int32_t gyo, int32_t gye, int32_t lMn, int32_t lXn)
+    {
+        Ml0 = lane0_set(wave_shr1z(Mn[R - 1]), lMn); Xl0 = lane0_set(wave_shr1z(Xn[R - 1]), lXn);
+        int32_t a = DP_NEG_INF, Ml = Ml0, Xl = Xl0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int32_t t = max(Ml, Xl) + gyo;
+            a = r == 0 ? max(t, DP_NEG_INF) : max(max(t, a + gye), DP_NEG_INF);
+            Ml = Mn[r]; Xl = Xn[r];
+        }
+        pv = wave_prefix_max(a - E);
+    }
+    __device__ __forceinline__ uint32_t phase3(int32_t gyo, int32_t gye, int32_t carry, int32_t lYn)
+    {
+        const int32_t yout = max(E + pv, carry + E);
+        int32_t Yl = lane0_set(wave_shr1z(yout), lYn);
+        int32_t Ml = Ml0, Xl = Xl0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int32_t ya = Ml + gyo, yb = Xl + gyo, yc = Yl + gye;
+            const int32_t by = max(max(ya, yb), yc);
+            const uint32_t py = ya == by ? 0u : (yb == by ? 16u : 32u);
+            tb |= py << (8 * r);
+            Yl = max(by, DP_NEG_INF);
+            Y[r] = Yl; Ml = Mn[r]; Xl = Xn[r]; M[r] = Mn[r]; X[r] = Xn[r];
+        }
+        return tb;
+    }
+};
+
+// orientation A over the whole workgroup.  Every wave of the workgroup calls it (uniform barriers); (m, n) is left in S.fin.
+template <int R, int W>
+__device__ __forceinline__ void dpw_sweep_a(DpwShared &S, int lane, int wv, int32_t m, int32_t n, const uint32_t *Pc, const uint8_t *seq, const DpScoring &sc,
+                                            int32_t krows, int32_t *rowbuf, uint8_t *tbp, int32_t mpad)
+{
+    constexpr int DPW_BAND = 64 * R, DPW_WAVES = W;
+    static_assert(DPW_BAND * DPW_WAVES == DPW_SB, "a super-band is 2048 rows");
+    const int32_t nsb = (m + DPW_SB - 1) / DPW_SB;
+    const int32_t gyo = sc.go * krows, gye = sc.ge * krows;
+    for (int32_t q = 0; q < nsb; q++) {
+        const int32_t sb0 = q * DPW_SB;
+        const int32_t nw = min(DPW_WAVES, (m - sb0 + DPW_BAND - 1) / DPW_BAND);        // waves that hold rows of the profile
+        const bool act = wv < nw;
+        DpwA<R> L;
+        const int32_t i0 = sb0 + wv * DPW_BAND + lane * R;
+        const int32_t bsum = L.constants(Pc, i0, m, sc);
+        const int32_t el = wave_prefix_sum(bsum);
+        if (lane == 63) S.esum[wv] = el;
+        __syncthreads();
+        int32_t eoff = 0;
+        for (int u = 0; u < wv; u++) eoff += S.esum[u];
+        L.E = el + eoff;                                         // prefix sums of gxe over the rows of the SUPER-band
+        const int32_t *rin = rowbuf + (size_t)((q & 1) ^ 1) * 3 * (n + 1);
+        int32_t *rout = rowbuf + (size_t)(q & 1) * 3 * (n + 1);
+        const bool park = q + 1 < nsb && wv == DPW_WAVES - 1;     // (a super-band that is followed by another one is full)
+        const bool writes = act && i0 < mpad;
+        // per column from outside the super-band: the base, and the parked row of the super-band above (dp3_sweep_a's chunks; every wave
+        // keeps its own copy: the base and the X of that row are needed by all of them)
+        auto chunk = [&](int32_t k, uint32_t &sq, int32_t &cM, int32_t &cX, int32_t &cY) {
+            const int32_t col = 64 * k + lane;
+            sq = (uint32_t)seq[min(max(col - 1, 0), n - 1)];
+            if (q == 0) { cM = col == 0 ? 0 : DP_NEG_INF; cX = DP_NEG_INF; cY = col == 0 ? DP_NEG_INF : gyo + (col - 1) * gye; }
+            else { const int32_t cc = min(col, n); cM = rin[cc]; cX = rin[(n + 1) + cc]; cY = rin[2 * (n + 1) + cc]; }
+        };
+        uint32_t sq_cur, sq_nxt; int32_t cM_cur, cX_cur, cY_cur, cM_nxt, cX_nxt, cY_nxt;
+        chunk(0, sq_nxt, cM_nxt, cX_nxt, cY_nxt);
+        int32_t tMo = DP_NEG_INF, tXo = DP_NEG_INF, tYo = DP_NEG_INF;
+        uint8_t *tw = tbp + i0;                                   // one byte per row, R of them per lane: dp3's layout for R = 4 (P(x) = x)
+        for (int32_t k = 0; 64 * k <= n; k++) {
+            sq_cur = sq_nxt; cM_cur = cM_nxt; cX_cur = cX_nxt; cY_cur = cY_nxt;
+            chunk(k + 1, sq_nxt, cM_nxt, cX_nxt, cY_nxt);
+            const int32_t jend = min(64 * k + 63, n);
+            for (int32_t j = 64 * k; j <= jend; j++, tw += mpad) {
+                const int sel = j & 63;
+                const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int32_t)sq_cur, sel);
+                const int32_t sM = __builtin_amdgcn_readlane(cM_cur, sel), sX = __builtin_amdgcn_readlane(cX_cur, sel), sY = __builtin_amdgcn_readlane(cY_cur, sel);
+                if (act) {
+                    L.phase1(b, j >= 1, gyo, gye, tMo, tXo, tYo);
+                    if (lane == 63) { S.botM[wv] = L.Mn[R - 1]; S.botE[wv] = L.Yn[R - 1]; }
+                }
+                __syncthreads();
+                int32_t tMn = sM, tYn = sY;
+                if (act) {
+                    if (wv > 0) { tMn = S.botM[wv - 1]; tYn = S.botE[wv - 1]; }
+                    L.phase2(tMn, tYn);
+                    if (lane == 63) S.agg[wv] = L.pv;
+                }
+                __syncthreads();
+                if (act) {
+                    const int32_t carry = max(sX, dpw_carry(S.agg, wv, lane));
+                    const int32_t tXn = wv > 0 ? carry + eoff : sX;      // = what the last row of the wave above holds: E_last + max(its aggregate, its carry)
+                    const uint32_t tbw = L.phase3(carry, tXn);
+                    if (writes) { if (R == 4) *reinterpret_cast<uint32_t *>(tw) = tbw; else *reinterpret_cast<uint16_t *>(tw) = (uint16_t)tbw; }
+                    if (park && lane == 63) { rout[j] = L.M[R - 1]; rout[(n + 1) + j] = L.X[R - 1]; rout[2 * (n + 1) + j] = L.Y[R - 1]; }
+                    tMo = tMn; tXo = tXn; tYo = tYn;
+                }
+            }
+        }
+        if (q == nsb - 1) {
+            const int32_t rel = m - 1 - sb0;                        // the row of (m, .) inside the super-band
+            if (wv == rel / DPW_BAND && lane == (rel % DPW_BAND) / R) {
+                const int ro = rel % R;
+                int32_t a = L.M[0], b2 = L.X[0], c2 = L.Y[0];
+#pragma unroll
+                for (int r = 1; r < R; r++) if (ro == r) { a = L.M[r]; b2 = L.X[r]; c2 = L.Y[r]; }
+                S.fin[0] = a; S.fin[1] = b2; S.fin[2] = c2;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();                                          // parked row, esum and fin before anybody goes on
+    }
+}
+
+// orientation B over the whole workgroup
+template <int R, int W>
+__device__ __forceinline__ void dpw_sweep_b(DpwShared &S, int lane, int wv, int32_t m, int32_t n, const uint32_t *Pc, const uint8_t *seq, const DpScoring &sc,
+                                            int32_t krows, int32_t *rowbuf, uint8_t *tbp, int32_t npad)
+{
+    constexpr int DPW_BAND = 64 * R, DPW_WAVES = W;
+    static_assert(DPW_BAND * DPW_WAVES == DPW_SB, "a super-band is 2048 rows");
+    const int32_t nsb = (n + DPW_SB - 1) / DPW_SB;
+    const int32_t gyo = sc.go * krows, gye = sc.ge * krows;
+    for (int32_t q = 0; q < nsb; q++) {
+        const int32_t sb0 = q * DPW_SB;
+        const int32_t nw = min(DPW_WAVES, (n - sb0 + DPW_BAND - 1) / DPW_BAND);
+        const bool act = wv < nw;
+        DpwB<R> L;
+        const int32_t j0 = sb0 + wv * DPW_BAND + lane * R;          // 0-based first column index (j - 1) of the lane
+        L.bases = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            L.bases |= (uint32_t)(j0 + r < n ? seq[j0 + r] : 0) << (2 * r);
+            L.M[r] = DP_NEG_INF; L.X[r] = DP_NEG_INF; L.Y[r] = gyo + (j0 + r) * gye;     // row 0: only Y exists (analytic, not clamped)
+        }
+        const int32_t eoff = wv * DPW_BAND * gye;
+        L.E = (lane + 1) * R * gye + eoff;                          // prefix sums of gye over the columns of the SUPER-band
+        const int32_t *cin = rowbuf + (size_t)((q & 1) ^ 1) * 3 * (m + 1);
+        int32_t *cout = rowbuf + (size_t)(q & 1) * 3 * (m + 1);
+        const bool park = q + 1 < nsb && wv == DPW_WAVES - 1;
+        const bool writes = act && j0 < npad;
+        auto chunk = [&](int32_t k, uint32_t &pc, int32_t &cM, int32_t &cX, int32_t &cY) {
+            const int32_t row = min(64 * k + lane + 1, m);
+            pc = Pc[row - 1];
+            if (q == 0) { cM = cX = cY = DP_NEG_INF; }
+            else { cM = cin[row]; cX = cin[(m + 1) + row]; cY = cin[2 * (m + 1) + row]; }
+        };
+        // the column left of the wave's first one at row 0: (0, 0) for the first wave of all, the analytic row 0 otherwise (what the band to the
+        // left holds there: M and X do not exist, Y is the gap from the corner); the parked column of the super-band to the left has the same
+        int32_t lMo, lXo, lYo;
+        if (wv == 0 && q == 0) { lMo = 0; lXo = DP_NEG_INF; lYo = DP_NEG_INF; }
+        else if (wv == 0) { lMo = __builtin_amdgcn_readfirstlane(cin[0]); lXo = __builtin_amdgcn_readfirstlane(cin[(m + 1)]); lYo = __builtin_amdgcn_readfirstlane(cin[2 * (m + 1)]); }
+        else { lMo = DP_NEG_INF; lXo = DP_NEG_INF; lYo = gyo + (sb0 + wv * DPW_BAND - 1) * gye; }
+        // (the super-band's own left column at row i - 1, for the chain down column 0 of the first super-band)
+        int32_t sMo = lMo, sXo = lXo, sYo = lYo;
+        if (wv != 0) { if (q == 0) { sMo = 0; sXo = DP_NEG_INF; sYo = DP_NEG_INF; } }
+        if (park && lane == 63) { cout[0] = L.M[R - 1]; cout[(m + 1)] = L.X[R - 1]; cout[2 * (m + 1)] = L.Y[R - 1]; }
+        uint32_t pc_cur, pc_nxt; int32_t cM_cur, cX_cur, cY_cur, cM_nxt, cX_nxt, cY_nxt;
+        chunk(0, pc_nxt, cM_nxt, cX_nxt, cY_nxt);
+        uint8_t *tw = tbp + j0;
+        for (int32_t k = 0; 64 * k < m; k++) {
+            pc_cur = pc_nxt; cM_cur = cM_nxt; cX_cur = cX_nxt; cY_cur = cY_nxt;
+            chunk(k + 1, pc_nxt, cM_nxt, cX_nxt, cY_nxt);
+            const int32_t iend = min(64 * k + 64, m);
+            for (int32_t i = 64 * k + 1; i <= iend; i++, tw += npad) {
+                const int sel = (i - 1) & 63;
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int32_t)pc_cur, sel);
+                const int32_t c0 = c & 255, c1 = (c >> 8) & 255, c2 = (c >> 16) & 255, c3 = c >> 24, rr = c0 + c1 + c2 + c3;
+                const int32_t s0 = c0 * sc.s[0][0] + c1 * sc.s[1][0] + c2 * sc.s[2][0] + c3 * sc.s[3][0];
+                const int32_t s1 = c0 * sc.s[0][1] + c1 * sc.s[1][1] + c2 * sc.s[2][1] + c3 * sc.s[3][1];
+                const int32_t s2 = c0 * sc.s[0][2] + c1 * sc.s[1][2] + c2 * sc.s[2][2] + c3 * sc.s[3][2];
+                const int32_t s3 = c0 * sc.s[0][3] + c1 * sc.s[1][3] + c2 * sc.s[2][3] + c3 * sc.s[3][3];
+                const int32_t gxo = sc.go * rr, gxe = sc.ge * rr;
+                // the column left of the SUPER-band at row i (wave-uniform, every wave computes it: its Y is the carry's floor)
+                int32_t sMn, sXn, sYn;
+                if (q == 0) {
+                    const int32_t xa = sMo + gxo, xb = sXo + gxe, xc = sYo + gxo, bx = max(max(xa, xb), xc);
+                    sMn = DP_NEG_INF; sYn = DP_NEG_INF; sXn = max(bx, DP_NEG_INF);
+                } else { sMn = __builtin_amdgcn_readlane(cM_cur, sel); sXn = __builtin_amdgcn_readlane(cX_cur, sel); sYn = __builtin_amdgcn_readlane(cY_cur, sel); }
+                if (act) {
+                    L.phase1(s0, s1, s2, s3, gxo, gxe, lMo, lXo, lYo);
+                    if (lane == 63) { S.botM[wv] = L.Mn[R - 1]; S.botE[wv] = L.Xn[R - 1]; }
+                }
+                __syncthreads();
+                int32_t lMn = sMn, lXn = sXn;
+                if (act) {
+                    if (wv > 0) { lMn = S.botM[wv - 1]; lXn = S.botE[wv - 1]; }
+                    L.phase2(gyo, gye, lMn, lXn);
+                    if (lane == 63) S.agg[wv] = L.pv;
+                }
+                __syncthreads();
+                if (act) {
+                    const int32_t carry = max(sYn, dpw_carry(S.agg, wv, lane));
+                    const int32_t lYn = wv > 0 ? carry + eoff : sYn;
+                    const uint32_t tbw = L.phase3(gyo, gye, carry, lYn);
+                    if (writes) { if (R == 4) *reinterpret_cast<uint32_t *>(tw) = tbw; else *reinterpret_cast<uint16_t *>(tw) = (uint16_t)tbw; }
+                    if (park && lane == 63) { cout[i] = L.M[R - 1]; cout[(m + 1) + i] = L.X[R - 1]; cout[2 * (m + 1) + i] = L.Y[R - 1]; }
+                    lMo = lMn; lXo = lXn; lYo = lYn;
+                }
+                sMo = sMn; sXo = sXn; sYo = sYn;
+            }
+        }
+        if (q == nsb - 1) {
+            const int32_t rel = n - 1 - sb0;
+            if (wv == rel / DPW_BAND && lane == (rel % DPW_BAND) / R) {
+                const int ro = rel % R;
+                int32_t a = L.M[0], b2 = L.X[0], c2 = L.Y[0];
+#pragma unroll
+                for (int r = 1; r < R; r++) if (ro == r) { a = L.M[r]; b2 = L.X[r]; c2 = L.Y[r]; }
+                S.fin[0] = a; S.fin[1] = b2; S.fin[2] = c2;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// one interval, all its progressive steps, by the whole workgroup (dp3_interval's structure; the walk is wave 0's, the rebuild everybody's)
+template <int R, int W>
+__device__ void dp_interval_wide(int nseq, int64_t iv, const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
+                                 uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA, uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
+                                 uint8_t *__restrict__ tb, const int64_t *__restrict__ tb_off, int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
+                                 uint8_t *__restrict__ ops, const DpScoring &sc)
+{
+    __shared__ DpwShared S;
+    __shared__ __attribute__((aligned(16))) uint8_t s_wwin[DP2_TB_DW * 4];       // traceback window of the walk (wave 0)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
+    const int64_t base = seq_off[iv * nseq];
+    for (int g = 0; g < nseq; g++) {
+        const int64_t so = seq_off[iv * nseq + g];
+        const int32_t n = (int32_t)(seq_off[iv * nseq + g + 1] - so);
+        if (n == 0) continue;
+        const uint8_t *seq = codes + so;
+        uint32_t *Pc = (mt.cur ? cntB : cntA) + base, *Pm = (mt.cur ? maskB : maskA) + base;
+        uint32_t *Qc = (mt.cur ? cntA : cntB) + base, *Qm = (mt.cur ? maskA : maskB) + base;
+        if (mt.krows == 0) {
+            for (int32_t c = threadIdx.x; c < n; c += 64 * W) { Pc[c] = 1u << (8 * seq[c]); Pm[c] = 1u << g; }
+            mt.m = n; mt.krows = 1;
+            __threadfence_block();
+            __syncthreads();
+            continue;
+        }
+        const int32_t m = mt.m;
+        uint8_t *tbp = tb + tb_off[iv];
+        int32_t *rowbuf = rows + rows_off[iv];
+        Dp3Walk Wk; Wk.win = s_wwin; Wk.cap = DP2_TB_DW * 4; Wk.tb = tbp;
+        const bool wide_b = dpw_orient_b(m, n);
+        if ((wide_b ? n : m) > DP3_BAND) {
+            // the lane dimension has several bands: all waves
+            const int32_t pad = (int32_t)dp3_pad(wide_b ? n : m);
+            Wk.orient_b = wide_b; Wk.R = 4; Wk.stride = pad;              // (a byte per row / column: the walk's R = 4 layout whatever R the sweep ran with)
+            if (!wide_b) dpw_sweep_a<R, W>(S, lane, wv, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad);
+            else dpw_sweep_b<R, W>(S, lane, wv, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad);
+        } else {
+            // small in the dimension the cost rule picks: the one-wave sweep, by wave 0 (dp3_interval's choice of orientation and of R)
+            const bool ob = dp3_orient_b(m, n);
+            const int32_t ldim = ob ? n : m, R1 = dp3_rows_per_lane(ldim), pad = (int32_t)dp3_pad(ldim);
+            Wk.orient_b = ob; Wk.R = R1; Wk.stride = pad;
+            if (wv == 0) {
+                int32_t fM = DP_NEG_INF, fX = DP_NEG_INF, fY = DP_NEG_INF;
+                if (!ob) {
+                    if (R1 == 1) dp3_sweep_a<1>(lane, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, fM, fX, fY);
+                    else if (R1 == 2) dp3_sweep_a<2>(lane, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, fM, fX, fY);
+                    else dp3_sweep_a<4>(lane, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, fM, fX, fY);
+                } else {
+                    if (R1 == 1) dp3_sweep_b<1>(lane, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, fM, fX, fY);
+                    else if (R1 == 2) dp3_sweep_b<2>(lane, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, fM, fX, fY);
+                    else dp3_sweep_b<4>(lane, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, fM, fX, fY);
+                }
+                if (lane == 0) { S.fin[0] = fM; S.fin[1] = fX; S.fin[2] = fY; }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        const int32_t fM = S.fin[0], fX = S.fin[1], fY = S.fin[2];
+        int32_t best = fM; int state = 0;
+        if (fX > best) { best = fX; state = 1; }
+        if (fY > best) { best = fY; state = 2; }
+        uint8_t *opr = ops + base;                         // reversed ops, capacity m + n
+        if (wv == 0) {
+            const int32_t l0 = dp3_walk(Wk, m, n, state, opr, lane);
+            if (lane == 0) S.len = l0;
+        }
+        __threadfence_block();
+        __syncthreads();
+        const int32_t len = S.len;
+        // ---- new profile: every wave keeps the running source counts, chunk k is written by wave k mod W ----
+        int32_t carry_p = 0, carry_s = 0;
+        for (int32_t c0i = 0, k = 0; c0i < len; c0i += 64, k++) {
+            const int32_t c = c0i + lane;
+            const bool ok = c < len;
+            const uint32_t op = ok ? opr[len - 1 - c] : 0u;
+            const uint64_t bp = __ballot(ok && (op & 1)), bs = __ballot(ok && (op & 2));
+            if (ok && (k % W) == wv) {
+                const int32_t pi = carry_p + (int32_t)__popcll(bp & lt), sj = carry_s + (int32_t)__popcll(bs & lt);
+                uint32_t cv = 0, mv = 0;
+                if (op & 1) { cv = Pc[pi]; mv = Pm[pi]; }
+                if (op & 2) { cv += 1u << (8 * seq[sj]); mv |= 1u << g; }
+                Qc[c] = cv; Qm[c] = mv;
+            }
+            carry_p += (int32_t)__popcll(bp); carry_s += (int32_t)__popcll(bs);
+        }
+        mt.cells += (int64_t)m * n; mt.score += best; mt.m = len; mt.krows += 1; mt.cur ^= 1;
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) meta[iv] = mt;
+}
+
+// The workgroup launches (second stream), both over the same list entries: dp_step_wide takes the intervals the scans admit, dp_step_big --
+// the systolic stripe pipeline (dp_interval_mw) -- the banded ones and whatever the scans do not admit; each leaves the
+// other's entries alone (a workgroup-uniform test).  Two kernels, so that neither pays for the other's registers.
+__device__ __forceinline__ bool dp_takes_wide(int nseq, int64_t iv, const int64_t *__restrict__ seq_off, const DpScoring &sc, int64_t band_from, int wide)
+{
+    int64_t longest = 0;
+    for (int g = 0; g < nseq; g++) longest = max(longest, seq_off[iv * nseq + g + 1] - seq_off[iv * nseq + g]);
+    return wide && longest <= band_from && dp3_admissible(seq_off[(iv + 1) * nseq] - seq_off[iv * nseq], nseq, sc.ge, sc.go);
+}
+__global__ void __launch_bounds__(64 * DP_MW_WAVES) dp_step_big(int nseq, const int64_t *__restrict__ list, const uint8_t *__restrict__ codes,
+                                               const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
+                                               uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
+                                               uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
+                                               uint8_t *__restrict__ tb, const int64_t *__restrict__ tb_off,
+                                               int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
+                                               uint8_t *__restrict__ ops, DpScoring sc, int64_t band_from, int wide)
+{
+    const int64_t iv = list[blockIdx.x];
+    if (dp_takes_wide(nseq, iv, seq_off, sc, band_from, wide)) return;
+    dp_interval_mw(nseq, iv, codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, sc, band_from);
+}
+template <int R, int W>
+__global__ void __launch_bounds__(64 * W) dp_step_wide(int nseq, const int64_t *__restrict__ list, const uint8_t *__restrict__ codes,
+                                               const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
+                                               uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA,
+                                               uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
+                                               uint8_t *__restrict__ tb, const int64_t *__restrict__ tb_off,
+                                               int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
+                                               uint8_t *__restrict__ ops, DpScoring sc, int64_t band_from)
+{
+    const int64_t iv = list[blockIdx.x];
+    if (!dp_takes_wide(nseq, iv, seq_off, sc, band_from, 1)) return;
+    dp_interval_wide<R, W>(nseq, iv, codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, sc);
+}
+
 // The register-blocked launch: block ranges [one wave per interval | G = 16 | G = 8 | G = 4], the long ones first.
 __global__ void __launch_bounds__(64 * DP2_WAVES) dp_step2(int nseq, const int64_t *__restrict__ list, DpClasses cl, const uint8_t *__restrict__ codes,
                                                const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
@@ -1659,16 +2140,17 @@ __global__ void __launch_bounds__(256) dp_gather_codes(const uint64_t *__restric
     }
 }
 
-// Which intervals get a workgroup (dp_step_big) instead of a wave: candidates whose single-wave estimate exceeds
-// factor x the balanced share of a wave slot, at most max of them (MAUVE_DP_BIG_FACTOR4 = 4 x factor, MAUVE_DP_BIG_MAX).
+// Which intervals get a workgroup (dp_step_big) instead of a wave: candidates (a step with several bands) whose single-wave estimate is
+// at least MAUVE_DP_WIDE_MIN scan steps, at most MAUVE_DP_BIG_MAX of them.
 static int dp_class_mode()
 {
     static const int m = []() { const char *e = getenv("MAUVE_DP_CLASS"); return !e ? 0 : (!strcmp(e, "bound") ? 1 : (!strcmp(e, "wild") ? 2 : 0)); }();
     return m;
 }
 static bool dp_old_kernels() { static const bool o = getenv("MAUVE_DP_OLD") != nullptr; return o; }   // A/B switch: the systolic one-row-per-lane kernels
-static int64_t dp_big_factor4() { static const int64_t f = getenv("MAUVE_DP_BIG_FACTOR4") ? atoll(getenv("MAUVE_DP_BIG_FACTOR4")) : 16; return f; }
-static int64_t dp_big_max() { static const int64_t m = getenv("MAUVE_DP_BIG_MAX") ? atoll(getenv("MAUVE_DP_BIG_MAX")) : 128; return m; }
+static int64_t dp_wide_min() { static const int64_t f = getenv("MAUVE_DP_WIDE_MIN") ? atoll(getenv("MAUVE_DP_WIDE_MIN")) : 1024; return f; }
+static int64_t dp_big_max() { static const int64_t m = getenv("MAUVE_DP_BIG_MAX") ? atoll(getenv("MAUVE_DP_BIG_MAX")) : 256; return m; }
+static bool dp_wide_on() { static const bool o = getenv("MAUVE_DP_NO_WIDE") == nullptr; return o; }   // A/B switch: the workgroup entries all through the systolic stripe pipeline
 
 // the two DP launches: dp_step_big (workgroup per interval, second stream) beside dp_step (wave / sub-wave per interval),
 // over the positions [a, b) of the launch list [workgroup | one wave | two per wave | four per wave]; tb_base is
@@ -1695,29 +2177,50 @@ static int dp_launch_steps(mauve_ctx *ctx, int nseq, int64_t a, int64_t b, int64
     const uint32_t blocks = cl.blocks_med + cl.blocks_c + cl.blocks_s32 + (uint32_t)std::min<int64_t>(oldk ? (cl.n_s16 + 15) / 16 : (cl.n_s16 + 16 * wpb - 1) / (16 * wpb), cap);
     uint8_t *tb = ctx->dp_tb.as<uint8_t>() - tb_base;                   // only offsets >= tb_base are used in this round
     KernelTimer t(ctx, MAUVE_K_DP, b - a);
-    if (bn) {   // the workgroup-per-interval launch runs beside the one-wave launch on a second stream
+    // The workgroup-per-interval launches run beside the one-wave launch; THEY go first, on the main stream, and the one-wave launch follows on the
+    // second stream behind an event: a two-wave workgroup of dp_step2 takes a quarter of a CU's LDS and registers, four of them leave room for
+    // nothing else, and every slot one of them frees is refilled by the next -- a 1024-thread workgroup dispatched after them waits until that
+    // whole launch has drained (measured at C5: the largest interval began 1.2 ms late, the stage took 3.0 ms instead of 1.8).  Dispatched a few
+    // microseconds ahead, the large workgroups have their CUs and the small ones fill in around and behind them.
+    hipStream_t small_stream = bn ? ctx->stream2 : ctx->stream;
+    if (bn) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        hipLaunchKernelGGL(dp_step_big, dim3((uint32_t)bn), dim3(64 * DP_MW_WAVES), 0, ctx->stream2, nseq,
-                           ctx->dp_list.as<int64_t>() + bf, ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(),
-                           ctx->dp_prof_cnt.as<uint32_t>(), ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
-                           ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(),
-                           d_rows_off, ctx->dp_score.as<uint8_t>(), sc, band_from);
-        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+        const bool wide = dp_wide_on();
+        static const bool r4 = getenv("MAUVE_DP_WIDE_R4") != nullptr;      // A/B switch: 8 waves x 4 rows per lane instead of 16 x 2
+        if (wide && r4)
+            hipLaunchKernelGGL((dp_step_wide<4, 8>), dim3((uint32_t)bn), dim3(64 * 8), 0, ctx->stream, nseq,
+                               ctx->dp_list.as<int64_t>() + bf, ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(),
+                               ctx->dp_prof_cnt.as<uint32_t>(), ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
+                               ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(),
+                               d_rows_off, ctx->dp_score.as<uint8_t>(), sc, band_from);
+        else if (wide)
+            hipLaunchKernelGGL((dp_step_wide<2, 16>), dim3((uint32_t)bn), dim3(64 * 16), 0, ctx->stream, nseq,
+                               ctx->dp_list.as<int64_t>() + bf, ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(),
+                               ctx->dp_prof_cnt.as<uint32_t>(), ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
+                               ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(),
+                               d_rows_off, ctx->dp_score.as<uint8_t>(), sc, band_from);
+        // (the stripe pipeline: every entry without the wide sweep; with it, only where banded intervals or an inadmissible scoring scheme can occur)
+        if (!wide || band_from != INT64_MAX || !dp3_admissible(1, nseq, sc.ge, sc.go))
+            hipLaunchKernelGGL(dp_step_big, dim3((uint32_t)bn), dim3(64 * DP_MW_WAVES), 0, ctx->stream, nseq,
+                               ctx->dp_list.as<int64_t>() + bf, ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(),
+                               ctx->dp_prof_cnt.as<uint32_t>(), ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
+                               ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(),
+                               d_rows_off, ctx->dp_score.as<uint8_t>(), sc, band_from, wide ? 1 : 0);
     }
     if (blocks && oldk)
-        hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, ctx->stream, nseq, ctx->dp_list.as<int64_t>(), cl,
+        hipLaunchKernelGGL(dp_step, dim3(blocks), dim3(256), 0, small_stream, nseq, ctx->dp_list.as<int64_t>(), cl,
                            ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
                            ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
                            ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(),
                            d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
     else if (blocks)
-        hipLaunchKernelGGL(dp_step2, dim3(blocks), dim3(64 * DP2_WAVES), 0, ctx->stream, nseq, ctx->dp_list.as<int64_t>(), cl,
+        hipLaunchKernelGGL(dp_step2, dim3(blocks), dim3(64 * DP2_WAVES), 0, small_stream, nseq, ctx->dp_list.as<int64_t>(), cl,
                            ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(), ctx->dp_prof_cnt.as<uint32_t>(),
                            ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
                            ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(),
                            d_rows_off, ctx->dp_score.as<uint8_t>(), sc);
-    if (bn) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    if (bn) { HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2)); HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); }
     return MAUVE_OK;
 }
 
@@ -1793,9 +2296,11 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
                 rneed = std::max(rneed, dp3_rows_need(mmax, n));
                 need = std::max(need, tbn);
                 nmax = std::max(nmax, n);
-                // a step with >= 3 stripes against >= 256 columns pipelines over several waves
-                if (mmax > 128 && n >= 256 && !no_mw) big = 1;
-                es += tbo / 64;                                        // systolic steps of a single wave
+                // a step with several bands in one dimension spreads over the waves of a workgroup (wide sweep); weight: scan steps of one wave,
+                // from the estimate of the profile length (at least its longest member, rarely much more)
+                const int64_t e_m = std::min(mmax, mmin + mmin / 8 + 2);
+                if (std::max(e_m, n) > DP3_BAND && !no_mw) big = 1;
+                es += dp3_scan_steps(e_m, n);
                 mmax += n; mmin = std::max(mmin, n);
             }
             if (banded && nmax) big = 2;                               // banded steps exist only in the workgroup kernel
@@ -1824,14 +2329,13 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
         for (int64_t iv = 0; iv < n_iv; iv++) lst[(size_t)cnt[cls(iv)]++] = iv;
     }
     // workgroup-per-interval entries first (still largest first), one-wave entries after them
-    // A 16-wave workgroup fills a CU, so it only pays for the tail: intervals well above what a balanced one-wave
-    // schedule (3072 resident waves) would take, and at most half the CUs' worth of them.
+    // A 16-wave workgroup takes half a CU's wave slots, so it is for the tail of the launch: intervals that would keep ONE wave busy for
+    // dp_wide_min() scan steps or more (the rest of the launch is over by then), the largest dp_big_max() of them.
     int64_t n_big = 0;
     {
-        const int64_t balanced = est_total / 3072;
         for (int64_t k = 0; k < n_iv; k++) {          // lst is largest first
             uint8_t &b = is_big[(size_t)lst[(size_t)k]];
-            if (b == 1 && (n_big >= dp_big_max() || est[(size_t)lst[(size_t)k]] * 4 <= dp_big_factor4() * balanced)) b = 0;
+            if (b == 1 && (n_big >= dp_big_max() || est[(size_t)lst[(size_t)k]] < dp_wide_min())) b = 0;
             n_big += b != 0;
         }
     }
@@ -2036,8 +2540,9 @@ __global__ void __launch_bounds__(256) dpf_desc(const int32_t *__restrict__ alen
         rneed = max(rneed, dp3_rows_need(mmax, n));
         nd = max(nd, tbn);
         nmax = max(nmax, n);
-        if (mmax > 128 && n >= 256 && !no_mw) big = 1;       // a step with >= 3 stripes against >= 256 columns pipelines over several waves
-        es += tbo / 64;
+        const int64_t e_m = min(mmax, mmin + mmin / 8 + 2);      // (dp_core: the same weights)
+        if (max(e_m, n) > DP3_BAND && !no_mw) big = 1;
+        es += dp3_scan_steps(e_m, n);
         mmax += n; mmin = max(mmin, n);
     }
     if (banded && nmax) big = 2;                             // banded steps exist only in the workgroup kernel
@@ -2059,11 +2564,11 @@ __global__ void __launch_bounds__(256) dpf_tb_scatter(const int64_t *__restrict_
     if (j < n) tb_off[order[j]] = tb_list[j];
 }
 
-// workgroup-pipeline entries: candidates well above a balanced one-wave share, the first 128 of them in size order
+// workgroup entries: candidates that would keep one wave busy for wide_min scan steps or more, the first maxn of them in size order
 struct DpBigPick {
-    const uint32_t *order; const uint8_t *cand, *cls; const int64_t *est; const DpFrontTotals *tot; uint32_t *key2; int64_t factor4; uint32_t maxn;
+    const uint32_t *order; const uint8_t *cand, *cls; const int64_t *est; const DpFrontTotals *tot; uint32_t *key2; int64_t wide_min; uint32_t maxn;
     __device__ uint32_t domain(int) const { return (uint32_t)tot->n_dp; }
-    __device__ bool flag(uint32_t j, int) const { const uint32_t s = order[j]; return cand[s] == 1 && est[s] * 4 > factor4 * (tot->est / 3072); }
+    __device__ bool flag(uint32_t j, int) const { const uint32_t s = order[j]; return cand[s] == 1 && est[s] >= wide_min; }
     __device__ void each(uint32_t j, uint32_t before, bool fl, int) const { key2[j] = ((fl && before < maxn) || cand[order[j]] == 2) ? 0u : (uint32_t)cls[order[j]]; }
     __device__ void emit(uint32_t, uint32_t, int) const {}
     __device__ void total(uint32_t, int) const {}
@@ -2177,7 +2682,7 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     int rc = sort_pairs_u32(ctx, n_dp, 6, &ok, &ov, k2, v2, MAUVE_K_MISC);
     if (rc) return rc;
     uint32_t *fk = ok == k1 ? k2 : k1, *fv = ov == v1 ? v2 : v1;        // free pair
-    const DpBigPick bp{ov, cand, cls, est, tot, fk, dp_big_factor4(), (uint32_t)dp_big_max()};
+    const DpBigPick bp{ov, cand, cls, est, tot, fk, dp_wide_min(), (uint32_t)dp_big_max()};
     hipLaunchKernelGGL((cmp_count<DpBigPick>), dim3(nbd), dim3(256), 0, ctx->stream, bp, bcnt);
     hipLaunchKernelGGL((cmp_write<DpBigPick>), dim3(nbd), dim3(256), 0, ctx->stream, bp, bcnt);
     uint32_t *ck = fk, *cv = ov;

@@ -778,7 +778,7 @@ template <typename KeyT>
 __global__ void __launch_bounds__(256) run_summary(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t n,
                                                    GenomeTab tab, int has_invalid, uint32_t *__restrict__ rstart,
                                                    uint32_t *__restrict__ rlen, uint32_t *__restrict__ runiq,
-                                                   uint32_t *__restrict__ counter)
+                                                   uint32_t *__restrict__ counter, uint32_t cap)
 {
     // 1024 entries per workgroup (four per thread, strided), one block scan and ONE global atomic per workgroup: with one atomic per
     // wave, 250 k of them on the same counter were the kernel's whole run time (2.9 ms for 16 M entries)
@@ -812,7 +812,7 @@ __global__ void __launch_bounds__(256) run_summary(const KeyT *__restrict__ keys
     uint32_t r = s_base + off;
 #pragma unroll
     for (int it = 0; it < ITEMS; it++)
-        if (uniq[it]) { rstart[r] = base + it * 256 + threadIdx.x; rlen[r] = len[it]; runiq[r] = uniq[it]; r++; }
+        if (uniq[it]) { if (r < cap) { rstart[r] = base + it * 256 + threadIdx.x; rlen[r] = len[it]; runiq[r] = uniq[it]; } r++; }   // (the counter keeps counting: the host sees a list that outgrew its buffer)
 }
 
 __global__ void __launch_bounds__(256) join_pair(const uint32_t *__restrict__ vals, GenomeTab tab, const uint32_t *__restrict__ rstart,
@@ -970,7 +970,7 @@ template <bool SEG>
 __device__ __forceinline__ void mum_runs_body(const GenomeTab &tab, int span, const uint32_t *__restrict__ tmask,
                                               const uint32_t *__restrict__ tpos, uint32_t P, int all,
                                               uint32_t *__restrict__ cand, uint32_t *__restrict__ counters,
-                                              const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t p0)
+                                              const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t p0, uint32_t cand_cap)
 {
     __shared__ uint32_t lds[8];
     __shared__ uint32_t s_base;
@@ -1027,25 +1027,25 @@ __device__ __forceinline__ void mum_runs_body(const GenomeTab &tab, int span, co
     uint32_t o = s_base + off;
 #pragma unroll
     for (int it = 0; it < RUNS_ITEMS; it++)
-        if (flags >> it & 1) cand[o++] = base + it * 256 + threadIdx.x;
+        if (flags >> it & 1) { if (o < cand_cap) cand[o] = base + it * 256 + threadIdx.x; o++; }     // never past the list: counters[1] still counts, the host refuses a list that outgrew its buffer
 }
 template <bool SEG>
 __global__ void __launch_bounds__(256) mum_runs(GenomeTab tab, int span, const uint32_t *__restrict__ tmask,
                                                 const uint32_t *__restrict__ tpos, uint32_t P, int all,
                                                 uint32_t *__restrict__ cand, uint32_t *__restrict__ counters,
-                                                const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t p0 = 0)
+                                                const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t cand_cap, uint32_t p0 = 0)
 {
-    mum_runs_body<SEG>(tab, span, tmask, tpos, P, all, cand, counters, seg, nseg, p0);
+    mum_runs_body<SEG>(tab, span, tmask, tpos, P, all, cand, counters, seg, nseg, p0, cand_cap);
 }
 // Several passes of the pairwise finder at once: pairs with DIFFERENT lower genomes write disjoint slices of the hit table, so a group of
 // them shares the table, one candidate list and one counter (mum_extend tells the pairs apart by the hit's mask).  blockIdx.y = pair.
 struct PairGroup { int n; int ga[MAUVE_MAX_SEQ], gb[MAUVE_MAX_SEQ]; uint32_t lo[MAUVE_MAX_SEQ], hi[MAUVE_MAX_SEQ]; };
 __global__ void __launch_bounds__(256) mum_runs_group(GenomeTab tab, int span, const uint32_t *__restrict__ tmask, const uint32_t *__restrict__ tpos, PairGroup grp, int all,
-                                                      uint32_t *__restrict__ cand, uint32_t *__restrict__ counters)
+                                                      uint32_t *__restrict__ cand, uint32_t *__restrict__ counters, uint32_t cand_cap)
 {
     const uint32_t lo = grp.lo[blockIdx.y], hi = grp.hi[blockIdx.y];
     if (lo + blockIdx.x * (256u * RUNS_ITEMS) >= hi) return;                     // (workgroup-uniform: the grid covers the longest slice)
-    mum_runs_body<false>(tab, span, tmask, tpos, hi, all, cand, counters, nullptr, 0u, lo);
+    mum_runs_body<false>(tab, span, tmask, tpos, hi, all, cand, counters, nullptr, 0u, lo, cand_cap);
 }
 __global__ void __launch_bounds__(256) join_pair_group(const uint32_t *__restrict__ vals, GenomeTab tab, const uint32_t *__restrict__ rstart,
                                                        const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ runiq,
@@ -1545,7 +1545,13 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     const uint32_t P = n;
     HIPCHK(ctx, ctx->posmask.ensure((size_t)P * 4));             // tmask
     HIPCHK(ctx, ctx->hit_pos.ensure((size_t)P * 4 * N));         // tpos [P][N]
-    HIPCHK(ctx, ctx->cand.ensure((size_t)(P / 2 + 1) * 4));      // a hit needs >= 2 entries
+    // Capacities of the compacted lists are handed to the kernels that fill them (a store past the end is skipped, the counter still counts)
+    // and checked against the counts that come back.  MAUVE_LIST_CAP: test knob, shrinks them so that the check can be seen to fire.
+    static const uint32_t list_cap_env = getenv("MAUVE_LIST_CAP") ? (uint32_t)strtoul(getenv("MAUVE_LIST_CAP"), nullptr, 10) : 0u;
+    uint32_t cand_cap = P / 2 + 1;                               // a hit needs >= 2 entries
+    HIPCHK(ctx, ctx->cand.ensure((size_t)cand_cap * 4));
+    if (list_cap_env) cand_cap = std::min(cand_cap, list_cap_env);
+    auto cand_overflow = [&](uint32_t nc) { if (nc <= cand_cap) return false; ctx->err = "seed pass: " + std::to_string(nc) + " candidates for a list of " + std::to_string(cand_cap); return true; };
     uint32_t *tmask = ctx->posmask.as<uint32_t>(), *tpos = ctx->hit_pos.as<uint32_t>();
     struct FinderPass { uint32_t consider, want; int rule; };
     std::vector<FinderPass> passes;
@@ -1567,17 +1573,19 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     uint32_t *rstart = nullptr, *rlen = nullptr, *runiq = nullptr;
     if (use_summary) {
         const size_t cap = (size_t)ns / 2 + 1;
+        const uint32_t run_cap = list_cap_env ? std::min<uint32_t>((uint32_t)cap, list_cap_env) : (uint32_t)cap;
         HIPCHK(ctx, ctx->run_sum.ensure(3 * cap * 4));
         rstart = ctx->run_sum.as<uint32_t>(); rlen = rstart + cap; runiq = rlen + cap;
         HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
         { KernelTimer t(ctx, MAUVE_K_JOIN, ns);
           hipLaunchKernelGGL((run_summary<KeyT>), dim3((ns + 1023) / 1024), dim3(256), 0, ctx->stream, keys, vals, ns, tab,
-                             has_invalid, rstart, rlen, runiq, ctx->counters.as<uint32_t>() + 2); }
+                             has_invalid, rstart, rlen, runiq, ctx->counters.as<uint32_t>() + 2, run_cap); }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, ctx->pin_seed.ensure(64));
         HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         nruns = ctx->pin_seed.as<uint32_t>()[2];
+        if (nruns > run_cap) { ctx->err = "seed pass: " + std::to_string(nruns) + " runs for a list of " + std::to_string(run_cap); return MAUVE_ERR_LIMIT; }
         TRACE(ctx, "run summary");
     }
     // ---- the passes of the pairwise finder in groups: pairs with different lower genomes write disjoint slices of the hit table, so up to
@@ -1589,6 +1597,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         // one candidate list per group: a pair has at most one hit per window of its lower genome, the lower genomes of a group are
         // different, so a group has at most P candidates (a single pass: P / 2, "a hit needs two entries" -- not enough here)
         HIPCHK(ctx, ctx->cand.ensure(((size_t)P + 1) * 4));
+        cand_cap = list_cap_env ? std::min<uint32_t>(P + 1, list_cap_env) : P + 1;
         std::vector<char> used(passes.size(), 0);
         for (size_t left = passes.size(); left;) {
             PairGroup grp; memset(&grp, 0, sizeof grp);
@@ -1612,13 +1621,14 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             TRACE(ctx, "join");
             { KernelTimer t(ctx, MAUVE_K_RUNS, slices);
               hipLaunchKernelGGL(mum_runs_group, dim3((maxslice + 256 * RUNS_ITEMS - 1) / (256 * RUNS_ITEMS), (uint32_t)grp.n), dim3(256), 0, ctx->stream, tab, sh.span, tmask, tpos, grp,
-                                 extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>()); }
+                                 extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), cand_cap); }
             HIPCHK(ctx, hipGetLastError());
             if (ctx->shadow) { std::function<void()> fsh; fsh.swap(ctx->shadow); fsh(); }
             HIPCHK(ctx, ctx->pin_seed.ensure(64));
             HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             const uint32_t nc = ctx->pin_seed.as<uint32_t>()[1];
+            if (cand_overflow(nc)) return MAUVE_ERR_LIMIT;
             TRACE(ctx, "runs");
             if (g_trace) fprintf(stderr, "[trace]   %u candidates of %u windows (%d pairs at once)\n", nc, slices, grp.n);
             if (nc == 0) continue;
@@ -1682,7 +1692,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         { KernelTimer t(ctx, MAUVE_K_RUNS, s_hi - s_lo);
           hipLaunchKernelGGL((mum_runs<SEG>), dim3((s_hi - s_lo + 256 * RUNS_ITEMS - 1) / (256 * RUNS_ITEMS)), dim3(256), 0, ctx->stream, tab,
                              sh.span, tmask, tpos, s_hi, extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg,
-                             nseg, s_lo); }
+                             nseg, cand_cap, s_lo); }
         HIPCHK(ctx, hipGetLastError());
         if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // the kernels above are still running
         HIPCHK(ctx, ctx->pin_seed.ensure(64));
@@ -1716,13 +1726,14 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             { KernelTimer t(ctx, MAUVE_K_RUNS, P);
               hipLaunchKernelGGL((mum_runs<SEG>), dim3((P + 256 * RUNS_ITEMS - 1) / (256 * RUNS_ITEMS)), dim3(256), 0, ctx->stream, tab,
                                  sh.span, tmask, tpos, P, extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg,
-                                 nseg); }
+                                 nseg, cand_cap); }
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             nc = ctx->pin_seed.as<uint32_t>()[1];
             if (g_trace) fprintf(stderr, "[trace]   join_hash handed back %u range(s)\n", novf);
         }
+        if (cand_overflow(nc)) return MAUVE_ERR_LIMIT;
         TRACE(ctx, "runs");
         if (g_trace) fprintf(stderr, "[trace]   %u candidates of %u windows\n", nc, P);
         if (nc == 0) continue;

@@ -1038,6 +1038,61 @@ def test_dp_scan_kernels():
         assert r.returncode == 0 and r.stdout.strip().endswith("OK"), str(extra) + "\n" + r.stdout + r.stderr[-3000:]
 
 
+
+WIDE_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from mauvealigner_amd import _lib, synth
+from oracle import pyoracle as O
+rng = np.random.default_rng(33)
+ctx = _lib.Context(0)
+def seqs(lens, div=0.15):
+    base = rng.integers(0, 4, max(max(lens), 1), dtype=np.uint8)
+    out = []
+    for L in lens:
+        if L == 0:
+            out.append(np.zeros(0, np.uint8)); continue
+        x = synth.mutate(base, div, rng, indel_frac=0.3)[:L]
+        if len(x) < L:
+            x = np.concatenate([x, rng.integers(0, 4, L - len(x), dtype=np.uint8)])
+        out.append(x)
+    return out
+def check(ivs):
+    cols, score = ctx.dp_batch(ivs)
+    for iv, c, s in zip(ivs, cols, score):
+        ec, es = O.align_interval(iv)
+        assert len(c) == len(ec) and np.array_equal(c, ec) and int(s) == es, [len(x) for x in iv]
+# two sequences: one band against several, several against several, one and more than one super-band (8 waves x 256) in either dimension,
+# band and super-band edges, tall-thin and flat-long
+shapes2 = [(6700, 20), (20, 6700), (1600, 1600), (257, 3), (3, 257), (256, 257), (257, 256), (512, 513), (2048, 300), (2049, 300), (300, 2049), (2047, 2050),
+           (4100, 130), (130, 4100), (4097, 2), (2, 4097), (1030, 1025), (700, 699), (5000, 900), (900, 5000), (3000, 1)]
+check([seqs(list(s)) for s in shapes2])
+# unrelated sequences (long gap runs) and identical ones (one diagonal), beside small intervals of the other kernels
+a = rng.integers(0, 4, 2600, dtype=np.uint8)
+check([[a, rng.integers(0, 4, 40, dtype=np.uint8)], [rng.integers(0, 4, 40, dtype=np.uint8), a], [a, a.copy()], [a[:700], a[:700].copy()],
+       [rng.integers(0, 4, 1400, dtype=np.uint8), rng.integers(0, 4, 1380, dtype=np.uint8)]] + [seqs([int(rng.integers(1, 60)), int(rng.integers(1, 60))]) for _ in range(100)])
+# more sequences: the long one first, in the middle, last; empty members; a profile that outgrows a band / a super-band while it is built
+check([seqs(l) for l in ([2300, 20, 18, 22, 19], [20, 18, 2300, 22, 19], [20, 18, 22, 19, 2300], [250, 260, 255, 0, 258], [0, 1300, 0, 1400, 1350],
+                         [700, 750, 800, 850, 900], [300, 10, 0, 2100, 12], [5, 5, 600, 600, 5])])
+check([seqs([2040, 2040, 30, 2040]), seqs([30, 2600, 2500, 28])])
+check([seqs([int(rng.integers(0, 700)) for _ in range(4)], div=0.1) for _ in range(40)])
+print("OK")
+"""
+
+
+def test_dp_wide_sweeps():
+    """The workgroup class runs the wide sweep (dp_step_wide: the scan-formulated sweep over all waves of a workgroup, one column / row of a
+    whole super-band per step): with MAUVE_DP_WIDE_MIN=1 every interval with a dimension beyond one band goes through it -- both
+    orientations, one and several super-bands, the one-wave fallback for steps small in both dimensions, several sequences.  Bit-exact against
+    the oracle; the stripe pipeline that banded intervals keep (MAUVE_DP_NO_WIDE) must agree on the same shapes."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({"MAUVE_DP_WIDE_MIN": "1"}, {"MAUVE_DP_WIDE_MIN": "1", "MAUVE_DP_BIG_MAX": "7"}, {"MAUVE_DP_WIDE_MIN": "1", "MAUVE_DP_NO_WIDE": "1"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", WIDE_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), str(extra) + "\n" + r.stdout + r.stderr[-3000:]
+
+
 ORDER_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, %(root)r)
