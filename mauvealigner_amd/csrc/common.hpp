@@ -260,7 +260,7 @@ struct mauve_ctx {
 
     // DP workspace
     DevBuf dp_desc, dp_list, dp_codes, dp_off, dp_prof_cnt, dp_prof_mask, dp_prof2_cnt, dp_prof2_mask, dp_tb, dp_meta, dp_score,
-        dp_cols, dp_rows, dp_sp;
+        dp_cols, dp_rows, dp_sp, dp_pick;
 
     // the seed pass may leave its match list on the device only (sorted_rec) when the caller says so: mauve_align's device tail
     bool pair_sums_only = false;          // seed pass for the guide tree: per-pair length sums instead of the match list
@@ -273,6 +273,8 @@ struct mauve_ctx {
     int match_nseq = 0;
     // where dp_run_from_anchors left its device-side results (valid until the next DP launch)
     struct DpFrontOut { const int32_t *alen, *ast, *alcb, *gapcode; const int64_t *col_off, *score; const uint32_t *cols; int64_t n_dp, n_cols; } dpf_out{};
+    std::vector<DpSeqDesc> prog_desc;      // progressive.cpp: the descriptors of a node's intervals and of their refinement candidates (kept: no fresh pages per node)
+    const int64_t *dp_last_col_off = nullptr; int64_t dp_last_n = 0;     // column offsets (device) and size of the batch dp_core ran last: dp_fetch_picked
     int64_t dp_band_from = INT64_MAX;     // intervals whose longest sequence exceeds this run the banded DP (dp_batch.hip)
     DevBuf dpf_anch, dpf_work, dpf_tot;   // device front end of the DP stage (dp_run_from_anchors)
 
@@ -403,5 +405,6 @@ bool fetch_tables_direct(mauve_ctx *c, int64_t *mum_length, int64_t *mum_start, 
 bool host_pointer_is_pinned(const void *p);
 int host_genomes(mauve_ctx *c);
 int seed_matches_to_host(mauve_ctx *ctx);
+int dp_fetch_picked(mauve_ctx *ctx, int64_t n_pick, const int64_t *pick, const int64_t *col_off, uint32_t *out, int64_t *out_off);
 int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, const int64_t *seq_off,
                  const mauve_scoring *sc, uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells);

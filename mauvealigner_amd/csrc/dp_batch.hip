@@ -2419,6 +2419,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     }
     col_off[n_iv] = tc;
     if (cells) *cells = ncell;
+    ctx->dp_last_col_off = d_col_off; ctx->dp_last_n = n_iv;
     if (tc) {
         HIPCHK(ctx, hipMemcpyAsync(d_col_off, col_off, (size_t)(n_iv + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
         const uint32_t gblocks = (uint32_t)std::min<int64_t>((n_iv + 3) / 4, 256 * 8);
@@ -2435,7 +2436,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemcpyAsync(ctx->pin_meta.p, ctx->dp_sp.p, (size_t)n_iv * 8, hipMemcpyDeviceToHost, ctx->stream));   // (the meta records were read above)
         }
-        HIPCHK(ctx, hipMemcpyAsync(cols, ctx->dp_cols.p, (size_t)tc * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (cols) HIPCHK(ctx, hipMemcpyAsync(cols, ctx->dp_cols.p, (size_t)tc * 4, hipMemcpyDeviceToHost, ctx->stream));     // (null: they stay in dp_cols for dp_fetch_picked)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (sp && nseq >= 2) memcpy(sp, ctx->pin_meta.p, (size_t)n_iv * 8);
     }
@@ -2775,6 +2776,44 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     }
     if (trace) fprintf(stderr, "[trace] dp (device front): %u intervals (%lld workgroup, %lld one-wave, %lld two/wave, %lld four/wave), %d round(s); gaps+slots %.3f ms, sizing+order %.3f, kernels+offsets %.3f, columns %.3f\n",
                        n_dp, (long long)n_big, (long long)cl.n_med, (long long)cl.n_s32, (long long)cl.n_s16, rounds, t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
+    return MAUVE_OK;
+}
+
+// columns of picked intervals of the last dp_core batch, one behind the other: a wave per pick
+__global__ void __launch_bounds__(256) dp_pick_cols(const uint32_t *__restrict__ cols, const int64_t *__restrict__ col_off, const int64_t *__restrict__ pick,
+                                                    const int64_t *__restrict__ out_off, int64_t n_pick, uint32_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t q = wave; q < n_pick; q += nw) {
+        const int64_t iv = pick[q], a = col_off[iv], n = col_off[iv + 1] - a, o = out_off[q];
+        for (int64_t c = lane; c < n; c += 64) out[o + c] = cols[a + c];
+    }
+}
+
+// The columns of n_pick intervals of the batch dp_core has just run with cols == nullptr (their ids, ascending or not), compacted on the device and
+// copied out in pick order; col_off: the batch's host offsets (lengths), out_off[n_pick + 1]: where each pick's columns start in `out`.
+int dp_fetch_picked(mauve_ctx *ctx, int64_t n_pick, const int64_t *pick, const int64_t *col_off, uint32_t *out, int64_t *out_off)
+{
+    out_off[0] = 0;
+    for (int64_t q = 0; q < n_pick; q++) {
+        if (pick[q] < 0 || pick[q] >= ctx->dp_last_n) { ctx->err = "dp_fetch_picked: interval outside the last batch"; return MAUVE_ERR_ARG; }
+        out_off[q + 1] = out_off[q] + (col_off[pick[q] + 1] - col_off[pick[q]]);
+    }
+    const int64_t total = out_off[n_pick];
+    if (!total) return MAUVE_OK;
+    HIPCHK(ctx, ctx->dp_pick.ensure((size_t)(2 * n_pick + 1) * 8 + (size_t)total * 4 + 64));
+    HIPCHK(ctx, ctx->pin_dp_in.ensure((size_t)(2 * n_pick + 1) * 8));
+    int64_t *hp = ctx->pin_dp_in.as<int64_t>();
+    memcpy(hp, pick, (size_t)n_pick * 8); memcpy(hp + n_pick, out_off, (size_t)(n_pick + 1) * 8);
+    int64_t *d_pick = ctx->dp_pick.as<int64_t>(), *d_off = d_pick + n_pick;
+    uint32_t *d_out = reinterpret_cast<uint32_t *>(d_off + n_pick + 1);
+    HIPCHK(ctx, hipMemcpyAsync(d_pick, hp, (size_t)(2 * n_pick + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(dp_pick_cols, dim3((uint32_t)std::min<int64_t>((n_pick + 3) / 4, 256 * 8)), dim3(256), 0, ctx->stream, ctx->dp_cols.as<uint32_t>(), ctx->dp_last_col_off, d_pick,
+                       d_off, n_pick, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, d_out, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return MAUVE_OK;
 }
 

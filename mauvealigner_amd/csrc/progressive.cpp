@@ -274,14 +274,17 @@ int prog_node(Prog &P, int node)
     c->dp_band_from = INT64_MAX;            // the progressive path splits long intervals instead
     const bool refine = p->refine_rounds > 0 && n >= 3 && n_dp > 0;
     std::vector<int64_t> dsp; if (refine) dsp.assign((size_t)n_dp + 1, 0);
-    rc = dp_batch_run_desc(c, n, n_dp, desc.data(), &p->scoring, dcols, dcol_off.data(), dscore.data(), &cells, true, refine ? dsp.data() : nullptr);   // (several contexts: the node's intervals are dealt out)
-    if (rc) return rc;
+    // DESIGN.md S13 (setRefinement): every interval of k >= 3 sequences is also aligned in the rotated orders r = 1 .. min(rounds, k-1) and keeps the
+    // alignment whose sum-of-pairs score (dp_sp_scores) is highest, lowest rotation on ties.  A candidate's slots hold the rotated sequences, so its
+    // column bits are slots of the rotation.  The candidates do not depend on the first alignment, only the choice does: ONE batch holds the
+    // intervals and all their candidates (one sizing pass, one launch with more to balance), the columns stay on the device, the scores come back,
+    // and only the winners' columns are compacted and copied out (dp_fetch_picked) -- at C4's root 57 k candidates of 29 k intervals, 1 k of them win.
+    // Several contexts (mauve_set_shard) keep the two exchanged batches.
+    struct Cand { int64_t iv; int r, k; int nz[MAUVE_MAX_SEQ]; };
+    std::vector<Cand> cands;
     if (refine) {
-        // DESIGN.md S13 (setRefinement): every interval of k >= 3 sequences is aligned again in the rotated orders r = 1 .. min(rounds, k-1)
-        // -- ONE more batch with all candidates -- and keeps the alignment whose sum-of-pairs score (dp_sp_scores) is highest, lowest
-        // rotation on ties.  A candidate's slots hold the rotated sequences, so its column bits are slots of the rotation.
-        struct Cand { int64_t iv; int r, k; int nz[MAUVE_MAX_SEQ]; };
-        std::vector<Cand> cands; std::vector<DpSeqDesc> cdesc; int64_t ccodes = 0;
+        int64_t ccodes = 0;
+        std::vector<DpSeqDesc> &all = c->prog_desc; all.assign(desc.begin(), desc.end());
         for (int64_t iv = 0; iv < n_dp; iv++) {
             Cand cd; cd.iv = iv; cd.k = 0;
             int64_t tot = 0;
@@ -292,47 +295,78 @@ int prog_node(Prog &P, int node)
                 for (int j = 0; j < n; j++) {
                     DpSeqDesc d; d.genome = gm[0]; d.rev = 0; d.lo0 = 0; d.len = 0;
                     if (j < cd.k) d = desc[(size_t)(iv * n + cd.nz[(j + r) % cd.k])];
-                    cdesc.push_back(d);
+                    all.push_back(d);
                 }
                 ccodes += tot;
             }
         }
-        const int64_t nc = (int64_t)cands.size();
-        if (nc) {
-            std::vector<uint32_t> ccols((size_t)ccodes + 1);
-            std::vector<int64_t> ccol_off((size_t)nc + 1, 0), cscore((size_t)nc + 1, 0), csp((size_t)nc + 1, 0);
-            int64_t cells2 = 0;
-            rc = dp_batch_run_desc(c, n, nc, cdesc.data(), &p->scoring, ccols.data(), ccol_off.data(), cscore.data(), &cells2, true, csp.data());
+        const int64_t nc = (int64_t)cands.size(), na = n_dp + nc;
+        const bool one_batch = c->shard_world <= 1;
+        std::vector<int64_t> aoff((size_t)na + 1, 0), ascore((size_t)na + 1, 0), asp((size_t)na + 1, 0);
+        std::vector<uint32_t> ccols;                             // (the exchanged form only)
+        if (one_batch) {
+            rc = dp_batch_run_desc(c, n, na, all.data(), &p->scoring, nullptr, aoff.data(), ascore.data(), &cells, false, asp.data());
             if (rc) return rc;
-            cells += cells2;
-            std::vector<int64_t> pick((size_t)n_dp, -1);
-            int64_t replaced = 0;
-            for (int64_t q = 0; q < nc; q++) {                 // candidates of an interval are consecutive, rotations ascending
-                const int64_t iv = cands[(size_t)q].iv;
-                if (csp[(size_t)q] > dsp[(size_t)iv]) { dsp[(size_t)iv] = csp[(size_t)q]; replaced += pick[(size_t)iv] < 0; pick[(size_t)iv] = q; }
+        } else {
+            rc = dp_batch_run_desc(c, n, n_dp, all.data(), &p->scoring, dcols, aoff.data(), ascore.data(), &cells, true, asp.data());
+            if (rc) return rc;
+            if (nc) {
+                ccols.resize((size_t)ccodes + 1);
+                std::vector<int64_t> coff((size_t)nc + 1, 0);
+                int64_t cells2 = 0;
+                rc = dp_batch_run_desc(c, n, nc, all.data() + (size_t)n_dp * n, &p->scoring, ccols.data(), coff.data(), ascore.data() + n_dp, &cells2, true, asp.data() + n_dp);
+                if (rc) return rc;
+                cells += cells2;
+                for (int64_t q = 0; q <= nc; q++) aoff[(size_t)(n_dp + q)] = aoff[(size_t)n_dp] + coff[(size_t)q];
             }
+        }
+        std::vector<int64_t> pick((size_t)n_dp);                // the batch entry whose alignment the interval keeps
+        int64_t replaced = 0;
+        for (int64_t iv = 0; iv < n_dp; iv++) { pick[(size_t)iv] = iv; dsp[(size_t)iv] = asp[(size_t)iv]; }
+        for (int64_t q = 0; q < nc; q++) {                     // candidates of an interval are consecutive, rotations ascending
+            const int64_t iv = cands[(size_t)q].iv;
+            if (asp[(size_t)(n_dp + q)] > dsp[(size_t)iv]) { dsp[(size_t)iv] = asp[(size_t)(n_dp + q)]; replaced += pick[(size_t)iv] == iv; pick[(size_t)iv] = n_dp + q; }
+        }
+        if (one_batch) {
+            rc = dp_fetch_picked(c, n_dp, pick.data(), aoff.data(), dcols, dcol_off.data());
+            if (rc) return rc;
+        } else {
+            // (the originals are in dcols already; winners' columns are spliced in below)
+            std::copy(aoff.begin(), aoff.begin() + n_dp + 1, dcol_off.begin());
             if (replaced) {
                 std::vector<uint32_t> ncols; ncols.reserve((size_t)dcol_off[(size_t)n_dp]);
                 std::vector<int64_t> noff((size_t)n_dp + 1, 0);
                 for (int64_t iv = 0; iv < n_dp; iv++) {
                     noff[(size_t)iv] = (int64_t)ncols.size();
                     const int64_t q = pick[(size_t)iv];
-                    if (q < 0) { ncols.insert(ncols.end(), dcols + dcol_off[(size_t)iv], dcols + dcol_off[(size_t)iv + 1]); continue; }
-                    const Cand &cd = cands[(size_t)q];
-                    for (int64_t k = ccol_off[(size_t)q]; k < ccol_off[(size_t)q + 1]; k++) {
-                        const uint32_t mc = ccols[(size_t)k]; uint32_t o = 0;
-                        for (int j = 0; j < cd.k; j++) if (mc >> j & 1u) o |= 1u << cd.nz[(j + cd.r) % cd.k];
-                        ncols.push_back(o);
-                    }
-                    dscore[(size_t)iv] = cscore[(size_t)q];
+                    if (q == iv) ncols.insert(ncols.end(), dcols + dcol_off[(size_t)iv], dcols + dcol_off[(size_t)iv + 1]);
+                    else ncols.insert(ncols.end(), ccols.data() + (aoff[(size_t)q] - aoff[(size_t)n_dp]), ccols.data() + (aoff[(size_t)q + 1] - aoff[(size_t)n_dp]));
                 }
                 noff[(size_t)n_dp] = (int64_t)ncols.size();
                 if ((int64_t)ncols.size() > code_total) { c->err = "refinement: more columns than bases"; return MAUVE_ERR_STATE; }
                 memcpy(dcols, ncols.data(), ncols.size() * sizeof(uint32_t));
                 dcol_off.swap(noff);
             }
-            if (trace) fprintf(stderr, "[trace] node %d: refinement: %lld candidate alignments of %lld intervals, %lld replaced\n", node, (long long)nc, (long long)n_dp, (long long)replaced);
         }
+        if (dcol_off[(size_t)n_dp] > code_total) { c->err = "refinement: more columns than bases"; return MAUVE_ERR_STATE; }
+        // winners that are rotations: their column bits are slots of the rotation -> the node's slots
+        for (int64_t iv = 0; iv < n_dp; iv++) {
+            const int64_t q = pick[(size_t)iv];
+            dscore[(size_t)iv] = ascore[(size_t)q];
+            if (q == iv) continue;
+            const Cand &cd = cands[(size_t)(q - n_dp)];
+            uint32_t map[MAUVE_MAX_SEQ];
+            for (int j = 0; j < cd.k; j++) map[j] = 1u << cd.nz[(j + cd.r) % cd.k];
+            for (int64_t k = dcol_off[(size_t)iv]; k < dcol_off[(size_t)iv + 1]; k++) {
+                const uint32_t mc = dcols[(size_t)k]; uint32_t o = 0;
+                for (int j = 0; j < cd.k; j++) if (mc >> j & 1u) o |= map[j];
+                dcols[(size_t)k] = o;
+            }
+        }
+        if (trace) fprintf(stderr, "[trace] node %d: refinement: %lld candidate alignments of %lld intervals, %lld replaced\n", node, (long long)nc, (long long)n_dp, (long long)replaced);
+    } else {
+        rc = dp_batch_run_desc(c, n, n_dp, desc.data(), &p->scoring, dcols, dcol_off.data(), dscore.data(), &cells, true, nullptr);   // (several contexts: the node's intervals are dealt out)
+        if (rc) return rc;
     }
     P.n_gap_dp += n_dp; P.n_cells += cells;
     { const double tn4 = now_ms(); P.t_seed += tn1 - tn0; P.t_chain += tn2 - tn1; P.t_rec += tn3 - tn2; P.t_dp += tn4 - tn3; }
