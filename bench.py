@@ -163,7 +163,7 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
-def committed_traffic(kernel):
+def committed_traffic(kernel, config="C3"):
     """roofline.traffic: HBM bytes per launch from the committed PMC passes (profiles/roofline_traffic.json, made by
     tools/summarize_profile.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command).  The file carries the
     digest of the kernel sources it was measured on; when the sources have changed since, the figure is dropped (null)
@@ -174,6 +174,10 @@ def committed_traffic(kernel):
             t = json.load(f)
     except Exception:
         return None, "no committed PMC profile"
+    if config != "C3":
+        t = t.get("_configs", {}).get(config, {})
+        if not t:
+            return None, "no committed PMC profile of %s" % config
     meta = t.get("_meta", {})
     if meta.get("kernel_source_digest") != kernel_source_digest():
         return None, "committed PMC profile (%s) predates the current kernel sources" % meta.get("round", "?")
@@ -194,7 +198,8 @@ def kernel_profile(rn, weight, nprof=3, params=None):
     kernels = ctx.profile_get()
     tot_b, per_kernel, K, R = algorithmic_bytes_per_position(weight)
     timed = [k for k in kernels if kernels[k]["launches"]]
-    overall = max(timed, key=lambda k: kernels[k]["ms"])
+    # the dominant kernel of a pass: the one kernel with the most time in it (canon_sort / misc_sort are classes of ~20 small launches, not kernels)
+    overall = max((k for k in timed if k not in ("canon_sort", "misc_sort")), key=lambda k: kernels[k]["ms"])
     hbm_kernels = [k for k in timed if per_kernel.get(k)]
     dom = max(hbm_kernels, key=lambda k: kernels[k]["ms"])
     d = kernels[dom]
@@ -202,13 +207,29 @@ def kernel_profile(rn, weight, nprof=3, params=None):
     units = d["units"] / d["launches"]
     bpp = per_kernel[dom]
     achieved = bpp * units / (avg_ms * 1e-3) / 1e9
-    traffic, tnote = committed_traffic(dom) if rn.name == "C3" else (None, "PMC passes are collected on the C3 command only")
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tnote,
-                "algorithmic_bytes_per_launch": bpp * units, "avg_launch_ms": round(avg_ms, 4),
-                "launches_timed": d["launches"],
-                "dominant_overall": {"kernel": overall, "ms_per_pass": round(kernels[overall]["ms"] / nprof, 4),
-                                     "bound": "hbm" if per_kernel.get(overall) else "valu/shuffle (no HBM or MFMA roofline applies)"}}
+    traffic, tnote = committed_traffic(dom, rn.name)
+    hbm = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tnote,
+           "algorithmic_bytes_per_launch": bpp * units, "avg_launch_ms": round(avg_ms, 4), "launches_timed": d["launches"]}
+    dp_ms = kernels["dp_step"]["ms"] / nprof
+    cells = sizes["n_dp_cells"]
+    dp_traffic, dp_tnote = committed_traffic("dp_step2", rn.name)
+    dp = {"bound": "valu", "kernel": "dp_step (dp_step2 + dp_step_wide side by side)", "cells": cells, "kernel_ms": round(dp_ms, 4),
+          "achieved": round(cells / (dp_ms * 1e-3) / 1e9, 2) if dp_ms else None, "peak": round(DP_PEAK_GCUPS, 1), "unit": "GCUPS",
+          "frac": round(cells / (dp_ms * 1e-3) / 1e9 / DP_PEAK_GCUPS, 4) if dp_ms else None,
+          "peak_note": "256 CUs x 64 lanes x 2.4 GHz / 12 integer operations per cell (SURVEY.md 8d): no HBM or MFMA roofline applies to the gapped DP",
+          "traffic": dp_traffic, "traffic_source": dp_tnote, "launches_timed": kernels["dp_step"]["launches"]}
+    dp["gcups"] = dp["achieved"]; dp["peak_gcups"] = dp["peak"]
+    # the line's roofline object describes the DOMINANT kernel of the pass, whatever bounds it; the dominant HBM kernel and the DP ride beside it
+    roofline = dict(dp if overall == "dp_step" else (hbm if overall == dom else
+                    {"bound": "hbm" if per_kernel.get(overall) else "latency (gather / look-back: no HBM or MFMA roofline applies)", "kernel": overall,
+                     "achieved": round(per_kernel.get(overall, 0.0) * kernels[overall]["units"] / kernels[overall]["ms"] / 1e6, 1) if per_kernel.get(overall) else None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(per_kernel.get(overall, 0.0) * kernels[overall]["units"] / kernels[overall]["ms"] / 1e6 / HBM_PEAK_GBS, 4) if per_kernel.get(overall) else None,
+                     "traffic": committed_traffic(overall, rn.name)[0]}))
+    roofline["dominant_by"] = "kernel time per pass (HIP events): %s %.4f ms" % (overall, kernels[overall]["ms"] / nprof)
+    roofline["hbm_kernel"] = hbm
+    roofline["dp"] = dp
     seed_k = ["seed_extract", "rs_hist", "rs_rowscan", "rs_scatter", "mum_join"]
     seed_ms = sum(kernels[k]["ms"] for k in seed_k) / nprof
     P = kernels["seed_extract"]["units"] / nprof                     # positions of all seed passes of one step
@@ -222,12 +243,6 @@ def kernel_profile(rn, weight, nprof=3, params=None):
                              "sort_passes_run": kernels["rs_scatter"]["launches"] // nprof,
                              "note": "B_seed is SURVEY 8(d)'s figure for a full LSD sort of ceil(2w/8) passes; the N-way seed pass "
                                      "sorts the high mer bits only and joins through an LDS hash table (DESIGN.md section 4)"}
-    dp_ms = kernels["dp_step"]["ms"] / nprof
-    cells = sizes["n_dp_cells"]
-    roofline["dp"] = {"bound": "valu", "cells": cells, "kernel_ms": round(dp_ms, 4),
-                      "gcups": round(cells / (dp_ms * 1e-3) / 1e9, 2) if dp_ms else None,
-                      "peak_gcups": round(DP_PEAK_GCUPS, 1),
-                      "frac": round(cells / (dp_ms * 1e-3) / 1e9 / DP_PEAK_GCUPS, 4) if dp_ms else None}
     kern_ms = {k: round(v["ms"] / nprof, 4) for k, v in kernels.items()}
     return roofline, kern_ms
 
@@ -264,13 +279,14 @@ def cpu_baseline(name, scale, weight, gpu_result, genomes, sample_scale):
     return cpu
 
 
-def all_cores_baseline(config, scale, weight):
-    """the same baseline on every core this process may use: independent copies of the workload (the path has no intra-job CPU
-    parallelism to offer; throughput adds up), at 1/5 size so that the memory of all copies fits"""
+def all_cores_baseline(config, scale, weight, wscale_rel=0.2):
+    """the same baseline on every core this process may use: independent copies of the workload (the oracle is single-threaded like the reference's
+    default build, and the reference's optional OpenMP build parallelises over the same independent units -- LCB intervals -- so throughput of
+    independent copies is its upper bound), at a fraction of the size so that the memory of all copies fits"""
     import subprocess
     try:
         ncore = max(1, len(os.sched_getaffinity(0)))
-        wscale = 0.2 * scale
+        wscale = wscale_rel * scale
         ws = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", config, str(wscale), str(weight)], cwd=ROOT,
                                stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for _ in range(ncore)]
         for w in ws:
@@ -340,6 +356,8 @@ def secondary_leg(ctx, name, scale, steps, warmup, barrier, cpu_sample):
            "stages_ms": stages, "kernels_ms": kern, "roofline": roof, "result_sizes": sizes, "generate_s": round(tgen, 1)}
     if cpu_sample:
         out["cpu_baseline"] = cpu_baseline(name, scale, weight, gpu_result, genomes, cpu_sample)
+        if name in ("C4", "C5"):           # every host core: independent copies of the workload at a size whose copies fit the memory together
+            out["cpu_baseline"]["all_cores"] = all_cores_baseline(name, scale, weight if cfg["weight"] else 0, 0.1 if name == "C4" else 0.01)
     if rn.progressive:
         # last round's option set (length-weighted LCBs, no weight scaling, no refinement) as a named extra, never the leg's value
         from mauvealigner_amd import _lib
@@ -501,8 +519,7 @@ def main():
     if side and not args.no_cpu_baseline:
         sample = 1.0 if args.config in ("C2", "C3", "C4") else 0.1
         cpu = cpu_baseline(args.config, args.scale, weight, gpu_result, genomes, sample)
-        if cfg["path"] == "align" and args.config != "C5":
-            cpu["all_cores"] = all_cores_baseline(args.config, args.scale, weight)
+        cpu["all_cores"] = all_cores_baseline(args.config, args.scale, weight if cfg["weight"] else 0, 0.2 if args.config != "C5" else 0.01)
 
     # ---- the other BASELINE configs ----
     legs = {}

@@ -2088,33 +2088,51 @@ __global__ void __launch_bounds__(256) dp_gather(int nseq, int64_t n_iv, const i
     }
 }
 
-// DESIGN.md S13 (refinement objective): sum-of-pairs score of every interval's columns.  One thread per (interval, pair of
-// sequence slots): it walks the interval's columns once -- both -> substitution score, a run of one-sided columns -> open +
-// extends -- and adds its pair's sum to the interval's total.  The threads of an interval read the same column words.
+// DESIGN.md S13 (refinement objective): sum-of-pairs score of every interval's columns.  One WAVE per interval: for every pair of its non-empty
+// sequence slots it goes over the columns 64 at a time -- two ballots give the pair's presence masks, a lane finds its bases by prefix
+// popcounts and the state of the previous column that holds one of the two (the gap rule: open for the first column of a one-sided run, extend
+// for the others; columns that hold neither are skipped) by one bit scan below itself.  (One thread per (interval, pair) walking the
+// columns one dependent load after the other took 4 ms for the 6.7 kb intervals of C4's root; the 28 pairs re-read the column words from L1.)
 __global__ void __launch_bounds__(256) dp_sp_scores(int nseq, int64_t n_iv, const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
                                                     const uint32_t *__restrict__ cols, const int64_t *__restrict__ col_off, DpScoring sc,
                                                     unsigned long long *__restrict__ out)
 {
-    const int npair = nseq * (nseq - 1) / 2;
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_iv * npair) return;
-    const int64_t iv = t / npair; int q = (int)(t % npair);
-    int a = 0; while (q >= nseq - 1 - a) { q -= nseq - 1 - a; a++; }
-    const int b = a + 1 + q;
-    const int64_t oa = seq_off[iv * nseq + a], ob = seq_off[iv * nseq + b];
-    if (seq_off[iv * nseq + a + 1] == oa || seq_off[iv * nseq + b + 1] == ob) return;
-    const uint8_t *sa = codes + oa, *sb = codes + ob;
-    const int64_t c0 = col_off[iv], c1 = col_off[iv + 1];
-    int64_t total = 0; int prev = 0;
-    for (int64_t c = c0; c < c1; c++) {
-        const uint32_t m = cols[c];
-        const uint32_t ha = m >> a & 1u, hb = m >> b & 1u;
-        if (ha & hb) { total += sc.s[*sa & 3][*sb & 3]; prev = 0; }
-        else if (ha) { total += prev == 1 ? sc.ge : sc.go; prev = 1; }
-        else if (hb) { total += prev == 2 ? sc.ge : sc.go; prev = 2; }
-        sa += ha; sb += hb;
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t iv = wave; iv < n_iv; iv += nw) {
+        const int64_t c0 = col_off[iv], c1 = col_off[iv + 1];
+        uint32_t have = 0;
+        for (int g = 0; g < nseq; g++) if (seq_off[iv * nseq + g + 1] > seq_off[iv * nseq + g]) have |= 1u << g;
+        int64_t total = 0;
+        for (int a = 0; a < nseq; a++) {
+            if (!(have >> a & 1u)) continue;
+            for (int b = a + 1; b < nseq; b++) {
+                if (!(have >> b & 1u)) continue;
+                const uint8_t *sa = codes + seq_off[iv * nseq + a], *sb = codes + seq_off[iv * nseq + b];
+                int64_t na = 0, nb = 0; int prev = 0;                      // bases consumed so far; 1 / 2: the last column that held one of the two held only a / only b
+                for (int64_t cb = c0; cb < c1; cb += 64) {
+                    const int64_t c = cb + lane;
+                    const uint32_t m = c < c1 ? cols[c] : 0u;
+                    const uint64_t A = __ballot(m >> a & 1u), B = __ballot(m >> b & 1u);
+                    const uint64_t rel = A | B, oa = A & ~B, ob = B & ~A;
+                    const bool ha = (A >> lane) & 1ULL, hb = (B >> lane) & 1ULL;
+                    if (ha | hb) {
+                        int pv = prev;                                     // state in front of this lane's column
+                        const uint64_t below = rel & lt;
+                        if (below) { const int pbit = 63 - __clzll((long long)below); pv = (oa >> pbit & 1ULL) ? 1 : ((ob >> pbit & 1ULL) ? 2 : 0); }
+                        if (ha & hb) total += sc.s[sa[na + __popcll(A & lt)] & 3][sb[nb + __popcll(B & lt)] & 3];
+                        else if (ha) total += pv == 1 ? sc.ge : sc.go;
+                        else total += pv == 2 ? sc.ge : sc.go;
+                    }
+                    if (rel) { const int pbit = 63 - __clzll((long long)rel); prev = (oa >> pbit & 1ULL) ? 1 : ((ob >> pbit & 1ULL) ? 2 : 0); }
+                    na += __popcll(A); nb += __popcll(B);
+                }
+            }
+        }
+        for (int o = 32; o; o >>= 1) total += __shfl_xor(total, o);
+        if (lane == 0) out[iv] = (unsigned long long)total;
     }
-    atomicAdd(&out[iv], (unsigned long long)total);
 }
 
 // bases of the interval sequences, gathered on the device from the resident packed genomes:
@@ -2430,8 +2448,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
         if (sp && nseq >= 2) {                  // the refinement's objective, from the columns while they are here
             HIPCHK(ctx, ctx->dp_sp.ensure((size_t)n_iv * 8 + 64));
             HIPCHK(ctx, hipMemsetAsync(ctx->dp_sp.p, 0, (size_t)n_iv * 8, ctx->stream));
-            const int64_t nthreads = n_iv * (nseq * (nseq - 1) / 2);
-            hipLaunchKernelGGL(dp_sp_scores, dim3((uint32_t)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream, nseq, n_iv, ctx->dp_codes.as<uint8_t>(), d_seq_off,
+            hipLaunchKernelGGL(dp_sp_scores, dim3((uint32_t)std::min<int64_t>((n_iv + 3) / 4, 256 * 16)), dim3(256), 0, ctx->stream, nseq, n_iv, ctx->dp_codes.as<uint8_t>(), d_seq_off,
                                ctx->dp_cols.as<uint32_t>(), d_col_off, sc, ctx->dp_sp.as<unsigned long long>());
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemcpyAsync(ctx->pin_meta.p, ctx->dp_sp.p, (size_t)n_iv * 8, hipMemcpyDeviceToHost, ctx->stream));   // (the meta records were read above)

@@ -319,8 +319,13 @@ int extend_lcbs_device(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
             uw[(size_t)T.n + i] = ext.len(i) * N;
         }
         host_lcb_chain(U, lcbw, p->collinear != 0, ul, nl2, nullptr, uw.data());
+        static const bool force_decline = getenv("MAUVE_EXT_DECLINE") != nullptr;      // test knob: hand the first round that finds matches back as if an LCB had died
         for (int64_t l = 0; l < T.n; l++)
-            if (ul[(size_t)l] < 0) { restore(); c->err = "lcb extension: an LCB fell below the minimum weight while being extended"; return MAUVE_ERR_STATE; }
+            if (ul[(size_t)l] < 0 || force_decline) {
+                // an old LCB died in the re-chaining of the units (--collinear, which goes down to ONE LCB, is kept off this route; anything else that
+                // gets here is handed back the same way): the caller takes the match-level rounds on the host, which make no such assumption
+                restore(); c->err = "lcb extension: an LCB fell below the minimum weight while being extended"; return MAUVE_ERR_LIMIT;
+            }
         bool grew = false;
         for (size_t i = 0; i < ext.size() && !grew; i++) grew = ul[(size_t)T.n + i] >= 0;
         if (trace) fprintf(stderr, "[trace] lcb extension (device) round %d: units %.3f ms, %lld -> %lld LCBs, %s\n", iter, now_ms() - tr2, (long long)T.n, (long long)nl2,

@@ -383,13 +383,18 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
                 if (rc) return rc;
                 const uint32_t cap = (uint32_t)c->dev_rec_n;
                 S.dv_len = c->ch_anch.as<int32_t>(); S.dv_st = S.dv_len + cap; S.dv_lcb = S.dv_st + (size_t)cap * N;
+                bool ext_declined = false;
                 if (do_extend && na >= 1) {
                     std::vector<int64_t> lw;
                     rc = extend_lcbs_device(c, p, w, lcbw, N, &S.dv_len, &S.dv_st, &S.dv_lcb, &na, &nl, &nrec, lw);
-                    if (rc) return rc;
-                    R.lcb_weight.swap(lw); S.lw_from_host = true;
+                    // MAUVE_ERR_LIMIT: the unit-level rounds met a case they do not cover (an old LCB would die) and have put everything back: the
+                    // chains go to the host as after any other device chain and the match-level rounds run there (extend_lcbs below)
+                    if (rc == MAUVE_ERR_LIMIT) { ext_declined = true; rc = MAUVE_OK; c->err.clear(); }
+                    else if (rc) return rc;
+                    else { R.lcb_weight.swap(lw); S.lw_from_host = true; }
                 }
-                if (na >= 2 && (!p->recursive || nrec == 0)) {
+                if (ext_declined) { S.dv_len = S.dv_st = S.dv_lcb = nullptr; }
+                else if (na >= 2 && (!p->recursive || nrec == 0)) {
                     S.nl = nl; S.n_anchor = na; S.dev_tail = true;
                     const double t2 = now_ms();
                     c->stage.chain_ms = t2 - t1;
@@ -398,7 +403,7 @@ static int align_begin(mauve_ctx *c, const mauve_params *p, bool device_front = 
                     S.open = true;
                     return MAUVE_OK;
                 }
-                if (do_extend) {
+                if (do_extend && !ext_declined) {
                     // the extension is done; what follows (recursion) wants the chains on the host: the anchors come over as they are
                     const size_t rb = (size_t)na * (2 + (size_t)N) * 4;
                     HIPCHK(c, c->pin_chain.ensure(256 + rb + (size_t)na + 64));

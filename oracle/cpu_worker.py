@@ -1,6 +1,6 @@
 """One CPU-baseline worker: aligns a synthetic config with the oracle and prints the seconds it took.
 Test infrastructure (bench.py's cpu_baseline leg starts several of these to measure the all-cores figure);
-never imported by the product.  usage: python -m oracle.cpu_worker <config> <scale> <seed_weight>"""
+never imported by the product.  usage: python -m oracle.cpu_worker <config> <scale> <seed_weight; 0 = the default weight>"""
 import sys
 import time
 
@@ -13,7 +13,11 @@ def main():
     print("ready", flush=True)
     sys.stdin.readline()                       # start line: all workers begin together
     t0 = time.perf_counter()
-    O.align(gs, O.default_params(seed_weight=weight))
+    kw = dict(seed_weight=weight) if weight > 0 else {}
+    if cfg == "C4":                            # the progressiveMauve path at its call site's defaults (bench.py: params_for)
+        O.progressive_align(gs, O.default_progressive_params(**kw))
+    else:
+        O.align(gs, O.default_params(**kw))
     print("%.6f %d" % (time.perf_counter() - t0, sum(len(g) for g in gs)), flush=True)
 
 

@@ -1093,6 +1093,55 @@ def test_dp_wide_sweeps():
         assert r.returncode == 0 and r.stdout.strip().endswith("OK"), str(extra) + "\n" + r.stdout + r.stderr[-3000:]
 
 
+
+GUARD_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from mauvealigner_amd import _lib, synth
+from oracle import pyoracle as O
+what = sys.argv[1]
+ctx = _lib.Context(0)
+if what == "cand":            # a candidate list deliberately too small: the kernel skips the stores past its end, the host refuses the list
+    gs = synth.star_genomes(3, 60_000, 0.03, 9)
+    ctx.set_genomes(gs)
+    try:
+        ctx.seed_mums(O.get_seed(11, 0), mode=0, mask=0)
+        print("NO ERROR")
+    except RuntimeError as e:
+        print("OK" if "(-4)" in str(e) and "candidates for a list" in str(e) else "WRONG: %%s" %% e)
+elif what == "runs":          # ... the run list of the pairwise finder
+    gs = synth.star_genomes(4, 40_000, 0.03, 10)
+    ctx.set_genomes(gs)
+    try:
+        ctx.guide_tree(O.get_seed(11, 0))
+        print("NO ERROR")
+    except RuntimeError as e:
+        print("OK" if "(-4)" in str(e) and "runs for a list" in str(e) else "WRONG: %%s" %% e)
+else:                         # the device extension hands a round back: the host rounds give the oracle's alignment
+    gs = synth.star_genomes(4, 1_500_000, 0.05, 78, inversions=12)
+    ctx.set_genomes(gs)
+    p = _lib.default_params(seed_weight=15)
+    r = ctx.align(p); e = O.align(gs, O.default_params(seed_weight=15))["aln"]
+    assert r["n_mums"] > 16384
+    for k in ("anchor_start", "anchor_length", "anchor_lcb", "left", "right", "reverse", "col_off", "cols", "dp_score"):
+        assert np.array_equal(r[k], e[k]), k
+    print("OK")
+"""
+
+
+def test_list_capacity_guards_and_extension_fallback():
+    """Every compaction store of the seed pass is bounded by the capacity of its list (the counter keeps counting, the host turns a list
+    that outgrew its buffer into MAUVE_ERR_LIMIT instead of a wild write): with MAUVE_LIST_CAP the candidate list and the pairwise
+    finder's run list are made too small on purpose.  And the device LCB extension, when it meets a round it does not cover, puts everything
+    back and the match-level rounds run on the host (MAUVE_EXT_DECLINE forces that hand-back): same alignment as the oracle."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for what, extra in (("cand", {"MAUVE_LIST_CAP": "50"}), ("runs", {"MAUVE_LIST_CAP": "50"}), ("ext", {"MAUVE_EXT_DECLINE": "1"})):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", GUARD_SCRIPT % {"root": root}, what], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), what + "\n" + r.stdout + r.stderr[-3000:]
+
+
 ORDER_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, %(root)r)

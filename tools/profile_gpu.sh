@@ -5,10 +5,11 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r02}
+CFG=${3:-C3}
 OUT=$R/gpurun_out/prof_$TAG
+if [ "$CFG" != "C3" ]; then OUT=$R/gpurun_out/prof_${TAG}_$CFG; fi
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CFG=${3:-C3}
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --config $CFG"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace_bench.json 2> $OUT/trace.err
 echo "trace done" >> $OUT/progress.log

@@ -11,7 +11,8 @@ pattern: the main sort's rs_hist launch reads exactly 4*P key bytes and writes a
 The radix-sort kernels run in two very different sizes in one pass of the hot path: the main sort of the P seed keys
 and ~20 small sorts (chaining, canonical order, DP launch list) of ~50 k entries that are launch-latency bound.  The
 two are kept apart here (by grid size; the small ones are tagged [small]) -- one average over both describes neither.
-Usage: python tools/summarize_profile.py <round-tag>   (e.g. r02)
+Usage: python tools/summarize_profile.py <round-tag> [C4|C5|C2]   (e.g. r04, r04 C5).  Without a config: the C3 command, written to
+profiles/<tag>_* and to the top level of profiles/roofline_traffic.json; with one: profiles/<tag>_<cfg>_* and the "_configs" section of that file.
 """
 import csv
 import glob
@@ -80,13 +81,16 @@ def read_pmc(src, sub, counters):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-    src = os.path.join(ROOT, "gpurun_out", "prof_%s" % tag)
+    cfg = sys.argv[2] if len(sys.argv) > 2 else "C3"
+    src = os.path.join(ROOT, "gpurun_out", "prof_%s" % tag if cfg == "C3" else "prof_%s_%s" % (tag, cfg))
+    if cfg != "C3":
+        tag = "%s_%s" % (tag, cfg.lower())
     os.makedirs(DST, exist_ok=True)
     stats = latest(src, "trace", "*kernel_stats.csv")
     trace = list(csv.DictReader(open(latest(src, "trace", "*kernel_trace.csv"))))
     with open(os.path.join(src, "trace_bench.json")) as f:
         bench = json.loads(f.read().strip().splitlines()[-1])
-    P = bench["roofline"]["seed_pass"]["positions"]
+    P = bench["roofline"]["seed_pass"]["positions"] / max(1, bench["roofline"]["seed_pass"].get("seed_passes_per_step", 1)) if cfg == "C4" else bench["roofline"]["seed_pass"]["positions"]
     mx = size_classes(trace, "Grid_Size_X")
     dur = {}
     for r in trace:
@@ -102,8 +106,8 @@ def main():
     traffic = {}
     lines = ["# rocprofv3 summary, round %s" % tag, "",
              "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
-             "--no-cpu-baseline --no-secondary` (%d passes of the hot path in the process: warmup, timed host-to-host, device-resident and HIP-event "
-             "legs, all over BASELINE config C3, 5 x 5 Mbp, w = 15, P = %d windows).  PMC "
+             "--no-cpu-baseline --no-secondary --config " + cfg + "` (%d passes of the hot path in the process: warmup, timed host-to-host, device-resident and HIP-event "
+             "legs, all over BASELINE config " + cfg + ": " + bench["config"]["workload"][:60] + " ..., P = %d windows per pass).  PMC "
              "passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and `--pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES "
              "SQ_WAIT_ANY`, separate runs (tools/profile_gpu.sh).  The raw `--stats` table is %s_kernel_stats.csv; the table "
              "below is built from the kernel trace of the same run so that the main sort and the ~20 small sorts per pass "
@@ -147,9 +151,23 @@ def main():
     except Exception:
         commit = "?"
     traffic["_meta"] = {"round": tag, "commit": commit, "kernel_source_digest": kernel_source_digest(),
-                        "command": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"}
-    with open(os.path.join(DST, "roofline_traffic.json"), "w") as f:
-        json.dump(traffic, f, indent=1, sort_keys=True)
+                        "command": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --config " + cfg}
+    tpath = os.path.join(DST, "roofline_traffic.json")
+    if cfg == "C3":
+        try:
+            keep = json.load(open(tpath)).get("_configs", {})        # the other configs' sections stay (each carries its own digest)
+        except Exception:
+            keep = {}
+        traffic["_configs"] = keep
+        out = traffic
+    else:
+        try:
+            out = json.load(open(tpath))
+        except Exception:
+            out = {}
+        out.setdefault("_configs", {})[cfg] = traffic
+    with open(tpath, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
     shutil.copy(stats, os.path.join(DST, "%s_kernel_stats.csv" % tag))
     for c, d in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
         with open(os.path.join(DST, "%s_%s_per_kernel.csv" % (tag, c.lower())), "w") as f:
