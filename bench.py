@@ -119,23 +119,25 @@ class Runner:
     def upload(self):
         self.ctx.set_genomes_packed(self.packed, self.lens)
 
-    def run(self, params=None, fetch=False, out=None):
+    def run(self, params=None, fetch=False, out=None, compact=False):
         p = params or self.params
         if self.progressive:
-            return self.ctx.progressive_align(p, fetch=fetch, out=out)
-        return self.ctx.align(p, fetch=fetch, out=out)
+            return self.ctx.progressive_align(p, fetch=fetch, out=out, compact=compact)
+        return self.ctx.align(p, fetch=fetch, out=out, compact=compact)
 
-    def step_host(self, params=None):                     # host RAM -> host RAM
+    def step_host(self, params=None, compact=True):       # host RAM -> host RAM
+        # every result array comes back, in the narrowest types that hold it (mauve_align_fetch_compact: a byte per column for up to 8 genomes, int32
+        # tables); compact=False: the int64 / uint32 arrays of mauve_align_fetch (reported beside `value` as `fetch_wide`)
         self.upload()
-        return self.run(params, fetch=True, out=self.bufs)
+        return self.run(params, fetch=True, out=self.bufs, compact=compact)
 
-    def time_host(self, steps, warmup, params=None):
+    def time_host(self, steps, warmup, params=None, compact=True):
         for _ in range(warmup):
-            self.step_host(params)
+            self.step_host(params, compact)
         self.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            r = self.step_host(params)
+            r = self.step_host(params, compact)
         self.barrier()
         return time.perf_counter() - t0, r
 
@@ -326,7 +328,8 @@ def option_set(params, progressive):
         o.update(lcb_scoring="sp" if params.lcb_scoring == 1 else "length", weight_scaling=int(params.weight_scaling),
                  conservation_scale_ppm=int(params.conservation_scale_ppm), bp_dist_scale_ppm=int(params.bp_dist_scale_ppm),
                  refine_rounds=int(params.refine_rounds), seed_family=int(params.seed_family),
-                 source="mauve_default_progressive_params (progressiveMauve.cpp:578-579,624-637)")
+                 source="mauve_default_progressive_params (progressiveMauve.cpp:578-579,624-637)" if params.lcb_scoring == 1 and params.refine_rounds == 2 and params.weight_scaling
+                 else "mauve_default_params: last round's option set, NOT the call site's defaults")
     else:
         o["source"] = "mauve_default_params (mauveAligner.cpp:92-99)"
     return o
@@ -344,11 +347,13 @@ def secondary_leg(ctx, name, scale, steps, warmup, barrier, cpu_sample):
     e_h, res = rn.time_host(steps, warmup)
     gpu_result = {k: np.array(v, copy=True) for k, v in res.items() if isinstance(v, np.ndarray)} if cpu_sample >= 1.0 else None
     e_r, stages, sizes = rn.time_resident(steps, 1)
+    e_w, _ = rn.time_host(max(2, steps // 2), 1, compact=False)
     roof, kern = kernel_profile(rn, weight, nprof=2)
     out = {"workload": cfg["text"] % L, "metric": "aligned Mbp/s (seed+extend+DP)", "value": round(rn.total_bp / 1e6 / (e_h / steps), 2), "unit": "Mbp/s",
            "ms_per_step": round(e_h / steps * 1e3, 3), "steps": steps,
-           "timed_region": "packed genomes in page-locked host RAM -> upload -> %s -> every result array in page-locked host RAM" %
+           "timed_region": "packed genomes in page-locked host RAM -> upload -> %s -> every result array in page-locked host RAM (mauve_align_fetch_compact)" %
                            ("mauve_progressive_align" if rn.progressive else "mauve_align"),
+           "fetch_wide": {"ms_per_step": round(e_w / max(2, steps // 2) * 1e3, 3), "note": "the same step with mauve_align_fetch (uint32 columns, int64 tables)"},
            "total_bp": rn.total_bp, "seed_weight": weight, "extend_lcbs": int(params.extend_lcbs),
            "config": option_set(params, rn.progressive),
            "device_resident": {"ms_per_step": round(e_r / steps * 1e3, 3), "Mbp_s": round(rn.total_bp / 1e6 / (e_r / steps), 2),
@@ -458,6 +463,10 @@ def main():
 
     roofline, kern_ms, extras, stages = None, {}, {}, {}
     if rank == 0 and not shard_lcb:
+        nw = max(3, args.steps // 2)
+        e_w, _ = rn.time_host(nw, 1, compact=False)
+        extras["fetch_wide"] = {"ms_per_step": round(e_w / nw * 1e3, 3), "Mbp_s": round(total_bp / 1e6 / (e_w / nw), 2),
+                                "note": "the same step with mauve_align_fetch (uint32 columns, int64 tables) instead of mauve_align_fetch_compact"}
         # ---- the same pass with the genomes resident in HBM and the results left there (a named extra, never `value`) ----
         e_r, stages, _ = rn.time_resident(args.steps, 1)
         extras["device_resident"] = {"ms_per_step": round(e_r / args.steps * 1e3, 3), "Mbp_s": round(total_bp / 1e6 / (e_r / args.steps), 2),
@@ -546,7 +555,7 @@ def main():
                        "genomes_per_gpu": cfg["n"], "genome_length": L, "seed_weight": weight, "parallelism": par,
                        "extend_lcbs": int(params.extend_lcbs), "max_extension_iters": int(params.max_extension_iters),
                        "options": option_set(params, cfg["path"] == "progressive"),
-                       "timed_region": "packed genomes in page-locked host RAM -> upload -> %s -> every result array in page-locked host RAM (SURVEY.md 8d)" %
+                       "timed_region": "packed genomes in page-locked host RAM -> upload -> %s -> every result array in page-locked host RAM, narrowest types (mauve_align_fetch_compact; SURVEY.md 8d)" %
                                        ("mauve_progressive_align" if cfg["path"] == "progressive" else "mauve_align")},
             "roofline": roofline, "cpu_baseline": cpu, "accuracy_vs_truth": acc,
             "stages_ms": stages, "kernels_ms": kern_ms, "result_sizes": sizes, "upload_ms": round(t_upload * 1e3, 2), "device": ctx.device_name(),

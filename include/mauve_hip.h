@@ -242,6 +242,17 @@ int mauve_align_fetch(mauve_ctx *ctx,
                       int64_t *anchor_length, int64_t *anchor_start, int64_t *anchor_lcb,
                       int64_t *iv_left, int64_t *iv_right, int8_t *iv_reverse,   /* [n_iv*nseq] */
                       int64_t *col_off, uint32_t *cols, int64_t *dp_score);     /* [n_iv+1],[n_cols],[n_iv] */
+/* The same result in the narrowest types that hold it (no reference counterpart: libMems hands out objects; this is what a caller that
+   wants the arrays moves).  cols: col_bytes bytes per column (1: up to 8 genomes, 2: up to 16, 4: any; MAUVE_ERR_ARG when a column does not
+   fit); match and anchor tables as int32 (a context holds fewer than 2^31 bases, so every start and length fits); the small per-LCB and
+   per-interval tables as in mauve_align_fetch.  From page-locked buffers (mauve_host_alloc) the bulk arrays are narrowed on the device and
+   copied once; any pointer may be NULL.  mauve_align_fetch is unchanged. */
+int mauve_align_fetch_compact(mauve_ctx *ctx, int col_bytes,
+                              int32_t *mum_length, int32_t *mum_start,
+                              int64_t *lcb_left, int64_t *lcb_right, int64_t *lcb_weight,
+                              int32_t *anchor_length, int32_t *anchor_start, int32_t *anchor_lcb,
+                              int64_t *iv_left, int64_t *iv_right, int8_t *iv_reverse,
+                              int64_t *col_off, void *cols, int64_t *dp_score);
 /* ---- the same path in three phases, for sharding the gapped alignment of ONE alignment over several GPUs
         (mauveAligner.cpp:130-131 --realign-lcb "for parallelization of LCB alignment").  Every rank
         calls mauve_align_begin (deterministic: identical anchors and interval table everywhere), aligns its

@@ -24,7 +24,7 @@ EXPORTS = [
     "mauve_default_params", "mauve_default_progressive_params", "mauve_packed_words", "mauve_pack_ascii", "mauve_pack_codes", "mauve_set_genomes", "mauve_set_genomes_contigs",
     "mauve_ambiguity_bitmap",
     "mauve_sorted_mer_list", "mauve_seed_mums", "mauve_get_matches", "mauve_extend_hits", "mauve_seed_match_enumerate",
-    "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_dp_batch_banded", "mauve_match_sp_scores", "mauve_align", "mauve_align_fetch",
+    "mauve_eliminate_overlaps", "mauve_lcb_chain", "mauve_dp_batch", "mauve_dp_batch_banded", "mauve_match_sp_scores", "mauve_align", "mauve_align_fetch", "mauve_align_fetch_compact",
     "mauve_align_matches", "mauve_align_lcbs", "mauve_align_begin", "mauve_align_begin_matches", "mauve_align_dp_anchors", "mauve_align_dp_cost", "mauve_align_dp", "mauve_align_finish",
     "mauve_guide_tree", "mauve_breakpoint_counts", "mauve_hmm_params_from", "mauve_apply_homology", "mauve_apply_homology_alignment", "mauve_progressive_align", "mauve_progressive_align_tree",
     "mauve_backbone", "mauve_backbone_alignment", "mauve_backbone_fetch", "mauve_merge_matches",
@@ -464,7 +464,7 @@ class Context:
                                                C.byref(sc), _p(out, C.c_int64)), "mauve_match_sp_scores")
         return out[:len(length)].copy()
 
-    def align(self, params=None, fetch=True, names=None, want_xmfa=False, out=None):
+    def align(self, params=None, fetch=True, names=None, want_xmfa=False, out=None, compact=False):
         """out: a ResultBuffers the result arrays are fetched into (reused from call to call; views)"""
         p = params or default_params()
         sz = AlignSizes()
@@ -472,9 +472,34 @@ class Context:
         res = {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
         if not fetch:
             return res
-        return self._fetch(sz, names, want_xmfa, out)
+        return self._fetch(sz, names, want_xmfa, out, compact)
 
-    def _fetch(self, sz, names=None, want_xmfa=False, bufs=None):
+    def _fetch_compact(self, sz, bufs=None):
+        """mauve_align_fetch_compact: columns in 1 / 2 / 4 bytes by the genome count, match and anchor tables as int32"""
+        N = self.nseq
+        out = {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
+        cb = 1 if N <= 8 else (2 if N <= 16 else 4)
+        cdt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[cb]
+        shapes = {
+            "mum_length": (sz.n_mums, np.int32), "mum_start": ((sz.n_mums, N), np.int32),
+            "lcb_left": ((sz.n_lcb, N), np.int64), "lcb_right": ((sz.n_lcb, N), np.int64), "lcb_weight": (sz.n_lcb, np.int64),
+            "anchor_length": (sz.n_anchor, np.int32), "anchor_start": ((sz.n_anchor, N), np.int32), "anchor_lcb": (sz.n_anchor, np.int32),
+            "left": ((sz.n_iv, N), np.int64), "right": ((sz.n_iv, N), np.int64), "reverse": ((sz.n_iv, N), np.int8),
+            "col_off": (sz.n_iv + 1, np.int64), "cols": (sz.n_cols, cdt), "dp_score": (sz.n_iv, np.int64),
+        }
+        a = {k: (np.zeros(sh, dt) if bufs is None else bufs.get("c_" + k, sh, dt)) for k, (sh, dt) in shapes.items()}
+        self.L.mauve_align_fetch_compact.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 14
+        vp = lambda x: x.ctypes.data_as(C.c_void_p)
+        self._chk(self.L.mauve_align_fetch_compact(self.h, cb, vp(a["mum_length"]), vp(a["mum_start"]), vp(a["lcb_left"]), vp(a["lcb_right"]), vp(a["lcb_weight"]),
+                                                   vp(a["anchor_length"]), vp(a["anchor_start"]), vp(a["anchor_lcb"]), vp(a["left"]), vp(a["right"]), vp(a["reverse"]),
+                                                   vp(a["col_off"]), vp(a["cols"]), vp(a["dp_score"])), "mauve_align_fetch_compact")
+        out.update(a)
+        out["col_bytes"] = cb
+        return out
+
+    def _fetch(self, sz, names=None, want_xmfa=False, bufs=None, compact=False):
+        if compact and not want_xmfa:
+            return self._fetch_compact(sz, bufs)
         N = self.nseq
         out = {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
         shapes = {
@@ -560,7 +585,7 @@ class Context:
         self._chk(self.L.mauve_breakpoint_counts(self.h, C.c_uint64(pattern), C.c_int64(min_len), _p(bp, C.c_int64)), "mauve_breakpoint_counts")
         return bp
 
-    def progressive_align(self, params=None, fetch=True, names=None, want_xmfa=False, tree=None, out=None):
+    def progressive_align(self, params=None, fetch=True, names=None, want_xmfa=False, tree=None, out=None, compact=False):
         """tree=(left, right): align along the caller's guide tree (mauve_progressive_align_tree).  out: ResultBuffers."""
         p = params or default_params()
         N = self.nseq
@@ -578,7 +603,7 @@ class Context:
                 raise ValueError("guide tree must have 2*nseq-1 nodes")
             self._chk(self.L.mauve_progressive_align_tree(self.h, C.byref(p), C.byref(sz), _p(left, C.c_int32),
                                                           _p(right, C.c_int32)), "mauve_progressive_align_tree")
-        res = self._fetch(sz, names, want_xmfa, out) if fetch else {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
+        res = self._fetch(sz, names, want_xmfa, out, compact) if fetch else {k: int(getattr(sz, k)) for k, _ in AlignSizes._fields_}
         res["tree"] = (left, right)
         res["dist"] = dist
         return res

@@ -395,6 +395,81 @@ bool fetch_tables_direct(mauve_ctx *c, int64_t *mum_length, int64_t *mum_start, 
     return true;                                              // (the stream is drained by the column copy that follows, or by the caller)
 }
 
+// ---- compact fetch (mauve_align_fetch_compact): the result in the narrowest types that hold it ----
+template <typename T>
+__global__ void __launch_bounds__(256) as_narrow_cols(const uint32_t *__restrict__ in, size_t n, T *__restrict__ out)
+{
+    // sixteen columns per thread: four 16-byte loads, one (u8) or two (u16) 16-byte stores
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i0 + 16 <= n) {
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = reinterpret_cast<const uint4 *>(in + i0)[q];
+        T o[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { o[4 * q] = (T)v[q].x; o[4 * q + 1] = (T)v[q].y; o[4 * q + 2] = (T)v[q].z; o[4 * q + 3] = (T)v[q].w; }
+        uint4 *dst = reinterpret_cast<uint4 *>(out + i0);
+#pragma unroll
+        for (int q = 0; q < (int)(sizeof(T) * 16 / 16); q++) dst[q] = reinterpret_cast<const uint4 *>(o)[q];
+    } else
+        for (size_t i = i0; i < n; i++) out[i] = (T)in[i];
+}
+__global__ void __launch_bounds__(256) as_narrow_i64(const int64_t *__restrict__ in, size_t n, int32_t *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (int32_t)in[i];
+}
+
+// The device-resident bulk of a result straight into page-locked caller buffers in compact form: the anchor table as the int32 arrays the chain
+// stage left (no widening), the match list narrowed to int32, the columns narrowed to col_bytes each.  Returns false when something is
+// not where this needs it (not pending on the device, a pageable buffer): the caller then converts the host copy.
+bool fetch_compact_direct(mauve_ctx *c, int col_bytes, int32_t *mum_length, int32_t *mum_start, int32_t *anchor_length, int32_t *anchor_start, int32_t *anchor_lcb,
+                          void *cols, bool *tables_done, bool *cols_done, int *rc_out)
+{
+    AlignResult &R = c->res;
+    *rc_out = MAUVE_OK; *tables_done = false; *cols_done = false;
+    auto chk = [&](hipError_t e) { if (e != hipSuccess && *rc_out == MAUVE_OK) { c->err = std::string("fetch_compact: ") + hipGetErrorString(e); *rc_out = MAUVE_ERR_HIP; } };
+    const int N = c->ast.N; const size_t na = R.dev_na, nm = R.dev_nm;
+    bool any = false;
+    if (R.dev_pending && mum_length && mum_start && anchor_length && anchor_start && anchor_lcb &&
+        (!nm || (host_pointer_is_pinned(mum_length) && host_pointer_is_pinned(mum_start))) &&
+        (!na || (host_pointer_is_pinned(anchor_length) && host_pointer_is_pinned(anchor_start) && host_pointer_is_pinned(anchor_lcb)))) {
+        chk(hipSetDevice(c->device));
+        if (na) {
+            chk(hipMemcpyAsync(anchor_length, R.dev_alen, na * 4, hipMemcpyDeviceToHost, c->stream));
+            chk(hipMemcpyAsync(anchor_start, R.dev_ast, na * N * 4, hipMemcpyDeviceToHost, c->stream));
+            chk(hipMemcpyAsync(anchor_lcb, R.dev_alcb, na * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        if (nm) {
+            const size_t n = nm * (1 + (size_t)N);
+            chk(c->as_wide.ensure(n * 4 + 64));
+            if (*rc_out) return true;
+            hipLaunchKernelGGL(as_narrow_i64, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->sorted_rec.as<int64_t>(), n, c->as_wide.as<int32_t>());
+            chk(hipGetLastError());
+            chk(hipMemcpyAsync(mum_length, c->as_wide.as<int32_t>(), nm * 4, hipMemcpyDeviceToHost, c->stream));
+            chk(hipMemcpyAsync(mum_start, c->as_wide.as<int32_t>() + nm, nm * N * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        *tables_done = true; any = true;
+    }
+    if (cols && R.n_cols && R.cols_pending && host_pointer_is_pinned(cols)) {
+        chk(hipSetDevice(c->device));
+        const size_t n = R.n_cols;
+        if (col_bytes == 4) chk(hipMemcpyAsync(cols, c->res_cols.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+        else {
+            chk(c->res_narrow.ensure(n * (size_t)col_bytes + 64));
+            if (*rc_out) return true;
+            const uint32_t blocks = (uint32_t)((n + 4095) / 4096);
+            if (col_bytes == 1) hipLaunchKernelGGL(as_narrow_cols<uint8_t>, dim3(blocks), dim3(256), 0, c->stream, c->res_cols.as<uint32_t>(), n, c->res_narrow.as<uint8_t>());
+            else hipLaunchKernelGGL(as_narrow_cols<uint16_t>, dim3(blocks), dim3(256), 0, c->stream, c->res_cols.as<uint32_t>(), n, c->res_narrow.as<uint16_t>());
+            chk(hipGetLastError());
+            chk(hipMemcpyAsync(cols, c->res_narrow.p, n * (size_t)col_bytes, hipMemcpyDeviceToHost, c->stream));
+        }
+        *cols_done = true; any = true;
+    }
+    if (any) chk(hipStreamSynchronize(c->stream));
+    return any;
+}
+
 // ... and the columns into page-locked staging (the XMFA writer, a fetch into pageable memory); idempotent
 int materialize_result(mauve_ctx *c)
 {

@@ -231,7 +231,8 @@ struct mauve_ctx {
     DevBuf ch_anch, ch_lw;               // the chains in chain order and the LCB weights (chain_order_device)
     DevBuf ch_anch2, ext_work, sorted_rec_keep;   // device-resident LCB extension (extend_dev.hip): the extended anchor list, its work area, the main pass's match list set aside
     PinnedBuf pin_ext;
-    DevBuf as_wide;                      // the anchor table widened to int64 for a direct fetch
+    DevBuf as_wide;                      // the anchor table widened to int64 for a direct fetch (compact fetch: the match list narrowed to int32)
+    DevBuf res_narrow;                   // the columns narrowed to 8 / 16 bits for a compact fetch
     DevBuf hom_cols;                     // homology pass (backbone_dev.hip): the re-split columns, swapped with res_cols when done
     DevBuf as_work, as_isl, res_cols;    // device assembly (assemble_dev.hip): work area, islands, result columns
     PinnedBuf pin_tab;                   // anchor table and match list of a device-assembled result on their way to the host
@@ -401,6 +402,8 @@ int assemble_device(mauve_ctx *c, int64_t na, int64_t cells, mauve_align_sizes *
 int materialize_result(mauve_ctx *c);
 int materialize_tables(mauve_ctx *c);
 int fetch_columns(mauve_ctx *c, uint32_t *dst);
+bool fetch_compact_direct(mauve_ctx *c, int col_bytes, int32_t *mum_length, int32_t *mum_start, int32_t *anchor_length, int32_t *anchor_start, int32_t *anchor_lcb,
+                          void *cols, bool *tables_done, bool *cols_done, int *rc_out);
 bool fetch_tables_direct(mauve_ctx *c, int64_t *mum_length, int64_t *mum_start, int64_t *anchor_length, int64_t *anchor_start, int64_t *anchor_lcb, int *rc_out);
 bool host_pointer_is_pinned(const void *p);
 int host_genomes(mauve_ctx *c);

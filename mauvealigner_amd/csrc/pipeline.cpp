@@ -1071,6 +1071,40 @@ int mauve_align_fetch(mauve_ctx *c, int64_t *mum_length, int64_t *mum_start, int
     return MAUVE_OK;
 }
 
+// The same result in the narrowest types that hold it (mauve_hip.h): one byte per column for up to 8 genomes (two up to 16), 32-bit match and
+// anchor tables (a context holds fewer than 2^31 bases).  The copy out is what the host-to-host metric pays for beyond the pass itself: at
+// C5 the uint32 columns alone are 490 MB for a two-genome alignment.
+int mauve_align_fetch_compact(mauve_ctx *c, int col_bytes, int32_t *mum_length, int32_t *mum_start, int64_t *lcb_left, int64_t *lcb_right,
+                              int64_t *lcb_weight, int32_t *anchor_length, int32_t *anchor_start, int32_t *anchor_lcb,
+                              int64_t *iv_left, int64_t *iv_right, int8_t *iv_reverse, int64_t *col_off, void *cols, int64_t *dp_score)
+{
+    if (!c) return MAUVE_ERR_ARG;
+    if (col_bytes != 1 && col_bytes != 2 && col_bytes != 4) { c->err = "align_fetch_compact: col_bytes must be 1, 2 or 4"; return MAUVE_ERR_ARG; }
+    if (c->res.stale) { c->err = "align_fetch_compact: the genomes were replaced after this alignment was made; its device-resident part is gone"; return MAUVE_ERR_STATE; }
+    const int64_t n_iv = c->res.sz.n_iv;
+    const int Nres = n_iv ? (int)(c->res.iv_left.size() / (size_t)n_iv) : c->nseq;
+    if (Nres > 8 * col_bytes) { c->err = "align_fetch_compact: a column needs one bit per genome (nseq <= 8 x col_bytes)"; return MAUVE_ERR_ARG; }
+    bool tables_done = false, cols_done = false; int rcd = MAUVE_OK;
+    (void)fetch_compact_direct(c, col_bytes, mum_length, mum_start, anchor_length, anchor_start, anchor_lcb, cols, &tables_done, &cols_done, &rcd);
+    if (rcd) return rcd;
+    if (!tables_done) { int rcm = materialize_tables(c); if (rcm) return rcm; }
+    const AlignResult &R = c->res;
+    auto narrow = [](int32_t *dst, const std::vector<int64_t> &v) { if (dst) for (size_t i = 0; i < v.size(); i++) dst[i] = (int32_t)v[i]; };
+    if (!tables_done || R.dev_nm == 0) { narrow(mum_length, R.mum_length); narrow(mum_start, R.mum_start); }
+    if (!tables_done || R.dev_na == 0) { narrow(anchor_length, R.anchor_length); narrow(anchor_start, R.anchor_start); narrow(anchor_lcb, R.anchor_lcb); }
+    CPY(lcb_left, R.lcb_left); CPY(lcb_right, R.lcb_right); CPY(lcb_weight, R.lcb_weight);
+    CPY(iv_left, R.iv_left); CPY(iv_right, R.iv_right); CPY(iv_reverse, R.iv_reverse);
+    CPY(col_off, R.col_off); CPY(dp_score, R.dp_score);
+    if (cols && R.n_cols && !cols_done) {
+        { int rcm = materialize_result(c); if (rcm) return rcm; }
+        const uint32_t *src = c->res.cols_data(); const size_t n = c->res.n_cols;
+        if (col_bytes == 4) memcpy(cols, src, n * 4);
+        else if (col_bytes == 2) { uint16_t *d = static_cast<uint16_t *>(cols); for (size_t i = 0; i < n; i++) d[i] = (uint16_t)src[i]; }
+        else { uint8_t *d = static_cast<uint8_t *>(cols); for (size_t i = 0; i < n; i++) d[i] = (uint8_t)src[i]; }
+    }
+    return MAUVE_OK;
+}
+
 // IntervalList::WriteStandardAlignment [EXT] (mauveAligner.cpp:746-760); text format pinned by the in-tree
 // writer mfa2xmfa.cpp:64 (header), :89-91 (#Sequence lines), :104-115 (entry line, 80-column rows, '=').
 int mauve_write_xmfa(mauve_ctx *c, const char *const *names, char *buf, int64_t *len)

@@ -2,6 +2,7 @@
 golden fixtures.  Integer scores and alignment columns must match bit-exactly."""
 import os
 
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -1092,6 +1093,36 @@ def test_dp_wide_sweeps():
         r = subprocess.run([sys.executable, "-c", WIDE_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and r.stdout.strip().endswith("OK"), str(extra) + "\n" + r.stdout + r.stderr[-3000:]
 
+
+
+def test_compact_fetch_equals_the_wide_one(ctx):
+    """mauve_align_fetch_compact: one byte per column for up to 8 genomes (two up to 16, four beyond), int32 match and anchor tables -- the same
+    values as mauve_align_fetch, from page-locked buffers (narrowed on the device, one DMA each) and from pageable ones (converted on the host),
+    for a device-assembled result, a host-chained one and a progressive one; a column type too narrow for the genome count is refused."""
+    from mauvealigner_amd import _lib
+    keys = ("mum_length", "mum_start", "lcb_left", "lcb_right", "lcb_weight", "anchor_length", "anchor_start", "anchor_lcb", "left", "right", "reverse", "col_off", "cols", "dp_score")
+    cases = [(synth.make_config("C3", scale=0.4), dict(seed_weight=15), False, 1), (synth.make_config("C3", scale=0.02), {}, False, 1),
+             (synth.star_genomes(10, 20_000, 0.04, 3), {}, False, 2), (synth.star_genomes(17, 8_000, 0.04, 4), {}, False, 4),
+             (synth.make_config("C4", scale=0.05), {}, True, 1)]
+    for gs, kw, prog, cb in cases:
+        ctx.set_genomes(gs)
+        run = (lambda **k: ctx.progressive_align(_lib.default_progressive_params(**kw), **k)) if prog else (lambda **k: ctx.align(_lib.default_params(**kw), **k))
+        wide = run()
+        for bufs in (None, _lib.ResultBuffers()):
+            r = run(out=bufs, compact=True)
+            assert r["col_bytes"] == cb and r["cols"].dtype.itemsize == cb and r["anchor_start"].dtype == np.int32
+            for k in keys:
+                if prog and k.startswith(("mum_", "anchor_", "lcb_")):
+                    continue
+                assert np.array_equal(r[k], wide[k]), (len(gs), k)
+    gs = synth.star_genomes(9, 5_000, 0.04, 5)
+    ctx.set_genomes(gs)
+    sz = ctx.align(_lib.default_params(), fetch=False)
+    L = ctx.L
+    L.mauve_align_fetch_compact.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 14
+    assert L.mauve_align_fetch_compact(ctx.h, 1, *([None] * 14)) == -1          # nine genomes do not fit a byte
+    assert L.mauve_align_fetch_compact(ctx.h, 3, *([None] * 14)) == -1
+    assert L.mauve_align_fetch_compact(ctx.h, 2, *([None] * 14)) == 0
 
 
 GUARD_SCRIPT = r"""
