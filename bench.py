@@ -429,10 +429,19 @@ def main():
     rn.upload()                                   # first upload: allocates the device buffers
     t_upload = time.perf_counter() - t_up0
 
+    rccl_comm = None
     if shard_lcb:
         from mauvealigner_amd import parallel
-
-        parallel.attach_shard(ctx, dist)          # mauve_set_shard: the same calls on every rank, the independent units dealt out inside them
+        # mauve_set_shard_rccl: the same calls on every rank, the independent units dealt out inside them, the exchanges run by the library itself
+        # (ncclAllGather on its stream); torch.distributed only carries rank 0's unique id to the others.  MAUVE_BENCH_SHARD_CALLBACK: the callback
+        # form through torch.distributed (mauve_set_shard) instead.
+        if os.environ.get("MAUVE_BENCH_SHARD_CALLBACK"):
+            parallel.attach_shard(ctx, dist)
+        else:
+            box = [parallel.RcclComm.new_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            rccl_comm = parallel.RcclComm(rank, world, box[0])
+            parallel.attach_shard_rccl(ctx, rccl_comm)
 
         def step():
             return rn.step_host()
@@ -544,6 +553,13 @@ def main():
                 legs[name.lower()] = {"error": repr(ex)}
 
     if rank == 0:
+        if shard_lcb:
+            from mauvealigner_amd import parallel
+            st = parallel.shard_stats(ctx)
+            nst = args.steps + args.warmup
+            extras["shard_exchanges"] = {"per_step": round(st["exchanges"] / nst, 2), "bytes_sent_per_step": int(st["bytes_sent"] / nst),
+                                         "bytes_received_per_step": int(st["bytes_received"] / nst), "ms_per_step": round(st["ms"] / nst, 3),
+                                         "collective": "callback (torch.distributed)" if rccl_comm is None else "ncclAllGather inside the library (mauve_set_shard_rccl)"}
         par = ("one alignment: pairwise finder passes, recursion gaps and DP intervals LPT-sharded over the ranks, results exchanged with RCCL all_gathers" if shard_lcb
                else "independent genome sets per GPU (no data-path collective)")
         out = {
@@ -565,6 +581,8 @@ def main():
         out.update(legs)
         print(json.dumps(out, default=lambda o: o.tolist() if hasattr(o, 'tolist') else repr(o)))
     ctx.close()
+    if rccl_comm is not None:
+        rccl_comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -285,6 +285,15 @@ int mauve_align_finish(mauve_ctx *ctx, const uint32_t *cols, const int64_t *col_
         world <= 1 or fn == NULL switches the sharding off. ---- */
 typedef int (*mauve_allgather_fn)(void *user, const void *send, int64_t send_bytes, const void **recv, int64_t *recv_bytes);
 int mauve_set_shard(mauve_ctx *ctx, int rank, int world, mauve_allgather_fn fn, void *user);
+/* The same with RCCL inside the library: nccl_comm is the caller's ncclComm_t (one rank per GPU, created with ncclCommInitRank on the context's
+   device).  Every exchange is one ncclAllGather of the ranks' sizes and one of the padded payloads, issued by the library on its own stream
+   between device buffers; nothing goes through a callback.  RCCL is resolved at this call from what the process has loaded (the librccl the
+   caller's communicator comes from; librccl.so.1 is opened if none is), so the library itself does not link it.  world == 1 switches the
+   sharding off like mauve_set_shard (with MAUVE_SHARD_SINGLE set the one rank still runs every exchange: a single-GPU rehearsal of the path).
+   mauve_shard_get_stats: exchanges, bytes sent and received, and milliseconds spent in them since the collective was set. */
+int mauve_set_shard_rccl(mauve_ctx *ctx, int rank, int world, void *nccl_comm);
+typedef struct { int64_t exchanges, bytes_sent, bytes_received; double ms; } mauve_shard_stats;
+int mauve_shard_get_stats(mauve_ctx *ctx, mauve_shard_stats *out);
 
 /* ---- progressiveMauve path: guide tree + ProgressiveAligner::align(seq_table, interval_list)
         (progressiveMauve.cpp:575-710; distance matrix / guide tree mauveAligner.cpp:616-623).  Frozen replacement

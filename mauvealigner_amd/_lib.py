@@ -19,7 +19,7 @@ KERNEL_NAMES = ["seed_extract", "rs_hist", "rs_rowscan", "rs_scatter", "mum_join
 # every symbol include/mauve_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = [
     "mauve_ctx_create", "mauve_ctx_destroy", "mauve_last_error", "mauve_device_name", "mauve_synchronize",
-    "mauve_host_alloc", "mauve_host_free", "mauve_set_shard",
+    "mauve_host_alloc", "mauve_host_free", "mauve_set_shard", "mauve_set_shard_rccl", "mauve_shard_get_stats",
     "mauve_get_seed", "mauve_seed_length", "mauve_seed_weight", "mauve_default_seed_weight", "mauve_default_scoring",
     "mauve_default_params", "mauve_default_progressive_params", "mauve_packed_words", "mauve_pack_ascii", "mauve_pack_codes", "mauve_set_genomes", "mauve_set_genomes_contigs",
     "mauve_ambiguity_bitmap",

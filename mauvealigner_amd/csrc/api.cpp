@@ -1,5 +1,6 @@
 // api.cpp -- context management and the seed-side entry points of the C-ABI (include/mauve_hip.h).
 #include "common.hpp"
+#include <dlfcn.h>
 #include <algorithm>
 #include <cstring>
 
@@ -53,10 +54,78 @@ int host_genomes(mauve_ctx *c)
     return MAUVE_OK;
 }
 
+// ---- RCCL, resolved at run time (mauve_set_shard_rccl): the library does not link librccl, it uses the one the caller's communicator belongs to ----
+namespace {
+struct RcclApi {
+    int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;      // ncclAllGather(send, recv, count, ncclDataType_t, ncclComm_t, stream)
+    const char *(*error_string)(int) = nullptr;                                               // ncclGetErrorString
+    bool ok = false;
+};
+RcclApi &rccl_api()
+{
+    static RcclApi api = []() {
+        RcclApi a;
+        void *sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+        void *lib = nullptr;
+        if (!sym) { lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL); if (lib) sym = dlsym(lib, "ncclAllGather"); }
+        if (sym) {
+            a.all_gather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, hipStream_t)>(sym);
+            void *es = lib ? dlsym(lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString");
+            a.error_string = reinterpret_cast<const char *(*)(int)>(es);
+            a.ok = true;
+        }
+        return a;
+    }();
+    return api;
+}
+constexpr int NCCL_INT8 = 0, NCCL_INT64 = 4;          // ncclDataType_t (rccl.h: ncclInt8 = 0, ncclInt64 = 4)
+
+// one exchange through RCCL: sizes (one int64 per rank), then the payloads padded to the largest; host -> device -> all-gather -> host
+int shard_allgather_rccl(mauve_ctx *c, const void *send, size_t bytes, std::vector<std::pair<const char *, size_t>> &parts)
+{
+    RcclApi &api = rccl_api();
+    const int W = c->shard_world;
+    const double t0 = now_ms();
+    HIPCHK(c, hipSetDevice(c->device));
+    auto nccl = [&](int r, const char *what) {
+        if (r == 0) return MAUVE_OK;
+        c->err = std::string("shard (RCCL): ") + what + " failed: " + (api.error_string ? api.error_string(r) : std::to_string(r)); return MAUVE_ERR_HIP;
+    };
+    // sizes
+    HIPCHK(c, c->shard_pin.ensure((size_t)(W + 1) * 8));
+    HIPCHK(c, c->shard_dev.ensure((size_t)(W + 1) * 8 + 64));
+    int64_t *hs = c->shard_pin.as<int64_t>(), *ds = c->shard_dev.as<int64_t>();
+    hs[0] = (int64_t)bytes;
+    HIPCHK(c, hipMemcpyAsync(ds, hs, 8, hipMemcpyHostToDevice, c->stream));
+    { const int rc = nccl(api.all_gather(ds, ds + 1, 1, NCCL_INT64, c->shard_comm, c->stream), "ncclAllGather (sizes)"); if (rc) return rc; }
+    HIPCHK(c, hipMemcpyAsync(hs + 1, ds + 1, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<int64_t> sz(hs + 1, hs + 1 + W);
+    int64_t mx = 16;
+    for (int r = 0; r < W; r++) { if (sz[(size_t)r] < 0) { c->err = "shard (RCCL): negative size"; return MAUVE_ERR_STATE; } mx = std::max(mx, sz[(size_t)r]); }
+    mx = (mx + 15) & ~(int64_t)15;
+    // payloads, padded to the largest
+    const size_t o_send = (((size_t)(W + 1) * 8) + 63) & ~(size_t)63, o_recv = o_send + (size_t)mx, total = o_recv + (size_t)W * mx;
+    HIPCHK(c, c->shard_pin.ensure(total));
+    HIPCHK(c, c->shard_dev.ensure(total + 64));
+    char *hp = c->shard_pin.as<char>(), *dp = c->shard_dev.as<char>();
+    if (bytes) memcpy(hp + o_send, send, bytes);
+    if (bytes) HIPCHK(c, hipMemcpyAsync(dp + o_send, hp + o_send, bytes, hipMemcpyHostToDevice, c->stream));
+    { const int rc = nccl(api.all_gather(dp + o_send, dp + o_recv, (size_t)mx, NCCL_INT8, c->shard_comm, c->stream), "ncclAllGather (payloads)"); if (rc) return rc; }
+    HIPCHK(c, hipMemcpyAsync(hp + o_recv, dp + o_recv, (size_t)W * mx, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int r = 0; r < W; r++) { parts.push_back({hp + o_recv + (size_t)r * mx, (size_t)sz[(size_t)r]}); c->shard_stat.bytes_received += sz[(size_t)r]; }
+    c->shard_stat.exchanges++; c->shard_stat.bytes_sent += (int64_t)bytes; c->shard_stat.ms += now_ms() - t0;
+    return MAUVE_OK;
+}
+}  // namespace
+
 int shard_allgather(mauve_ctx *c, const void *send, size_t bytes, std::vector<std::pair<const char *, size_t>> &parts)
 {
     parts.clear();
+    if (c->shard_comm && c->shard_on) return shard_allgather_rccl(c, send, bytes, parts);
     if (c->shard_world <= 1 || !c->shard_fn) { parts.push_back({static_cast<const char *>(send), bytes}); return MAUVE_OK; }
+    const double t0 = now_ms();
     const void *recv = nullptr;
     std::vector<int64_t> sz((size_t)c->shard_world, 0);
     const int rc = c->shard_fn(c->shard_user, send, (int64_t)bytes, &recv, sz.data());
@@ -65,7 +134,9 @@ int shard_allgather(mauve_ctx *c, const void *send, size_t bytes, std::vector<st
     for (int r = 0; r < c->shard_world; r++) {
         if (sz[(size_t)r] < 0) { c->err = "shard: negative size from the all-gather"; return MAUVE_ERR_STATE; }
         parts.push_back({p, (size_t)sz[(size_t)r]}); p += sz[(size_t)r];
+        c->shard_stat.bytes_received += sz[(size_t)r];
     }
+    c->shard_stat.exchanges++; c->shard_stat.bytes_sent += (int64_t)bytes; c->shard_stat.ms += now_ms() - t0;
     return MAUVE_OK;
 }
 
@@ -142,11 +213,11 @@ void mauve_ctx_destroy(mauve_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     delete c->pool; c->pool = nullptr;
     DevBuf *bufs[] = {&c->genomes, &c->keysA, &c->keysB, &c->valsA, &c->valsB, &c->hist, &c->totals, &c->posmask,
-                      &c->hit_mask, &c->hit_pos, &c->hit_seg, &c->base_invalid, &c->contig_mask, &c->node_cmask, &c->run_sum, &c->join_ovf, &c->join_bound, &c->dpf_anch, &c->dpf_work, &c->dpf_tot, &c->ch_len, &c->ch_st, &c->ch_crop, &c->ch_ent, &c->ch_ord, &c->ch_rank, &c->ch_node, &c->ch_graph, &c->ch_cnt, &c->ch_anch, &c->ch_lw, &c->ch_anch2, &c->ext_work, &c->bp_work, &c->dp_sp, &c->hom_cols, &c->sorted_rec_keep, &c->ch_big, &c->gap_work, &c->as_wide, &c->res_narrow, &c->dp_pick, &c->as_work, &c->as_isl, &c->res_cols, &c->sorted_rec, &c->canon_k1, &c->canon_k2, &c->canon_v1, &c->canon_v2, &c->rec_genomes, &c->rec_seg, &c->rec_vinv, &c->rec_vcm, &c->placed_mask, &c->bb_cols, &c->bb_work, &c->bb_query, &c->cand, &c->mlen, &c->mstart, &c->counters, &c->dp_desc, &c->dp_list, &c->dp_codes, &c->dp_off,
+                      &c->hit_mask, &c->hit_pos, &c->hit_seg, &c->base_invalid, &c->contig_mask, &c->node_cmask, &c->run_sum, &c->join_ovf, &c->join_bound, &c->dpf_anch, &c->dpf_work, &c->dpf_tot, &c->ch_len, &c->ch_st, &c->ch_crop, &c->ch_ent, &c->ch_ord, &c->ch_rank, &c->ch_node, &c->ch_graph, &c->ch_cnt, &c->ch_anch, &c->ch_lw, &c->ch_anch2, &c->ext_work, &c->bp_work, &c->dp_sp, &c->hom_cols, &c->sorted_rec_keep, &c->ch_big, &c->gap_work, &c->as_wide, &c->res_narrow, &c->dp_pick, &c->shard_dev, &c->as_work, &c->as_isl, &c->res_cols, &c->sorted_rec, &c->canon_k1, &c->canon_k2, &c->canon_v1, &c->canon_v2, &c->rec_genomes, &c->rec_seg, &c->rec_vinv, &c->rec_vcm, &c->placed_mask, &c->bb_cols, &c->bb_work, &c->bb_query, &c->cand, &c->mlen, &c->mstart, &c->counters, &c->dp_desc, &c->dp_list, &c->dp_codes, &c->dp_off,
                       &c->dp_prof_cnt, &c->dp_prof_mask, &c->dp_prof2_cnt, &c->dp_prof2_mask, &c->dp_tb, &c->dp_meta,
                       &c->dp_score, &c->dp_cols, &c->dp_rows};
     for (DevBuf *b : bufs) b->release();
-    c->pin_genomes.release(); c->pin_tail.release(); c->pin_ext.release(); c->pin_chain.release(); c->pin_mask.release(); c->pin_bb.release(); c->pin_asm.release(); c->pin_tab.release(); c->pin_cols.release(); c->pin_anch.release(); c->pin_dcols.release(); c->pin_meta.release(); c->pin_seed.release(); c->pin_dp_in.release();
+    c->pin_genomes.release(); c->pin_tail.release(); c->pin_ext.release(); c->pin_chain.release(); c->pin_mask.release(); c->pin_bb.release(); c->pin_asm.release(); c->pin_tab.release(); c->pin_cols.release(); c->pin_anch.release(); c->pin_dcols.release(); c->pin_meta.release(); c->pin_seed.release(); c->pin_dp_in.release(); c->shard_pin.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -175,9 +246,31 @@ int mauve_synchronize(mauve_ctx *c)
 int mauve_set_shard(mauve_ctx *c, int rank, int world, mauve_allgather_fn fn, void *user)
 {
     if (!c) return MAUVE_ERR_ARG;
-    if (world <= 1 || !fn) { c->shard_rank = 0; c->shard_world = 1; c->shard_fn = nullptr; c->shard_user = nullptr; return MAUVE_OK; }
+    c->shard_comm = nullptr; c->shard_stat = mauve_shard_stats{0, 0, 0, 0.0};
+    if (world <= 1 || !fn) { c->shard_rank = 0; c->shard_world = 1; c->shard_fn = nullptr; c->shard_user = nullptr; c->shard_on = false; return MAUVE_OK; }
     if (rank < 0 || rank >= world) { c->err = "set_shard: rank outside the world"; return MAUVE_ERR_ARG; }
-    c->shard_rank = rank; c->shard_world = world; c->shard_fn = fn; c->shard_user = user;
+    c->shard_rank = rank; c->shard_world = world; c->shard_fn = fn; c->shard_user = user; c->shard_on = true;
+    return MAUVE_OK;
+}
+
+int mauve_set_shard_rccl(mauve_ctx *c, int rank, int world, void *nccl_comm)
+{
+    if (!c) return MAUVE_ERR_ARG;
+    c->shard_fn = nullptr; c->shard_user = nullptr; c->shard_comm = nullptr; c->shard_on = false; c->shard_rank = 0; c->shard_world = 1;
+    c->shard_stat = mauve_shard_stats{0, 0, 0, 0.0};
+    if (world < 1 || !nccl_comm) return world <= 1 ? MAUVE_OK : (c->err = "set_shard_rccl: a communicator is required", MAUVE_ERR_ARG);
+    if (rank < 0 || rank >= world) { c->err = "set_shard_rccl: rank outside the world"; return MAUVE_ERR_ARG; }
+    if (!rccl_api().ok) { c->err = "set_shard_rccl: no RCCL in this process (ncclAllGather not found, librccl.so.1 not loadable)"; return MAUVE_ERR_STATE; }
+    static const bool single = getenv("MAUVE_SHARD_SINGLE") != nullptr;
+    if (world == 1 && !single) return MAUVE_OK;                 // one rank: nothing to deal out
+    c->shard_rank = rank; c->shard_world = world; c->shard_comm = nccl_comm; c->shard_on = true;
+    return MAUVE_OK;
+}
+
+int mauve_shard_get_stats(mauve_ctx *c, mauve_shard_stats *out)
+{
+    if (!c || !out) return MAUVE_ERR_ARG;
+    *out = c->shard_stat;
     return MAUVE_OK;
 }
 

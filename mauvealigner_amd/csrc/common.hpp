@@ -311,6 +311,11 @@ struct mauve_ctx {
 
     // one alignment spread over several contexts (mauve_set_shard): this rank, their number, the caller's all-gather
     int shard_rank = 0, shard_world = 1; mauve_allgather_fn shard_fn = nullptr; void *shard_user = nullptr;
+    bool shard_on = false;                // the independent units inside the calls are dealt out and exchanged (world > 1; a one-rank RCCL communicator with MAUVE_SHARD_SINGLE: the same code, one part)
+    void *shard_comm = nullptr;           // ncclComm_t of mauve_set_shard_rccl: the library runs the all-gathers itself, on its stream, through device buffers
+    DevBuf shard_dev;                     // device side of an RCCL exchange: [my size | all sizes | my payload | all payloads]
+    PinnedBuf shard_pin;                  // ... and its page-locked host side
+    mauve_shard_stats shard_stat = {0, 0, 0, 0.0};
 
     AlignResult res;
     AlignState ast;

@@ -2844,7 +2844,7 @@ int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *d
                       uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells, bool may_shard, int64_t *sp)
 {
     std::vector<int64_t> &seq_off = ctx->dph.seq_off;
-    if (may_shard && ctx->shard_world > 1 && n_iv >= 2 * ctx->shard_world) {
+    if (may_shard && ctx->shard_on && n_iv >= 2 * ctx->shard_world) {
         // Several contexts, one alignment (mauve_set_shard): the intervals are LPT-dealt by their cell bound, this rank aligns its
         // share, and everybody's columns, lengths and scores are exchanged -- [n, cells, len[n], score[n], cols...] per rank.
         std::vector<int64_t> cost((size_t)n_iv);

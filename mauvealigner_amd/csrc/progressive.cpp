@@ -301,7 +301,7 @@ int prog_node(Prog &P, int node)
             }
         }
         const int64_t nc = (int64_t)cands.size(), na = n_dp + nc;
-        const bool one_batch = c->shard_world <= 1;
+        const bool one_batch = !c->shard_on;
         std::vector<int64_t> aoff((size_t)na + 1, 0), ascore((size_t)na + 1, 0), asp((size_t)na + 1, 0);
         std::vector<uint32_t> ccols;                             // (the exchanged form only)
         if (one_batch) {
@@ -470,7 +470,7 @@ static int guide_tree_core(mauve_ctx *c, uint64_t pattern, int64_t *dist, int32_
     c->pair_sums_only = false; c->bp_min_len = -1;
     if (rc) return rc;
     std::vector<int64_t> S((size_t)N * N, 0);
-    if (c->shard_world > 1) {
+    if (c->shard_on) {
         // every rank ran the finder passes of its share of the genome pairs (seed_pass.hip): the sums of the others arrive here
         const size_t nn = (size_t)N * N;
         std::vector<int64_t> mine(2 * nn, 0);                 // length sums, then breakpoints

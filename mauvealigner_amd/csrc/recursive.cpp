@@ -184,7 +184,7 @@ int recursive_anchoring(mauve_ctx *c, const mauve_params *p, int w0, std::vector
             // the same work list.  ids: this rank's gaps; pos_of[k]: their places in the whole batch (the order results are applied in).
             const std::vector<size_t> &ids_all = cls.second;
             std::vector<size_t> ids_mine; std::vector<uint32_t> pos_of;
-            const bool sharded = c->shard_world > 1 && ids_all.size() >= (size_t)(2 * c->shard_world);
+            const bool sharded = c->shard_on && ids_all.size() >= (size_t)(2 * c->shard_world);
             if (sharded) {
                 std::vector<int64_t> cost(ids_all.size(), 0);
                 for (size_t q = 0; q < ids_all.size(); q++)

@@ -1559,7 +1559,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         // (guide tree over several contexts, mauve_set_shard: this rank's share of the pairs, dealt round robin; the sums are exchanged)
         int pi = 0;
         for (int i = 0; i < N; i++) for (int j = i + 1; j < N; j++, pi++)
-            if (!ctx->pair_sums_only || ctx->shard_world <= 1 || pi % ctx->shard_world == ctx->shard_rank)
+            if (!ctx->pair_sums_only || !ctx->shard_on || pi % ctx->shard_world == ctx->shard_rank)
                 passes.push_back({(1u << i) | (1u << j), (1u << i) | (1u << j), MAUVE_MODE_MEM});
     } else passes.push_back({0xffffffffu, (uint32_t)mask, mode});
     ctx->n_matches = 0; ctx->match_len.clear(); ctx->match_start.clear(); ctx->matches_pending = false;
@@ -1569,7 +1569,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     uint32_t cand_total = 0;
     // pairwise mode: the runs that can matter to any pair, listed once (see run_summary)
     uint32_t nruns = 0;
-    const bool use_summary = mode == MAUVE_MODE_PAIRWISE && !SEG && (passes.size() > 1 || (ctx->pair_sums_only && ctx->shard_world > 1 && !passes.empty()));
+    const bool use_summary = mode == MAUVE_MODE_PAIRWISE && !SEG && (passes.size() > 1 || (ctx->pair_sums_only && ctx->shard_on && !passes.empty()));
     uint32_t *rstart = nullptr, *rlen = nullptr, *runiq = nullptr;
     if (use_summary) {
         const size_t cap = (size_t)ns / 2 + 1;

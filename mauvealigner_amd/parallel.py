@@ -186,3 +186,69 @@ def align_sharded(ctx, params=None, dist=None, group=None, names=None, want_xmfa
         all_cells = int(sum(int(x[0]) for x in g_cells))
     kw = {} if out is None else {"out": out}
     return ctx.align_finish(all_cols, all_score, all_cells, fetch=fetch, names=names, want_xmfa=want_xmfa, **kw)
+
+
+# ---- RCCL inside the library (mauve_set_shard_rccl): what a C++ caller -- which is what the reference is -- uses.  From Python the communicator is
+# made through ctypes on the RCCL the process resolves (librccl.so.1), not through torch.distributed, whose communicator handle is not exposed. ----
+class RcclComm:
+    """one rank's ncclComm_t, made with ncclCommInitRank on the current device; unique_id: bytes of rank 0's ncclGetUniqueId, carried to the
+    other ranks by the caller (a file, a socket, torch.distributed.broadcast_object_list ...)"""
+    UNIQUE_ID_BYTES = 128
+
+    @staticmethod
+    def new_unique_id(lib_path="librccl.so.1"):
+        """rank 0's ncclGetUniqueId as bytes (to be carried to every rank before any of them makes its communicator)"""
+        import ctypes as C
+        lib = C.CDLL(lib_path, mode=C.RTLD_GLOBAL)
+        uid = C.create_string_buffer(RcclComm.UNIQUE_ID_BYTES)
+        r = lib.ncclGetUniqueId(uid)
+        if r != 0:
+            raise RuntimeError("ncclGetUniqueId failed (%d)" % r)
+        return uid.raw
+
+    def __init__(self, rank, world, unique_id=None, lib_path="librccl.so.1"):
+        import ctypes as C
+        self.C = C
+        self.lib = C.CDLL(lib_path, mode=C.RTLD_GLOBAL)           # global: libmauve_hip resolves ncclAllGather from what the process has loaded
+        if unique_id is None:
+            assert world == 1, "several ranks: make the id on rank 0 (new_unique_id) and hand it to all of them"
+            unique_id = self.new_unique_id(lib_path)
+        self.unique_id = unique_id
+
+        class _Uid(C.Structure):
+            _fields_ = [("internal", C.c_char * self.UNIQUE_ID_BYTES)]
+        u = _Uid(); C.memmove(C.byref(u), unique_id, self.UNIQUE_ID_BYTES)
+        self.comm = C.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _Uid, C.c_int]
+        self._chk(self.lib.ncclCommInitRank(C.byref(self.comm), world, u, rank), "ncclCommInitRank")
+        self.rank, self.world = rank, world
+
+    def _chk(self, r, what):
+        if r != 0:
+            raise RuntimeError("%s failed (%d)" % (what, r))
+
+    def close(self):
+        if self.comm:
+            self.lib.ncclCommDestroy.argtypes = [self.C.c_void_p]
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+def attach_shard_rccl(ctx, comm):
+    """mauve_set_shard_rccl: the library runs the exchanges itself (ncclAllGather on its stream, device buffers)"""
+    import ctypes as C
+    ctx.L.mauve_set_shard_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    rc = ctx.L.mauve_set_shard_rccl(ctx.h, comm.rank, comm.world, comm.comm)
+    if rc:
+        raise RuntimeError("mauve_set_shard_rccl failed (%d): %s" % (rc, ctx.last_error() if hasattr(ctx, "last_error") else ""))
+
+
+def shard_stats(ctx):
+    import ctypes as C
+
+    class S(C.Structure):
+        _fields_ = [("exchanges", C.c_int64), ("bytes_sent", C.c_int64), ("bytes_received", C.c_int64), ("ms", C.c_double)]
+    s = S()
+    ctx.L.mauve_shard_get_stats.argtypes = [C.c_void_p, C.POINTER(S)]
+    ctx.L.mauve_shard_get_stats(ctx.h, C.byref(s))
+    return {"exchanges": int(s.exchanges), "bytes_sent": int(s.bytes_sent), "bytes_received": int(s.bytes_received), "ms": float(s.ms)}

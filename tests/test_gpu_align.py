@@ -1125,6 +1125,43 @@ def test_compact_fetch_equals_the_wide_one(ctx):
     assert L.mauve_align_fetch_compact(ctx.h, 2, *([None] * 14)) == 0
 
 
+RCCL_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from mauvealigner_amd import _lib, synth, parallel
+ctx = _lib.Context(0)                                            # (sets the device the communicator is made on)
+comm = parallel.RcclComm(0, 1)
+parallel.attach_shard_rccl(ctx, comm)
+keys = ("cols", "col_off", "dp_score", "left", "right", "reverse")
+for cfg, scale, prog in (("C5", 0.04, False), ("C4", 0.08, True)):
+    gs = synth.make_config(cfg, scale=scale)
+    ctx.set_genomes(gs)
+    r = ctx.progressive_align(_lib.default_progressive_params()) if prog else ctx.align(_lib.default_params())
+    st = parallel.shard_stats(ctx)
+    ctx.L.mauve_set_shard_rccl(ctx.h, 0, 1, None)                       # sharding off: the plain result
+    ref = ctx.progressive_align(_lib.default_progressive_params()) if prog else ctx.align(_lib.default_params())
+    parallel.attach_shard_rccl(ctx, comm)
+    for k in keys:
+        assert np.array_equal(r[k], ref[k]), (cfg, k)
+    assert st["exchanges"] >= 2 and st["bytes_received"] == st["bytes_sent"] > 0, st
+    print(cfg, st)
+comm.close(); ctx.close()
+print("OK")
+"""
+
+
+def test_rccl_exchange_inside_the_library():
+    """mauve_set_shard_rccl: the library runs its exchanges itself -- ncclAllGather of the sizes, then of the padded payloads, on its own stream
+    between device buffers; no callback, no Python in the data path.  One GPU here, so ONE rank rehearses the path (MAUVE_SHARD_SINGLE: the units
+    are still dealt out -- all to rank 0 -- and every exchange really goes through RCCL): recursion batches at C5, the guide tree's pairs and the
+    nodes' intervals at C4 give the same result as without the collective, and the counters show the traffic."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MAUVE_SHARD_SINGLE="1")
+    r = subprocess.run([sys.executable, "-c", RCCL_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr[-3000:]
+
+
 GUARD_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, %(root)r)
