@@ -1093,9 +1093,12 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
                                                   uint32_t P, const uint32_t *__restrict__ cand, uint32_t ncand,
                                                   int extend, int32_t *__restrict__ mlen, int32_t *__restrict__ mstart,
                                                   const uint32_t *__restrict__ seg, uint32_t nseg,
-                                                  const uint64_t *__restrict__ vmask, const uint64_t *__restrict__ cmask)
+                                                  const uint64_t *__restrict__ vmask, const uint64_t *__restrict__ cmask,
+                                                  const uint32_t *__restrict__ ncand_dev = nullptr)
 {
     __shared__ ExtComp s_comp[4][MAUVE_MAX_SEQ];
+    // ncand_dev: the count is still on the device (a tiny pass launches this kernel without having looked at it: ncand is then the capacity of the list)
+    if (ncand_dev) ncand = min(ncand, *ncand_dev);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -1567,6 +1570,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     // one record slot per candidate of every pass; length 0 = not a leftmost hit (host scratch kept across calls)
     std::vector<int32_t> &hl = ctx->sdh.hl, &hs = ctx->sdh.hs; hl.clear(); hs.clear();
     uint32_t cand_total = 0;
+    bool records_on_host = false;                 // hl / hs hold the candidates' records already (the one-round-trip form of a tiny pass)
     // pairwise mode: the runs that can matter to any pair, listed once (see run_summary)
     uint32_t nruns = 0;
     const bool use_summary = mode == MAUVE_MODE_PAIRWISE && !SEG && (passes.size() > 1 || (ctx->pair_sums_only && ctx->shard_on && !passes.empty()));
@@ -1695,6 +1699,35 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
                              nseg, cand_cap, s_lo); }
         HIPCHK(ctx, hipGetLastError());
         if (ctx->shadow) { std::function<void()> f; f.swap(ctx->shadow); f(); }     // the kernels above are still running
+        if (tiny && !hh && passes.size() == 1 && cand_total == 0 && cand_cap <= 8192) {
+            // A tiny pass (a round of the LCB extension, a small guide-tree node, a small recursion batch) is a handful of 5-10 us kernels: the round
+            // trip that fetched the candidate count before the extension kernel could be launched cost as much as the pass.  Its candidate list has
+            // at most a few thousand entries, so the extension is launched for the CAPACITY of the list with the count left on the device, and the
+            // counters come back together with the records: one synchronisation per pass instead of two.
+            HIPCHK(ctx, ctx->mlen.ensure((size_t)cand_cap * 4 + 4));
+            HIPCHK(ctx, ctx->mstart.ensure((size_t)cand_cap * 4 * N + 4));
+            { KernelTimer t(ctx, MAUVE_K_EXTEND, cand_cap);
+              hipLaunchKernelGGL((mum_extend<SEG>), dim3(std::min<uint32_t>((cand_cap + 3) / 4, 512)), dim3(256), 0, ctx->stream, packed, tab, sh, tmask, tpos, P,
+                                 ctx->cand.as<uint32_t>(), cand_cap, extend, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(), seg, nseg, vmask, cmask,
+                                 ctx->counters.as<uint32_t>() + 1); }
+            HIPCHK(ctx, hipGetLastError());
+            const size_t lbytes = ((size_t)cand_cap * 4 + 63) & ~(size_t)63, sbytes = (size_t)cand_cap * 4 * N;
+            HIPCHK(ctx, ctx->pin_seed.ensure(64 + lbytes + sbytes));
+            char *pin = ctx->pin_seed.as<char>();
+            HIPCHK(ctx, hipMemcpyAsync(pin, ctx->counters.p, 48, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(pin + 64, ctx->mlen.p, (size_t)cand_cap * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(pin + 64 + lbytes, ctx->mstart.p, sbytes, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            const uint32_t nc = reinterpret_cast<const uint32_t *>(pin)[1];
+            if (reinterpret_cast<const uint32_t *>(pin)[9]) { ctx->err = "tiny_join: anchor out of range (internal error)"; return MAUVE_ERR_HIP; }
+            if (cand_overflow(nc)) return MAUVE_ERR_LIMIT;
+            TRACE(ctx, "runs + extend (one round trip)");
+            if (g_trace) fprintf(stderr, "[trace]   %u candidates of %u windows\n", nc, P);
+            hl.assign(reinterpret_cast<const int32_t *>(pin + 64), reinterpret_cast<const int32_t *>(pin + 64) + nc);
+            hs.assign(reinterpret_cast<const int32_t *>(pin + 64 + lbytes), reinterpret_cast<const int32_t *>(pin + 64 + lbytes) + (size_t)nc * N);
+            cand_total = nc; records_on_host = true;
+            continue;
+        }
         HIPCHK(ctx, ctx->pin_seed.ensure(64));
         HIPCHK(ctx, hipMemcpyAsync(ctx->pin_seed.p, ctx->counters.p, 48, hipMemcpyDeviceToHost, ctx->stream));     // run counters + join_hash's overflow count
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1927,7 +1960,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         return MAUVE_OK;
     }
     // small sets: records to the host (page-locked staging), host sort
-    {
+    if (!records_on_host) {
         hl.resize(ncand); hs.resize((size_t)ncand * N);
         const size_t lbytes = ((size_t)ncand * 4 + 63) & ~(size_t)63, sbytes = (size_t)ncand * 4 * N;
         HIPCHK(ctx, ctx->pin_seed.ensure(64 + lbytes + sbytes));
