@@ -261,7 +261,7 @@ struct mauve_ctx {
 
     // DP workspace
     DevBuf dp_desc, dp_list, dp_codes, dp_off, dp_prof_cnt, dp_prof_mask, dp_prof2_cnt, dp_prof2_mask, dp_tb, dp_meta, dp_score,
-        dp_cols, dp_rows, dp_sp, dp_pick;
+        dp_cols, dp_rows, dp_sp, dp_pick, dp_wflags;
 
     // the seed pass may leave its match list on the device only (sorted_rec) when the caller says so: mauve_align's device tail
     bool pair_sums_only = false;          // seed pass for the guide tree: per-pair length sums instead of the match list

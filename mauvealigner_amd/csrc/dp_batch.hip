@@ -1134,7 +1134,12 @@ __host__ __device__ __forceinline__ int64_t dp3_tb_need(int64_t m, int64_t n)
 }
 // parked boundary entries: A keeps the last row of a band for every column, B (more than one band of columns) the last column for every row
 // (the wide sweeps below choose their orientation by super-bands, so either dimension may be the parked one)
-__host__ __device__ __forceinline__ int64_t dp3_rows_need(int64_t m, int64_t n) { return 6 * ((m > n ? m : n) + 1); }
+// A cluster of workgroups (below) keeps one parked line per super-band of 2048, not two by parity.
+__host__ __device__ __forceinline__ int64_t dp3_rows_need(int64_t m, int64_t n)
+{
+    const int64_t x = m > n ? m : n, nsb = (x + 2047) / 2048;
+    return 3 * (nsb > 2 ? nsb : 2) * (x + 1);
+}
 
 // column / row steps of one progressive step on ONE wave (lines x bands in the cheaper orientation): what the launch list weighs an
 // interval by when it picks the ones that get a whole workgroup (the wide sweep)
@@ -1583,6 +1588,50 @@ __device__ __forceinline__ int32_t dpw_carry(const int32_t *agg, int wv, int lan
     return __builtin_amdgcn_readlane(v, 15);
 }
 
+// ---- several workgroups on ONE interval (a cluster): the super-bands of a step go round-robin to the K workgroups and run as a pipeline ----
+// One CU does about 2 GCUPS of this recurrence whatever the schedule (the sweep is bound by vector issue), so an interval of several super-bands
+// -- C5's largest: 560 x 4 573, three super-bands of columns, 1.8 ms of a 1.9 ms stage -- can only get faster on several CUs.  Super-band
+// q + 1 needs from super-band q what a single workgroup parks between them anyway: its last row / column, line by line.  So workgroup q mod K takes
+// super-band q, parks its boundary line as before, and PUBLISHES how far it is every 64 lines (all its stores drained, an agent-scope release,
+// then a relaxed agent-scope store of a monotonic token: step, super-band, lines); the workgroup of q + 1 polls the token before it fetches the
+// next 64 boundary values (relaxed agent-scope loads, then an agent-scope acquire: MI355X_MICROARCH.md, inter-workgroup visibility) and so runs
+// two chunks behind.  The traceback walk and the profile rebuild stay with workgroup 0, which waits for the others' "done" tokens and then
+// publishes the step (new profile length, final cell) for them.  Every wait is bounded (about 3 s of s_memrealtime): a cluster that cannot
+// make progress marks the interval as failed (DpMeta.pad, turned into MAUVE_ERR_HIP by the host) instead of hanging the device.
+// Flag block of an interval (64-bit words, zeroed before the launch): [0, K) progress, [K, 2K) done, [2K] step done, [2K+1] profile length,
+// [2K+2 .. 2K+4] the final cell, [2K+5] failure.
+constexpr int DPW_KMAX = 4, DPW_FLAGS = 2 * DPW_KMAX + 8;
+struct DpwCluster {
+    int K, c; unsigned long long *flags; uint32_t step;
+    __device__ __forceinline__ bool on() const { return K > 1; }
+    __device__ __forceinline__ unsigned long long tok(int32_t q, int32_t lines) const { return ((unsigned long long)(step + 1) << 44) | ((unsigned long long)(uint32_t)q << 24) | (unsigned long long)(uint32_t)lines; }
+    __device__ __forceinline__ unsigned long long *failed() const { return flags + 2 * K + 5; }
+};
+// by ONE wave, after its own stores: everything it has written becomes visible to a workgroup that then sees v
+__device__ __forceinline__ void dpw_publish(unsigned long long *p, unsigned long long v)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// by every wave that is going to read what the token covers; false: the wait ran out (or another wave's did)
+__device__ __forceinline__ bool dpw_wait(const unsigned long long *p, unsigned long long want, unsigned long long *failed)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool ok = true;
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= want) break;
+        if (__hip_atomic_load(failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ULL) { ok = false; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ULL) { __hip_atomic_store(failed, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return ok;
+}
+
 // orientation A: rows on the lanes of all waves, column by column.  Dp3A::step cut at its two exchange points.
 template <int R>
 struct DpwA {
@@ -1716,13 +1765,14 @@ struct DpwB {
 // orientation A over the whole workgroup.  Every wave of the workgroup calls it (uniform barriers); (m, n) is left in S.fin.
 template <int R, int W>
 __device__ __forceinline__ void dpw_sweep_a(DpwShared &S, int lane, int wv, int32_t m, int32_t n, const uint32_t *Pc, const uint8_t *seq, const DpScoring &sc,
-                                            int32_t krows, int32_t *rowbuf, uint8_t *tbp, int32_t mpad)
+                                            int32_t krows, int32_t *rowbuf, uint8_t *tbp, int32_t mpad, const DpwCluster &CL)
 {
     constexpr int DPW_BAND = 64 * R, DPW_WAVES = W;
     static_assert(DPW_BAND * DPW_WAVES == DPW_SB, "a super-band is 2048 rows");
     const int32_t nsb = (m + DPW_SB - 1) / DPW_SB;
     const int32_t gyo = sc.go * krows, gye = sc.ge * krows;
     for (int32_t q = 0; q < nsb; q++) {
+        if (CL.on() && q % CL.K != CL.c) continue;               // a cluster: this workgroup's super-bands only
         const int32_t sb0 = q * DPW_SB;
         const int32_t nw = min(DPW_WAVES, (m - sb0 + DPW_BAND - 1) / DPW_BAND);        // waves that hold rows of the profile
         const bool act = wv < nw;
@@ -1735,10 +1785,14 @@ __device__ __forceinline__ void dpw_sweep_a(DpwShared &S, int lane, int wv, int3
         int32_t eoff = 0;
         for (int u = 0; u < wv; u++) eoff += S.esum[u];
         L.E = el + eoff;                                         // prefix sums of gxe over the rows of the SUPER-band
-        const int32_t *rin = rowbuf + (size_t)((q & 1) ^ 1) * 3 * (n + 1);
-        int32_t *rout = rowbuf + (size_t)(q & 1) * 3 * (n + 1);
+        // parked rows: two buffers by parity for a workgroup on its own; a cluster has several super-bands in flight: one buffer per super-band
+        const int32_t *rin = rowbuf + (size_t)(CL.on() ? q - 1 : ((q & 1) ^ 1)) * 3 * (n + 1);
+        int32_t *rout = rowbuf + (size_t)(CL.on() ? q : (q & 1)) * 3 * (n + 1);
         const bool park = q + 1 < nsb && wv == DPW_WAVES - 1;     // (a super-band that is followed by another one is full)
         const bool writes = act && i0 < mpad;
+        const bool feed = CL.on() && q > 0;                       // the row above comes from another workgroup: wait for its progress before every fetch
+        const unsigned long long *ptok = CL.flags + (feed ? (q - 1) % CL.K : 0);
+        bool good = true;
         // per column from outside the super-band: the base, and the parked row of the super-band above (dp3_sweep_a's chunks; every wave
         // keeps its own copy: the base and the X of that row are needed by all of them)
         auto chunk = [&](int32_t k, uint32_t &sq, int32_t &cM, int32_t &cX, int32_t &cY) {
@@ -1748,11 +1802,13 @@ __device__ __forceinline__ void dpw_sweep_a(DpwShared &S, int lane, int wv, int3
             else { const int32_t cc = min(col, n); cM = rin[cc]; cX = rin[(n + 1) + cc]; cY = rin[2 * (n + 1) + cc]; }
         };
         uint32_t sq_cur, sq_nxt; int32_t cM_cur, cX_cur, cY_cur, cM_nxt, cX_nxt, cY_nxt;
+        if (feed) good &= dpw_wait(ptok, CL.tok(q - 1, min(63, n) + 1), CL.failed());
         chunk(0, sq_nxt, cM_nxt, cX_nxt, cY_nxt);
         int32_t tMo = DP_NEG_INF, tXo = DP_NEG_INF, tYo = DP_NEG_INF;
         uint8_t *tw = tbp + i0;                                   // one byte per row, R of them per lane: dp3's layout for R = 4 (P(x) = x)
         for (int32_t k = 0; 64 * k <= n; k++) {
             sq_cur = sq_nxt; cM_cur = cM_nxt; cX_cur = cX_nxt; cY_cur = cY_nxt;
+            if (feed && 64 * (k + 1) <= n) good &= dpw_wait(ptok, CL.tok(q - 1, min(64 * k + 127, n) + 1), CL.failed());
             chunk(k + 1, sq_nxt, cM_nxt, cX_nxt, cY_nxt);
             const int32_t jend = min(64 * k + 63, n);
             for (int32_t j = 64 * k; j <= jend; j++, tw += mpad) {
@@ -1780,7 +1836,9 @@ __device__ __forceinline__ void dpw_sweep_a(DpwShared &S, int lane, int wv, int3
                     tMo = tMn; tXo = tXn; tYo = tYn;
                 }
             }
+            if (CL.on() && park) dpw_publish(CL.flags + CL.c, CL.tok(q, jend + 1));       // (wave-uniform: the parking wave) columns 0 .. jend are out
         }
+        if (!good && lane == 0) __hip_atomic_store(CL.failed(), 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (q == nsb - 1) {
             const int32_t rel = m - 1 - sb0;                        // the row of (m, .) inside the super-band
             if (wv == rel / DPW_BAND && lane == (rel % DPW_BAND) / R) {
@@ -1799,13 +1857,14 @@ __device__ __forceinline__ void dpw_sweep_a(DpwShared &S, int lane, int wv, int3
 // orientation B over the whole workgroup
 template <int R, int W>
 __device__ __forceinline__ void dpw_sweep_b(DpwShared &S, int lane, int wv, int32_t m, int32_t n, const uint32_t *Pc, const uint8_t *seq, const DpScoring &sc,
-                                            int32_t krows, int32_t *rowbuf, uint8_t *tbp, int32_t npad)
+                                            int32_t krows, int32_t *rowbuf, uint8_t *tbp, int32_t npad, const DpwCluster &CL)
 {
     constexpr int DPW_BAND = 64 * R, DPW_WAVES = W;
     static_assert(DPW_BAND * DPW_WAVES == DPW_SB, "a super-band is 2048 rows");
     const int32_t nsb = (n + DPW_SB - 1) / DPW_SB;
     const int32_t gyo = sc.go * krows, gye = sc.ge * krows;
     for (int32_t q = 0; q < nsb; q++) {
+        if (CL.on() && q % CL.K != CL.c) continue;
         const int32_t sb0 = q * DPW_SB;
         const int32_t nw = min(DPW_WAVES, (n - sb0 + DPW_BAND - 1) / DPW_BAND);
         const bool act = wv < nw;
@@ -1819,10 +1878,14 @@ __device__ __forceinline__ void dpw_sweep_b(DpwShared &S, int lane, int wv, int3
         }
         const int32_t eoff = wv * DPW_BAND * gye;
         L.E = (lane + 1) * R * gye + eoff;                          // prefix sums of gye over the columns of the SUPER-band
-        const int32_t *cin = rowbuf + (size_t)((q & 1) ^ 1) * 3 * (m + 1);
-        int32_t *cout = rowbuf + (size_t)(q & 1) * 3 * (m + 1);
+        const int32_t *cin = rowbuf + (size_t)(CL.on() ? q - 1 : ((q & 1) ^ 1)) * 3 * (m + 1);
+        int32_t *cout = rowbuf + (size_t)(CL.on() ? q : (q & 1)) * 3 * (m + 1);
         const bool park = q + 1 < nsb && wv == DPW_WAVES - 1;
         const bool writes = act && j0 < npad;
+        const bool feed = CL.on() && q > 0;                       // (lines of the parked column: row i is line i, row 0 included: i + 1 of them after row i)
+        const unsigned long long *ptok = CL.flags + (feed ? (q - 1) % CL.K : 0);
+        bool good = true;
+        if (feed) good &= dpw_wait(ptok, CL.tok(q - 1, min(64, m) + 1), CL.failed());
         auto chunk = [&](int32_t k, uint32_t &pc, int32_t &cM, int32_t &cX, int32_t &cY) {
             const int32_t row = min(64 * k + lane + 1, m);
             pc = Pc[row - 1];
@@ -1844,6 +1907,7 @@ __device__ __forceinline__ void dpw_sweep_b(DpwShared &S, int lane, int wv, int3
         uint8_t *tw = tbp + j0;
         for (int32_t k = 0; 64 * k < m; k++) {
             pc_cur = pc_nxt; cM_cur = cM_nxt; cX_cur = cX_nxt; cY_cur = cY_nxt;
+            if (feed && 64 * (k + 1) < m) good &= dpw_wait(ptok, CL.tok(q - 1, min(64 * k + 128, m) + 1), CL.failed());
             chunk(k + 1, pc_nxt, cM_nxt, cX_nxt, cY_nxt);
             const int32_t iend = min(64 * k + 64, m);
             for (int32_t i = 64 * k + 1; i <= iend; i++, tw += npad) {
@@ -1883,7 +1947,9 @@ __device__ __forceinline__ void dpw_sweep_b(DpwShared &S, int lane, int wv, int3
                 }
                 sMo = sMn; sXo = sXn; sYo = sYn;
             }
+            if (CL.on() && park) dpw_publish(CL.flags + CL.c, CL.tok(q, iend + 1));       // rows 0 .. iend of the parked column are out
         }
+        if (!good && lane == 0) __hip_atomic_store(CL.failed(), 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (q == nsb - 1) {
             const int32_t rel = n - 1 - sb0;
             if (wv == rel / DPW_BAND && lane == (rel % DPW_BAND) / R) {
@@ -1899,19 +1965,38 @@ __device__ __forceinline__ void dpw_sweep_b(DpwShared &S, int lane, int wv, int3
     }
 }
 
-// one interval, all its progressive steps, by the whole workgroup (dp3_interval's structure; the walk is wave 0's, the rebuild everybody's)
+// one interval, all its progressive steps, by the whole workgroup (dp3_interval's structure; the walk is wave 0's, the rebuild everybody's) -- or by a
+// cluster of K workgroups (CL): they all go through the steps together, the sweeps of steps with several super-bands are shared, workgroup 0 walks and
+// rebuilds and tells the others the outcome of every step
 template <int R, int W>
 __device__ void dp_interval_wide(int nseq, int64_t iv, const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off, DpMeta *__restrict__ meta,
                                  uint32_t *__restrict__ cntA, uint32_t *__restrict__ maskA, uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
                                  uint8_t *__restrict__ tb, const int64_t *__restrict__ tb_off, int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
-                                 uint8_t *__restrict__ ops, const DpScoring &sc)
+                                 uint8_t *__restrict__ ops, const DpScoring &sc, DpwCluster CL)
 {
     __shared__ DpwShared S;
     __shared__ __attribute__((aligned(16))) uint8_t s_wwin[DP2_TB_DW * 4];       // traceback window of the walk (wave 0)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const bool lead = !CL.on() || CL.c == 0;                 // the workgroup that walks, rebuilds and writes the result
     DpMeta mt; mt.m = 0; mt.krows = 0; mt.cur = 0; mt.pad = 0; mt.score = 0; mt.cells = 0;
     const int64_t base = seq_off[iv * nseq];
+    bool good = true;
+    CL.step = 0;
+    // what the lead has to say after a step: the profile length and the final cell (the others poll the step token, then read them)
+    auto tell = [&](int32_t len) {
+        if (!CL.on()) return;
+        if (threadIdx.x == 0) { CL.flags[2 * CL.K + 1] = (unsigned long long)(uint32_t)len; for (int t = 0; t < 3; t++) CL.flags[2 * CL.K + 2 + t] = (unsigned long long)(uint32_t)S.fin[t]; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's profile stores
+        __syncthreads();
+        if (wv == 0) dpw_publish(CL.flags + 2 * CL.K, (unsigned long long)(CL.step + 1));
+    };
+    auto hear = [&](int32_t &len) {                          // by every wave of a workgroup that is not the lead
+        good &= dpw_wait(CL.flags + 2 * CL.K, (unsigned long long)(CL.step + 1), CL.failed());
+        len = (int32_t)(uint32_t)CL.flags[2 * CL.K + 1];
+        if (threadIdx.x == 0) for (int t = 0; t < 3; t++) S.fin[t] = (int32_t)(uint32_t)CL.flags[2 * CL.K + 2 + t];
+        __syncthreads();
+    };
     for (int g = 0; g < nseq; g++) {
         const int64_t so = seq_off[iv * nseq + g];
         const int32_t n = (int32_t)(seq_off[iv * nseq + g + 1] - so);
@@ -1920,10 +2005,11 @@ __device__ void dp_interval_wide(int nseq, int64_t iv, const uint8_t *__restrict
         uint32_t *Pc = (mt.cur ? cntB : cntA) + base, *Pm = (mt.cur ? maskB : maskA) + base;
         uint32_t *Qc = (mt.cur ? cntA : cntB) + base, *Qm = (mt.cur ? maskA : maskB) + base;
         if (mt.krows == 0) {
-            for (int32_t c = threadIdx.x; c < n; c += 64 * W) { Pc[c] = 1u << (8 * seq[c]); Pm[c] = 1u << g; }
+            if (lead) for (int32_t c = threadIdx.x; c < n; c += 64 * W) { Pc[c] = 1u << (8 * seq[c]); Pm[c] = 1u << g; }
             mt.m = n; mt.krows = 1;
             __threadfence_block();
             __syncthreads();
+            if (CL.on()) { int32_t dummy; if (lead) { if (threadIdx.x == 0) S.fin[0] = S.fin[1] = S.fin[2] = 0; __syncthreads(); tell(n); } else hear(dummy); CL.step++; }
             continue;
         }
         const int32_t m = mt.m;
@@ -1931,16 +2017,40 @@ __device__ void dp_interval_wide(int nseq, int64_t iv, const uint8_t *__restrict
         int32_t *rowbuf = rows + rows_off[iv];
         Dp3Walk Wk; Wk.win = s_wwin; Wk.cap = DP2_TB_DW * 4; Wk.tb = tbp;
         const bool wide_b = dpw_orient_b(m, n);
-        if ((wide_b ? n : m) > DP3_BAND) {
-            // the lane dimension has several bands: all waves
-            const int32_t pad = (int32_t)dp3_pad(wide_b ? n : m);
+        const int32_t ldim = wide_b ? n : m;
+        int32_t nsb = 0;                                          // super-bands of this step (0: the one-wave sweep)
+        if (ldim > DP3_BAND) {
+            // the lane dimension has several bands: all waves (of all the cluster's workgroups that have a super-band)
+            nsb = (ldim + DPW_SB - 1) / DPW_SB;
+            const int32_t pad = (int32_t)dp3_pad(ldim);
             Wk.orient_b = wide_b; Wk.R = 4; Wk.stride = pad;              // (a byte per row / column: the walk's R = 4 layout whatever R the sweep ran with)
-            if (!wide_b) dpw_sweep_a<R, W>(S, lane, wv, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad);
-            else dpw_sweep_b<R, W>(S, lane, wv, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad);
-        } else {
+            DpwCluster C1 = CL; if (nsb < 2) C1.K = 1;                    // one super-band: nothing to share (the lead runs it as if alone)
+            if (C1.on() || lead) {
+                if (!wide_b) dpw_sweep_a<R, W>(S, lane, wv, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, C1);
+                else dpw_sweep_b<R, W>(S, lane, wv, m, n, Pc, seq, sc, mt.krows, rowbuf, tbp, pad, C1);
+            }
+            if (C1.on()) {
+                // the traceback bytes (and, from whoever ran the last super-band, the final cell) to the lead
+                const int owner = (nsb - 1) % CL.K;
+                if (CL.c == owner && threadIdx.x == 0) for (int t = 0; t < 3; t++) CL.flags[2 * CL.K + 2 + t] = (unsigned long long)(uint32_t)S.fin[t];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (!lead) { if (wv == 0 && CL.c < nsb) dpw_publish(CL.flags + CL.K + CL.c, (unsigned long long)(CL.step + 1)); }
+                else {
+                    if (wv == 0) {
+                        bool okw = true;
+                        for (int cc = 1; cc < CL.K && cc < nsb; cc++) okw &= dpw_wait(CL.flags + CL.K + cc, (unsigned long long)(CL.step + 1), CL.failed());
+                        if (!okw && lane == 0) __hip_atomic_store(CL.failed(), 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (owner != 0 && lane == 0) for (int t = 0; t < 3; t++) S.fin[t] = (int32_t)(uint32_t)CL.flags[2 * CL.K + 2 + t];
+                    }
+                    __syncthreads();
+                    // (the other waves of the lead read the traceback only through wave 0's walk; the rebuild reads Pc / Pm, which nobody else wrote)
+                }
+            }
+        } else if (lead) {
             // small in the dimension the cost rule picks: the one-wave sweep, by wave 0 (dp3_interval's choice of orientation and of R)
             const bool ob = dp3_orient_b(m, n);
-            const int32_t ldim = ob ? n : m, R1 = dp3_rows_per_lane(ldim), pad = (int32_t)dp3_pad(ldim);
+            const int32_t ld1 = ob ? n : m, R1 = dp3_rows_per_lane(ld1), pad = (int32_t)dp3_pad(ld1);
             Wk.orient_b = ob; Wk.R = R1; Wk.stride = pad;
             if (wv == 0) {
                 int32_t fM = DP_NEG_INF, fX = DP_NEG_INF, fY = DP_NEG_INF;
@@ -1958,39 +2068,49 @@ __device__ void dp_interval_wide(int nseq, int64_t iv, const uint8_t *__restrict
             __threadfence_block();
             __syncthreads();
         }
-        const int32_t fM = S.fin[0], fX = S.fin[1], fY = S.fin[2];
-        int32_t best = fM; int state = 0;
-        if (fX > best) { best = fX; state = 1; }
-        if (fY > best) { best = fY; state = 2; }
-        uint8_t *opr = ops + base;                         // reversed ops, capacity m + n
-        if (wv == 0) {
-            const int32_t l0 = dp3_walk(Wk, m, n, state, opr, lane);
-            if (lane == 0) S.len = l0;
-        }
-        __threadfence_block();
-        __syncthreads();
-        const int32_t len = S.len;
-        // ---- new profile: every wave keeps the running source counts, chunk k is written by wave k mod W ----
-        int32_t carry_p = 0, carry_s = 0;
-        for (int32_t c0i = 0, k = 0; c0i < len; c0i += 64, k++) {
-            const int32_t c = c0i + lane;
-            const bool ok = c < len;
-            const uint32_t op = ok ? opr[len - 1 - c] : 0u;
-            const uint64_t bp = __ballot(ok && (op & 1)), bs = __ballot(ok && (op & 2));
-            if (ok && (k % W) == wv) {
-                const int32_t pi = carry_p + (int32_t)__popcll(bp & lt), sj = carry_s + (int32_t)__popcll(bs & lt);
-                uint32_t cv = 0, mv = 0;
-                if (op & 1) { cv = Pc[pi]; mv = Pm[pi]; }
-                if (op & 2) { cv += 1u << (8 * seq[sj]); mv |= 1u << g; }
-                Qc[c] = cv; Qm[c] = mv;
+        int32_t len = 0;
+        if (lead) {
+            const int32_t fM = S.fin[0], fX = S.fin[1], fY = S.fin[2];
+            int state = 0; { int32_t best = fM; if (fX > best) { best = fX; state = 1; } if (fY > best) { best = fY; state = 2; } }
+            uint8_t *opr = ops + base;                         // reversed ops, capacity m + n
+            if (wv == 0) {
+                const int32_t l0 = dp3_walk(Wk, m, n, state, opr, lane);
+                if (lane == 0) S.len = l0;
             }
-            carry_p += (int32_t)__popcll(bp); carry_s += (int32_t)__popcll(bs);
+            __threadfence_block();
+            __syncthreads();
+            len = S.len;
+            // ---- new profile: every wave keeps the running source counts, chunk k is written by wave k mod W ----
+            int32_t carry_p = 0, carry_s = 0;
+            for (int32_t c0i = 0, k = 0; c0i < len; c0i += 64, k++) {
+                const int32_t c = c0i + lane;
+                const bool ok = c < len;
+                const uint32_t op = ok ? opr[len - 1 - c] : 0u;
+                const uint64_t bp = __ballot(ok && (op & 1)), bs = __ballot(ok && (op & 2));
+                if (ok && (k % W) == wv) {
+                    const int32_t pi = carry_p + (int32_t)__popcll(bp & lt), sj = carry_s + (int32_t)__popcll(bs & lt);
+                    uint32_t cv = 0, mv = 0;
+                    if (op & 1) { cv = Pc[pi]; mv = Pm[pi]; }
+                    if (op & 2) { cv += 1u << (8 * seq[sj]); mv |= 1u << g; }
+                    Qc[c] = cv; Qm[c] = mv;
+                }
+                carry_p += (int32_t)__popcll(bp); carry_s += (int32_t)__popcll(bs);
+            }
+            tell(len);
+        } else hear(len);
+        {
+            const int32_t fM = S.fin[0], fX = S.fin[1], fY = S.fin[2];
+            int32_t best = fM; if (fX > best) best = fX; if (fY > best) best = fY;
+            mt.cells += (int64_t)m * n; mt.score += best; mt.m = len; mt.krows += 1; mt.cur ^= 1;
         }
-        mt.cells += (int64_t)m * n; mt.score += best; mt.m = len; mt.krows += 1; mt.cur ^= 1;
+        CL.step++;
         __threadfence_block();
         __syncthreads();
     }
-    if (threadIdx.x == 0) meta[iv] = mt;
+    if (lead && threadIdx.x == 0) {
+        if (CL.on() && (!good || __hip_atomic_load(CL.failed(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ULL)) mt.pad = 1;     // a wait of the cluster ran out: the host refuses the batch
+        meta[iv] = mt;
+    }
 }
 
 // The workgroup launches (second stream), both over the same list entries: dp_step_wide takes the intervals the scans admit, dp_step_big --
@@ -2021,11 +2141,22 @@ __global__ void __launch_bounds__(64 * W) dp_step_wide(int nseq, const int64_t *
                                                uint32_t *__restrict__ cntB, uint32_t *__restrict__ maskB,
                                                uint8_t *__restrict__ tb, const int64_t *__restrict__ tb_off,
                                                int32_t *__restrict__ rows, const int64_t *__restrict__ rows_off,
-                                               uint8_t *__restrict__ ops, DpScoring sc, int64_t band_from)
+                                               uint8_t *__restrict__ ops, DpScoring sc, int64_t band_from, int K, unsigned long long *__restrict__ flags)
 {
-    const int64_t iv = list[blockIdx.x];
+    // K > 1: K consecutive workgroups share list entry blockIdx.x / K (a cluster); a workgroup that can never hold a super-band of this interval -- no
+    // profile and no sequence of it can be longer than all its sequences together -- leaves at once
+    const uint32_t entry = K > 1 ? blockIdx.x / (uint32_t)K : blockIdx.x;
+    const int64_t iv = list[entry];
     if (!dp_takes_wide(nseq, iv, seq_off, sc, band_from, 1)) return;
-    dp_interval_wide<R, W>(nseq, iv, codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, sc);
+    DpwCluster CL; CL.K = 1; CL.c = 0; CL.flags = nullptr; CL.step = 0;
+    if (K > 1) {
+        const int64_t total = seq_off[(iv + 1) * nseq] - seq_off[iv * nseq];
+        const int kk = (int)min((int64_t)K, (total + DPW_SB - 1) / DPW_SB);      // workgroups that can have work: the same for every workgroup of the cluster
+        const int c = (int)(blockIdx.x % (uint32_t)K);
+        if (c >= kk) return;
+        CL.K = kk; CL.c = c; CL.flags = flags + (size_t)entry * DPW_FLAGS;
+    }
+    dp_interval_wide<R, W>(nseq, iv, codes, seq_off, meta, cntA, maskA, cntB, maskB, tb, tb_off, rows, rows_off, ops, sc, CL);
 }
 
 // The register-blocked launch: block ranges [one wave per interval | G = 16 | G = 8 | G = 4], the long ones first.
@@ -2205,19 +2336,27 @@ static int dp_launch_steps(mauve_ctx *ctx, int nseq, int64_t a, int64_t b, int64
         HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         const bool wide = dp_wide_on();
-        static const bool r4 = getenv("MAUVE_DP_WIDE_R4") != nullptr;      // A/B switch: 8 waves x 4 rows per lane instead of 16 x 2
-        if (wide && r4)
-            hipLaunchKernelGGL((dp_step_wide<4, 8>), dim3((uint32_t)bn), dim3(64 * 8), 0, ctx->stream, nseq,
-                               ctx->dp_list.as<int64_t>() + bf, ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(),
-                               ctx->dp_prof_cnt.as<uint32_t>(), ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
-                               ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(),
-                               d_rows_off, ctx->dp_score.as<uint8_t>(), sc, band_from);
-        else if (wide)
-            hipLaunchKernelGGL((dp_step_wide<2, 16>), dim3((uint32_t)bn), dim3(64 * 16), 0, ctx->stream, nseq,
-                               ctx->dp_list.as<int64_t>() + bf, ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(),
-                               ctx->dp_prof_cnt.as<uint32_t>(), ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(),
-                               ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(),
-                               d_rows_off, ctx->dp_score.as<uint8_t>(), sc, band_from);
+        // 8 waves x 4 rows per lane; MAUVE_DP_WIDE_R2: 16 waves x 2 rows per lane (A/B: the same time per line -- the sweep is bound by vector issue, not by the
+        // number of waves -- and the 128-register budget of a 1024-thread workgroup makes it spill)
+        static const bool r4 = getenv("MAUVE_DP_WIDE_R2") == nullptr;
+        // the first entries of the list (the largest intervals) get a CLUSTER of up to DPW_KMAX workgroups each (dp_interval_wide); few enough that all
+        // of them are resident at once beside the rest.  MAUVE_DP_CLUSTER=0: off (A/B), =n: that many entries
+        static const int64_t cl_max = getenv("MAUVE_DP_CLUSTER") ? atoll(getenv("MAUVE_DP_CLUSTER")) : 32;
+        const int64_t n_cl = wide ? std::min<int64_t>(bn, cl_max) : 0;
+        unsigned long long *flags = nullptr;
+        if (n_cl) {
+            HIPCHK(ctx, ctx->dp_wflags.ensure((size_t)n_cl * DPW_FLAGS * 8));
+            HIPCHK(ctx, hipMemsetAsync(ctx->dp_wflags.p, 0, (size_t)n_cl * DPW_FLAGS * 8, ctx->stream));
+            flags = ctx->dp_wflags.as<unsigned long long>();
+        }
+#define DPW_LAUNCH(RR, WW, first, count, K) hipLaunchKernelGGL((dp_step_wide<RR, WW>), dim3((uint32_t)((count) * (K))), dim3(64 * WW), 0, ctx->stream, nseq, \
+                               ctx->dp_list.as<int64_t>() + bf + (first), ctx->dp_codes.as<uint8_t>(), d_seq_off, ctx->dp_meta.as<DpMeta>(), \
+                               ctx->dp_prof_cnt.as<uint32_t>(), ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_cnt.as<uint32_t>(), \
+                               ctx->dp_prof2_mask.as<uint32_t>(), tb, d_tb_off, ctx->dp_rows.as<int32_t>(), \
+                               d_rows_off, ctx->dp_score.as<uint8_t>(), sc, band_from, (int)(K), flags)
+        if (wide && r4) { if (n_cl) DPW_LAUNCH(4, 8, 0, n_cl, DPW_KMAX); if (bn > n_cl) DPW_LAUNCH(4, 8, n_cl, bn - n_cl, 1); }
+        else if (wide) { if (n_cl) DPW_LAUNCH(2, 16, 0, n_cl, DPW_KMAX); if (bn > n_cl) DPW_LAUNCH(2, 16, n_cl, bn - n_cl, 1); }
+#undef DPW_LAUNCH
         // (the stripe pipeline: every entry without the wide sweep; with it, only where banded intervals or an inadmissible scoring scheme can occur)
         if (!wide || band_from != INT64_MAX || !dp3_admissible(1, nseq, sc.ge, sc.go))
             hipLaunchKernelGGL(dp_step_big, dim3((uint32_t)bn), dim3(64 * DP_MW_WAVES), 0, ctx->stream, nseq,
@@ -2432,6 +2571,7 @@ static int dp_core(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes,
     const double td3 = now_ms();
     int64_t tc = 0, ncell = 0;
     for (int64_t iv = 0; iv < n_iv; iv++) {
+        if (hm[iv].pad) { ctx->err = "dp: a cluster of workgroups could not make progress on an interval (wide sweep)"; return MAUVE_ERR_HIP; }
         col_off[iv] = tc; tc += hm[iv].m; ncell += hm[iv].cells;
         if (score) score[iv] = hm[iv].score;
     }
@@ -2484,7 +2624,7 @@ namespace {
 using namespace devscan;
 
 struct DpFrontTotals {                       // device block read back once
-    int64_t codes, tb, rows, est, n_dp, first_med, first_s32, first_s16, cols, cells, first_c;
+    int64_t codes, tb, rows, est, n_dp, first_med, first_s32, first_s16, cols, cells, first_c, err;
 };
 
 __device__ __forceinline__ void dpf_gap(const int32_t *__restrict__ alen, const int32_t *__restrict__ ast, int N, uint32_t k, int g,
@@ -2605,10 +2745,10 @@ __global__ void __launch_bounds__(256) dpf_list(const uint32_t *__restrict__ key
 }
 struct MetaCols { const DpMeta *m; __device__ int64_t value(uint32_t i) const { return m[i].m; } };
 struct MetaCells { const DpMeta *m; __device__ int64_t value(uint32_t i) const { return m[i].cells; } };
-__global__ void __launch_bounds__(256) dpf_scores(const DpMeta *__restrict__ meta, uint32_t n, int64_t *__restrict__ score)
+__global__ void __launch_bounds__(256) dpf_scores(const DpMeta *__restrict__ meta, uint32_t n, int64_t *__restrict__ score, DpFrontTotals *__restrict__ tot)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) score[i] = meta[i].score;
+    if (i < n) { score[i] = meta[i].score; if (meta[i].pad) tot->err = 1; }       // pad: a cluster of workgroups gave up on this interval (dp_interval_wide)
 }
 
 }  // namespace
@@ -2757,7 +2897,7 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     hipLaunchKernelGGL((vscan_write<int64_t, MetaCols>), dim3(nbd), dim3(256), 0, ctx->stream, MetaCols{meta}, n_dp, bsum, d_col_off, &tot->cols);
     hipLaunchKernelGGL((vscan_partial<int64_t, MetaCells>), dim3(nbd), dim3(256), 0, ctx->stream, MetaCells{meta}, n_dp, bsum2);
     hipLaunchKernelGGL((vscan_write<int64_t, MetaCells>), dim3(nbd), dim3(256), 0, ctx->stream, MetaCells{meta}, n_dp, bsum2, rowsn /*scratch*/, &tot->cells);
-    hipLaunchKernelGGL(dpf_scores, dim3(blk_d), dim3(256), 0, ctx->stream, meta, n_dp, d_score);
+    hipLaunchKernelGGL(dpf_scores, dim3(blk_d), dim3(256), 0, ctx->stream, meta, n_dp, d_score, tot);
     {
         const uint32_t gblocks = (uint32_t)std::min<int64_t>(((int64_t)n_dp + 3) / 4, 256 * 8);
         hipLaunchKernelGGL(dp_gather, dim3(gblocks), dim3(256), 0, ctx->stream, N, (int64_t)n_dp, d_seq_off, meta, ctx->dp_prof_mask.as<uint32_t>(),
@@ -2768,6 +2908,7 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     if (stay_on_device) {
         HIPCHK(ctx, hipMemcpyAsync(ht, tot, sizeof(DpFrontTotals), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ht->err) { ctx->err = "dp: a cluster of workgroups could not make progress on an interval (wide sweep)"; return MAUVE_ERR_HIP; }
         if (cells) *cells = ht->cells;
         fo.cols = ctx->dp_cols.as<uint32_t>(); fo.n_cols = ht->cols;
         if (trace) fprintf(stderr, "[trace] dp (device front, results stay): %u intervals (%lld workgroup, %lld one-wave, %lld two/wave, %lld four/wave), %d round(s); gaps+slots %.3f ms, sizing+order %.3f, kernels+offsets %.3f\n",
@@ -2782,6 +2923,7 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     HIPCHK(ctx, hipMemcpyAsync(p_score, d_score, (size_t)n_dp * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const double t3 = now_ms();
+    if (ht->err) { ctx->err = "dp: a cluster of workgroups could not make progress on an interval (wide sweep)"; return MAUVE_ERR_HIP; }
     const int64_t tc = ht->cols;
     if (cells) *cells = ht->cells;
     memcpy(dcol_off.data(), p_off, ((size_t)n_dp + 1) * 8);

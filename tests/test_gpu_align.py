@@ -1085,10 +1085,13 @@ def test_dp_wide_sweeps():
     """The workgroup class runs the wide sweep (dp_step_wide: the scan-formulated sweep over all waves of a workgroup, one column / row of a
     whole super-band per step): with MAUVE_DP_WIDE_MIN=1 every interval with a dimension beyond one band goes through it -- both
     orientations, one and several super-bands, the one-wave fallback for steps small in both dimensions, several sequences.  Bit-exact against
-    the oracle; the stripe pipeline that banded intervals keep (MAUVE_DP_NO_WIDE) must agree on the same shapes."""
+    the oracle; the stripe pipeline that banded intervals keep (MAUVE_DP_NO_WIDE) must agree on the same shapes.  The largest intervals of a launch get a
+    cluster of up to four workgroups (super-bands pipelined across CUs through parked lines and progress tokens): on by default here, off
+    (MAUVE_DP_CLUSTER=0) and with the 16-wave shape as well."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ({"MAUVE_DP_WIDE_MIN": "1"}, {"MAUVE_DP_WIDE_MIN": "1", "MAUVE_DP_BIG_MAX": "7"}, {"MAUVE_DP_WIDE_MIN": "1", "MAUVE_DP_NO_WIDE": "1"}):
+    for extra in ({"MAUVE_DP_WIDE_MIN": "1"}, {"MAUVE_DP_WIDE_MIN": "1", "MAUVE_DP_BIG_MAX": "7"}, {"MAUVE_DP_WIDE_MIN": "1", "MAUVE_DP_NO_WIDE": "1"},
+                  {"MAUVE_DP_WIDE_MIN": "1", "MAUVE_DP_CLUSTER": "0"}, {"MAUVE_DP_WIDE_MIN": "1", "MAUVE_DP_WIDE_R2": "1", "MAUVE_DP_CLUSTER": "3"}):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", WIDE_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and r.stdout.strip().endswith("OK"), str(extra) + "\n" + r.stdout + r.stderr[-3000:]

@@ -8,4 +8,7 @@ step fuzz4  env MAUVE_CANON_DEVICE_MIN=1 FUZZ_IT_FILE=$D/fuzz4.it python tools/s
 step fuzz5  env MAUVE_CANON_DEVICE_MIN=1 FUZZ_IT_FILE=$D/fuzz5.it python tools/sweep/fuzz5.py $((S+3)) $T
 step fuzz4w env MAUVE_DP_CLASS=wild MAUVE_CH_CL_MAX=3 MAUVE_CANON_DEVICE_MIN=1 FUZZ_IT_FILE=$D/fuzz4w.it python tools/sweep/fuzz4.py $((S+4)) $T
 step fuzz5b env FUZZ_IT_FILE=$D/fuzz5b.it python tools/sweep/fuzz5.py $((S+5)) $T
+# round 4: every interval with a dimension beyond one band through the wide sweep (dp_step_wide), both of its shapes
+step fuzz4x env MAUVE_DP_WIDE_MIN=1 MAUVE_CANON_DEVICE_MIN=1 FUZZ_IT_FILE=$D/fuzz4x.it python tools/sweep/fuzz4.py $((S+6)) $T
+step fuzz1x env MAUVE_DP_WIDE_MIN=1 MAUVE_DP_WIDE_R2=1 FUZZ_IT_FILE=$D/fuzz1x.it python tools/sweep/fuzz.py $((S+7)) $T
 cat $D/summary.txt
