@@ -2712,6 +2712,43 @@ __global__ void __launch_bounds__(256) dpf_desc(const int32_t *__restrict__ alen
     sizekey[s] = (uint32_t)(63 - c);                         // largest traceback footprint first
     slotval[s] = s;
 }
+// the same sizing for a batch whose descriptors the host made (dp_run_from_desc: the intervals of a guide-tree node and their refinement candidates)
+__global__ void __launch_bounds__(256) dpf_size_desc(const DpSeqDesc *__restrict__ desc, int N, uint32_t n, DpFrontTotals *__restrict__ tot,
+                                                     int64_t *__restrict__ need, int64_t *__restrict__ rowsn, int64_t *__restrict__ est, uint8_t *__restrict__ cand,
+                                                     uint8_t *__restrict__ cls, uint32_t *__restrict__ sizekey, uint32_t *__restrict__ slotval, int no_mw, int no_groups,
+                                                     int64_t band_from, int class_mode)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s == 0) tot->n_dp = n;                               // (the block was cleared by a memset in front of this launch)
+    if (s >= n) return;
+    int64_t mmax = 0, mmin = 0, nd = 0, nmax = 0, es = 0, longest = 0, rneed = 0; bool first = true; uint8_t big = 0;
+    DpClassEst ce; ce.mode = class_mode & 7;
+    for (int g = 0; g < N; g++) longest = max(longest, desc[(size_t)s * N + g].len);
+    const bool banded = longest > band_from;
+    for (int g = 0; g < N; g++) {
+        const int64_t nn = desc[(size_t)s * N + g].len;
+        ce.add(nn);
+        if (nn == 0) continue;
+        if (first) { first = false; mmax = mmin = nn; continue; }
+        const int64_t tbo = dp_tb_need(mmin, mmax, nn, banded);
+        const int64_t tbn = banded ? tbo : max(tbo, max(dp2_tb_need(mmax, nn), dp3_tb_need(mmax, nn)));
+        rneed = max(rneed, dp3_rows_need(mmax, nn));
+        nd = max(nd, tbn);
+        nmax = max(nmax, nn);
+        const int64_t e_m = min(mmax, mmin + mmin / 8 + 2);
+        if (max(e_m, nn) > DP3_BAND && !no_mw) big = 1;
+        es += dp3_scan_steps(e_m, nn);
+        mmax += nn; mmin = max(mmin, nn);
+    }
+    if (banded && nmax) big = 2;
+    need[s] = nd; rowsn[s] = max(6 * (nmax + 1), rneed); est[s] = es; cand[s] = big;
+    uint8_t kc = 1;
+    if (!no_groups && !banded) kc = (uint8_t)(class_mode & 8 ? ce.klass(DP_GRP_TMAX) : ce.klass2(DP2_R, DP2_T));
+    cls[s] = kc;
+    int c = 0; for (int64_t f = nd; f > 1; f >>= 1) c++;
+    sizekey[s] = (uint32_t)(63 - c);
+    slotval[s] = s;
+}
 struct DescLen { const DpSeqDesc *d; __device__ int64_t value(uint32_t i) const { return d[i].len; } };
 struct ArrVal { const int64_t *a; __device__ int64_t value(uint32_t i) const { return a[i]; } };
 struct ListVal { const int64_t *a; const uint32_t *order; __device__ int64_t value(uint32_t j) const { return a[order[j]]; } };
@@ -2938,6 +2975,147 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
     return MAUVE_OK;
 }
 
+// A batch of intervals given by descriptors (the progressive path: the intervals of a guide-tree node and all their refinement candidates, 86 000 at
+// C4's root), through the device front end: the descriptors go up once, sizing, offsets and launch order are made by the kernels and scans of
+// dp_run_from_anchors (dp_core's host loops took 7 ms for that batch, beside 4 ms of DP kernels), the result offsets come from scans as well.
+// cols == nullptr: the columns stay in dp_cols (dp_fetch_picked).  sp: the refinement objective (dp_sp_scores), or nullptr.
+int dp_run_from_desc(mauve_ctx *ctx, int N, int64_t n_iv, const DpSeqDesc *h_desc, const mauve_scoring *scoring, uint32_t *cols, int64_t *col_off, int64_t *score,
+                     int64_t *cells, int64_t *sp)
+{
+    static const bool trace = getenv("MAUVE_TRACE") != nullptr;
+    static const bool no_mw = getenv("MAUVE_DP_ONE_WAVE") != nullptr, no_groups = getenv("MAUVE_DP_NO_GROUPS") != nullptr;
+    const double t0 = now_ms();
+    if (cells) *cells = 0;
+    col_off[0] = 0;
+    if (n_iv == 0) return MAUVE_OK;
+    if (n_iv >= (1LL << 31) / std::max(N, 1)) { ctx->err = "dp: too many intervals"; return MAUVE_ERR_LIMIT; }
+    const uint32_t na = (uint32_t)n_iv, n_dp = na, nb = (na + TILE - 1) / TILE;
+    HIPCHK(ctx, ctx->dp_desc.ensure((size_t)na * N * sizeof(DpSeqDesc)));
+    auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    const size_t o_cand = (size_t)na * 24, o_k = up8(o_cand + 2 * (size_t)na), o_bcnt = o_k + (size_t)na * 20, o_bsum = up8(o_bcnt + (size_t)nb * 4),
+                 o_bsum2 = o_bsum + ((size_t)nb * N + 8) * 8, w_total = o_bsum2 + ((size_t)nb + 8) * 8;
+    HIPCHK(ctx, ctx->dpf_work.ensure(w_total));
+    HIPCHK(ctx, ctx->dp_off.ensure(((size_t)na * N + 1 + 3 * ((size_t)na + 1)) * sizeof(int64_t)));
+    HIPCHK(ctx, ctx->dp_list.ensure((size_t)na * 8));
+    HIPCHK(ctx, ctx->dp_meta.ensure((size_t)na * sizeof(DpMeta)));
+    HIPCHK(ctx, ctx->dpf_tot.ensure(256));
+    DpSeqDesc *desc = ctx->dp_desc.as<DpSeqDesc>();
+    char *wk = ctx->dpf_work.as<char>();
+    int64_t *need = reinterpret_cast<int64_t *>(wk), *rowsn = need + na, *est = rowsn + na;
+    uint8_t *cand = reinterpret_cast<uint8_t *>(wk + o_cand), *cls = cand + na;
+    uint32_t *k1 = reinterpret_cast<uint32_t *>(wk + o_k), *v1 = k1 + na, *k2 = v1 + na, *v2 = k2 + na, *k3 = v2 + na;
+    uint32_t *bcnt = reinterpret_cast<uint32_t *>(wk + o_bcnt);
+    int64_t *bsum = reinterpret_cast<int64_t *>(wk + o_bsum), *bsum2 = reinterpret_cast<int64_t *>(wk + o_bsum2);
+    DpFrontTotals *tot = ctx->dpf_tot.as<DpFrontTotals>();
+    int64_t *d_seq_off = ctx->dp_off.as<int64_t>();
+    int64_t *d_tb_off = d_seq_off + ((size_t)na * N + 1), *d_rows_off = d_tb_off + (na + 1), *d_col_off = d_rows_off + (na + 1);
+    const size_t desc_bytes = (size_t)na * N * sizeof(DpSeqDesc);
+    HIPCHK(ctx, ctx->pin_dp_in.ensure(256 + desc_bytes));
+    DpFrontTotals *ht = ctx->pin_dp_in.as<DpFrontTotals>();
+    memcpy(ctx->pin_dp_in.as<char>() + 256, h_desc, desc_bytes);
+    HIPCHK(ctx, hipMemcpyAsync(desc, ctx->pin_dp_in.as<char>() + 256, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(tot, 0, 256, ctx->stream));
+    const uint32_t blk_d = (n_dp + 255) / 256;
+    hipLaunchKernelGGL(dpf_size_desc, dim3(blk_d), dim3(256), 0, ctx->stream, desc, N, n_dp, tot, need, rowsn, est, cand, cls, k1, v1, (int)no_mw, (int)no_groups,
+                       ctx->dp_band_from, dp_class_mode() | (dp_old_kernels() ? 8 : 0));
+    const uint32_t nbd = (n_dp + TILE - 1) / TILE, nbs = (n_dp * (uint32_t)N + TILE - 1) / TILE;
+    hipLaunchKernelGGL((vscan_partial<int64_t, DescLen>), dim3(nbs), dim3(256), 0, ctx->stream, DescLen{desc}, n_dp * (uint32_t)N, bsum);
+    hipLaunchKernelGGL((vscan_write<int64_t, DescLen>), dim3(nbs), dim3(256), 0, ctx->stream, DescLen{desc}, n_dp * (uint32_t)N, bsum, d_seq_off, &tot->codes);
+    hipLaunchKernelGGL((vscan_partial<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{rowsn}, n_dp, bsum);
+    hipLaunchKernelGGL((vscan_write<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{rowsn}, n_dp, bsum, d_rows_off, &tot->rows);
+    hipLaunchKernelGGL((vscan_partial<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{est}, n_dp, bsum2);
+    hipLaunchKernelGGL((vscan_write<int64_t, ArrVal>), dim3(nbd), dim3(256), 0, ctx->stream, ArrVal{est}, n_dp, bsum2, d_col_off /*scratch*/, &tot->est);
+    uint32_t *ok = k1, *ov = v1;
+    int rc = sort_pairs_u32(ctx, n_dp, 6, &ok, &ov, k2, v2, MAUVE_K_MISC);
+    if (rc) return rc;
+    uint32_t *fk = ok == k1 ? k2 : k1, *fv = ov == v1 ? v2 : v1;
+    const DpBigPick bp{ov, cand, cls, est, tot, fk, dp_wide_min(), (uint32_t)dp_big_max()};
+    hipLaunchKernelGGL((cmp_count<DpBigPick>), dim3(nbd), dim3(256), 0, ctx->stream, bp, bcnt);
+    hipLaunchKernelGGL((cmp_write<DpBigPick>), dim3(nbd), dim3(256), 0, ctx->stream, bp, bcnt);
+    uint32_t *ck = fk, *cv = ov;
+    rc = sort_pairs_u32(ctx, n_dp, 3, &ck, &cv, k3, fv, MAUVE_K_MISC);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dpf_list, dim3(blk_d), dim3(256), 0, ctx->stream, ck, cv, tot, ctx->dp_list.as<int64_t>());
+    int64_t *tb_list_dev = d_col_off;
+    hipLaunchKernelGGL((vscan_partial<int64_t, ListVal>), dim3(nbd), dim3(256), 0, ctx->stream, ListVal{need, cv}, n_dp, bsum2);
+    hipLaunchKernelGGL((vscan_write<int64_t, ListVal>), dim3(nbd), dim3(256), 0, ctx->stream, ListVal{need, cv}, n_dp, bsum2, tb_list_dev, &tot->tb);
+    hipLaunchKernelGGL(dpf_tb_scatter, dim3(blk_d), dim3(256), 0, ctx->stream, tb_list_dev, cv, n_dp, d_tb_off);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ht, tot, sizeof(DpFrontTotals), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t total = ht->codes, tbt = ht->tb, rwt = ht->rows;
+    DpClasses cl; memset(&cl, 0, sizeof cl);
+    const int64_t n_big = ht->first_med;
+    cl.first_med = ht->first_med; cl.n_med = ht->first_c - ht->first_med;
+    cl.first_c = ht->first_c; cl.n_c = ht->first_s32 - ht->first_c;
+    cl.first_s32 = ht->first_s32; cl.n_s32 = ht->first_s16 - ht->first_s32;
+    cl.first_s16 = ht->first_s16; cl.n_s16 = (int64_t)n_dp - ht->first_s16;
+    const double t1 = now_ms();
+    HIPCHK(ctx, ctx->dp_codes.ensure((size_t)total + 16));
+    HIPCHK(ctx, ctx->dp_prof_cnt.ensure((size_t)(total + 1) * 4));
+    HIPCHK(ctx, ctx->dp_prof_mask.ensure((size_t)(total + 1) * 4));
+    HIPCHK(ctx, ctx->dp_prof2_cnt.ensure((size_t)(total + 1) * 4));
+    HIPCHK(ctx, ctx->dp_prof2_mask.ensure((size_t)(total + 1) * 4));
+    HIPCHK(ctx, ctx->dp_tb.ensure((size_t)std::min<int64_t>(tbt, dp_tb_budget()) + 64));
+    HIPCHK(ctx, ctx->dp_rows.ensure((size_t)(rwt + 1) * 4));
+    HIPCHK(ctx, ctx->dp_score.ensure((size_t)total + 16));
+    HIPCHK(ctx, ctx->dp_cols.ensure((size_t)(total + 1) * 4));
+    std::vector<int64_t> &tb_list = ctx->dph.tb_list; tb_list.clear();
+    if (tbt > dp_tb_budget()) {
+        tb_list.resize((size_t)n_dp + 1);
+        HIPCHK(ctx, hipMemcpy(tb_list.data(), tb_list_dev, ((size_t)n_dp + 1) * 8, hipMemcpyDeviceToHost));
+    }
+    {
+        DpGenomeWords gw; memset(&gw, 0, sizeof gw);
+        for (int g = 0; g < ctx->nseq; g++) gw.word_off[g] = ctx->word_off[g];
+        const int64_t nd = (int64_t)n_dp * N;
+        hipLaunchKernelGGL(dp_gather_codes, dim3((uint32_t)std::min<int64_t>((nd + 3) / 4, 256 * 8)), dim3(256), 0, ctx->stream, ctx->genomes.as<uint64_t>(), gw, desc, d_seq_off, nd,
+                           ctx->dp_codes.as<uint8_t>());
+    }
+    DpScoring sc; sc.go = scoring->gap_open; sc.ge = scoring->gap_extend; memcpy(sc.s, scoring->matrix, sizeof sc.s);
+    int rounds = 1;
+    rc = dp_launch_rounds(ctx, N, n_dp, n_big, cl, d_seq_off, d_tb_off, d_rows_off, sc, tb_list.empty() ? nullptr : tb_list.data(), &rounds, ctx->dp_band_from);
+    if (rc) return rc;
+    const DpMeta *meta = ctx->dp_meta.as<DpMeta>();
+    int64_t *d_score = need;
+    hipLaunchKernelGGL((vscan_partial<int64_t, MetaCols>), dim3(nbd), dim3(256), 0, ctx->stream, MetaCols{meta}, n_dp, bsum);
+    hipLaunchKernelGGL((vscan_write<int64_t, MetaCols>), dim3(nbd), dim3(256), 0, ctx->stream, MetaCols{meta}, n_dp, bsum, d_col_off, &tot->cols);
+    hipLaunchKernelGGL((vscan_partial<int64_t, MetaCells>), dim3(nbd), dim3(256), 0, ctx->stream, MetaCells{meta}, n_dp, bsum2);
+    hipLaunchKernelGGL((vscan_write<int64_t, MetaCells>), dim3(nbd), dim3(256), 0, ctx->stream, MetaCells{meta}, n_dp, bsum2, rowsn /*scratch*/, &tot->cells);
+    hipLaunchKernelGGL(dpf_scores, dim3(blk_d), dim3(256), 0, ctx->stream, meta, n_dp, d_score, tot);
+    hipLaunchKernelGGL(dp_gather, dim3((uint32_t)std::min<int64_t>(((int64_t)n_dp + 3) / 4, 256 * 8)), dim3(256), 0, ctx->stream, N, (int64_t)n_dp, d_seq_off, meta,
+                       ctx->dp_prof_mask.as<uint32_t>(), ctx->dp_prof2_mask.as<uint32_t>(), d_col_off, ctx->dp_cols.as<uint32_t>());
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, ctx->pin_meta.ensure(((size_t)n_dp * 3 + 2) * 8));
+    int64_t *p_off = ctx->pin_meta.as<int64_t>(), *p_score = p_off + n_dp + 1, *p_sp = p_score + n_dp;
+    if (sp && N >= 2) {                     // the refinement's objective, from the columns while they are here
+        HIPCHK(ctx, ctx->dp_sp.ensure((size_t)n_dp * 8 + 64));
+        hipLaunchKernelGGL(dp_sp_scores, dim3((uint32_t)std::min<int64_t>(((int64_t)n_dp + 3) / 4, 256 * 16)), dim3(256), 0, ctx->stream, N, (int64_t)n_dp, ctx->dp_codes.as<uint8_t>(), d_seq_off,
+                           ctx->dp_cols.as<uint32_t>(), d_col_off, sc, ctx->dp_sp.as<unsigned long long>());
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(p_sp, ctx->dp_sp.p, (size_t)n_dp * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ht, tot, sizeof(DpFrontTotals), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(p_off, d_col_off, ((size_t)n_dp + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(p_score, d_score, (size_t)n_dp * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ht->err) { ctx->err = "dp: a cluster of workgroups could not make progress on an interval (wide sweep)"; return MAUVE_ERR_HIP; }
+    const int64_t tc = ht->cols;
+    if (cells) *cells = ht->cells;
+    memcpy(col_off, p_off, ((size_t)n_dp + 1) * 8);
+    if (score) memcpy(score, p_score, (size_t)n_dp * 8);
+    if (sp) { if (N >= 2) memcpy(sp, p_sp, (size_t)n_dp * 8); else memset(sp, 0, (size_t)n_dp * 8); }
+    ctx->dp_last_col_off = d_col_off; ctx->dp_last_n = n_dp;
+    if (cols && tc) {
+        if (host_pointer_is_pinned(cols)) HIPCHK(ctx, hipMemcpyAsync(cols, ctx->dp_cols.p, (size_t)tc * 4, hipMemcpyDeviceToHost, ctx->stream));
+        else HIPCHK(ctx, hipMemcpy(cols, ctx->dp_cols.p, (size_t)tc * 4, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (trace) fprintf(stderr, "[trace] dp (descriptor batch, device front): %u intervals (%lld workgroup, %lld one-wave, %lld two/wave, %lld four/wave), %d round(s); upload+sizing+order %.3f ms, kernels+results %.3f\n",
+                       n_dp, (long long)n_big, (long long)cl.n_med, (long long)cl.n_s32, (long long)cl.n_s16, rounds, t1 - t0, now_ms() - t1);
+    return MAUVE_OK;
+}
+
 // columns of picked intervals of the last dp_core batch, one behind the other: a wave per pick
 __global__ void __launch_bounds__(256) dp_pick_cols(const uint32_t *__restrict__ cols, const int64_t *__restrict__ col_off, const int64_t *__restrict__ pick,
                                                     const int64_t *__restrict__ out_off, int64_t n_pick, uint32_t *__restrict__ out)
@@ -3060,6 +3238,11 @@ int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *d
         if (cells) *cells = total_cells;
         return MAUVE_OK;
     }
+    // large batches: sizing, order and result offsets on the device (dp_run_from_desc); small ones keep the host loops (fewer launches).
+    // MAUVE_DP_DESC_HOST: A/B switch
+    static const bool desc_host = getenv("MAUVE_DP_DESC_HOST") != nullptr;
+    static const int64_t desc_min = getenv("MAUVE_DP_DESC_MIN") ? atoll(getenv("MAUVE_DP_DESC_MIN")) : 2048;
+    if (!desc_host && n_iv >= desc_min) return dp_run_from_desc(ctx, nseq, n_iv, desc, scoring, cols, col_off, score, cells, sp);
     seq_off.resize((size_t)(n_iv * nseq + 1));
     int64_t t = 0;
     for (int64_t i = 0; i < n_iv * nseq; i++) { seq_off[(size_t)i] = t; t += desc[i].len; }

@@ -95,23 +95,31 @@ def main():
     dur = {}
     for r in trace:
         dur.setdefault(klass(r, mx, "Grid_Size_X"), []).append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
-    passes = len(dur.get("dp_step2", []) or dur.get("dp_step", [])) or 1
+    # passes of the hot path in the process: a kernel that runs once per pass (the guide tree's run list on the progressive path, the assembly's fill otherwise)
+    passes = len(dur.get("run_summary", []) or dur.get("as_fill", []) or dur.get("dp_step2", []) or dur.get("dp_step", [])) or 1
     total = sum(sum(v) for v in dur.values())
     fetch = read_pmc(src, "pmc_fetch", ("FETCH_SIZE",))
     write = read_pmc(src, "pmc_write", ("WRITE_SIZE",))
     lds = read_pmc(src, "pmc_lds", ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"))
     cal = 1.0
-    if "rs_hist" in fetch and P:
-        cal = (4.0 * P) / (avg(fetch["rs_hist"]["FETCH_SIZE"]) * 1024.0)
+    if cfg == "C3":
+        if "rs_hist" in fetch and P:
+            cal = (4.0 * P) / (avg(fetch["rs_hist"]["FETCH_SIZE"]) * 1024.0)
+    else:
+        # the other configs run seed passes of many sizes (and 64-bit keys): no single launch with a known byte count.  The factor is a property of
+        # the access pattern, not of the workload: the one calibrated on the C3 command of the same round is applied
+        try:
+            t3 = json.load(open(os.path.join(DST, "roofline_traffic.json")))
+            cal = next(v["fetch_calibration"] for k, v in t3.items() if isinstance(v, dict) and "fetch_calibration" in v)
+        except Exception:
+            cal = 2.0                                  # MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of a wide coalesced streaming read
     traffic = {}
-    lines = ["# rocprofv3 summary, round %s" % tag, "",
-             "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
-             "--no-cpu-baseline --no-secondary --config " + cfg + "` (%d passes of the hot path in the process: warmup, timed host-to-host, device-resident and HIP-event "
-             "legs, all over BASELINE config " + cfg + ": " + bench["config"]["workload"][:60] + " ..., P = %d windows per pass).  PMC "
-             "passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and `--pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES "
-             "SQ_WAIT_ANY`, separate runs (tools/profile_gpu.sh).  The raw `--stats` table is %s_kernel_stats.csv; the table "
-             "below is built from the kernel trace of the same run so that the main sort and the ~20 small sorts per pass "
-             "(tagged [small], split by grid size) are not averaged together." % (passes, P, tag), "",
+    cmd_text = ("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --config " + cfg +
+                "` (" + str(passes) + " passes of the hot path in the process: warmup, timed host-to-host, device-resident and HIP-event legs, all over BASELINE config " + cfg + ": " +
+                bench["config"]["workload"][:70] + " ..., P = " + str(int(P)) + " windows per pass).  PMC passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and `--pmc SQ_LDS_BANK_CONFLICT "
+                "SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY`, separate runs (tools/profile_gpu.sh).  The raw `--stats` table is " + tag + "_kernel_stats.csv; the table below is built "
+                "from the kernel trace of the same run so that the main sort and the ~20 small sorts per pass (tagged [small], split by grid size) are not averaged together.")
+    lines = ["# rocprofv3 summary, round %s" % tag, "", cmd_text, "",
              "Kernel time per pass of the hot path: %.3f ms (sum of all kernel durations / %d passes)." % (total / passes / 1e6, passes), "",
              "| kernel | launches/pass | avg us | us/pass | share % | FETCH_SIZE KiB/launch (raw) | WRITE_SIZE KiB/launch | HBM bytes/launch (calibrated) |",
              "|---|---|---|---|---|---|---|---|"]
@@ -137,7 +145,7 @@ def main():
         lines.append("| %s | %.3g | %.3g | %s | %.3g | %s |" % (k, ia, bc, ("%.2f" % (bc / ia)) if ia else "-", wc,
                                                              ("%.2f" % (wa / wc)) if wc else "-"))
         traffic.setdefault(k, {}).update({"lds_idx_active": round(ia), "lds_bank_conflict": round(bc)})
-    lines += ["", "FETCH_SIZE calibration factor (4*P bytes / raw FETCH_SIZE of the main sort's rs_hist launch): %.3f "
+    lines += ["", "FETCH_SIZE calibration factor (C3: 4*P bytes / raw FETCH_SIZE of the main sort's rs_hist launch; other configs: the C3 factor of the same round): %.3f "
               "(MI355X_MICROARCH.md gives 2x for coalesced streaming reads on gfx950; the measured factor is applied to every kernel's FETCH_SIZE)." % cal, "",
               "Bench line of the profiled run:", "", "```json", json.dumps(bench), "```"]
     with open(os.path.join(DST, "%s_summary.md" % tag), "w") as f:
