@@ -213,7 +213,7 @@ void mauve_ctx_destroy(mauve_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     delete c->pool; c->pool = nullptr;
     DevBuf *bufs[] = {&c->genomes, &c->keysA, &c->keysB, &c->valsA, &c->valsB, &c->hist, &c->totals, &c->posmask,
-                      &c->hit_mask, &c->hit_pos, &c->hit_seg, &c->base_invalid, &c->contig_mask, &c->node_cmask, &c->run_sum, &c->join_ovf, &c->join_bound, &c->dpf_anch, &c->dpf_work, &c->dpf_tot, &c->ch_len, &c->ch_st, &c->ch_crop, &c->ch_ent, &c->ch_ord, &c->ch_rank, &c->ch_node, &c->ch_graph, &c->ch_cnt, &c->ch_anch, &c->ch_lw, &c->ch_anch2, &c->ext_work, &c->bp_work, &c->dp_sp, &c->hom_cols, &c->sorted_rec_keep, &c->ch_big, &c->gap_work, &c->as_wide, &c->res_narrow, &c->dp_pick, &c->dp_wflags, &c->shard_dev, &c->as_work, &c->as_isl, &c->res_cols, &c->sorted_rec, &c->canon_k1, &c->canon_k2, &c->canon_v1, &c->canon_v2, &c->rec_genomes, &c->rec_seg, &c->rec_vinv, &c->rec_vcm, &c->placed_mask, &c->bb_cols, &c->bb_work, &c->bb_query, &c->cand, &c->mlen, &c->mstart, &c->counters, &c->dp_desc, &c->dp_list, &c->dp_codes, &c->dp_off,
+                      &c->hit_mask, &c->hit_pos, &c->hit_seg, &c->base_invalid, &c->contig_mask, &c->node_cmask, &c->run_sum, &c->join_ovf, &c->join_bound, &c->dpf_anch, &c->dpf_work, &c->dpf_tot, &c->ch_len, &c->ch_st, &c->ch_crop, &c->ch_ent, &c->ch_ord, &c->ch_rank, &c->ch_node, &c->ch_graph, &c->ch_cnt, &c->ch_anch, &c->ch_lw, &c->ch_anch2, &c->ext_work, &c->bp_work, &c->dp_sp, &c->hom_cols, &c->sorted_rec_keep, &c->ch_big, &c->gap_work, &c->as_wide, &c->res_narrow, &c->dp_pick, &c->dp_wflags, &c->ch_mw, &c->shard_dev, &c->as_work, &c->as_isl, &c->res_cols, &c->sorted_rec, &c->canon_k1, &c->canon_k2, &c->canon_v1, &c->canon_v2, &c->rec_genomes, &c->rec_seg, &c->rec_vinv, &c->rec_vcm, &c->placed_mask, &c->bb_cols, &c->bb_work, &c->bb_query, &c->cand, &c->mlen, &c->mstart, &c->counters, &c->dp_desc, &c->dp_list, &c->dp_codes, &c->dp_off,
                       &c->dp_prof_cnt, &c->dp_prof_mask, &c->dp_prof2_cnt, &c->dp_prof2_mask, &c->dp_tb, &c->dp_meta,
                       &c->dp_score, &c->dp_cols, &c->dp_rows};
     for (DevBuf *b : bufs) b->release();

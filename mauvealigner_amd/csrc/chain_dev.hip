@@ -170,6 +170,7 @@ struct FinalRanks {                         // y = genome: its order without the
 struct LcbNodes {
     const int32_t *len, *st; uint32_t n; int N; const uint32_t *ordc, *rank; uint32_t *cnt; int32_t *node_of;
     unsigned long long *weight; uint32_t *orient; const uint32_t *gapid;        // gapid (recursion batches): a node never spans two gaps
+    const int64_t *mw;                                                            // per-match weights (sum-of-pairs scoring), or null
     __device__ uint32_t domain(int) const { return cnt[0]; }
     __device__ bool flag(uint32_t k, int) const
     {
@@ -188,7 +189,8 @@ struct LcbNodes {
     {
         const uint32_t i = ordc[k], nd = o + (fl ? 1u : 0u) - 1u;
         node_of[i] = (int32_t)nd;
-        atomicAdd(&weight[nd], (unsigned long long)len[i] * (unsigned long long)N);
+        // LCB weight: columns x genomes (Aligner::align), or the matches' extant sum-of-pairs scores (two's complement: a sum of signed scores)
+        atomicAdd(&weight[nd], mw ? (unsigned long long)mw[i] : (unsigned long long)len[i] * (unsigned long long)N);
     }
     __device__ void emit(uint32_t k, uint32_t o, int) const
     {
@@ -549,7 +551,39 @@ int chain_order_device(mauve_ctx *c, int N, int64_t nl, int64_t min_gap, int64_t
 // Elimination and LCB graph of the device-resident list (cropped records in c->ch_len / c->ch_st, node of every match behind
 // the lengths).  The compact graph arrives on the host in c->pin_chain (ChainGraphHost): weight[K], orient[K], prev[K*N],
 // next[K*N].  seg0 != nullptr: a recursion batch (forward matches only, nodes confined to their gaps).
-int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *seg0, uint32_t nseg, ChainGraphHost *G, bool graph_to_host)
+// extant sum-of-pairs score of every cropped record of the chain (sp_score_matches' rule on the chain's int32 records): a wave per match,
+// a lane takes every 64th column; dead records (length <= 0) score 0
+struct ChSpGenomes { uint64_t word_off[MAUVE_MAX_SEQ]; int32_t s[4][4]; };
+__global__ void __launch_bounds__(256) ch_sp_scores(const uint64_t *__restrict__ packed, ChSpGenomes G, int N, const int32_t *__restrict__ len, const int32_t *__restrict__ st,
+                                                    uint32_t n, int64_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nw = (gridDim.x * 256u) >> 6;
+    for (uint32_t i = wave; i < n; i += nw) {
+        const int64_t L = len[i];
+        int64_t acc = 0;
+        for (int64_t c = lane; c < L; c += 64) {
+            uint32_t have = 0, bases = 0;
+            for (int g = 0; g < N; g++) {
+                const int64_t s0 = st[(size_t)i * N + g];
+                if (!s0) continue;
+                const int64_t p = s0 > 0 ? s0 - 1 + c : -s0 - 1 + (L - 1 - c);
+                uint32_t b = (uint32_t)(packed[G.word_off[g] + (uint64_t)(p >> 5)] >> (2 * (p & 31))) & 3u;
+                if (s0 < 0) b = 3u - b;
+                have |= 1u << g; bases |= b << (2 * g);
+            }
+            for (int x = 0; x < N; x++) {
+                if (!(have >> x & 1)) continue;
+                const uint32_t bx = (bases >> (2 * x)) & 3u;
+                for (int y = x + 1; y < N; y++) if (have >> y & 1) acc += G.s[bx][(bases >> (2 * y)) & 3u];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) out[i] = acc;
+    }
+}
+
+int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *seg0, uint32_t nseg, ChainGraphHost *G, bool graph_to_host, const mauve_scoring *sp_scoring)
 {
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     const double t0 = now_ms();
@@ -613,7 +647,18 @@ int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *s
     uint32_t *orient = reinterpret_cast<uint32_t *>(weight + n);
     int32_t *prevv = reinterpret_cast<int32_t *>(orient + n), *nextv = prevv + (size_t)n * N, *seq = nextv + (size_t)n * N;
     int32_t *final_dev = seq + (size_t)n * N;
-    const LcbNodes ln{len, st, n, N, ordc, rank, cnt, node_of, weight, orient, gapid};
+    const int64_t *mw = nullptr;
+    if (sp_scoring) {                                         // score-weighted LCBs: the scores of the records as the elimination left them
+        if (N > 16) { c->err = "sum-of-pairs LCB scoring: at most 16 genomes"; return MAUVE_ERR_LIMIT; }
+        HIPCHK(c, c->ch_mw.ensure((size_t)n * 8 + 64));
+        ChSpGenomes SG; memset(&SG, 0, sizeof SG);
+        for (int g = 0; g < N; g++) SG.word_off[g] = c->word_off[(size_t)g];
+        memcpy(SG.s, sp_scoring->matrix, sizeof SG.s);
+        hipLaunchKernelGGL(ch_sp_scores, dim3((uint32_t)std::min<size_t>(((size_t)n + 3) / 4, 256 * 8)), dim3(256), 0, c->stream, c->genomes.as<uint64_t>(), SG, N, len, st, n,
+                           c->ch_mw.as<int64_t>());
+        mw = c->ch_mw.as<int64_t>();
+    }
+    const LcbNodes ln{len, st, n, N, ordc, rank, cnt, node_of, weight, orient, gapid, mw};
     hipLaunchKernelGGL((cmp_count<LcbNodes>), dim3(nb), dim3(256), 0, c->stream, ln, bcnt);
     hipLaunchKernelGGL((cmp_write<LcbNodes>), dim3(nb), dim3(256), 0, c->stream, ln, bcnt);
     const NodeSeq ns{n, ordc, cnt, node_of, seq};
@@ -651,12 +696,12 @@ int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *s
 
 // Elimination, LCB graph, greedy breakpoint elimination, labels: everything stays on the device (cropped records in
 // c->ch_len / c->ch_st, final LCB id per match behind them).  chain_device_copy_back brings them to the host.
-int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, int64_t &n_lcb)
+int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, int64_t &n_lcb, const mauve_scoring *sp_scoring)
 {
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     int64_t maxlen = 1; for (int g = 0; g < N; g++) maxlen = std::max<int64_t>(maxlen, c->lens[(size_t)g]);
     ChainGraphHost G;
-    int rc = chain_device_graph(c, N, maxlen, nullptr, 0, &G);
+    int rc = chain_device_graph(c, N, maxlen, nullptr, 0, &G, true, sp_scoring);
     if (rc) return rc;
     const double t1 = now_ms();
     const uint32_t n = (uint32_t)c->dev_rec_n, K = G.K, blocks = (n + 255) / 256;
@@ -846,9 +891,9 @@ int chain_device_copy_back(mauve_ctx *c, int N, MatchVec &m, std::vector<int64_t
     return MAUVE_OK;
 }
 
-int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchVec &m, std::vector<int64_t> &match_lcb, int64_t &n_lcb)
+int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchVec &m, std::vector<int64_t> &match_lcb, int64_t &n_lcb, const mauve_scoring *sp_scoring)
 {
-    int rc = chain_device_core(c, N, min_weight, collinear, n_lcb);
+    int rc = chain_device_core(c, N, min_weight, collinear, n_lcb, sp_scoring);
     if (rc) return rc;
     return chain_device_copy_back(c, N, m, match_lcb);
 }

@@ -231,6 +231,7 @@ struct mauve_ctx {
     DevBuf ch_anch, ch_lw;               // the chains in chain order and the LCB weights (chain_order_device)
     DevBuf ch_anch2, ext_work, sorted_rec_keep;   // device-resident LCB extension (extend_dev.hip): the extended anchor list, its work area, the main pass's match list set aside
     PinnedBuf pin_ext;
+    DevBuf ch_mw;                        // sum-of-pairs scores of the chain's cropped records (score-weighted LCBs on the device chain)
     DevBuf as_wide;                      // the anchor table widened to int64 for a direct fetch (compact fetch: the match list narrowed to int32)
     DevBuf res_narrow;                   // the columns narrowed to 8 / 16 bits for a compact fetch
     DevBuf hom_cols;                     // homology pass (backbone_dev.hip): the re-split columns, swapped with res_cols when done
@@ -364,12 +365,12 @@ int seedpass_sorted_list(mauve_ctx *ctx, const GenomeSet &gs, int seq, uint64_t 
 int sort_pairs_u32(mauve_ctx *ctx, uint32_t n, int key_bits, uint32_t **keys_io, uint32_t **vals_io, uint32_t *keys_alt, uint32_t *vals_alt,
                    int timer_id);
 // device chain (chain_dev.hip): EliminateOverlaps + LCBs of the N-way list the seed pass left in ctx->sorted_rec
-int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchVec &m, std::vector<int64_t> &match_lcb, int64_t &n_lcb);
+int chain_device(mauve_ctx *c, int N, int64_t min_weight, bool collinear, MatchVec &m, std::vector<int64_t> &match_lcb, int64_t &n_lcb, const mauve_scoring *sp_scoring = nullptr);
 struct ChainGraphHost { uint32_t na, K; int64_t *weight; uint32_t *orient; int32_t *prev, *next; int32_t *final_stage; int32_t *final_dev; };
-int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0, uint32_t nseg, ChainGraphHost *G, bool graph_to_host = true);
+int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0, uint32_t nseg, ChainGraphHost *G, bool graph_to_host = true, const mauve_scoring *sp_scoring = nullptr);
 int chain_device_gaps_compact(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0_dev, uint32_t nseg, const int32_t **hl_out, const int32_t **hs_out,
                               const uint32_t **hgap_out, uint32_t *ns_out);
-int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, int64_t &n_lcb);
+int chain_device_core(mauve_ctx *c, int N, int64_t min_weight, bool collinear, int64_t &n_lcb, const mauve_scoring *sp_scoring = nullptr);
 int chain_device_gaps(mauve_ctx *c, int N, int64_t maxlen, const uint32_t *seg0_dev, uint32_t nseg, const int32_t **hl_out, const int32_t **hs_out,
                       std::vector<uint8_t> &survive);
 int chain_device_copy_back(mauve_ctx *c, int N, MatchVec &m, std::vector<int64_t> &match_lcb);

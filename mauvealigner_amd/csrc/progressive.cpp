@@ -188,8 +188,14 @@ int prog_node(Prog &P, int node)
     // a list the device chain declines comes back as MAUVE_ERR_LIMIT: the host chain for those.  MAUVE_HOST_CHAIN: A/B switch.
     static const bool host_chain_env = getenv("MAUVE_HOST_CHAIN") != nullptr;
     bool chained = false;
-    if (!host_chain_env && !p->seed_family && n == P.N && nm > 0 && c->dev_rec_n == nm && p->lcb_scoring == MAUVE_LCB_SCORE_LENGTH) {
-        rc = chain_device(c, n, lcbw, p->collinear != 0, m, match_lcb, nl);
+    if (!host_chain_env && !p->seed_family && n == P.N && nm > 0 && c->dev_rec_n == nm && (p->lcb_scoring == MAUVE_LCB_SCORE_LENGTH || n <= 16)) {
+        if (p->lcb_scoring == MAUVE_LCB_SCORE_SP) {          // the matches' scores are summed on the device too (ch_sp_scores, on the cropped records)
+            int64_t minw = p->lcb_weight >= 0 ? p->lcb_weight * ((int64_t)n * (n - 1) / 2) / ((int64_t)P.N * (P.N - 1) / 2)
+                                              : sp_default_min_weight(w, n, &p->scoring);
+            if (scaled) minw = std::max(minw * factor_ppm / 1000000, p->min_scaled_penalty);
+            rc = chain_device(c, n, minw, p->collinear != 0, m, match_lcb, nl, &p->scoring);
+        } else
+            rc = chain_device(c, n, lcbw, p->collinear != 0, m, match_lcb, nl);
         if (rc == MAUVE_OK) chained = true;
         else if (rc != MAUVE_ERR_LIMIT) return rc;
     }
