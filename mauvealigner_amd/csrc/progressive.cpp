@@ -286,28 +286,39 @@ int prog_node(Prog &P, int node)
     // intervals and all their candidates (one sizing pass, one launch with more to balance), the columns stay on the device, the scores come back,
     // and only the winners' columns are compacted and copied out (dp_fetch_picked) -- at C4's root 57 k candidates of 29 k intervals, 1 k of them win.
     // Several contexts (mauve_set_shard) keep the two exchanged batches.
-    struct Cand { int64_t iv; int r, k; int nz[MAUVE_MAX_SEQ]; };
+    struct Cand { int64_t iv; int r, k; uint8_t nz[MAUVE_MAX_SEQ]; };
     std::vector<Cand> cands;
     if (refine) {
+        const double tr0 = now_ms();
         int64_t ccodes = 0;
-        std::vector<DpSeqDesc> &all = c->prog_desc; all.assign(desc.begin(), desc.end());
+        // (sized once and filled in place: 86 000 descriptor rows at C4's root; push_back by push_back this took 3 ms)
+        std::vector<DpSeqDesc> &all = c->prog_desc;
+        int64_t nc0 = 0;
+        for (int64_t iv = 0; iv < n_dp; iv++) {
+            int k = 0; for (int j = 0; j < n; j++) k += desc[(size_t)(iv * n + j)].len != 0;
+            if (k >= 3) nc0 += std::min(p->refine_rounds, k - 1);
+        }
+        all.resize((size_t)(n_dp + nc0) * n);
+        std::copy(desc.begin(), desc.end(), all.begin());
+        cands.resize((size_t)nc0);
+        DpSeqDesc none; none.genome = gm[0]; none.rev = 0; none.lo0 = 0; none.len = 0;
+        int64_t q0 = 0;
         for (int64_t iv = 0; iv < n_dp; iv++) {
             Cand cd; cd.iv = iv; cd.k = 0;
             int64_t tot = 0;
-            for (int j = 0; j < n; j++) if (desc[(size_t)(iv * n + j)].len) { cd.nz[cd.k++] = j; tot += desc[(size_t)(iv * n + j)].len; }
+            const DpSeqDesc *di = &desc[(size_t)(iv * n)];
+            for (int j = 0; j < n; j++) if (di[j].len) { cd.nz[cd.k++] = (uint8_t)j; tot += di[j].len; }
             if (cd.k < 3) continue;
-            for (int r = 1; r <= p->refine_rounds && r < cd.k; r++) {
-                cd.r = r; cands.push_back(cd);
-                for (int j = 0; j < n; j++) {
-                    DpSeqDesc d; d.genome = gm[0]; d.rev = 0; d.lo0 = 0; d.len = 0;
-                    if (j < cd.k) d = desc[(size_t)(iv * n + cd.nz[(j + r) % cd.k])];
-                    all.push_back(d);
-                }
+            for (int r = 1; r <= p->refine_rounds && r < cd.k; r++, q0++) {
+                cd.r = r; cands[(size_t)q0] = cd;
+                DpSeqDesc *o = &all[(size_t)(n_dp + q0) * n];
+                for (int j = 0; j < n; j++) o[j] = j < cd.k ? di[cd.nz[(j + r) % cd.k]] : none;
                 ccodes += tot;
             }
         }
         const int64_t nc = (int64_t)cands.size(), na = n_dp + nc;
         const bool one_batch = !c->shard_on;
+        const double tr1 = now_ms();
         std::vector<int64_t> aoff((size_t)na + 1, 0), ascore((size_t)na + 1, 0), asp((size_t)na + 1, 0);
         std::vector<uint32_t> ccols;                             // (the exchanged form only)
         if (one_batch) {
@@ -326,6 +337,7 @@ int prog_node(Prog &P, int node)
                 for (int64_t q = 0; q <= nc; q++) aoff[(size_t)(n_dp + q)] = aoff[(size_t)n_dp] + coff[(size_t)q];
             }
         }
+        const double tr2 = now_ms();
         std::vector<int64_t> pick((size_t)n_dp);                // the batch entry whose alignment the interval keeps
         int64_t replaced = 0;
         for (int64_t iv = 0; iv < n_dp; iv++) { pick[(size_t)iv] = iv; dsp[(size_t)iv] = asp[(size_t)iv]; }
@@ -369,7 +381,8 @@ int prog_node(Prog &P, int node)
                 dcols[(size_t)k] = o;
             }
         }
-        if (trace) fprintf(stderr, "[trace] node %d: refinement: %lld candidate alignments of %lld intervals, %lld replaced\n", node, (long long)nc, (long long)n_dp, (long long)replaced);
+        if (trace) fprintf(stderr, "[trace] node %d: refinement: %lld candidate alignments of %lld intervals, %lld replaced; candidates %.3f ms, batch %.3f, pick + fetch + remap %.3f\n", node,
+                           (long long)nc, (long long)n_dp, (long long)replaced, tr1 - tr0, tr2 - tr1, now_ms() - tr2);
     } else {
         rc = dp_batch_run_desc(c, n, n_dp, desc.data(), &p->scoring, dcols, dcol_off.data(), dscore.data(), &cells, true, nullptr);   // (several contexts: the node's intervals are dealt out)
         if (rc) return rc;
