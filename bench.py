@@ -575,7 +575,7 @@ def main():
                                        ("mauve_progressive_align" if cfg["path"] == "progressive" else "mauve_align")},
             "roofline": roofline, "cpu_baseline": cpu, "accuracy_vs_truth": acc,
             "stages_ms": stages, "kernels_ms": kern_ms, "result_sizes": sizes, "upload_ms": round(t_upload * 1e3, 2), "device": ctx.device_name(),
-            "prng": "numpy PCG64 (SURVEY 8d names xoshiro256**; the workloads are defined by mauvealigner_amd/synth.py, BASELINE.md section 4)",
+            "prng": "xoshiro256** seeded through splitmix64, base seed 0x4D41555645 + config id (SURVEY 8d; mauvealigner_amd/synth.py, csrc/synth_rng.c)",
         }
         out.update(extras)
         out.update(legs)

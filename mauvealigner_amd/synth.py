@@ -5,17 +5,112 @@ per-lineage rate d/2 (pairwise divergence ~ d); events are 90 % substitutions (u
 alternatives) and 10 % indels (half insertions, half deletions; geometric length, mean 3, cap 50).
 Inversions reverse-complement non-overlapping segments with log-uniform lengths.
 
-PRNG: numpy PCG64 seeded with 0x4D41555645 + config id (+ genome index); only `integers` and
-`random` draws are used, in a fixed order, so a (config, scale) pair always yields the same genomes.
-Bases are returned as uint8 codes A,C,G,T = 0..3.
+PRNG: xoshiro256** seeded through splitmix64, base seed 0x4D41555645 + config id.  A stream is named by a tuple of keys
+(config id, then e.g. the genome index): seed = BASE_SEED; for every key: seed = splitmix64(seed + key); the four state words are the next four
+splitmix64 outputs.  Draws (class Xoshiro, the handful of numpy-Generator methods this module uses, in a fixed order): random() = (x >> 11) * 2^-53;
+integers(lo, hi) = lo + (((x >> 32) * (hi - lo)) >> 32) for ranges below 2^32; uniform base codes = x >> 62; geometric(p): round by round one draw
+per still-unfinished sample in index order, success when x < floor(p * 2^64); uniform(a, b) = a + (b - a) * random().  The raw stream comes from
+csrc/synth_rng.c (libmauve_synth.so, plain C; compiled on the spot with gcc if it is missing), so a C or C++ caller reproduces the workloads from the
+same twenty lines.  Bases are returned as uint8 codes A,C,G,T = 0..3.  (Rounds 1-3 used numpy's PCG64 for the same distributions.)
 """
+import ctypes
+import os
+import subprocess
+
 import numpy as np
 
 BASE_SEED = 0x4D41555645
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    """-> (next state, output)"""
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return x, z ^ (z >> 31)
+
+
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        here = os.path.dirname(os.path.abspath(__file__))
+        so = os.path.join(here, "libmauve_synth.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(here, "csrc", "synth_rng.c")])
+        L = ctypes.CDLL(so)
+        L.xo_fill.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+        L.xo_fill_bases.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+        _LIB = L
+    return _LIB
+
+
+class Xoshiro:
+    """xoshiro256** with the numpy-Generator methods synth.py uses (module docstring: how each draw is made)"""
+
+    def __init__(self, *keys):
+        seed = BASE_SEED
+        for k in keys:
+            _, seed = _splitmix64((seed + int(k)) & _M64)
+        st, w = seed, []
+        for _ in range(4):
+            st, o = _splitmix64(st)
+            w.append(o)
+        self.s = np.array(w, dtype=np.uint64)
+
+    def raw(self, n):
+        out = np.empty(int(n), dtype=np.uint64)
+        if n:
+            _lib().xo_fill(self.s.ctypes.data, out.ctypes.data, int(n))
+        return out
+
+    def random(self, size=None):
+        x = (self.raw(1 if size is None else size) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        return float(x[0]) if size is None else x
+
+    def uniform(self, low, high):
+        return low + (high - low) * self.random()
+
+    def integers(self, low, high=None, size=None, dtype=np.int64):
+        if high is None:
+            low, high = 0, low
+        rng_ = int(high) - int(low)
+        if rng_ <= 0 or rng_ > (1 << 32):
+            raise ValueError("Xoshiro.integers: range must be in 1 .. 2^32")
+        n = 1 if size is None else int(size)
+        if rng_ == 4 and int(low) == 0 and np.dtype(dtype) == np.uint8:          # base codes: the top two bits
+            out = np.empty(n, dtype=np.uint8)
+            if n:
+                _lib().xo_fill_bases(self.s.ctypes.data, out.ctypes.data, n)
+            return out[0] if size is None else out
+        x = ((self.raw(n) >> np.uint64(32)) * np.uint64(rng_)) >> np.uint64(32)
+        out = (x.astype(np.int64) + int(low)).astype(dtype)
+        return out[0] if size is None else out
+
+    def geometric(self, p, size=None):
+        n = 1 if size is None else int(size)
+        thr = min(int(p * 18446744073709551616.0), _M64)
+        out = np.zeros(n, dtype=np.int64)
+        todo = np.arange(n)
+        k = 0
+        while len(todo):
+            k += 1
+            x = self.raw(len(todo))
+            hit = x < np.uint64(thr)
+            out[todo[hit]] = k
+            todo = todo[~hit]
+            if k >= 4096:
+                out[todo] = k
+                break
+        return int(out[0]) if size is None else out
 
 
 def _rng(*keys):
-    return np.random.Generator(np.random.PCG64([BASE_SEED, *[int(k) for k in keys]]))
+    return Xoshiro(*keys)
 
 
 def random_genome(length, rng):

@@ -186,10 +186,12 @@ def test_inconsistent_columns_are_refused(ctx):
     """A caller's alignment whose columns do not hold the residues its ends announce (the homology pass would turn the surplus into
     base addresses outside the interval -- below 0 on the reverse strand) is refused with MAUVE_ERR_ARG by both _alignment entry
     points, before any kernel reads a genome through it; the consistent array goes through and equals the oracle's."""
-    gs = synth.star_genomes(3, 20_000, 0.05, 5)
+    gs = synth.star_genomes(3, 20_000, 0.05, 7)
     ctx.set_genomes(gs)
     e = O.align(gs, O.default_params())["aln"]
     left, right, rev, off, cols = e["left"], e["right"], e["reverse"], e["col_off"], e["cols"]
+    nz = np.count_nonzero(left, axis=1)
+    assert (nz >= 2).any() and (nz == 1).any()           # the cases below need an interval of each kind
     noff, ncols, moved = ctx.apply_homology_alignment(left, right, rev, off, cols)
     eoff, ecols, emoved = O.homology_apply(gs, left, right, rev, off, cols)
     assert moved == emoved and np.array_equal(noff, eoff) and np.array_equal(ncols, ecols)
@@ -207,6 +209,7 @@ def test_inconsistent_columns_are_refused(ctx):
     l4[multi, 0], r4[multi, 0], v4[multi, 0] = 1, n0 - 5, 1
     bad.append((l4, r4, v4, cols))
     for l, r, v, c in bad:
+        assert not (np.array_equal(l, left) and np.array_equal(c, cols))
         with pytest.raises(RuntimeError, match=r"\(-1\)"):
             ctx.apply_homology_alignment(l, r, v, off, c)
         with pytest.raises(RuntimeError, match=r"\(-1\)"):
