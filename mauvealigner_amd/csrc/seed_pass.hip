@@ -972,45 +972,85 @@ __global__ void __launch_bounds__(256) enum_write(const KeyT *__restrict__ keys,
 // ------------------------------------------------------------------------------------------------
 // One component of the hit a wave is extending: where its windows live, the window index at offset 0, its walking
 // direction relative to the anchor and the window range it may use.  Built once per candidate (LDS, per wave).
-struct ExtComp { const uint64_t *G; const uint64_t *VM; const uint64_t *CM; int64_t pos, lo, hi; uint32_t rev, pad; };
+struct ExtComp { const uint64_t *G; const uint64_t *VM; const uint64_t *CM; int64_t pos, lo, hi; uint32_t rev, maxw /* last word of the genome's buffer */, g, pad; };
 
-// Does offset k agree?  Components are handled four at a time: the window loads of a batch are issued together from
-// clamped (always valid) addresses and compared afterwards, so a call costs one memory round trip per batch rather
-// than one per component.  Masked windows are compared in place (XOR under the 2-bit care mask) -- equal care
-// digits <=> equal masked mers; a reverse component is compared with the reverse complement of the anchor window.
-__device__ __forceinline__ bool agree_at(const ExtComp *__restrict__ comp, int nc, const SeedShape &sh, int64_t k)
+// ---- does offset k agree? ----
+// Offset k agrees when, for every component c and every care position t of the seed, S_c(k + t) == S_0(k + t), where S_c(j) is the
+// component's base stream along the generalized diagonal: base(pos_c + j) for a component on the anchor's strand, the COMPLEMENT of
+// base(pos_c + span - 1 - j) for one on the opposite strand (its window at pos_c - k against the reverse complement of the anchor's; the
+// pattern is a palindrome, so t and span - 1 - t are care positions together).  A round of 64 offsets from j0 on needs S(j0 .. j0 + 63 +
+// span - 1): 128 digits, four words per component.  The wave builds them with its lanes side by side -- eight lanes per component, lane i
+// of a group fetches word i of the stretch (ONE load instruction for up to eight components) -- XORs each with the anchor's, ORs the
+// differences over the components and hands the four words out as wave-uniform values; a lane then cuts its window out of them and tests
+// it under the care mask.  (Every lane fetching its own window, three words per component, and a version with the streams built by the
+// scalar unit, both spent their time issuing instructions: 800 and 550 per round against about 200.)
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 {
-    bool ok = true, have_rc = false;
-    uint64_t alo = 0, ahi = 0, rlo = 0, rhi = 0;
-    for (int c0 = 0; c0 < nc; c0 += 4) {
-        uint64_t wl[4], wh[4]; uint32_t rv[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            wl[i] = 0; wh[i] = 0; rv[i] = 0;
-            if (c0 + i < nc) {
-                const ExtComp &C = comp[c0 + i];
-                const int64_t q = C.rev ? C.pos - k : C.pos + k;
-                const bool inb = q >= C.lo && q <= C.hi;
-                const uint32_t qq = (uint32_t)(inb ? q : C.lo);
-                ok &= inb;
-                if (C.VM || C.CM) ok &= !window_blocked(C.VM, C.CM, qq, sh.span);
-                window_at(C.G, qq, wl[i], wh[i]);
-                rv[i] = C.rev;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (c0 + i >= nc) continue;
-            if (c0 + i == 0) { alo = wl[0]; ahi = wh[0]; continue; }     // the anchor
-            if (rv[i]) {
-                if (!have_rc) { window_revcomp(alo, ahi, sh.span, rlo, rhi); have_rc = true; }
-                ok &= (((wl[i] ^ rlo) & sh.care_lo) | ((wh[i] ^ rhi) & sh.care_hi)) == 0;
-            } else {
-                ok &= (((wl[i] ^ alo) & sh.care_lo) | ((wh[i] ^ ahi) & sh.care_hi)) == 0;
-            }
-        }
+    return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src) << 32);
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
+{
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)v, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)(v >> 32), l) << 32);
+}
+// M: OR over the components of S_c ^ S_0 for j = j0 .. j0 + 127 (two bits per digit), wave-uniform
+__device__ __forceinline__ void ext_mismatch(const ExtComp *__restrict__ comp, int nc, int span, int64_t j0, int lane, uint64_t M[4])
+{
+    typedef const uint64_t __attribute__((address_space(1))) *gptr;
+    const int i = lane & 7, grp = lane >> 3;
+    uint64_t acc = 0, A = 0;
+    for (int c0 = 0; c0 < nc; c0 += 8) {                   // (wave-uniform: more than eight components only with more than eight genomes)
+        const int c = c0 + grp;
+        const ExtComp &C = comp[min(c, nc - 1)];
+        const uint32_t rev = C.rev;
+        // opposite strand: the forward stretch F that ends at base top = pos + span - 1 - j0; S digit k = ~F digit (127 - k)
+        const int64_t b = rev ? C.pos + span - 1 - j0 - 127 : C.pos + j0;
+        const int64_t q = b >> 5; const int r = (int)(b & 31) * 2;
+        // (b may lie outside the genome: word indices are clamped into its buffer; what they hold there only reaches offsets the bounds test
+        // rejects anyway)
+        int64_t x = q + i; x = x < 0 ? 0 : (x > (int64_t)C.maxw ? (int64_t)C.maxw : x);
+        const uint64_t w = ((gptr)(uintptr_t)C.G)[x];
+        const uint64_t wn = shfl64(w, lane + 1);           // (lanes i >= 4 compute along, unused)
+        const uint64_t W = r ? ((w >> r) | (wn << (64 - r))) : w;
+        const uint64_t Wr = ~digit_reverse64(shfl64(W, (lane & ~7) | (3 - (i & 3))));
+        const uint64_t S = rev ? Wr : W;
+        if (c0 == 0) A = shfl64(S, i & 3);                 // the anchor (component 0, never reversed) word i, in every group
+        if (c > 0 && c < nc && i < 4) acc |= S ^ A;
     }
-    return ok;
+    acc |= shfl64(acc, lane ^ 8); acc |= shfl64(acc, lane ^ 16); acc |= shfl64(acc, lane ^ 32);      // over the groups
+#pragma unroll
+    for (int k = 0; k < 4; k++) M[k] = readlane64(acc, k);
+}
+// The walk over one round's agreement bitmap A (bit i: offset i of the round agrees), from bit 0: jump to the next agreeing offset at most
+// `span` away and over its run, until `span` offsets in a row disagree (done) or the bitmap cannot tell any more (the caller starts a fresh
+// round at the returned position).  Closed form of that loop: the walk stops at the first run of >= span zeros that the 64 bits show whole,
+// else at the first end of a run of ones beyond bit 64 - span.  Returns the offsets consumed; every agreeing offset below it was visited.
+__device__ __forceinline__ int walk_round(uint64_t A, int span, bool &done)
+{
+    uint64_t R = ~A; int len = 1;
+    while (2 * len <= span) { R &= R >> len; len *= 2; }
+    if (len < span) R &= R >> (span - len);                // R bit i: offsets i .. i + span - 1 all disagree (zeros shifted in: never across bit 63)
+    if (R) { done = true; return __ffsll((unsigned long long)R) - 1; }
+    const uint64_t ends = A & ~(A >> 1) & (~0ULL << (64 - span));     // last offsets of the runs that reach beyond 64 - span (not empty when R is)
+    return __ffsll((unsigned long long)ends);
+}
+// the window of the lane's offset: digits d .. d + span - 1 of M (0 <= d < 64), under the care mask
+__device__ __forceinline__ bool ext_window_clean(const uint64_t M[4], int d, const SeedShape &sh)
+{
+    const bool up = d >= 32; const int r = (d & 31) * 2;
+    const uint64_t a = up ? M[1] : M[0], b = up ? M[2] : M[1], c = up ? M[3] : M[2];
+    const uint64_t lo = r ? ((a >> r) | (b << (64 - r))) : a, hi = r ? ((b >> r) | (c << (64 - r))) : b;
+    return ((lo & sh.care_lo) | (hi & sh.care_hi)) == 0;
+}
+// placed / ambiguous bases and contig starts under the windows of offset k (only when the pass has such bitmaps)
+__device__ __forceinline__ bool ext_blocked(const ExtComp *__restrict__ comp, int nc, int span, int64_t k)
+{
+    bool b = false;
+    for (int c = 0; c < nc; c++) {
+        const ExtComp &C = comp[c];
+        const int64_t q = C.rev ? C.pos - k : C.pos + k;
+        if ((C.VM || C.CM) && q >= C.lo && q <= C.hi) b |= window_blocked(C.VM, C.CM, (uint32_t)q, span);
+    }
+    return b;
 }
 
 // phase A (streaming, no genome access): one thread per window position.  A hit anchored at p that has a
@@ -1018,6 +1058,7 @@ __device__ __forceinline__ bool agree_at(const ExtComp *__restrict__ comp, int n
 // left walk of S4 never jumps over an agreeing offset, and that hit agrees).  Everything else is a
 // candidate for phase B.  all != 0 (no extension): every hit is a candidate.
 constexpr int RUNS_ITEMS = 16;
+constexpr uint32_t RUNS_TILE = 256u * RUNS_ITEMS, RUNS_HALO = 64 /* >= MAUVE_MAX_SEED_SPAN */;
 
 // same generalized diagonal: every component of hit p sits d windows after (forward) / before (reverse) the
 // corresponding component of hit q = p - d, with the same relative strands
@@ -1044,51 +1085,117 @@ __device__ __forceinline__ void mum_runs_body(const GenomeTab &tab, int span, co
 {
     __shared__ uint32_t lds[8];
     __shared__ uint32_t s_base;
-    // 4096 windows per workgroup: one block scan and ONE global atomic per 4096 windows.  [p0, P): the positions looked at (a pass of
+    __shared__ uint32_t s_mask[RUNS_HALO + RUNS_TILE];
+    // RUNS_TILE windows per workgroup: one block scan and ONE global atomic per tile.  [p0, P): the positions looked at (a pass of
     // the pairwise finder only has hits in its lower genome)
-    const uint32_t base = p0 + blockIdx.x * (256u * RUNS_ITEMS);
+    const uint32_t base = p0 + blockIdx.x * RUNS_TILE;
     const int N = tab.nseq;
     uint32_t flags = 0, cnt = 0;
-    // Inside a conserved stretch nearly every hit has its predecessor right at p - 1, so that test runs first for
-    // all items as straight-line streaming loads (mask words, then the two records); only the few hits it does
-    // not settle -- cluster starts and hits just after a gap -- walk the offsets 2 .. span.
-    uint32_t mm[RUNS_ITEMS], mq[RUNS_ITEMS];
+    uint32_t mm[RUNS_ITEMS];
+    uint32_t hits = 0;
 #pragma unroll
     for (int it = 0; it < RUNS_ITEMS; it++) {
         const uint32_t p = base + it * 256 + threadIdx.x;
         mm[it] = p < P ? tmask[p] : 0u;
-        mq[it] = (p < P && p > 0) ? tmask[p - 1] : 0u;
+        if (mm[it]) hits |= 1u << it;
     }
-    uint32_t slow = 0;
+    if (all) { flags = hits; cnt = __popc(hits); }
+    else if (__syncthreads_or(hits != 0)) {
+        // Three phases, each with all its memory operations in flight at once (a hit-by-hit walk with dependent loads is what this kernel used
+        // to spend its time in): (1) the mask words of the tile (and RUNS_HALO words in front of it) in LDS: every hit finds the nearest
+        // earlier position with the same mask inside its genome / gap segment, at most span away -- none: a candidate; (2) the records of the
+        // hit and of that position, all items together: on the same diagonal, the hit is not the leftmost of its cluster; (3) the rare hit
+        // whose nearest same-mask neighbour lies on ANOTHER diagonal walks on from there, one offset at a time.
 #pragma unroll
-    for (int it = 0; it < RUNS_ITEMS; it++) {
-        const uint32_t m = mm[it];
-        if (!m) continue;
-        if (all) { flags |= 1u << it; cnt++; continue; }
-        const uint32_t p = base + it * 256 + threadIdx.x;
-        const int a = __ffs(m) - 1;
-        uint32_t g0 = tab.gpos_off[a];
-        if (SEG) {      // a predecessor only counts inside the same gap segment
-            const uint32_t *sg = seg + (size_t)a * (nseg + 1);
-            g0 += sg[seg_of(sg, nseg, p - g0)];
+        for (int it = 0; it < RUNS_ITEMS; it++) s_mask[RUNS_HALO + it * 256 + threadIdx.x] = mm[it];
+        if (threadIdx.x < RUNS_HALO) {
+            const int64_t q = (int64_t)base - RUNS_HALO + threadIdx.x;
+            s_mask[threadIdx.x] = (q >= 0 && q < (int64_t)P) ? tmask[q] : 0u;
         }
-        if (p >= g0 + 1 && mq[it] == m && same_diagonal(tpos + (size_t)p * N, tpos + (size_t)(p - 1) * N, m, a, N, 1u)) continue;
-        slow |= 1u << it;
-    }
-    while (slow) {
-        const int it = __ffs(slow) - 1; slow &= slow - 1;
-        const uint32_t p = base + it * 256 + threadIdx.x, m = mm[it];
-        const int a = __ffs(m) - 1;
-        uint32_t g0 = tab.gpos_off[a];
-        if (SEG) { const uint32_t *sg = seg + (size_t)a * (nseg + 1); g0 += sg[seg_of(sg, nseg, p - g0)]; }
-        bool is_cand = true;
-        for (int d = 2; d <= span && is_cand; d++) {
-            if (p < g0 + (uint32_t)d) break;
-            const uint32_t q = p - d;
-            if (tmask[q] != m) continue;
-            if (same_diagonal(tpos + (size_t)p * N, tpos + (size_t)q * N, m, a, N, (uint32_t)d)) is_cand = false;
+        __syncthreads();
+        // (phases 1 and 2 are written without per-lane branches: the exec-mask bookkeeping of sixteen unrolled items was what the scalar unit
+        // -- one per compute unit -- spent the kernel on)
+        const int lane = threadIdx.x & 63;
+        uint32_t dd[RUNS_ITEMS];
+        uint32_t pend = 0, any = 0;
+#pragma unroll
+        for (int it = 0; it < RUNS_ITEMS; it++) {
+            dd[it] = 0;
+            const uint32_t m = mm[it];
+            uint64_t left = __ballot(m != 0);
+            if (left == 0) continue;                          // (wave-uniform)
+            const uint32_t p = base + it * 256 + threadIdx.x;
+            const int a = m ? __ffs(m) - 1 : 0;
+            uint32_t g0 = tab.gpos_off[a];
+            if (SEG) { if (m) { const uint32_t *sg = seg + (size_t)a * (nseg + 1); g0 += sg[seg_of(sg, nseg, p - g0)]; } }
+            const uint32_t lim = m ? min((uint32_t)span, p - g0) : 0u;
+            // the nearest earlier position with the same mask, from ballots: one pair per distinct mask among the wave's hits (few), the 64
+            // positions in front of a lane as one word with p - 1 at bit 63
+            const uint32_t mprev = s_mask[RUNS_HALO + it * 256 + threadIdx.x - 64];
+            uint32_t d = 0;
+            while (left) {
+                const uint32_t mv = (uint32_t)__builtin_amdgcn_readlane((int32_t)m, __ffsll((unsigned long long)left) - 1);
+                const uint64_t Bc = __ballot(m == mv), Bp = __ballot(mprev == mv);
+                left &= ~Bc;
+                const uint64_t W = lane ? ((Bp >> lane) | (Bc << (64 - lane))) : Bp;
+                const uint32_t dist = W ? (uint32_t)__clzll((long long)W) + 1u : 0u;
+                d = m == mv ? dist : d;
+            }
+            const bool pd = d != 0 && d <= lim, cd = m != 0 && !pd;      // has such a neighbour / is a candidate already
+            dd[it] = pd ? d : 0u;
+            pend |= (pd ? 1u : 0u) << it; any |= pd ? m : 0u;
+            flags |= (cd ? 1u : 0u) << it; cnt += cd ? 1u : 0u;
         }
-        if (is_cand) { flags |= 1u << it; cnt++; }
+        uint32_t sa_bits = 0, sq_bits = 0, bad = 0;
+        // (32-bit offsets from a wave-uniform base keep the sixteen address pairs out of the register file)
+        const uint32_t base_h = base >= RUNS_HALO ? base - RUNS_HALO : 0u;
+        const uint32_t *tb = tpos + (size_t)base_h * N;
+        constexpr int RB = 8;                                 // items per batch of loads
+#pragma unroll
+        for (int i0 = 0; i0 < RUNS_ITEMS; i0 += RB) {
+            if (!__any((pend >> i0) & ((1u << RB) - 1u))) continue;
+            for (int g = 0; g < N; g++) {
+                if (!__any((any >> g) & 1u)) continue;        // (wave-uniform: no pending hit of this wave has a component in genome g)
+                uint32_t vp[RB], vq[RB];
+#pragma unroll
+                for (int i = 0; i < RB; i++) {                // (a lane with nothing to ask reads word 0 of the stretch: no branch)
+                    const int it = i0 + i;
+                    const uint32_t po = base - base_h + it * 256 + threadIdx.x;
+                    const bool mine = ((pend >> it) & 1u) && ((mm[it] >> g) & 1u);
+                    vp[i] = tb[mine ? po * (uint32_t)N + (uint32_t)g : 0u];
+                    vq[i] = tb[mine ? (po - dd[it]) * (uint32_t)N + (uint32_t)g : 0u];
+                }
+#pragma unroll
+                for (int i = 0; i < RB; i++) {
+                    const int it = i0 + i;
+                    const bool mine = ((pend >> it) & 1u) && ((mm[it] >> g) & 1u);
+                    const bool first = g == __ffs(mm[it]) - 1;             // the anchor's component: its strands are the reference
+                    sa_bits |= (mine && first) ? (vp[i] >> 31) << it : 0u; sq_bits |= (mine && first) ? (vq[i] >> 31) << it : 0u;
+                    // same_diagonal(p, p - d), component g
+                    const uint32_t o = (vp[i] >> 31) ^ ((sa_bits >> it) & 1u);
+                    const uint32_t pp = vp[i] & 0x7fffffffu, pq = vq[i] & 0x7fffffffu;
+                    const bool off = (((vq[i] >> 31) ^ ((sq_bits >> it) & 1u)) != o) || !(o ? (pq == pp + dd[it]) : (pq + dd[it] == pp));
+                    bad |= (mine && !first && off) ? 1u << it : 0u;
+                }
+            }
+        }
+        const uint32_t again = pend & bad;
+#pragma unroll
+        for (int it = 0; it < RUNS_ITEMS; it++) {             // (unrolled: a run-time index would put mm / dd into scratch memory)
+            if (!((again >> it) & 1u)) continue;
+            const uint32_t p = base + it * 256 + threadIdx.x, m = mm[it];
+            const int a = __ffs(m) - 1;
+            uint32_t g0 = tab.gpos_off[a];
+            if (SEG) { const uint32_t *sg = seg + (size_t)a * (nseg + 1); g0 += sg[seg_of(sg, nseg, p - g0)]; }
+            const uint32_t *sm = s_mask + RUNS_HALO + it * 256 + threadIdx.x;
+            const uint32_t lim = min((uint32_t)span, p - g0);
+            bool is_cand = true;
+            for (uint32_t d = dd[it] + 1; d <= lim && is_cand; d++) {
+                if (sm[-(int)d] != m) continue;
+                if (same_diagonal(tpos + (size_t)p * N, tpos + (size_t)(p - d) * N, m, a, N, d)) is_cand = false;
+            }
+            if (is_cand) { flags |= 1u << it; cnt++; }
+        }
     }
     uint32_t total;
     const uint32_t off = block_excl_scan(cnt, &total, lds);
@@ -1100,7 +1207,7 @@ __device__ __forceinline__ void mum_runs_body(const GenomeTab &tab, int span, co
         if (flags >> it & 1) { if (o < cand_cap) cand[o] = base + it * 256 + threadIdx.x; o++; }     // never past the list: counters[1] still counts, the host refuses a list that outgrew its buffer
 }
 template <bool SEG>
-__global__ void __launch_bounds__(256) mum_runs(GenomeTab tab, int span, const uint32_t *__restrict__ tmask,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) mum_runs(GenomeTab tab, int span, const uint32_t *__restrict__ tmask,
                                                 const uint32_t *__restrict__ tpos, uint32_t P, int all,
                                                 uint32_t *__restrict__ cand, uint32_t *__restrict__ counters,
                                                 const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t cand_cap, uint32_t p0 = 0)
@@ -1110,11 +1217,11 @@ __global__ void __launch_bounds__(256) mum_runs(GenomeTab tab, int span, const u
 // Several passes of the pairwise finder at once: pairs with DIFFERENT lower genomes write disjoint slices of the hit table, so a group of
 // them shares the table, one candidate list and one counter (mum_extend tells the pairs apart by the hit's mask).  blockIdx.y = pair.
 struct PairGroup { int n; int ga[MAUVE_MAX_SEQ], gb[MAUVE_MAX_SEQ]; uint32_t lo[MAUVE_MAX_SEQ], hi[MAUVE_MAX_SEQ]; };
-__global__ void __launch_bounds__(256) mum_runs_group(GenomeTab tab, int span, const uint32_t *__restrict__ tmask, const uint32_t *__restrict__ tpos, PairGroup grp, int all,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) mum_runs_group(GenomeTab tab, int span, const uint32_t *__restrict__ tmask, const uint32_t *__restrict__ tpos, PairGroup grp, int all,
                                                       uint32_t *__restrict__ cand, uint32_t *__restrict__ counters, uint32_t cand_cap)
 {
     const uint32_t lo = grp.lo[blockIdx.y], hi = grp.hi[blockIdx.y];
-    if (lo + blockIdx.x * (256u * RUNS_ITEMS) >= hi) return;                     // (workgroup-uniform: the grid covers the longest slice)
+    if (lo + blockIdx.x * RUNS_TILE >= hi) return;                     // (workgroup-uniform: the grid covers the longest slice)
     mum_runs_body<false>(tab, span, tmask, tpos, hi, all, cand, counters, nullptr, 0u, lo, cand_cap);
 }
 __global__ void __launch_bounds__(256) join_pair_group(const uint32_t *__restrict__ vals, GenomeTab tab, const uint32_t *__restrict__ rstart,
@@ -1157,6 +1264,10 @@ __global__ void __launch_bounds__(256) join_pair_group(const uint32_t *__restric
 // phase B: one wave per candidate; the 64 lanes test 64 consecutive offsets at a time and the resulting
 // agreement bitmap is walked with scalar bit operations.  Record slot = candidate index; length 0 marks a
 // candidate that turned out not to be the leftmost hit of its cluster.
+#ifdef MAUVE_EXT_STATS
+// measurement build only (-DMAUVE_EXT_STATS): [0] rounds, [2] sum of wave times, [3] longest wave time (10 ns ticks), [4] waves, [5] most rounds of one wave, [1] / [6] / [7] time in set-up / left walk / right walk
+__device__ unsigned long long g_ext_stats[8];
+#endif
 template <bool SEG>
 __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ packed, GenomeTab tab, SeedShape sh,
                                                   const uint32_t *__restrict__ tmask, const uint32_t *__restrict__ tpos,
@@ -1175,7 +1286,16 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
     const uint64_t spanmask = (sh.span >= 64) ? ~0ULL : ((1ULL << sh.span) - 1ULL);
     const int N = tab.nseq;
     ExtComp *comp = s_comp[wv];
+#ifdef MAUVE_EXT_STATS
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime(); unsigned long long st_rounds = 0, st_setup = 0, st_left = 0, st_right = 0;
+#endif
     for (uint32_t ci = wave_global; ci < ncand; ci += nwaves) {
+#ifdef MAUVE_EXT_STATS
+        unsigned long long st_r = 0; const unsigned long long st_c0 = __builtin_amdgcn_s_memrealtime(); unsigned long long st_c1 = st_c0, st_c2 = st_c0;
+#define EXT_STAT_ROUND st_r++
+#else
+#define EXT_STAT_ROUND
+#endif
         const uint32_t ap = cand[ci];
         const uint32_t mask = tmask[ap];
         const int anchor = __ffs(mask) - 1;
@@ -1191,56 +1311,64 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
             C.VM = vmask ? vmask + tab.mask_off[g] : nullptr;
             C.CM = cmask ? cmask + tab.mask_off[g] : nullptr;
             C.pos = (int64_t)((vg & 0x7fffffffu) - tab.gpos_off[g]);
-            C.rev = (vg >> 31) ^ sa; C.pad = 0;
+            C.rev = (vg >> 31) ^ sa; C.g = (uint32_t)g; C.pad = 0;
             C.lo = 0; C.hi = (int64_t)tab.nwin[g] - 1;
+            C.maxw = (uint32_t)(((uint64_t)tab.nwin[g] + (uint32_t)sh.span - 1 + 31) / 32 + 2);       // mauve_packed_words - 1
             if (SEG) { const uint32_t *sg = seg + (size_t)g * (nseg + 1) + segid; C.lo = sg[0]; C.hi = (int64_t)sg[1] - sh.span; }
             comp[__popc(mask & ((1u << g) - 1u))] = C;
         }
         __threadfence_block();          // the table is read by every lane of this wave
+#ifdef MAUVE_EXT_STATS
+        st_c1 = __builtin_amdgcn_s_memrealtime(); st_setup += st_c1 - st_c0;
+#endif
         int64_t klo = 0, khi = 0;
         bool leftmost = true;
         if (extend) {
+            // offsets every component's window stays inside its genome / gap segment for
+            int64_t kmin = INT64_MIN, kmax = INT64_MAX;
+            for (int c = 0; c < nc; c++) {
+                const ExtComp &C = comp[c];
+                const int64_t a = C.rev ? C.pos - C.hi : C.lo - C.pos, b = C.rev ? C.pos - C.lo : C.hi - C.pos;
+                kmin = max(kmin, a); kmax = min(kmax, b);
+            }
+            const bool masks = vmask || cmask;
+            uint64_t M[4];
             // ---- left walk: offsets cur-1 .. cur-64 per round ----
             int64_t cur = 0;
             for (bool done = false; !done;) {
                 const int64_t k = cur - 1 - lane;
                 const int64_t hq = (int64_t)ap + k;
-                const uint32_t hm = (hq >= 0) ? tmask[hq] : 0u;       // issued beside the window loads
-                const bool a = agree_at(comp, nc, sh, k);
+                const uint32_t hm = (hq >= 0) ? tmask[hq] : 0u;       // issued beside the genome words
+                EXT_STAT_ROUND;
+                ext_mismatch(comp, nc, sh.span, cur - 64, lane, M);
+                bool a = k >= kmin && k <= kmax && ext_window_clean(M, 63 - lane, sh);
+                if (masks) a = a && !ext_blocked(comp, nc, sh.span, k);
                 const bool hh = a && hm == mask;
                 const uint64_t A = __ballot(a), H = __ballot(hh);
-                int p = 0;                      // offsets consumed in this round
-                for (;;) {
-                    if (p + sh.span > 64) break;                       // need a fresh round from cur-p
-                    const uint64_t x = (A >> p) & spanmask;
-                    if (x == 0) { done = true; break; }
-                    // jump to the next agreeing offset and over the whole run of agreeing offsets behind it
-                    const int b = p + __ffsll((unsigned long long)x) - 1;
-                    const uint64_t y = ~(A >> b);
-                    const int run = y ? __ffsll((unsigned long long)y) - 1 : 64 - b;
-                    const uint64_t visited = (run >= 64 ? ~0ULL : ((1ULL << run) - 1ULL)) << b;
-                    if (H & visited) { leftmost = false; done = true; break; }
-                    p = b + run;
-                }
+                const int p = walk_round(A, sh.span, done);                          // offsets consumed in this round
+                if (H & (p >= 64 ? ~0ULL : ((1ULL << p) - 1ULL))) { leftmost = false; done = true; }      // a same-mask hit among the visited offsets
                 cur -= p;
             }
-            if (!leftmost) { if (lane == 0) mlen[ci] = 0; __threadfence_block(); continue; }
+            if (!leftmost) {
+#ifdef MAUVE_EXT_STATS
+                st_rounds += st_r; st_left += __builtin_amdgcn_s_memrealtime() - st_c1;
+#endif
+                if (lane == 0) mlen[ci] = 0; __threadfence_block(); continue;
+            }
             klo = cur;
+#ifdef MAUVE_EXT_STATS
+            st_c2 = __builtin_amdgcn_s_memrealtime(); st_left += st_c2 - st_c1;
+#endif
             // ---- right walk ----
             cur = 0;
             for (bool done = false; !done;) {
                 const int64_t k = cur + 1 + lane;
-                const bool a = agree_at(comp, nc, sh, k);
+                EXT_STAT_ROUND;
+                ext_mismatch(comp, nc, sh.span, cur + 1, lane, M);
+                bool a = k >= kmin && k <= kmax && ext_window_clean(M, lane, sh);
+                if (masks) a = a && !ext_blocked(comp, nc, sh.span, k);
                 const uint64_t A = __ballot(a);
-                int p = 0;
-                for (;;) {
-                    if (p + sh.span > 64) break;
-                    const uint64_t x = (A >> p) & spanmask;
-                    if (x == 0) { done = true; break; }
-                    const int b = p + __ffsll((unsigned long long)x) - 1;
-                    const uint64_t y = ~(A >> b);
-                    p = b + (y ? __ffsll((unsigned long long)y) - 1 : 64 - b);
-                }
+                const int p = walk_round(A, sh.span, done);
                 cur += p;
             }
             khi = cur;
@@ -1255,7 +1383,17 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
             mstart[(size_t)ci * N + lane] = st;
         }
         __threadfence_block();          // the next candidate overwrites the table
+#ifdef MAUVE_EXT_STATS
+        st_rounds += st_r; st_right += __builtin_amdgcn_s_memrealtime() - st_c2;
+#endif
     }
+#ifdef MAUVE_EXT_STATS
+    if (lane == 0) {
+        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - st_t0;
+        atomicAdd(&g_ext_stats[0], st_rounds); atomicAdd(&g_ext_stats[2], dt); atomicMax(&g_ext_stats[3], dt); atomicAdd(&g_ext_stats[4], 1ULL); atomicMax(&g_ext_stats[5], st_rounds);
+        atomicAdd(&g_ext_stats[1], st_setup); atomicAdd(&g_ext_stats[6], st_left); atomicAdd(&g_ext_stats[7], st_right);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1694,7 +1832,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             HIPCHK(ctx, hipGetLastError());
             TRACE(ctx, "join");
             { KernelTimer t(ctx, MAUVE_K_RUNS, slices);
-              hipLaunchKernelGGL(mum_runs_group, dim3((maxslice + 256 * RUNS_ITEMS - 1) / (256 * RUNS_ITEMS), (uint32_t)grp.n), dim3(256), 0, ctx->stream, tab, sh.span, tmask, tpos, grp,
+              hipLaunchKernelGGL(mum_runs_group, dim3((maxslice + RUNS_TILE - 1) / RUNS_TILE, (uint32_t)grp.n), dim3(256), 0, ctx->stream, tab, sh.span, tmask, tpos, grp,
                                  extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), cand_cap); }
             HIPCHK(ctx, hipGetLastError());
             if (ctx->shadow) { std::function<void()> fsh; fsh.swap(ctx->shadow); fsh(); }
@@ -1764,7 +1902,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         TRACE(ctx, "join");
         // extension phase A: run starts from the table
         { KernelTimer t(ctx, MAUVE_K_RUNS, s_hi - s_lo);
-          hipLaunchKernelGGL((mum_runs<SEG>), dim3((s_hi - s_lo + 256 * RUNS_ITEMS - 1) / (256 * RUNS_ITEMS)), dim3(256), 0, ctx->stream, tab,
+          hipLaunchKernelGGL((mum_runs<SEG>), dim3((s_hi - s_lo + RUNS_TILE - 1) / RUNS_TILE), dim3(256), 0, ctx->stream, tab,
                              sh.span, tmask, tpos, s_hi, extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg,
                              nseg, cand_cap, s_lo); }
         HIPCHK(ctx, hipGetLastError());
@@ -1827,7 +1965,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
             { KernelTimer t(ctx, MAUVE_K_RUNS, P);
-              hipLaunchKernelGGL((mum_runs<SEG>), dim3((P + 256 * RUNS_ITEMS - 1) / (256 * RUNS_ITEMS)), dim3(256), 0, ctx->stream, tab,
+              hipLaunchKernelGGL((mum_runs<SEG>), dim3((P + RUNS_TILE - 1) / RUNS_TILE), dim3(256), 0, ctx->stream, tab,
                                  sh.span, tmask, tpos, P, extend ? 0 : 1, ctx->cand.as<uint32_t>(), ctx->counters.as<uint32_t>(), seg,
                                  nseg, cand_cap); }
             HIPCHK(ctx, hipGetLastError());
@@ -1850,6 +1988,15 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
                                ctx->cand.as<uint32_t>(), nc, extend, ctx->mlen.as<int32_t>() + cand_total,
                                ctx->mstart.as<int32_t>() + (size_t)cand_total * N, seg, nseg, vmask, cmask);
             HIPCHK(ctx, hipGetLastError());
+#ifdef MAUVE_EXT_STATS
+            if (g_trace) {
+                unsigned long long h[8]; hipStreamSynchronize(ctx->stream);
+                hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ext_stats), sizeof h); unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_ext_stats), z, sizeof z);
+                fprintf(stderr, "[trace]   extend stats: %llu rounds, %llu waves, wave time mean %.1f us max %.1f us (setup %.1f, left walk %.1f, right walk %.1f), most rounds of a wave %llu\n", h[0], h[4],
+                        h[4] ? h[2] / (double)h[4] / 100.0 : 0.0, h[3] / 100.0, h[4] ? h[1] / (double)h[4] / 100.0 : 0.0, h[4] ? h[6] / (double)h[4] / 100.0 : 0.0,
+                        h[4] ? h[7] / (double)h[4] / 100.0 : 0.0, h[5]);
+            }
+#endif
         }
         cand_total += nc;
         TRACE(ctx, "extend");

@@ -26,7 +26,11 @@ if len(sys.argv) > 2 and sys.argv[1] == "--read":
     print("pass: %.3f ms from the main extract to as_fill, %d events, busy %.3f ms, idle %.3f ms in %d gaps" % (span / 1e6, len(seg), busy / 1e6, (span - busy) / 1e6, len(gaps)))
     for g, a, b in sorted(gaps, reverse=True)[:45]:
         print("  %8.1f us   %-42s -> %s" % (g / 1e3, a, b))
-    import collections
+    if len(sys.argv) > 3 and sys.argv[3] == "--timeline":     # every event of the pass in order: start (us from the first), duration, gap in front of it
+        cur_end = seg[0][0]
+        for s, e, n in seg:
+            print("  t=%8.1f  dur %7.1f  gap %6.1f  %s" % ((s - seg[0][0]) / 1e3, (e - s) / 1e3, max(0, s - cur_end) / 1e3, n))
+            cur_end = max(cur_end, e)
     small = [g for g, a, b in gaps if g < 5000]
     print("gaps < 5 us: %d, %.3f ms;  5-15 us: %d, %.3f ms;  >= 15 us: %d, %.3f ms" % (len(small), sum(small) / 1e6, len([g for g, _, _ in gaps if 5000 <= g < 15000]),
           sum(g for g, _, _ in gaps if 5000 <= g < 15000) / 1e6, len([g for g, _, _ in gaps if g >= 15000]), sum(g for g, _, _ in gaps if g >= 15000) / 1e6))
