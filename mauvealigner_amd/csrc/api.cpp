@@ -198,6 +198,7 @@ int mauve_ctx_create(int device, mauve_ctx **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         snprintf(c->devname, sizeof c->devname, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+        if (prop.multiProcessorCount > 0) c->cus = prop.multiProcessorCount;
     }
     c->pool = new (std::nothrow) SpinPool(SpinPool::default_threads());
     if (!c->pool) { g_create_err = "out of host memory"; mauve_ctx_destroy(c); return MAUVE_ERR_ARG; }

@@ -201,6 +201,7 @@ struct mauve_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     char devname[256] = {0};
+    int cus = 256;                       // compute units of the device (launches sized to a whole number of waves per SIMD)
 
     // genomes
     int nseq = 0;

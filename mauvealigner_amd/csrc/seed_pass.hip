@@ -992,33 +992,57 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
 {
     return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)v, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)(v >> 32), l) << 32);
 }
-// M: OR over the components of S_c ^ S_0 for j = j0 .. j0 + 127 (two bits per digit), wave-uniform
-__device__ __forceinline__ void ext_mismatch(const ExtComp *__restrict__ comp, int nc, int span, int64_t j0, int lane, uint64_t M[4])
+// lane l <- lane l + 1 inside its row of 16 (the groups of eight never need the word of the next row)
+__device__ __forceinline__ uint64_t row_next64(uint64_t v)
+{
+    return (uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(uint32_t)v, 0x101, 0xf, 0xf, true) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(uint32_t)(v >> 32), 0x101, 0xf, 0xf, true) << 32);
+}
+// M: OR over the components of S_c ^ S_0 for j = j0 .. j0 + 127 (two bits per digit), wave-uniform.  NJ stretches at once (the first left and
+// the first right round of a candidate: their loads travel together).
+template <int NJ>
+__device__ __forceinline__ void ext_mismatch(const ExtComp *__restrict__ comp, int nc, int span, const int64_t (&j0)[NJ], int lane, uint64_t (&M)[NJ][4])
 {
     typedef const uint64_t __attribute__((address_space(1))) *gptr;
     const int i = lane & 7, grp = lane >> 3;
-    uint64_t acc = 0, A = 0;
+    uint64_t acc[NJ], A[NJ];
+#pragma unroll
+    for (int t = 0; t < NJ; t++) { acc[t] = 0; A[t] = 0; }
     for (int c0 = 0; c0 < nc; c0 += 8) {                   // (wave-uniform: more than eight components only with more than eight genomes)
         const int c = c0 + grp;
         const ExtComp &C = comp[min(c, nc - 1)];
         const uint32_t rev = C.rev;
-        // opposite strand: the forward stretch F that ends at base top = pos + span - 1 - j0; S digit k = ~F digit (127 - k)
-        const int64_t b = rev ? C.pos + span - 1 - j0 - 127 : C.pos + j0;
-        const int64_t q = b >> 5; const int r = (int)(b & 31) * 2;
-        // (b may lie outside the genome: word indices are clamped into its buffer; what they hold there only reaches offsets the bounds test
-        // rejects anyway)
-        int64_t x = q + i; x = x < 0 ? 0 : (x > (int64_t)C.maxw ? (int64_t)C.maxw : x);
-        const uint64_t w = ((gptr)(uintptr_t)C.G)[x];
-        const uint64_t wn = shfl64(w, lane + 1);           // (lanes i >= 4 compute along, unused)
-        const uint64_t W = r ? ((w >> r) | (wn << (64 - r))) : w;
-        const uint64_t Wr = ~digit_reverse64(shfl64(W, (lane & ~7) | (3 - (i & 3))));
-        const uint64_t S = rev ? Wr : W;
-        if (c0 == 0) A = shfl64(S, i & 3);                 // the anchor (component 0, never reversed) word i, in every group
-        if (c > 0 && c < nc && i < 4) acc |= S ^ A;
-    }
-    acc |= shfl64(acc, lane ^ 8); acc |= shfl64(acc, lane ^ 16); acc |= shfl64(acc, lane ^ 32);      // over the groups
+        const bool any_rev = __any(rev != 0);
+        const gptr G = (gptr)(uintptr_t)C.G;
+        const int64_t pos = C.pos, maxw = (int64_t)C.maxw;
+        uint64_t w[NJ]; int r[NJ];
 #pragma unroll
-    for (int k = 0; k < 4; k++) M[k] = readlane64(acc, k);
+        for (int t = 0; t < NJ; t++) {
+            // opposite strand: the forward stretch F that ends at base top = pos + span - 1 - j0; S digit k = ~F digit (127 - k)
+            const int64_t b = rev ? pos + span - 1 - j0[t] - 127 : pos + j0[t];
+            const int64_t q = b >> 5; r[t] = (int)(b & 31) * 2;
+            // (b may lie outside the genome: word indices are clamped into its buffer; what they hold there only reaches offsets the bounds
+            // test rejects anyway)
+            int64_t x = q + i; x = x < 0 ? 0 : (x > maxw ? maxw : x);
+            w[t] = G[x];
+        }
+#pragma unroll
+        for (int t = 0; t < NJ; t++) {
+            const uint64_t wn = row_next64(w[t]);          // (lanes i >= 4 compute along, unused)
+            const uint64_t W = r[t] ? ((w[t] >> r[t]) | (wn << (64 - r[t]))) : w[t];
+            uint64_t S = W;
+            if (any_rev) { const uint64_t Wr = ~digit_reverse64(shfl64(W, (lane & ~7) | (3 - (i & 3)))); S = rev ? Wr : W; }
+            if (c0 == 0) A[t] = shfl64(S, i & 3);          // the anchor (component 0, never reversed) word i, in every group
+            if (c > 0 && c < nc && i < 4) acc[t] |= S ^ A[t];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NJ; t++) {
+        uint64_t v = acc[t];
+        v |= shfl64(v, lane ^ 8); v |= shfl64(v, lane ^ 16); v |= shfl64(v, lane ^ 32);      // over the groups
+#pragma unroll
+        for (int k = 0; k < 4; k++) M[t][k] = readlane64(v, k);
+    }
 }
 // The walk over one round's agreement bitmap A (bit i: offset i of the round agrees), from bit 0: jump to the next agreeing offset at most
 // `span` away and over its run, until `span` offsets in a row disagree (done) or the bitmap cannot tell any more (the caller starts a fresh
@@ -1332,7 +1356,9 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
                 kmin = max(kmin, a); kmax = min(kmax, b);
             }
             const bool masks = vmask || cmask;
-            uint64_t M[4];
+            // the first round of either walk: offsets -64 .. -1 and 1 .. 64, fetched together
+            uint64_t M2[2][4];
+            { const int64_t jj[2] = {-64, 1}; ext_mismatch<2>(comp, nc, sh.span, jj, lane, M2); }
             // ---- left walk: offsets cur-1 .. cur-64 per round ----
             int64_t cur = 0;
             for (bool done = false; !done;) {
@@ -1340,14 +1366,17 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
                 const int64_t hq = (int64_t)ap + k;
                 const uint32_t hm = (hq >= 0) ? tmask[hq] : 0u;       // issued beside the genome words
                 EXT_STAT_ROUND;
-                ext_mismatch(comp, nc, sh.span, cur - 64, lane, M);
-                bool a = k >= kmin && k <= kmax && ext_window_clean(M, 63 - lane, sh);
+                uint64_t M1[1][4];
+                if (cur != 0) { const int64_t jj[1] = {cur - 64}; ext_mismatch<1>(comp, nc, sh.span, jj, lane, M1); }
+                else { for (int q = 0; q < 4; q++) M1[0][q] = M2[0][q]; }
+                bool a = k >= kmin && k <= kmax && ext_window_clean(M1[0], 63 - lane, sh);
                 if (masks) a = a && !ext_blocked(comp, nc, sh.span, k);
                 const bool hh = a && hm == mask;
                 const uint64_t A = __ballot(a), H = __ballot(hh);
                 const int p = walk_round(A, sh.span, done);                          // offsets consumed in this round
                 if (H & (p >= 64 ? ~0ULL : ((1ULL << p) - 1ULL))) { leftmost = false; done = true; }      // a same-mask hit among the visited offsets
                 cur -= p;
+                if (p == 0) done = true;                   // (p == 0 only happens with done set; keeps cur != 0 a valid "not the first round" test)
             }
             if (!leftmost) {
 #ifdef MAUVE_EXT_STATS
@@ -1364,8 +1393,10 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
             for (bool done = false; !done;) {
                 const int64_t k = cur + 1 + lane;
                 EXT_STAT_ROUND;
-                ext_mismatch(comp, nc, sh.span, cur + 1, lane, M);
-                bool a = k >= kmin && k <= kmax && ext_window_clean(M, lane, sh);
+                uint64_t M1[1][4];
+                if (cur != 0) { const int64_t jj[1] = {cur + 1}; ext_mismatch<1>(comp, nc, sh.span, jj, lane, M1); }
+                else { for (int q = 0; q < 4; q++) M1[0][q] = M2[1][q]; }
+                bool a = k >= kmin && k <= kmax && ext_window_clean(M1[0], lane, sh);
                 if (masks) a = a && !ext_blocked(comp, nc, sh.span, k);
                 const uint64_t A = __ballot(a);
                 const int p = walk_round(A, sh.span, done);
@@ -1982,7 +2013,10 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         HIPCHK(ctx, ctx->mlen.ensure_keep((size_t)(cand_total + nc) * 4 + 4, (size_t)cand_total * 4, ctx->stream));
         HIPCHK(ctx, ctx->mstart.ensure_keep((size_t)(cand_total + nc) * 4 * N + 4, (size_t)cand_total * 4 * N, ctx->stream));
         {
-            uint32_t blocks = std::min<uint32_t>((nc + 3) / 4, 256 * 8);
+            // six waves per SIMD fit (77 registers); two rounds of workgroups even out the candidates' different lengths (measured: 5 .. 8 per compute unit
+            // within 5 % of each other, 12 .. 14 another 10 % faster)
+            static const int per_cu = getenv("MAUVE_EXT_BLOCKS_PER_CU") ? atoi(getenv("MAUVE_EXT_BLOCKS_PER_CU")) : 12;
+            uint32_t blocks = std::min<uint32_t>((nc + 3) / 4, (uint32_t)(ctx->cus * per_cu));
             KernelTimer t(ctx, MAUVE_K_EXTEND, nc);
             hipLaunchKernelGGL((mum_extend<SEG>), dim3(blocks), dim3(256), 0, ctx->stream, packed, tab, sh, tmask, tpos, P,
                                ctx->cand.as<uint32_t>(), nc, extend, ctx->mlen.as<int32_t>() + cand_total,
