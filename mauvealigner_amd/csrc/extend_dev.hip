@@ -51,33 +51,40 @@ __global__ void __launch_bounds__(256) ext_lcb_extents(const int32_t *__restrict
 // round's bitmap) between two of them.  Thread (g, j) writes packed word j.  piece k of genome g: virtual start vs[g*(K+1)+k]
 // (vs[..+K] = total length), real 0-based start rs[g*K+k], length ln[g*K+k]; unused entries have length 0 at the total.
 struct ExtGatherArgs { uint64_t src_word_off[MAUVE_MAX_SEQ], dst_word_off[MAUVE_MAX_SEQ], dst_words[MAUVE_MAX_SEQ]; };
+// (one thread per BASE -- one search of the piece table, one load -- and the wave packs its 64 bases into two words by ballots; a thread per word that
+// walked its 32 bases one after the other, three dependent loads each, took 20 us for a few kilobases)
+__device__ __forceinline__ uint64_t spread_bits32(uint32_t x)       // bit b -> bit 2 b
+{
+    uint64_t v = x;
+    v = (v | (v << 16)) & 0x0000ffff0000ffffULL; v = (v | (v << 8)) & 0x00ff00ff00ff00ffULL; v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0fULL;
+    v = (v | (v << 2)) & 0x3333333333333333ULL; v = (v | (v << 1)) & 0x5555555555555555ULL;
+    return v;
+}
 __global__ void __launch_bounds__(256) ext_gather(const uint64_t *__restrict__ genomes, uint64_t *__restrict__ out, ExtGatherArgs ga,
                                                   const uint32_t *__restrict__ vs, const int64_t *__restrict__ rs, const uint32_t *__restrict__ ln, uint32_t K)
 {
     const int g = blockIdx.y;
-    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= ga.dst_words[g]) return;
+    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;      // virtual base; a wave covers words 2 w, 2 w + 1
+    const uint64_t w0 = p >> 5 & ~(uint64_t)1;
+    if (w0 >= ga.dst_words[g]) return;                                 // (wave-uniform)
     const uint32_t *v = vs + (size_t)g * (K + 1);
     const uint32_t tot = v[K];
-    const uint64_t base0 = j * 32;
-    uint64_t word = 0;
-    if (base0 < tot) {
-        uint32_t lo = 0, hi = K;                                  // last k with v[k] <= base0
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (v[mid] <= base0) lo = mid; else hi = mid; }
-        uint32_t k = lo;
-        const uint64_t *G = genomes + ga.src_word_off[g];
-        for (int b = 0; b < 32; b++) {
-            const uint64_t p = base0 + b;
-            if (p >= tot) break;
-            while (k + 1 < K && p >= v[k + 1]) k++;
-            const uint64_t off = p - v[k];
-            if (off < ln[(size_t)g * K + k]) {                    // (else: the separator behind piece k)
-                const int64_t src = rs[(size_t)g * K + k] + (int64_t)off;
-                word |= ((G[src >> 5] >> (2 * (src & 31))) & 3ULL) << (2 * b);
-            }
+    uint32_t code = 0;
+    if (p < tot) {
+        uint32_t lo = 0, hi = K;                                      // last k with v[k] <= p
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (v[mid] <= p) lo = mid; else hi = mid; }
+        const uint64_t off = p - v[lo];
+        if (off < ln[(size_t)g * K + lo]) {                           // (else: the separator behind piece lo)
+            const int64_t src = rs[(size_t)g * K + lo] + (int64_t)off;
+            code = (uint32_t)((genomes[ga.src_word_off[g] + (src >> 5)] >> (2 * (src & 31))) & 3ULL);
         }
     }
-    out[ga.dst_word_off[g] + j] = word;
+    const uint64_t b0 = __ballot(code & 1u), b1 = __ballot(code & 2u);
+    const int lane = threadIdx.x & 63;
+    if (lane < 2 && w0 + lane < ga.dst_words[g]) {
+        const uint32_t h0 = (uint32_t)(b0 >> (32 * lane)), h1 = (uint32_t)(b1 >> (32 * lane));
+        out[ga.dst_word_off[g] + w0 + lane] = spread_bits32(h0) | (spread_bits32(h1) << 1);
+    }
 }
 
 // the kept matches slipped into the anchor list: both are ordered by their start in genome 0 (always forward there)
@@ -253,11 +260,10 @@ int extend_lcbs_device(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
         HIPCHK(c, c->rec_genomes.ensure((words + 4) * sizeof(uint64_t)));
         const size_t b_vs = (vstart.size() * 4 + 7) & ~(size_t)7, b_rs = rstart.size() * 8, b_ln = (plen.size() * 4 + 7) & ~(size_t)7, b_mask = mwords * 8;
         HIPCHK(c, c->pin_ext.ensure(b_vs + b_rs + b_ln + b_mask + 64));
-        HIPCHK(c, c->rec_seg.ensure(b_vs + b_rs + b_ln + 64));
-        HIPCHK(c, c->rec_vinv.ensure(b_mask + 64));
+        HIPCHK(c, c->rec_vinv.ensure(b_mask + b_vs + b_rs + b_ln + 64));          // the bitmap, the side tables behind it: one upload
         char *pin = c->pin_ext.as<char>();
-        memcpy(pin, vstart.data(), vstart.size() * 4); memcpy(pin + b_vs, rstart.data(), b_rs); memcpy(pin + b_vs + b_rs, plen.data(), plen.size() * 4);
-        uint64_t *bits = reinterpret_cast<uint64_t *>(pin + b_vs + b_rs + b_ln);
+        uint64_t *bits = reinterpret_cast<uint64_t *>(pin);
+        { char *ps = pin + b_mask; memcpy(ps, vstart.data(), vstart.size() * 4); memcpy(ps + b_vs, rstart.data(), b_rs); memcpy(ps + b_vs + b_rs, plen.data(), plen.size() * 4); }
         memset(bits, 0, b_mask);
         for (int g = 0; g < N; g++) {
             const auto &pg = pieces[(size_t)g];
@@ -266,10 +272,9 @@ int extend_lcbs_device(mauve_ctx *c, const mauve_params *p, int w, int64_t lcbw,
                 bits[vs.mask_off[(size_t)g] + (sep >> 6)] |= 1ULL << (sep & 63);
             }
         }
-        char *side = c->rec_seg.as<char>();
-        HIPCHK(c, hipMemcpyAsync(side, pin, b_vs + b_rs + b_ln, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->rec_vinv.p, bits, b_mask, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(ext_gather, dim3((uint32_t)((max_words + 255) / 256), (uint32_t)N), dim3(256), 0, c->stream, c->genomes.as<uint64_t>(),
+        char *side = c->rec_vinv.as<char>() + b_mask;
+        HIPCHK(c, hipMemcpyAsync(c->rec_vinv.p, bits, b_mask + b_vs + b_rs + b_ln, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(ext_gather, dim3((uint32_t)((max_words * 32 + 255) / 256), (uint32_t)N), dim3(256), 0, c->stream, c->genomes.as<uint64_t>(),
                            c->rec_genomes.as<uint64_t>(), ga, (const uint32_t *)side, (const int64_t *)(side + b_vs), (const uint32_t *)(side + b_vs + b_rs), (uint32_t)K);
         HIPCHK(c, hipGetLastError());
         vs.vmask = &c->rec_vinv;

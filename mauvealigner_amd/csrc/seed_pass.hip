@@ -752,12 +752,16 @@ constexpr int TJ_ROWS = TJ_MAX / 1024;
 __global__ void __launch_bounds__(1024) tiny_join(const uint64_t *__restrict__ packed, GenomeTab tab, SeedShape sh, uint32_t P,
                                                   const uint64_t *__restrict__ vmask, const uint64_t *__restrict__ cmask, int mode, uint32_t want_mask,
                                                   uint32_t *__restrict__ tmask, uint32_t *__restrict__ tpos, uint32_t *__restrict__ err_cnt,
-                                                  const uint32_t *__restrict__ seg, uint32_t nseg)
+                                                  const uint32_t *__restrict__ seg, uint32_t nseg, uint32_t *__restrict__ counters, uint32_t clr_lo, uint32_t clr_hi)
 {
     extern __shared__ uint32_t tj_lds[];
     uint32_t *skey = tj_lds, *som = tj_lds + TJ_SLOTS;
     constexpr uint32_t EMPTY = 0xffffffffu;       // never a canonical mer (the smaller of a mer and its reverse complement)
     const int tid = threadIdx.x;
+    // the pass's clears, here instead of two 5 us fill launches: the counter block and the slice of the hit table (the barriers below order them
+    // before this workgroup's own stores to the table)
+    if (counters && tid < 16) counters[tid] = 0;
+    for (uint32_t i = clr_lo + tid; i < clr_hi; i += 1024) tmask[i] = 0;
     for (int i = tid; i < TJ_SLOTS; i += 1024) { skey[i] = EMPTY; som[i] = 0; }
     uint32_t v[TJ_ROWS], slot[TJ_ROWS], gbit[TJ_ROWS], key[TJ_ROWS];
 #pragma unroll
@@ -1299,10 +1303,13 @@ __global__ void __launch_bounds__(256) mum_extend(const uint64_t *__restrict__ p
                                                   int extend, int32_t *__restrict__ mlen, int32_t *__restrict__ mstart,
                                                   const uint32_t *__restrict__ seg, uint32_t nseg,
                                                   const uint64_t *__restrict__ vmask, const uint64_t *__restrict__ cmask,
-                                                  const uint32_t *__restrict__ ncand_dev = nullptr)
+                                                  const uint32_t *__restrict__ ncand_dev = nullptr, uint32_t *__restrict__ counters_out = nullptr)
 {
     __shared__ ExtComp s_comp[4][MAUVE_MAX_SEQ];
-    // ncand_dev: the count is still on the device (a tiny pass launches this kernel without having looked at it: ncand is then the capacity of the list)
+    // ncand_dev: the count is still on the device (a tiny pass launches this kernel without having looked at it: ncand is then the capacity of the list);
+    // counters_out: page-locked host memory that receives the pass's counter block (ncand_dev - 1 .. + 11) -- with mlen / mstart in host memory
+    // too, such a pass needs no copy at all
+    if (counters_out && blockIdx.x == 0 && threadIdx.x < 12) counters_out[threadIdx.x] = ncand_dev[(int)threadIdx.x - 1];
     if (ncand_dev) ncand = min(ncand, *ncand_dev);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1551,6 +1558,12 @@ __global__ void __launch_bounds__(256) canon_gather(const int32_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// candidates from which the canonical order is made on the device (below: the host sorts; MAUVE_CANON_DEVICE_MIN: tests force the device path)
+static uint32_t canon_device_min()
+{
+    static const uint32_t v = getenv("MAUVE_CANON_DEVICE_MIN") ? (uint32_t)atol(getenv("MAUVE_CANON_DEVICE_MIN")) : 16384u;
+    return v;
+}
 bool make_seed_shape(uint64_t pattern, SeedShape *sh)
 {
     memset(sh, 0, sizeof *sh);
@@ -1895,8 +1908,11 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
         uint32_t s_lo = 0, s_hi = P;
         if (use_summary && fp.consider) { const int ga = __builtin_ctz(fp.consider); s_lo = tab.gpos_off[ga]; s_hi = std::min<uint32_t>(tab.gpos_off[ga + 1], P); }
         if (s_hi <= s_lo) continue;                              // (a genome shorter than the seed has no window: nothing can be anchored in it)
-        HIPCHK(ctx, hipMemsetAsync(ctx->posmask.as<uint32_t>() + s_lo, 0, (size_t)(s_hi - s_lo) * 4, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+        const bool tiny_clears = tiny && !hh && !use_summary;           // tiny_join clears for itself
+        if (!tiny_clears) {
+            HIPCHK(ctx, hipMemsetAsync(ctx->posmask.as<uint32_t>() + s_lo, 0, (size_t)(s_hi - s_lo) * 4, ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+        }
         if (hh) {
             HIPCHK(ctx, ctx->run_sum.ensure((size_t)hh->n * (N + 1) * 4 + 64));
             HIPCHK(ctx, hipMemcpyAsync(ctx->run_sum.p, hh->rec, (size_t)hh->n * (N + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1912,7 +1928,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             if (!tj_attr) { ctx->err = "tiny_join: cannot reserve its LDS"; return MAUVE_ERR_HIP; }
             KernelTimer t(ctx, MAUVE_K_JOIN, P);
             hipLaunchKernelGGL(tiny_join, dim3(1), dim3(1024), TJ_SLOTS * 8, ctx->stream, packed, tab, sh, P, vmask, cmask, fp.rule, fp.want, tmask, tpos,
-                               ctx->counters.as<uint32_t>() + 9, SEG ? seg : (const uint32_t *)nullptr, nseg);
+                               ctx->counters.as<uint32_t>() + 9, SEG ? seg : (const uint32_t *)nullptr, nseg, ctx->counters.as<uint32_t>(), s_lo, s_hi);
         } else if (hash_path) {
             const uint32_t nchunk = (ns + HJ_T - 1) / HJ_T;
             HIPCHK(ctx, ctx->join_ovf.ensure((2 + 2 * (size_t)HJ_OVF_CAP) * 4));        // the ranges; their count sits in the counter block (words 8, 9)
@@ -1943,19 +1959,25 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
             // trip that fetched the candidate count before the extension kernel could be launched cost as much as the pass.  Its candidate list has
             // at most a few thousand entries, so the extension is launched for the CAPACITY of the list with the count left on the device, and the
             // counters come back together with the records: one synchronisation per pass instead of two.
-            HIPCHK(ctx, ctx->mlen.ensure((size_t)cand_cap * 4 + 4));
-            HIPCHK(ctx, ctx->mstart.ensure((size_t)cand_cap * 4 * N + 4));
-            { KernelTimer t(ctx, MAUVE_K_EXTEND, cand_cap);
-              hipLaunchKernelGGL((mum_extend<SEG>), dim3(std::min<uint32_t>((cand_cap + 3) / 4, 512)), dim3(256), 0, ctx->stream, packed, tab, sh, tmask, tpos, P,
-                                 ctx->cand.as<uint32_t>(), cand_cap, extend, ctx->mlen.as<int32_t>(), ctx->mstart.as<int32_t>(), seg, nseg, vmask, cmask,
-                                 ctx->counters.as<uint32_t>() + 1); }
-            HIPCHK(ctx, hipGetLastError());
+            // The records and the counters go straight into page-locked host memory (the device writes it in place: a handful of candidates), so the
+            // round trip is one synchronisation and no copy kernel.  (Not when the canonical order is to be made on the device -- a test setting for
+            // lists this small: then the records stay in device memory and are copied as well.)
             const size_t lbytes = ((size_t)cand_cap * 4 + 63) & ~(size_t)63, sbytes = (size_t)cand_cap * 4 * N;
             HIPCHK(ctx, ctx->pin_seed.ensure(64 + lbytes + sbytes));
             char *pin = ctx->pin_seed.as<char>();
-            HIPCHK(ctx, hipMemcpyAsync(pin, ctx->counters.p, 48, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(pin + 64, ctx->mlen.p, (size_t)cand_cap * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(pin + 64 + lbytes, ctx->mstart.p, sbytes, hipMemcpyDeviceToHost, ctx->stream));
+            const bool host_out = cand_cap < canon_device_min();
+            if (!host_out) { HIPCHK(ctx, ctx->mlen.ensure((size_t)cand_cap * 4 + 4)); HIPCHK(ctx, ctx->mstart.ensure((size_t)cand_cap * 4 * N + 4)); }
+            int32_t *o_len = host_out ? reinterpret_cast<int32_t *>(pin + 64) : ctx->mlen.as<int32_t>();
+            int32_t *o_st = host_out ? reinterpret_cast<int32_t *>(pin + 64 + lbytes) : ctx->mstart.as<int32_t>();
+            { KernelTimer t(ctx, MAUVE_K_EXTEND, cand_cap);
+              hipLaunchKernelGGL((mum_extend<SEG>), dim3(std::min<uint32_t>((cand_cap + 3) / 4, 512)), dim3(256), 0, ctx->stream, packed, tab, sh, tmask, tpos, P,
+                                 ctx->cand.as<uint32_t>(), cand_cap, extend, o_len, o_st, seg, nseg, vmask, cmask,
+                                 ctx->counters.as<uint32_t>() + 1, reinterpret_cast<uint32_t *>(pin)); }
+            HIPCHK(ctx, hipGetLastError());
+            if (!host_out) {
+                HIPCHK(ctx, hipMemcpyAsync(pin + 64, ctx->mlen.p, (size_t)cand_cap * 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(pin + 64 + lbytes, ctx->mstart.p, sbytes, hipMemcpyDeviceToHost, ctx->stream));
+            }
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             const uint32_t nc = reinterpret_cast<const uint32_t *>(pin)[1];
             if (reinterpret_cast<const uint32_t *>(pin)[9]) { ctx->err = "tiny_join: anchor out of range (internal error)"; return MAUVE_ERR_HIP; }
@@ -2109,7 +2131,7 @@ static int seedpass_impl(mauve_ctx *ctx, const GenomeSet &gs, const SeedShape &s
     }
     if (ncand == 0) return MAUVE_OK;
     // ---- canonical order (first component, |start|, mask, starts, length) ----
-    static const uint32_t dev_sort_min = getenv("MAUVE_CANON_DEVICE_MIN") ? (uint32_t)atol(getenv("MAUVE_CANON_DEVICE_MIN")) : 16384u;
+    const uint32_t dev_sort_min = canon_device_min();
     if (ncand >= dev_sort_min) {
         // large sets: sort on the device, gather, copy out in order.  (Own buffers: over several finder passes the
         // candidates can outnumber the windows, so the sorted-mer buffers are not guaranteed to be big enough.)
