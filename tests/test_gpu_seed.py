@@ -134,6 +134,13 @@ def test_many_genomes(ctx):
     pat = O.get_seed(9, 0)
     _same(ctx, gs, pat, mode=1)
     _same(ctx, gs, pat, mode=0, mask=(1 << 17) - 1)
+    # more than eight components per hit WITH components on the other strand (the extension builds the base streams of eight components at a
+    # time, the reversed ones from the complemented far end), matches that run into the genomes' ends included
+    gs = synth.star_genomes(12, 5000, 0.03, 9, inversions=14, inv_min=300, inv_max=1500)
+    gs[3] = gs[3][::-1].copy() ^ 3                       # one genome as its reverse complement altogether
+    for w in (9, 11):
+        _same(ctx, gs, O.get_seed(w, 0), mode=1)
+        _same(ctx, gs, O.get_seed(w, 0), mode=0, mask=(1 << 12) - 1)
 
 
 def test_sorted_mer_list(ctx):
