@@ -398,6 +398,11 @@ void lcb_greedy(int N, int32_t K, int64_t *weight, const uint32_t *orient_bits, 
 // DP (dp_batch.hip)
 int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *sc,
                       uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells, bool may_shard = false, int64_t *sp = nullptr);
+// the same with the rows behind n_orig made on the device as rotations of the first n_orig (cbase: first candidate of every interval, n_orig + 1 entries);
+// only when dp_desc_rotations_on_device(n_total)
+bool dp_desc_rotations_on_device(int64_t n_total);
+int dp_batch_run_desc_rot(mauve_ctx *ctx, int nseq, int64_t n_orig, const DpSeqDesc *desc, const int32_t *cbase, int64_t n_total, const mauve_scoring *sc,
+                          int64_t *col_off, int64_t *score, int64_t *cells, int64_t *sp);
 // gapped-alignment eligibility of an inter-anchor interval by its longest sequence: full DP up to max_gapped_len, banded
 // DP above it up to max_banded_len
 inline int64_t dp_len_limit(const mauve_params *p) { return p->max_banded_len > p->max_gapped_len ? p->max_banded_len : p->max_gapped_len; }

@@ -2979,8 +2979,34 @@ int dp_run_from_anchors(mauve_ctx *ctx, int N, int64_t na64, const int32_t *h_le
 // C4's root), through the device front end: the descriptors go up once, sizing, offsets and launch order are made by the kernels and scans of
 // dp_run_from_anchors (dp_core's host loops took 7 ms for that batch, beside 4 ms of DP kernels), the result offsets come from scans as well.
 // cols == nullptr: the columns stay in dp_cols (dp_fetch_picked).  sp: the refinement objective (dp_sp_scores), or nullptr.
+// The refinement candidates of a guide-tree node made where they are used: rows [n_orig, n_orig + cbase[n_orig]) of the descriptor table are
+// rotations of the intervals in front of them -- candidate cbase[iv] + r - 1 holds interval iv's non-empty sequences rotated by r, empty slots behind -- so
+// the host uploads the intervals and one offset each instead of building and copying three times as many rows (C4's root: 22 MB, 2 ms of the host).
+__global__ void __launch_bounds__(256) dpf_rotate_desc(DpSeqDesc *__restrict__ desc, int N, uint32_t n_orig, const int32_t *__restrict__ cbase)
+{
+    const uint32_t iv = blockIdx.x * 256u + threadIdx.x;
+    if (iv >= n_orig) return;
+    const int32_t c0 = cbase[iv], cnt = cbase[iv + 1] - c0;
+    if (cnt <= 0) return;
+    const DpSeqDesc *di = desc + (size_t)iv * N;
+    int k = 0;
+    for (int j = 0; j < N; j++) k += di[j].len != 0;
+    DpSeqDesc none = di[0]; none.rev = 0; none.lo0 = 0; none.len = 0;
+    for (int r = 1; r <= cnt; r++) {
+        DpSeqDesc *o = desc + ((size_t)n_orig + (size_t)c0 + (size_t)(r - 1)) * N;
+        // slot j takes the ((j + r) mod k)-th non-empty sequence: walk the non-empty ones once, starting at the r-th
+        int t = 0, filled = 0;
+        for (int j = 0; j < N; j++) {
+            if (!di[j].len) continue;
+            const int slot = ((t - r) % k + k) % k;            // the t-th non-empty sequence lands in slot (t - r) mod k
+            o[slot] = di[j]; t++; filled++;
+        }
+        for (int j = filled; j < N; j++) o[j] = none;
+    }
+}
+
 int dp_run_from_desc(mauve_ctx *ctx, int N, int64_t n_iv, const DpSeqDesc *h_desc, const mauve_scoring *scoring, uint32_t *cols, int64_t *col_off, int64_t *score,
-                     int64_t *cells, int64_t *sp)
+                     int64_t *cells, int64_t *sp, int64_t n_orig = -1, const int32_t *cbase = nullptr)
 {
     static const bool trace = getenv("MAUVE_TRACE") != nullptr;
     static const bool no_mw = getenv("MAUVE_DP_ONE_WAVE") != nullptr, no_groups = getenv("MAUVE_DP_NO_GROUPS") != nullptr;
@@ -3009,11 +3035,22 @@ int dp_run_from_desc(mauve_ctx *ctx, int N, int64_t n_iv, const DpSeqDesc *h_des
     DpFrontTotals *tot = ctx->dpf_tot.as<DpFrontTotals>();
     int64_t *d_seq_off = ctx->dp_off.as<int64_t>();
     int64_t *d_tb_off = d_seq_off + ((size_t)na * N + 1), *d_rows_off = d_tb_off + (na + 1), *d_col_off = d_rows_off + (na + 1);
-    const size_t desc_bytes = (size_t)na * N * sizeof(DpSeqDesc);
-    HIPCHK(ctx, ctx->pin_dp_in.ensure(256 + desc_bytes));
+    // cbase: only the first n_orig rows come from the host, the rest are their rotations (dpf_rotate_desc)
+    const bool rot = cbase != nullptr && n_orig >= 0 && n_orig < n_iv;
+    const size_t rows_up = rot ? (size_t)n_orig : (size_t)na;
+    const size_t desc_bytes = rows_up * N * sizeof(DpSeqDesc), cb_bytes = rot ? ((size_t)n_orig + 1) * 4 : 0;
+    HIPCHK(ctx, ctx->pin_dp_in.ensure(256 + desc_bytes + cb_bytes + 64));
     DpFrontTotals *ht = ctx->pin_dp_in.as<DpFrontTotals>();
     memcpy(ctx->pin_dp_in.as<char>() + 256, h_desc, desc_bytes);
     HIPCHK(ctx, hipMemcpyAsync(desc, ctx->pin_dp_in.as<char>() + 256, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (rot) {
+        if ((int64_t)cbase[n_orig] != n_iv - n_orig) { ctx->err = "dp: the rotation table does not match the batch"; return MAUVE_ERR_ARG; }
+        char *pcb = ctx->pin_dp_in.as<char>() + 256 + ((desc_bytes + 7) & ~(size_t)7);
+        memcpy(pcb, cbase, cb_bytes);
+        int32_t *d_cb = reinterpret_cast<int32_t *>(k1);                 // (the sort's key array is free until dpf_size_desc fills it)
+        HIPCHK(ctx, hipMemcpyAsync(d_cb, pcb, cb_bytes, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(dpf_rotate_desc, dim3((uint32_t)((n_orig + 255) / 256)), dim3(256), 0, ctx->stream, desc, N, (uint32_t)n_orig, d_cb);
+    }
     HIPCHK(ctx, hipMemsetAsync(tot, 0, 256, ctx->stream));
     const uint32_t blk_d = (n_dp + 255) / 256;
     hipLaunchKernelGGL(dpf_size_desc, dim3(blk_d), dim3(256), 0, ctx->stream, desc, N, n_dp, tot, need, rowsn, est, cand, cls, k1, v1, (int)no_mw, (int)no_groups,
@@ -3160,6 +3197,16 @@ int dp_batch_run(mauve_ctx *ctx, int nseq, int64_t n_iv, const uint8_t *codes, c
     return dp_core(ctx, nseq, n_iv, codes, nullptr, seq_off, scoring, cols, col_off, score, cells);
 }
 
+static bool dp_desc_host() { static const bool h = getenv("MAUVE_DP_DESC_HOST") != nullptr; return h; }
+static int64_t dp_desc_min() { static const int64_t m = getenv("MAUVE_DP_DESC_MIN") ? atoll(getenv("MAUVE_DP_DESC_MIN")) : 2048; return m; }
+// does a batch of n_total rows take the device front (where the rotated candidates can be made on the device)?
+bool dp_desc_rotations_on_device(int64_t n_total) { return !dp_desc_host() && n_total >= dp_desc_min(); }
+int dp_batch_run_desc_rot(mauve_ctx *ctx, int nseq, int64_t n_orig, const DpSeqDesc *desc, const int32_t *cbase, int64_t n_total, const mauve_scoring *scoring,
+                          int64_t *col_off, int64_t *score, int64_t *cells, int64_t *sp)
+{
+    if (!dp_desc_rotations_on_device(n_total)) { ctx->err = "dp: rotations on the device need the device front"; return MAUVE_ERR_STATE; }
+    return dp_run_from_desc(ctx, nseq, n_total, desc, scoring, nullptr, col_off, score, cells, sp, n_orig, cbase);
+}
 int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *desc, const mauve_scoring *scoring,
                       uint32_t *cols, int64_t *col_off, int64_t *score, int64_t *cells, bool may_shard, int64_t *sp)
 {
@@ -3240,9 +3287,7 @@ int dp_batch_run_desc(mauve_ctx *ctx, int nseq, int64_t n_iv, const DpSeqDesc *d
     }
     // large batches: sizing, order and result offsets on the device (dp_run_from_desc); small ones keep the host loops (fewer launches).
     // MAUVE_DP_DESC_HOST: A/B switch
-    static const bool desc_host = getenv("MAUVE_DP_DESC_HOST") != nullptr;
-    static const int64_t desc_min = getenv("MAUVE_DP_DESC_MIN") ? atoll(getenv("MAUVE_DP_DESC_MIN")) : 2048;
-    if (!desc_host && n_iv >= desc_min) return dp_run_from_desc(ctx, nseq, n_iv, desc, scoring, cols, col_off, score, cells, sp);
+    if (!dp_desc_host() && n_iv >= dp_desc_min()) return dp_run_from_desc(ctx, nseq, n_iv, desc, scoring, cols, col_off, score, cells, sp);
     seq_off.resize((size_t)(n_iv * nseq + 1));
     int64_t t = 0;
     for (int64_t i = 0; i < n_iv * nseq; i++) { seq_off[(size_t)i] = t; t += desc[i].len; }

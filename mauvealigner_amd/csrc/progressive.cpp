@@ -291,15 +291,19 @@ int prog_node(Prog &P, int node)
     if (refine) {
         const double tr0 = now_ms();
         int64_t ccodes = 0;
-        // (sized once and filled in place: 86 000 descriptor rows at C4's root; push_back by push_back this took 3 ms)
+        // (sized once and filled in place: 86 000 descriptor rows at C4's root; push_back by push_back this took 3 ms.  A batch large enough for the
+        // device front gets only the intervals and the index of every interval's first candidate: the rotated rows are made on the device.)
         std::vector<DpSeqDesc> &all = c->prog_desc;
+        std::vector<int32_t> cbase((size_t)n_dp + 1, 0);
         int64_t nc0 = 0;
         for (int64_t iv = 0; iv < n_dp; iv++) {
             int k = 0; for (int j = 0; j < n; j++) k += desc[(size_t)(iv * n + j)].len != 0;
+            cbase[(size_t)iv] = (int32_t)nc0;
             if (k >= 3) nc0 += std::min(p->refine_rounds, k - 1);
         }
-        all.resize((size_t)(n_dp + nc0) * n);
-        std::copy(desc.begin(), desc.end(), all.begin());
+        cbase[(size_t)n_dp] = (int32_t)nc0;
+        const bool rot_dev = !c->shard_on && nc0 > 0 && nc0 < (1LL << 30) && dp_desc_rotations_on_device(n_dp + nc0);
+        if (!rot_dev) { all.resize((size_t)(n_dp + nc0) * n); std::copy(desc.begin(), desc.end(), all.begin()); }
         cands.resize((size_t)nc0);
         DpSeqDesc none; none.genome = gm[0]; none.rev = 0; none.lo0 = 0; none.len = 0;
         int64_t q0 = 0;
@@ -311,8 +315,10 @@ int prog_node(Prog &P, int node)
             if (cd.k < 3) continue;
             for (int r = 1; r <= p->refine_rounds && r < cd.k; r++, q0++) {
                 cd.r = r; cands[(size_t)q0] = cd;
-                DpSeqDesc *o = &all[(size_t)(n_dp + q0) * n];
-                for (int j = 0; j < n; j++) o[j] = j < cd.k ? di[cd.nz[(j + r) % cd.k]] : none;
+                if (!rot_dev) {
+                    DpSeqDesc *o = &all[(size_t)(n_dp + q0) * n];
+                    for (int j = 0; j < n; j++) o[j] = j < cd.k ? di[cd.nz[(j + r) % cd.k]] : none;
+                }
                 ccodes += tot;
             }
         }
@@ -321,7 +327,10 @@ int prog_node(Prog &P, int node)
         const double tr1 = now_ms();
         std::vector<int64_t> aoff((size_t)na + 1, 0), ascore((size_t)na + 1, 0), asp((size_t)na + 1, 0);
         std::vector<uint32_t> ccols;                             // (the exchanged form only)
-        if (one_batch) {
+        if (one_batch && rot_dev) {
+            rc = dp_batch_run_desc_rot(c, n, n_dp, desc.data(), cbase.data(), na, &p->scoring, aoff.data(), ascore.data(), &cells, asp.data());
+            if (rc) return rc;
+        } else if (one_batch) {
             rc = dp_batch_run_desc(c, n, na, all.data(), &p->scoring, nullptr, aoff.data(), ascore.data(), &cells, false, asp.data());
             if (rc) return rc;
         } else {
