@@ -1095,11 +1095,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 template <int CTRL, int RM> __device__ __forceinline__ int32_t dpp_keep(int32_t v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xf, false); }
 template <int CTRL, int RM> __device__ __forceinline__ int32_t dpp_zero(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, RM, 0xf, false); }
 // inclusive prefix maximum / sum over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 and :31
+// (written out: the compiler turns each max(v, update_dpp(v, v, ...)) into v_mov, s_nop, v_mov_dpp, v_max -- four issue slots of a chain that every line
+// of every sweep waits for; v_max_i32_dpp does the shift and the maximum in one, a lane without a source keeps its value: two slots per level)
 __device__ __forceinline__ int32_t wave_prefix_max(int32_t v)
 {
-    v = max(v, dpp_keep<0x111, 0xf>(v)); v = max(v, dpp_keep<0x112, 0xf>(v));
-    v = max(v, dpp_keep<0x114, 0xf>(v)); v = max(v, dpp_keep<0x118, 0xf>(v));
-    v = max(v, dpp_keep<0x142, 0xa>(v)); v = max(v, dpp_keep<0x143, 0xc>(v));
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(v));
     return v;
 }
 __device__ __forceinline__ int32_t wave_prefix_sum(int32_t v)
