@@ -222,6 +222,23 @@ def kernel_profile(rn, weight, nprof=3, params=None):
           "peak_note": "256 CUs x 64 lanes x 2.4 GHz / 12 integer operations per cell (SURVEY.md 8d): no HBM or MFMA roofline applies to the gapped DP",
           "traffic": dp_traffic, "traffic_source": dp_tnote, "launches_timed": kernels["dp_step"]["launches"]}
     dp["gcups"] = dp["achieved"]; dp["peak_gcups"] = dp["peak"]
+    if not rn.progressive and params is None:
+        # the launch's critical path, measured: the DP of the single largest interval alone (mauve_align_begin / mauve_align_dp, same kernels).  The
+        # progressive steps of one interval are serial and one wave runs them, so the launch cannot be shorter than this whatever the other intervals do.
+        try:
+            import numpy as np
+            n_dp, cost, cap = ctx.align_begin(rn.params)
+            if n_dp:
+                top = np.array([int(np.argmax(cost))])
+                ctx.profile(True)
+                for _ in range(2):
+                    ctx.profile_reset(); ctx.align_dp(top, cap)
+                one = ctx.profile_get()["dp_step"]["ms"]
+                ctx.profile(False)
+                dp["largest_interval_alone"] = {"kernel_ms": round(one, 4), "share_of_launch": round(one / dp_ms, 3) if dp_ms else None, "cell_bound": int(cost[top[0]]),
+                                                "intervals": int(n_dp), "note": "the DP launch is bounded below by its largest interval's serial lines (DESIGN.md section 9)"}
+        except Exception as e:                                   # (a measurement beside the line, never a reason to lose the line)
+            dp["largest_interval_alone"] = {"error": str(e)[:200]}
     # the line's roofline object describes the DOMINANT kernel of the pass, whatever bounds it; the dominant HBM kernel and the DP ride beside it
     roofline = dict(dp if overall == "dp_step" else (hbm if overall == dom else
                     {"bound": "hbm" if per_kernel.get(overall) else "latency (gather / look-back: no HBM or MFMA roofline applies)", "kernel": overall,
