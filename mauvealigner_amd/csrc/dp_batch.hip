@@ -1095,17 +1095,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 template <int CTRL, int RM> __device__ __forceinline__ int32_t dpp_keep(int32_t v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xf, false); }
 template <int CTRL, int RM> __device__ __forceinline__ int32_t dpp_zero(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, RM, 0xf, false); }
 // inclusive prefix maximum / sum over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 and :31
-// (written out: the compiler turns each max(v, update_dpp(v, v, ...)) into v_mov, s_nop, v_mov_dpp, v_max -- four issue slots of a chain that every line
-// of every sweep waits for; v_max_i32_dpp does the shift and the maximum in one, a lane without a source keeps its value: two slots per level)
+// (the shifted operand's "no source lane" value is the identity of max, so that the compiler folds shift and maximum into ONE v_max_i32_dpp and
+// fills the hazard slot in front of it with other work; with the lane's own value there -- update_dpp(v, v, ...) -- it emitted v_mov, s_nop, v_mov_dpp,
+// v_max: four issue slots per level of a chain that every line of every sweep waits for)
+template <int CTRL, int RM> __device__ __forceinline__ int32_t dpp_min(int32_t v) { return __builtin_amdgcn_update_dpp(INT32_MIN, v, CTRL, RM, 0xf, false); }
 __device__ __forceinline__ int32_t wave_prefix_max(int32_t v)
 {
-    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
-                 : "+v"(v));
+    v = max(v, dpp_min<0x111, 0xf>(v)); v = max(v, dpp_min<0x112, 0xf>(v));
+    v = max(v, dpp_min<0x114, 0xf>(v)); v = max(v, dpp_min<0x118, 0xf>(v));
+    v = max(v, dpp_min<0x142, 0xa>(v)); v = max(v, dpp_min<0x143, 0xc>(v));
     return v;
 }
 __device__ __forceinline__ int32_t wave_prefix_sum(int32_t v)
@@ -1177,9 +1175,12 @@ struct Dp3A {
         E = wave_prefix_sum(bsum);
     }
     // column j from column j - 1.  b: base of column j (wave-uniform); t?o / t?n: the row above the band at columns j - 1 / j.
-    __device__ __forceinline__ uint32_t step(uint32_t b, bool j1, int32_t gyo, int32_t gye, int32_t tMo, int32_t tXo, int32_t tYo,
+    // (J1: j >= 1.  Column 0 has no M and no Y; it is peeled off the sweep's loop so that the other columns do not pay eight selects for it.)
+    template <bool J1>
+    __device__ __forceinline__ uint32_t step(uint32_t b, int32_t gyo, int32_t gye, int32_t tMo, int32_t tXo, int32_t tYo,
                                              int32_t tMn, int32_t tXn, int32_t tYn)
     {
+        constexpr bool j1 = J1;
         int32_t Md = lane0_set(wave_shr1z(M[R - 1]), tMo), Xd = lane0_set(wave_shr1z(X[R - 1]), tXo), Yd = lane0_set(wave_shr1z(Y[R - 1]), tYo);
         const bool lo = (b & 1u) != 0, hi = (b & 2u) != 0;
         int32_t Mn[R], Yn[R];
@@ -1393,16 +1394,19 @@ __device__ __forceinline__ void dp3_sweep_a(int lane, int32_t m, int32_t n, cons
             sq_cur = sq_nxt; cM_cur = cM_nxt; cX_cur = cX_nxt; cY_cur = cY_nxt;
             chunk(k + 1, sq_nxt, cM_nxt, cX_nxt, cY_nxt);
             const int32_t jend = min(64 * k + 63, n);
-            for (int32_t j = 64 * k; j <= jend; j++, tw += mpad) {
+            auto line = [&](int32_t j, auto first) {
                 const int sel = j & 63;
                 const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int32_t)sq_cur, sel);
                 const int32_t tMn = __builtin_amdgcn_readlane(cM_cur, sel), tXn = __builtin_amdgcn_readlane(cX_cur, sel),
                               tYn = __builtin_amdgcn_readlane(cY_cur, sel);
-                const uint32_t tbw = L.step(b, j >= 1, gyo, gye, tMo, tXo, tYo, tMn, tXn, tYn);
+                const uint32_t tbw = L.template step<!decltype(first)::value>(b, gyo, gye, tMo, tXo, tYo, tMn, tXn, tYn);
                 if (writes) *reinterpret_cast<uint32_t *>(tw) = tbw;
                 if (park && lane == 63) { rout[j] = L.M[R - 1]; rout[(n + 1) + j] = L.X[R - 1]; rout[2 * (n + 1) + j] = L.Y[R - 1]; }
                 tMo = tMn; tXo = tXn; tYo = tYn;
-            }
+            };
+            int32_t j = 64 * k;
+            if (k == 0) { line(0, std::true_type()); j = 1; tw += mpad; }           // column 0, peeled
+            for (; j <= jend; j++, tw += mpad) line(j, std::false_type());
         }
         __threadfence_block();
         if (s == nbands - 1) {
