@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) cl_partial(const int32_t *__restrict__ le
 __global__ void __launch_bounds__(256) cl_flags(const int32_t *__restrict__ len, uint32_t n, uint32_t dead_key, const uint32_t *__restrict__ eleft,
                                                 const uint32_t *__restrict__ eidx, const uint32_t *__restrict__ bmax,
                                                 const uint32_t *__restrict__ balive, uint32_t nb, uint8_t *__restrict__ cflag,
-                                                uint32_t *__restrict__ cnt)
+                                                uint32_t *__restrict__ cnt, uint32_t *__restrict__ bcnt)
 {
     __shared__ uint32_t lds[4];
     const uint32_t b = blockIdx.x, r0 = b * (uint32_t)CH_TILE + threadIdx.x * 4u;
@@ -127,11 +127,17 @@ __global__ void __launch_bounds__(256) cl_flags(const int32_t *__restrict__ len,
     for (int i = 0; i < 4; i++) { rt[i] = ch_right(len, n, dead_key, eleft, eidx, r0 + i); mx = max(mx, rt[i]); }
     uint32_t dummy;
     uint32_t run = max(before, bscan_max(mx, &dummy, lds));
+    uint32_t nflag = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t r = r0 + i;
-        if (r < n) cflag[r] = (rt[i] != 0 && (r == 0 || run < eleft[r])) ? 1 : 0;
+        if (r < n) { const bool f = rt[i] != 0 && (r == 0 || run < eleft[r]); cflag[r] = f ? 1 : 0; nflag += f ? 1u : 0u; }
         run = max(run, rt[i]);
+    }
+    {   // the tile's flag count, for the compaction of the cluster starts that follows (what cmp_count<ClusterStarts> would launch for)
+        uint32_t tc;
+        (void)bscan_add(nflag, &tc, lds);
+        if (threadIdx.x == 0) bcnt[b] = tc;
     }
     if (b == 0) {                                        // alive entries of the genome in turn -> cnt[5]
         uint32_t sa = 0, k;
@@ -630,9 +636,8 @@ int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *s
         // (a recursion batch starts with its non-forward matches dead: sorted like any other genome)
         if (g > 0 || seg0) { int rc = sort_pairs_u32(c, n, pos_bits + 1, &kk, &vv, k2, v2, MAUVE_K_MISC); if (rc) return rc; }
         hipLaunchKernelGGL(cl_partial, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive);
-        hipLaunchKernelGGL(cl_flags, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive, nb, cflag, cnt);
+        hipLaunchKernelGGL(cl_flags, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive, nb, cflag, cnt, bcnt);
         const ClusterStarts cs{cflag, n, sl, cnt};
-        hipLaunchKernelGGL((cmp_count<ClusterStarts>), dim3(nb), dim3(256), 0, c->stream, cs, bcnt);
         hipLaunchKernelGGL((cmp_write<ClusterStarts>), dim3(nb), dim3(256), 0, c->stream, cs, bcnt);
         hipLaunchKernelGGL(ch_cluster_pass, dim3(blocks), dim3(256), 0, c->stream, len, st, N, g, dead_key, kk, vv, sl, cnt + 4, cnt + 3, seg0 ? 1 : 0, cl_max);
         if (seg0) hipLaunchKernelGGL(ch_cluster_pass_big, dim3((n + 63) / 64), dim3(64), 0, c->stream, len, st, N, g, dead_key, kk, vv, sl, cnt + 4,
