@@ -126,15 +126,22 @@ void host_merge_matches(MatchVec &kept, const MatchVec &add)
         if (!dropped) take.push_back(j);
     }
     if (take.empty()) return;
-    // both lists are in canonical order: merge
-    MatchVec out(N); out.d.resize((nk + take.size()) * R1);
+    // both lists are in canonical order: merge.  (Nearly every comparison is decided by the start in the first genome when both records have one
+    // there -- the N-way lists of a seed family always do --; the full order only breaks the ties.  The buffer is kept from call to call: a fresh
+    // 4 MB vector per merge cost its page faults.)
+    static thread_local std::vector<int64_t> outbuf;
+    outbuf.resize((nk + take.size()) * R1);
+    auto less_fast = [&](const int64_t *x, const int64_t *y) {
+        if (x[1] && y[1]) { const int64_t sx = std::llabs(x[1]), sy = std::llabs(y[1]); if (sx != sy) return sx < sy; }
+        return canon_less(N, x, y);
+    };
     size_t a = 0, b = 0, o = 0;
     while (a < nk || b < take.size()) {
-        const bool ta = b >= take.size() || (a < nk && !canon_less(N, add.rec(take[b]), kept.rec(a)));
+        const bool ta = b >= take.size() || (a < nk && !less_fast(add.rec(take[b]), kept.rec(a)));
         const int64_t *src = ta ? kept.rec(a++) : add.rec(take[b++]);
-        std::copy(src, src + R1, out.d.begin() + (std::ptrdiff_t)(o++ * R1));
+        std::copy(src, src + R1, outbuf.begin() + (std::ptrdiff_t)(o++ * R1));
     }
-    kept.d.swap(out.d);
+    kept.d.swap(outbuf);
 }
 
 void MatchVec::sort_by_start0()

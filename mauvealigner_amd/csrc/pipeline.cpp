@@ -224,7 +224,8 @@ int seed_family_matches(mauve_ctx *c, const GenomeSet &gs, int w, int mode, uint
         int64_t nm = 0;
         const int rc = seedpass_run(c, gs, pat, mode, mask, 1, nullptr, 0, &nm);
         if (rc) return rc;
-        MatchVec cur(n); cur.resize((size_t)nm);
+        static thread_local MatchVec cur_keep(1);                  // (kept from call to call: no fresh megabytes and their page faults per search)
+        MatchVec &cur = cur_keep; cur.N = n; cur.d.clear(); cur.resize((size_t)nm);
         for (int64_t i = 0; i < nm; i++) {
             cur.len((size_t)i) = c->match_len[(size_t)i];
             std::copy(&c->match_start[(size_t)i * n], &c->match_start[(size_t)i * n] + n, cur.st((size_t)i));
