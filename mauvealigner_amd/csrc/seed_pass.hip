@@ -422,7 +422,7 @@ __device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v)
 __global__ void __launch_bounds__(256) rs_rowscan(uint32_t *__restrict__ hist, uint32_t nblk,
                                                   uint32_t *__restrict__ totals)
 {
-    __shared__ uint32_t part[4];
+    __shared__ uint32_t part[4];                             // (launched with 256 threads: four waves, a quarter of the row each)
     uint32_t *row = hist + (size_t)blockIdx.x * nblk;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t seg = (((nblk + 3) / 4) + 63) & ~63u;           // counts per wave, whole steps of 64
@@ -1119,6 +1119,8 @@ __device__ __forceinline__ bool ext_blocked(const ExtComp *__restrict__ comp, in
 // candidate for phase B.  all != 0 (no extension): every hit is a candidate.
 constexpr int RUNS_ITEMS = 16;
 constexpr uint32_t RUNS_TILE = 256u * RUNS_ITEMS, RUNS_HALO = 64 /* >= MAUVE_MAX_SEED_SPAN */;
+static_assert(RUNS_HALO >= MAUVE_MAX_SEED_SPAN && RUNS_HALO == 64, "mum_runs looks back at most one span, and reads the mask word 64 positions in front of every lane");
+static_assert(RUNS_ITEMS <= 32, "one bit per item in the hit / pending / flag words");
 
 // same generalized diagonal: every component of hit p sits d windows after (forward) / before (reverse) the
 // corresponding component of hit q = p - d, with the same relative strands
