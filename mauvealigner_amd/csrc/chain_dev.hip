@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) cl_partial(const int32_t *__restrict__ le
 __global__ void __launch_bounds__(256) cl_flags(const int32_t *__restrict__ len, uint32_t n, uint32_t dead_key, const uint32_t *__restrict__ eleft,
                                                 const uint32_t *__restrict__ eidx, const uint32_t *__restrict__ bmax,
                                                 const uint32_t *__restrict__ balive, uint32_t nb, uint8_t *__restrict__ cflag,
-                                                uint32_t *__restrict__ cnt, uint32_t *__restrict__ bcnt)
+                                                uint32_t *__restrict__ cnt, uint32_t *__restrict__ bcnt, uint32_t *__restrict__ alive_out)
 {
     __shared__ uint32_t lds[4];
     const uint32_t b = blockIdx.x, r0 = b * (uint32_t)CH_TILE + threadIdx.x * 4u;
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) cl_flags(const int32_t *__restrict__ len,
         uint32_t sa = 0, k;
         for (uint32_t t = threadIdx.x; t < nb; t += 256) sa += balive[t];
         (void)bscan_add(sa, &k, lds);
-        if (threadIdx.x == 0) cnt[5] = k;
+        if (threadIdx.x == 0) { cnt[5] = k; *alive_out = k; }      // (alive_out: kept per genome, the domain of FinalRanks)
     }
 }
 
@@ -155,18 +155,11 @@ struct ClusterStarts {                      // flagged entries -> cstart[]; csta
     __device__ void emit(uint32_t r, uint32_t o, int) const { cstart[o] = r; }
     __device__ void total(uint32_t J, int) const { cnt[4] = J; cstart[J] = cnt[5]; }
 };
-struct GenomeOrder {                        // the survivors of the genome in turn, in order -> ord[], their number -> *k_out
-    uint32_t dead_key; const uint32_t *eleft, *eidx; const uint32_t *cnt; uint32_t *ord; uint32_t *k_out;
-    __device__ uint32_t domain(int) const { return cnt[5]; }
-    __device__ bool flag(uint32_t r, int) const { return eleft[r] != dead_key; }
-    __device__ void each(uint32_t, uint32_t, bool, int) const {}
-    __device__ void emit(uint32_t r, uint32_t o, int) const { ord[o] = eidx[r]; }
-    __device__ void total(uint32_t k, int) const { *k_out = k; }
-};
-struct FinalRanks {                         // y = genome: its order without the matches that died later; rank of every survivor
-    const int32_t *len; uint32_t n; const uint32_t *ord; uint32_t *ordc, *rank; uint32_t *cnt;
+struct FinalRanks {                         // y = genome: its order (as its cluster pass left it: the entries alive BEFORE that pass, those it killed marked by
+                                            // the dead key) without the matches that died then or later; rank of every survivor
+    const int32_t *len; uint32_t n; const uint32_t *ord, *okey; uint32_t dead_key; uint32_t *ordc, *rank; uint32_t *cnt;
     __device__ uint32_t domain(int y) const { return cnt[8 + y]; }
-    __device__ bool flag(uint32_t r, int y) const { return len[ord[(size_t)y * n + r]] > 0; }
+    __device__ bool flag(uint32_t r, int y) const { return okey[(size_t)y * n + r] != dead_key && len[ord[(size_t)y * n + r]] > 0; }
     __device__ void each(uint32_t, uint32_t, bool, int) const {}
     __device__ void emit(uint32_t r, uint32_t o, int y) const { const uint32_t i = ord[(size_t)y * n + r]; ordc[(size_t)y * n + o] = i; rank[(size_t)y * n + i] = o; }
     __device__ void total(uint32_t na, int y) const { if (y == 0) cnt[0] = na; }
@@ -604,7 +597,7 @@ int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *s
     HIPCHK(c, c->ch_crop.ensure((size_t)n * 8));
     const uint32_t nb = (n + CH_TILE - 1) / CH_TILE;
     HIPCHK(c, c->ch_ent.ensure((size_t)n * 4 * 6 + 64 + (size_t)n + 64 + (size_t)nb * 4 * (2 + (size_t)N)));   // 2 x (key, val) for the sort, the cluster starts, flags, tile aggregates
-    HIPCHK(c, c->ch_ord.ensure((size_t)n * N * 4 * 2));           // ord[N][n], ordc[N][n]
+    HIPCHK(c, c->ch_ord.ensure((size_t)n * N * 4 * 3));           // ord[N][n], ordc[N][n], okey[N][n]: the genomes' orders and their keys as the cluster passes leave them
     HIPCHK(c, c->ch_rank.ensure((size_t)n * N * 4));
     HIPCHK(c, c->ch_cnt.ensure(256));
     if (seg0) HIPCHK(c, c->ch_big.ensure((size_t)n * 29 + 64));   // working arrays of the big clusters
@@ -615,10 +608,10 @@ int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *s
     uint32_t *k1 = c->ch_ent.as<uint32_t>(), *v1 = k1 + n, *k2 = v1 + n, *v2 = k2 + n, *sl = v2 + n;     // sl: cluster starts (up to n + 1)
     uint8_t *cflag = reinterpret_cast<uint8_t *>(sl + 2 * (size_t)n + 16);
     uint32_t *bmax = reinterpret_cast<uint32_t *>(cflag + (((size_t)n + 63) & ~(size_t)63)), *balive = bmax + nb, *bcnt = balive + nb;
-    uint32_t *ord = c->ch_ord.as<uint32_t>(), *ordc = ord + (size_t)n * N;
+    uint32_t *ord = c->ch_ord.as<uint32_t>(), *ordc = ord + (size_t)n * N, *okey = ordc + (size_t)n * N;
     uint32_t *rank = c->ch_rank.as<uint32_t>();
     uint32_t *cnt = c->ch_cnt.as<uint32_t>();                     // [0] na, [1] K, [2] link check, [3] fail, [4] clusters, [5] alive entries of the genome in turn,
-                                                                  // [8+g] survivors of genome g
+                                                                  // [8+g] entries of genome g alive before its cluster pass (the domain of FinalRanks)
     const int64_t *rlen = c->sorted_rec.as<int64_t>(), *rst = rlen + n;
     const uint32_t blocks = (n + 255) / 256;
     static const int big_max = []() { const char *e = getenv("MAUVE_CH_BIG_MAX"); const int v = e ? atoi(e) : 2048; return v < 1 ? 1 : v; }();        // cluster size the one-lane kernel still takes (tests lower it)
@@ -628,25 +621,34 @@ int chain_device_graph(mauve_ctx *c, int N, int64_t maxlen_in, const uint32_t *s
     unsigned long long *weight = c->ch_graph.as<unsigned long long>();
     if (seg0) hipLaunchKernelGGL(ch_init_seg, dim3(blocks), dim3(256), 0, c->stream, rlen, rst, n, N, seg0, nseg, len, st, crop, gapid, cnt, weight);
     else hipLaunchKernelGGL(ch_init, dim3(blocks), dim3(256), 0, c->stream, rlen, rst, n, N, len, st, crop, cnt, weight);
+    const int sort_passes = (pos_bits + 1 + 7) / 8;
     for (int g = 0; g < N; g++) {
-        hipLaunchKernelGGL(ch_keys, dim3(blocks), dim3(256), 0, c->stream, len, st, n, N, g, dead_key, k1, v1);
-        uint32_t *kk = k1, *vv = v1;
+        // The genome's order and keys stay where its cluster pass leaves them -- (okey, ord)[g] -- and FinalRanks compacts from there at the end: no
+        // compaction of the survivors per genome (two launches each).  The radix sort ends in its alternate buffers after an odd number of passes, so
+        // the buffers are handed to it the way that makes the result land there.
+        uint32_t *og = ord + (size_t)g * n, *kg = okey + (size_t)g * n;
         // genome 0: the list is in canonical order, i.e. already ordered by its left ends there (equal left ends keep their list order: every pass
         // below breaks ties by the list index, as the host chain does), nobody is dead yet
         // (a recursion batch starts with its non-forward matches dead: sorted like any other genome)
-        if (g > 0 || seg0) { int rc = sort_pairs_u32(c, n, pos_bits + 1, &kk, &vv, k2, v2, MAUVE_K_MISC); if (rc) return rc; }
+        const bool sorted = g > 0 || seg0;
+        const bool odd = sorted && (sort_passes & 1);
+        uint32_t *kk = odd ? k1 : kg, *vv = odd ? v1 : og;
+        hipLaunchKernelGGL(ch_keys, dim3(blocks), dim3(256), 0, c->stream, len, st, n, N, g, dead_key, kk, vv);
+        if (sorted) { int rc = sort_pairs_u32(c, n, pos_bits + 1, &kk, &vv, odd ? kg : k2, odd ? og : v2, MAUVE_K_MISC); if (rc) return rc; }
+        if (kk != kg || vv != og) {                               // (the sort took another number of passes than counted here: put the result in place)
+            HIPCHK(c, hipMemcpyAsync(kg, kk, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(og, vv, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
+            kk = kg; vv = og;
+        }
         hipLaunchKernelGGL(cl_partial, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive);
-        hipLaunchKernelGGL(cl_flags, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive, nb, cflag, cnt, bcnt);
+        hipLaunchKernelGGL(cl_flags, dim3(nb), dim3(256), 0, c->stream, len, n, dead_key, kk, vv, bmax, balive, nb, cflag, cnt, bcnt, cnt + 8 + g);
         const ClusterStarts cs{cflag, n, sl, cnt};
         hipLaunchKernelGGL((cmp_write<ClusterStarts>), dim3(nb), dim3(256), 0, c->stream, cs, bcnt);
         hipLaunchKernelGGL(ch_cluster_pass, dim3(blocks), dim3(256), 0, c->stream, len, st, N, g, dead_key, kk, vv, sl, cnt + 4, cnt + 3, seg0 ? 1 : 0, cl_max);
         if (seg0) hipLaunchKernelGGL(ch_cluster_pass_big, dim3((n + 63) / 64), dim3(64), 0, c->stream, len, st, N, g, dead_key, kk, vv, sl, cnt + 4,
                                      c->ch_big.as<uint32_t>(), n, cl_max, cnt + 3, big_max);
-        const GenomeOrder go{dead_key, kk, vv, cnt, ord + (size_t)g * n, cnt + 8 + g};
-        hipLaunchKernelGGL((cmp_count<GenomeOrder>), dim3(nb), dim3(256), 0, c->stream, go, bcnt);
-        hipLaunchKernelGGL((cmp_write<GenomeOrder>), dim3(nb), dim3(256), 0, c->stream, go, bcnt);
     }
-    const FinalRanks fr{len, n, ord, ordc, rank, cnt};
+    const FinalRanks fr{len, n, ord, okey, dead_key, ordc, rank, cnt};
     hipLaunchKernelGGL((cmp_count<FinalRanks>), dim3(nb, N), dim3(256), 0, c->stream, fr, bcnt);
     hipLaunchKernelGGL((cmp_write<FinalRanks>), dim3(nb, N), dim3(256), 0, c->stream, fr, bcnt);
     uint32_t *orient = reinterpret_cast<uint32_t *>(weight + n);
