@@ -860,3 +860,35 @@ def test_homology_pass_restated():
     same = [g0, g0.copy()]
     off, oc, moved = O.homology_apply(same, left[:1, :2] * 0 + [[1, 1]], np.array([[400, 400]]), np.zeros((1, 2), np.int8), np.array([0, 400]), np.full(400, 3, np.uint32), h)
     assert moved == 0 and np.array_equal(oc, np.full(400, 3, np.uint32))
+
+
+def test_workload_generator_is_xoshiro256starstar():
+    """SURVEY 8(d) names xoshiro256** seeded through splitmix64 for the synthetic workloads.  Known answers of the two published generators
+    (xoshiro256** from the state {1, 2, 3, 4}; splitmix64 from the seed 1234567 -- the vectors the reference implementations' test suites
+    carry), and the C stream of mauvealigner_amd/csrc/synth_rng.c against a restatement of the recurrence written out here."""
+    M = (1 << 64) - 1
+    x = synth.Xoshiro(0)
+    x.s = np.array([1, 2, 3, 4], dtype=np.uint64)
+    assert x.raw(10).tolist() == [11520, 0, 1509978240, 1215971899390074240, 1216172134540287360, 607988272756665600,
+                                  16172922978634559625, 8476171486693032832, 10595114339597558777, 2904607092377533576]
+    st, out = 1234567, []
+    for _ in range(5):
+        st, v = synth._splitmix64(st)
+        out.append(v)
+    assert out == [6457827717110365317, 3203168211198807973, 9817491932198370423, 4593380528125082431, 16408922859458223821]
+
+    def rotl(v, k):
+        return ((v << k) | (v >> (64 - k))) & M
+    g = synth.Xoshiro(3, 7)                               # the way a config seeds its streams: splitmix64 over the keys, four more for the state
+    s = [int(v) for v in g.s]
+    want = []
+    for _ in range(1000):
+        want.append((rotl((s[1] * 5) & M, 7) * 9) & M)
+        t = (s[1] << 17) & M
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45)
+    assert g.raw(1000).tolist() == want
+    # the draws synth.py makes from the stream (module docstring): base codes are the top two bits, integers the multiply-shift of the top 32
+    g2 = synth.Xoshiro(3, 7)
+    assert g2.integers(0, 4, 1000, dtype=np.uint8).tolist() == [w >> 62 for w in want]
+    g3 = synth.Xoshiro(3, 7)
+    assert g3.integers(10, 1010, 1000).tolist() == [10 + (((w >> 32) * 1000) >> 32) for w in want]
