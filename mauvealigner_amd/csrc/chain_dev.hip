@@ -176,13 +176,15 @@ struct LcbNodes {
         if (k == 0) return true;
         const uint32_t i = ordc[k], p = ordc[k - 1];
         if (gapid && gapid[i] != gapid[p]) return true;
+        // (no early exit: the genomes' loads are independent and travel together; with a return per genome they were a chain of N - 1 round trips)
+        bool brk = false;
+#pragma unroll 4
         for (int g = 1; g < N; g++) {
             const bool oi = st[(size_t)i * N + g] < 0, op = st[(size_t)p * N + g] < 0;
-            if (oi != op) return true;
             const uint32_t ri = rank[(size_t)g * n + i], rp = rank[(size_t)g * n + p];
-            if (!oi ? ri != rp + 1 : ri + 1 != rp) return true;
+            brk |= (oi != op) | (!oi ? ri != rp + 1 : ri + 1 != rp);
         }
-        return false;
+        return brk;
     }
     __device__ void each(uint32_t k, uint32_t o, bool fl, int) const
     {
