@@ -418,6 +418,7 @@ def main():
     if world > 1 or os.environ.get("MAUVE_BENCH_FORCE_DIST"):      # the env hook lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")           # (a forced single-rank rehearsal outside torchrun has no rendezvous in its environment)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
